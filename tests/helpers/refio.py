@@ -1,0 +1,276 @@
+"""Plain-Python readers/writers for the reference's file formats -- TEST INFRASTRUCTURE.
+
+Independent of the product's host C++ (taxator-tk_amd/host): the parity tests feed the same files through both
+and through the oracle.  Each function cites the reference lines it restates (paths relative to
+/root/reference/core).
+"""
+import gzip
+import os
+
+import numpy as np
+
+DEFAULT_RANKS = ("superkingdom", "phylum", "class", "order", "family", "genus", "species")  # src/constants.hh:33
+
+# seqan/basic/alphabet_residue_tabs.h:107-140 (Dna5) and :397-430 (AminoAcid), as data
+_DNA5 = np.full(256, 4, np.uint8)
+for _c, _o in (("A", 0), ("C", 1), ("G", 2), ("T", 3), ("U", 3)):
+    _DNA5[ord(_c)] = _o
+    _DNA5[ord(_c.lower())] = _o
+AA_LETTERS = "ABCDEFGHIJKLMNOPQRSTUVWYZX*"
+_AA27 = np.full(256, 25, np.uint8)
+for _o, _c in enumerate(AA_LETTERS):
+    _AA27[ord(_c)] = _o
+    _AA27[ord(_c.lower())] = _o
+
+
+def encode(seq_bytes, alphabet):
+    tab = _DNA5 if alphabet == 0 else _AA27
+    return tab[np.frombuffer(seq_bytes, np.uint8)]
+
+
+def _open(path):
+    return gzip.open(path, "rt") if path.endswith(".gz") else open(path)
+
+
+class FlatTaxonomy:
+    """NCBI dump -> pruned, flattened arrays.
+
+    src/ncbidata.cpp:17-166 (parse nodes.dmp / names.dmp, build from taxid "1", nested-set values, depth),
+    src/taxontree.cpp:55-70 (deleteUnmarkedNodes: keep the root and nodes whose rank is in `ranks`; children of a
+    deleted node move to its parent) and :169-178 (depth = number of kept ancestors).
+    Node 0 is the root.  Sibling order is ours (it only changes the nested-set numbering, not LCA/ancestry).
+    """
+
+    def __init__(self, folder, ranks=DEFAULT_RANKS, prune=True):
+        nodes = os.path.join(folder, "nodes.dmp")
+        if os.path.exists(nodes + ".gz"):
+            nodes += ".gz"
+        parent_of, rank_of, order = {}, {}, []
+        with _open(nodes) as f:
+            for line in f:
+                fields = line.rstrip("\n").split("\t|\t")
+                taxid, par, rank = fields[0], fields[1], fields[2]
+                parent_of[taxid] = par
+                rank_of[taxid] = rank
+                order.append(taxid)
+        children = {}
+        for t in order:
+            if t == "1" and parent_of[t] == "1":
+                continue
+            children.setdefault(parent_of[t], []).append(t)
+        keep = set(ranks)
+        self.taxid = []
+        parent, depth, left, right = [], [], [], []
+        counter = 0
+        # iterative DFS from the root over the ORIGINAL tree, emitting only kept nodes
+        stack = [("1", -1, 0, False)]
+        index_of = {}
+        while stack:
+            t, kept_parent, d, closing = stack.pop()
+            if closing:
+                counter += 1
+                right[index_of[t]] = counter
+                continue
+            is_kept = (t == "1") or (not prune) or (rank_of[t] in keep)
+            if is_kept:
+                idx = len(self.taxid)
+                index_of[t] = idx
+                self.taxid.append(t)
+                parent.append(kept_parent if kept_parent >= 0 else 0)
+                depth.append(d)
+                counter += 1
+                left.append(counter)
+                right.append(0)
+                stack.append((t, kept_parent, d, True))
+                kp, kd = idx, d + 1
+            else:
+                kp, kd = kept_parent, d
+            for c in reversed(children.get(t, [])):
+                stack.append((c, kp, kd, False))
+        self.parent = np.array(parent, np.uint32)
+        self.depth = np.array(depth, np.uint8)
+        self.left = np.array(left, np.uint32)
+        self.right = np.array(right, np.uint32)
+        self.index_of = index_of  # only kept taxids: a mapping to a deleted taxid aborts the reference (taxontree.cpp:59-64)
+        self.names = {}
+        names = os.path.join(folder, "names.dmp")
+        if os.path.exists(names + ".gz"):
+            names += ".gz"
+        if os.path.exists(names):
+            with _open(names) as f:
+                for line in f:
+                    fields = line.rstrip("\n").split("\t|\t")
+                    if len(fields) >= 4 and fields[3].startswith("scientific name"):
+                        self.names[fields[0]] = fields[1]
+
+
+def read_mapping(path):
+    """src/accessconv.hh:75-99: `seqid \\t taxid` lines, '#' comments."""
+    m = {}
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line or line[0] == "#":
+                continue
+            k, v = line.split("\t")[:2]
+            m[k] = v
+    return m
+
+
+class Fasta:
+    """Whole-file FASTA as a sequence store (ordinals), ids = header up to the first whitespace (src/faidx.h:590).
+    Models the *indexed* store (src/sequencestorage.hh:318-406): any byte outside the alphabet becomes N / X."""
+
+    def __init__(self, path, alphabet):
+        self.ids, seqs = [], []
+        cur = None
+        with open(path, "rb") as f:
+            for line in f:
+                line = line.rstrip(b"\r\n")
+                if line.startswith(b">"):
+                    self.ids.append(line[1:].split()[0].decode() if line[1:].split() else "")
+                    cur = []
+                    seqs.append(cur)
+                elif cur is not None:
+                    cur.append(b"".join(line.split()))
+        enc = [encode(b"".join(s), alphabet) for s in seqs]
+        self.offsets = np.zeros(len(enc) + 1, np.uint64)
+        if enc:
+            self.offsets[1:] = np.cumsum([len(e) for e in enc])
+        self.residues = np.concatenate(enc) if enc else np.zeros(0, np.uint8)
+        self.index = {n: i for i, n in enumerate(self.ids)}
+
+    def length(self, i):
+        return int(self.offsets[i + 1] - self.offsets[i])
+
+
+class AlignmentRecord:
+    __slots__ = ("qid", "qstart", "qstop", "qlen", "rid", "rstart", "rstop", "score", "evalue", "identities",
+                 "alnlen", "filtered", "serial")
+
+
+def parse_alignments(path_or_lines):
+    """src/alignmentrecord.hh:95-158 + src/fileparser.hh:61-67: '#' lines skipped, leading '*' = masked,
+    >= 11 tab fields: qid qstart qstop qlen rid rstart rstop score evalue identities alnlen [code]."""
+    lines = open(path_or_lines) if isinstance(path_or_lines, str) else path_or_lines
+    recs = []
+    for line in lines:
+        line = line.rstrip("\n")
+        if line and line[0] == "#":
+            continue
+        if len(line) <= 1:
+            raise ValueError("alignment line too short")
+        r = AlignmentRecord()
+        r.filtered = line[0] == "*"
+        f = (line[1:] if r.filtered else line).split("\t", 11)
+        if len(f) < 11:
+            raise ValueError("bad number of fields in alignment line")
+        r.qid, r.qstart, r.qstop, r.qlen = f[0], int(f[1]), int(f[2]), int(f[3])
+        if r.qstart > r.qstop:
+            raise ValueError("reverse query positions not allowed")
+        r.rid, r.rstart, r.rstop = f[4], int(f[5]), int(f[6])
+        r.score = np.float32(f[7])
+        r.evalue = float(f[8])
+        r.identities, r.alnlen = int(f[9]), int(f[10])
+        r.serial = len(recs)
+        recs.append(r)
+    return recs
+
+
+def record_sets(recs, split=True):
+    """src/alignmentrecord.hh:457-504 (RecordSetGeneratorUnsorted<split=true>): consecutive lines of one query id,
+    sorted by (qstart, qstop, <allocation order>), cut where qstart > running max qstop.  split=False: :543-566."""
+    out = []
+    i = 0
+    while i < len(recs):
+        j = i
+        while j < len(recs) and recs[j].qid == recs[i].qid:
+            j += 1
+        group = recs[i:j]
+        i = j
+        if not split:
+            out.append(group)
+            continue
+        group = sorted(group, key=lambda r: (r.qstart, r.qstop, r.serial))
+        cur, rstop = [group[0]], group[0].qstop
+        for r in group[1:]:
+            if r.qstart > rstop:
+                out.append(cur)
+                cur = [r]
+                rstop = r.qstop
+            else:
+                rstop = max(rstop, r.qstop)
+                cur.append(r)
+        out.append(cur)
+    return out
+
+
+def fmt_float(v):
+    """default ostream formatting of a float: %g with 6 significant digits."""
+    return "%g" % float(v)
+
+
+def gff3_line(qid, qlen, pred, tax, prev_ival):
+    """src/predictionrecord.hh:248-308.  `pred` has lower/upper/rtax/support/begin/end/ival/flags; the PredictionRecord
+    is reused across calls (taxator.cpp:66), so a record set with no active alignment prints the previous ival."""
+    ival = prev_ival if (int(pred["flags"]) & 1) else float(pred["ival"])
+    lower, upper, support = int(pred["lower"]), int(pred["upper"]), int(pred["support"])
+    parts = []
+    last = 0
+    node = lower
+    while node != upper:  # uniform support along the path (setNodeRange, :152-167)
+        if support != last:
+            parts.append("%s:%d-" % (tax.taxid[node], support))
+            last = support
+        node = int(tax.parent[node])
+    t = "".join(parts) + tax.taxid[upper]
+    if support != last:
+        t += ":%d" % support
+    line = "%s\ttaxator-tk\tsequence_feature\t%d\t%d\t0\t.\t.\tseqlen=%d;tax=%s;rtax=%s" % (
+        qid, int(pred["begin"]), int(pred["end"]), qlen, t, tax.taxid[int(pred["rtax"])])
+    if 0.0 <= ival < 1.0:
+        line += ";ival=" + fmt_float(np.float32(ival))
+    return line, ival
+
+
+class Dataset:
+    """A directory with tax/{nodes,names}.dmp, mapping.tax, a reference FASTA, a query FASTA and an alignments TSV."""
+
+    def __init__(self, folder, alphabet=0, ref_name=None, query_name=None, aln_name="aln.tsv"):
+        ext = ".fna" if alphabet == 0 else ".faa"
+        self.alphabet = alphabet
+        self.tax = FlatTaxonomy(os.path.join(folder, "tax"))
+        self.mapping = read_mapping(os.path.join(folder, "mapping.tax"))
+        self.ref = Fasta(os.path.join(folder, ref_name or ("ref" + ext)), alphabet)
+        self.query = Fasta(os.path.join(folder, query_name or ("query" + ext)), alphabet)
+        self.records = parse_alignments(os.path.join(folder, aln_name))
+        self.sets = record_sets(self.records)
+
+    def batch(self):
+        """Flatten to the SoA/AoS arrays the oracle and the engine take."""
+        from . import oracle as O
+        nrec = sum(len(s) for s in self.sets)
+        recs = np.zeros(nrec, O.RECORD_DTYPE)
+        offsets = np.zeros(len(self.sets) + 1, np.uint32)
+        qseq = np.zeros(len(self.sets), np.uint32)
+        qlen = np.zeros(len(self.sets), np.uint32)
+        qids = []
+        k = 0
+        for s, group in enumerate(self.sets):
+            qids.append(group[0].qid)
+            qseq[s] = self.query.index[group[0].qid]
+            qlen[s] = group[0].qlen
+            for r in group:
+                recs[k] = (r.qstart, r.qstop, r.rstart, r.rstop, r.score, r.identities, r.alnlen, self.ref.index[r.rid],
+                           self.tax.index_of[self.mapping[r.rid]], 1 if r.filtered else 0)
+                k += 1
+            offsets[s + 1] = k
+        return dict(recs=recs, offsets=offsets, qseq=qseq, qlen=qlen, qids=qids)
+
+    def gff3(self, preds, qids, qlens):
+        lines = ["##gff-version 3"]
+        prev = -1.0  # PredictionRecordBase ctor: interpolation_value_(-1.), predictionrecord.hh:40
+        for p, qid, ql in zip(preds, qids, qlens):
+            line, prev = gff3_line(qid, int(ql), p, self.tax, prev)
+            lines.append(line)
+        return "\n".join(lines) + "\n"
