@@ -1,0 +1,166 @@
+/* include/taxator_rpa.h -- C ABI of the MI355X-native realignment-placement (RPA) engine.
+ *
+ * Drop-in boundary for ONE path of fungs/taxator-tk v1.5.0: RPAPredictionModel::predict and everything below it
+ * (pairwise re-alignment, distance ranking, taxon-tree LCA placement).  The reference has no FFI; the seam it
+ * offers is the C++ plugin class
+ *     template<class ContainerT> class TaxonPredictionModel { virtual void predict(ContainerT& recordset,
+ *         PredictionRecord& prec, std::ostream& logsink) = 0; };          core/src/taxonpredictionmodel.hh:36-52
+ *     RPAPredictionModel(const Taxonomy*, QStorType&, const DBStorType&, float exclude_factor,
+ *         float reeval_bandwidth)                                         core/src/taxonpredictionmodelsequence.hh:329
+ * called once per record set from core/taxator.cpp:69-74 (serial) / :159-176 (threads).  This header is what a
+ * batched replacement of that seam binds: plain pointers and sizes, no C++ / torch types.  INTEGRATION.md shows
+ * the reference-side adapter.  Every entry point returns RPA_OK or an error code; rpa_last_error() gives the text
+ * (the reference throws Exception subclasses, core/src/exception.hh:29-73; nothing is thrown across this ABI).
+ *
+ * All kernels are hand-written HIP for gfx950; there is no CPU fallback behind these symbols.
+ */
+#ifndef TAXATOR_RPA_H
+#define TAXATOR_RPA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPA_ABI_VERSION 1
+
+enum { RPA_DNA = 0, RPA_PROTEIN = 1 };              /* taxator -b nucleotide|protein, core/taxator.cpp:280,362-371 */
+enum { RPA_STORE_QUERY = 0, RPA_STORE_DB = 1 };      /* query_sequences_ / db_sequences_, taxonpredictionmodelsequence.hh:842-843 */
+enum { RPA_MEM_HOST = 0, RPA_MEM_DEVICE = 1 };       /* where caller-owned arrays live */
+
+enum {
+  RPA_OK = 0,
+  RPA_ERR_INVALID = 1,   /* bad argument / inconsistent batch */
+  RPA_ERR_DEVICE = 2,    /* HIP runtime error, no device, out of device memory */
+  RPA_ERR_RANGE = 3,     /* SequenceRangeError: segment start beyond the sequence (sequencestorage.hh:341-362) */
+  RPA_ERR_SEQ_ID = 4,    /* SequenceNotFound (sequencestorage.hh:348-351): sequence index outside the store */
+  RPA_ERR_ASSERT = 5,    /* an assert that is live in the reference build would abort the run (CMakeLists.txt:38) */
+  RPA_ERR_UNSUPPORTED = 6
+};
+
+/* Pruned taxonomy, flattened (core/src/taxontree.hh:45-70 after TaxonTree::deleteUnmarkedNodes, taxontree.cpp:55-70).
+ * Node 0 is the root and parent[0] == 0.  left/right are any valid nested-set numbering; depth = root_pathlength.
+ * Replaces TaxonomyInterface::getLCA / isParentOf / getRoot (core/src/taxonomyinterface.cpp:16,52-55,67-77). */
+typedef struct {
+  uint32_t n_nodes;
+  const uint32_t* parent;
+  const uint32_t* left;
+  const uint32_t* right;
+  const uint8_t* depth;
+} rpa_taxonomy;
+
+typedef struct {
+  int alphabet;                    /* RPA_DNA | RPA_PROTEIN */
+  float exclude_alignments_factor; /* -x, default 0.5   (taxator.cpp:286, ctor arg exclude_factor) */
+  float reeval_bandwidth;          /* -t, default 0.05  (taxator.cpp:287, ctor arg reeval_bandwidth) */
+  int device;                      /* HIP device ordinal */
+  uint32_t reserved[4];            /* must be zero */
+} rpa_params;
+
+typedef struct rpa_engine rpa_engine;
+
+int rpa_abi_version(void);
+void rpa_default_params(rpa_params* p);
+
+/* RPAPredictionModel ctor (taxonpredictionmodelsequence.hh:329-339): copies the taxonomy to the device. */
+int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** out);
+void rpa_destroy(rpa_engine* e);
+/* Text of the last error on this engine (or of the last failed rpa_create when e == NULL). */
+const char* rpa_last_error(const rpa_engine* e);
+
+/* Run on a caller-provided hipStream_t (e.g. the current stream of the framework that owns the device buffers).
+ * NULL restores the engine's own stream. */
+int rpa_set_stream(rpa_engine* e, void* hip_stream);
+
+/* Sequence stores, resident in HBM -- replaces RandomSeqStoreROInterface::getSequence /
+ * getSequenceReverseComplement (core/src/sequencestorage.hh:41-52; indexed store :318-466, reader core/src/faidx.h:315-350).
+ * `letters` are the raw FASTA residue bytes of all sequences back to back (no line breaks); sequence i occupies
+ * [offsets[i], offsets[i+1]).  Bytes are mapped to alphabet ordinals on the device exactly as the indexed store does
+ * (seqan/basic/alphabet_residue_tabs.h:107-140 Dna5: ACGT(U) any case, everything else N; :397-430 AminoAcid: 27
+ * letters, everything else X) and packed (4 bit/base DNA, 8 bit/residue protein).  Coordinates in a batch are the
+ * reference's: 1-based inclusive; rstart > rstop means reverse strand. */
+int rpa_store_load(rpa_engine* e, int which, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets,
+                   int mem_kind);
+
+/* One batch of record sets = what RecordSetGenerator*::getNext hands to predict() one at a time
+ * (core/src/alignmentrecord.hh:457-631), as structure-of-arrays.  Record fields are exactly those predict() reads
+ * (SURVEY.md 8b): AlignmentRecord getters core/src/alignmentrecord.hh:40-88, reference node :229-231. */
+typedef struct {
+  uint32_t n_sets;
+  uint32_t n_records;
+  const uint32_t* set_offsets; /* n_sets+1; records of set s are [set_offsets[s], set_offsets[s+1]) in generator order */
+  const uint32_t* query_seq;   /* n_sets: index of the query sequence in the QUERY store (getQueryIdentifier) */
+  const uint32_t* query_len;   /* n_sets: getQueryLength() of the set's first record */
+  /* n_records each: */
+  const uint32_t* qstart;      /* getQueryStart  */
+  const uint32_t* qstop;       /* getQueryStop   */
+  const uint32_t* rstart;      /* getReferenceStart */
+  const uint32_t* rstop;       /* getReferenceStop  */
+  const float* score;          /* getScore       */
+  const uint32_t* identities;  /* getIdentities  */
+  const uint32_t* alnlen;      /* getAlignmentLength */
+  const uint32_t* ref_seq;     /* index of getReferenceIdentifier() in the DB store */
+  const uint32_t* node;        /* taxonomy node index of getReferenceNode() */
+  const uint8_t* filtered;     /* isFiltered() (leading '*' in the input line); may be NULL = none */
+  int mem_kind;                /* RPA_MEM_HOST | RPA_MEM_DEVICE for every pointer above */
+} rpa_batch;
+
+#define RPA_FLAG_IVAL_UNTOUCHED 1u /* no active record: setUnclassified(), ival keeps its previous value (:359-368) */
+#define RPA_FLAG_SHORTCUT 2u       /* best hit identical to the query range: no alignment (:431-472) */
+#define RPA_FLAG_SINGLE 4u         /* one active record (:371-388) */
+
+/* What predict() writes into the PredictionRecord (taxonpredictionmodelsequence.hh:828-833): 32 bytes per set,
+ * also the row that ranks gather to rank 0.  Node fields are taxonomy indices. */
+typedef struct {
+  uint32_t lower;   /* setNodeRange lower node */
+  uint32_t upper;   /* setNodeRange upper node */
+  uint32_t rtax;    /* setBestReferenceTaxon */
+  uint32_t support; /* setNodeRange support */
+  uint32_t begin;   /* setQueryFeatureBegin */
+  uint32_t end;     /* setQueryFeatureEnd */
+  float ival;       /* setInterpolationValue */
+  uint32_t flags;
+} rpa_prediction;
+
+/* Per-set alignment counters = the reference's STATS log line (:837): n, pass_0/1/2_counter. */
+typedef struct {
+  uint32_t n, pass0, pass1, pass2;
+} rpa_stats;
+
+/* predict() for every set of the batch.  `out` (n_sets rows) and `stats` (n_sets rows or NULL) live where out_mem_kind
+ * says.  Results are in input order.  Synchronous: returns when the rows are written. */
+int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind);
+
+/* Pair-level entry: getAlignment<StringType>(A, B) (taxonpredictionmodelsequence.hh:133-171 DNA, :173-242 protein)
+ * for explicit pairs of sequences of a store-shaped arena (letters/offsets as in rpa_store_load; not kept).
+ * Used by the parity tests and the kernel benchmark; same kernels as rpa_predict_batch. */
+typedef struct {
+  uint32_t matches, mismatches, gaps, length;
+  float distance, similarity;
+} rpa_alignment;
+
+int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, uint32_t n_pairs,
+                    const uint32_t* pair_a, const uint32_t* pair_b, rpa_alignment* out, int mem_kind);
+
+/* Live kernel timing (HIP events on the engine's stream around each launch of the alignment kernels). */
+typedef struct {
+  uint64_t launches;       /* alignment-kernel launches since reset */
+  uint64_t pairs;          /* alignments computed (including speculative ones the control flow then ignores) */
+  uint64_t residue_bytes;  /* sum over computed pairs of len_a + len_b + 8 (SURVEY.md 8d algorithmic bytes) */
+  uint64_t cells;          /* sum over computed pairs of len_a * len_b */
+  double align_ms;         /* device time inside alignment kernels */
+  double total_ms;         /* device time of whole rpa_predict_batch / rpa_align_pairs calls */
+  uint64_t demanded;       /* alignments the reference control flow demanded (sum of pass0+pass1+pass2) */
+  uint64_t rounds;         /* plan/align/decide rounds */
+} rpa_profile;
+
+int rpa_profile_enable(rpa_engine* e, int on);
+int rpa_profile_get(rpa_engine* e, rpa_profile* out);
+int rpa_profile_reset(rpa_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAXATOR_RPA_H */

@@ -1,0 +1,217 @@
+"""taxator_tk_amd -- Python face of the MI355X-native RPA engine (ctypes over the C ABI in include/taxator_rpa.h).
+
+The directory is named `taxator-tk_amd`; import it through `__graft_entry__.load_package()` (module name
+`taxator_tk_amd`).  Everything here is plumbing around `librpa_hip.so` (hand-written HIP for gfx950, built by
+`taxator-tk_amd/csrc/Makefile`).  There is NO CPU implementation behind this module: if the shared library is
+missing or no gfx950 device answers, construction raises.  The CPU oracle lives in /oracle and is never imported here.
+
+Mirrors the reference's seam (core/src/taxonpredictionmodelsequence.hh:326-339): `RPAPredictionModel(tax, query_store,
+db_store, exclude_factor, reeval_bandwidth)` with `predict(batch)` for a whole batch of record sets.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librpa_hip.so")
+
+DNA, PROTEIN = 0, 1
+STORE_QUERY, STORE_DB = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_IVAL_UNTOUCHED, FLAG_SHORTCUT, FLAG_SINGLE = 1, 2, 4
+
+PRED_DTYPE = np.dtype([("lower", "<u4"), ("upper", "<u4"), ("rtax", "<u4"), ("support", "<u4"), ("begin", "<u4"),
+                       ("end", "<u4"), ("ival", "<f4"), ("flags", "<u4")])
+STATS_DTYPE = np.dtype([("n", "<u4"), ("pass0", "<u4"), ("pass1", "<u4"), ("pass2", "<u4")])
+ALN_DTYPE = np.dtype([("matches", "<u4"), ("mismatches", "<u4"), ("gaps", "<u4"), ("length", "<u4"),
+                      ("distance", "<f4"), ("similarity", "<f4")])
+
+ERROR_NAMES = {0: "OK", 1: "INVALID", 2: "DEVICE", 3: "RANGE", 4: "SEQ_ID", 5: "ASSERT", 6: "UNSUPPORTED"}
+
+# every symbol include/taxator_rpa.h declares (checked by the CPU-side ABI test)
+ABI_SYMBOLS = ["rpa_abi_version", "rpa_default_params", "rpa_create", "rpa_destroy", "rpa_last_error", "rpa_set_stream",
+               "rpa_store_load", "rpa_predict_batch", "rpa_align_pairs", "rpa_profile_enable", "rpa_profile_get",
+               "rpa_profile_reset"]
+
+
+class RpaError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("rpa error %d (%s): %s" % (code, ERROR_NAMES.get(code, "?"), text))
+        self.code = code
+
+
+class _Taxonomy(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("parent", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
+                ("depth", C.c_void_p)]
+
+
+class _Params(C.Structure):
+    _fields_ = [("alphabet", C.c_int), ("exclude_alignments_factor", C.c_float), ("reeval_bandwidth", C.c_float),
+                ("device", C.c_int), ("reserved", C.c_uint32 * 4)]
+
+
+class _Batch(C.Structure):
+    _fields_ = [("n_sets", C.c_uint32), ("n_records", C.c_uint32), ("set_offsets", C.c_void_p), ("query_seq", C.c_void_p),
+                ("query_len", C.c_void_p), ("qstart", C.c_void_p), ("qstop", C.c_void_p), ("rstart", C.c_void_p),
+                ("rstop", C.c_void_p), ("score", C.c_void_p), ("identities", C.c_void_p), ("alnlen", C.c_void_p),
+                ("ref_seq", C.c_void_p), ("node", C.c_void_p), ("filtered", C.c_void_p), ("mem_kind", C.c_int)]
+
+
+class _Profile(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("pairs", C.c_uint64), ("residue_bytes", C.c_uint64), ("cells", C.c_uint64),
+                ("align_ms", C.c_double), ("total_ms", C.c_double), ("demanded", C.c_uint64), ("rounds", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen librpa_hip.so and declare the ABI.  Raises if it was not built -- there is no fallback."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("%s not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()')" % path)
+    L = C.CDLL(path)
+    L.rpa_abi_version.restype = C.c_int
+    L.rpa_default_params.argtypes = [C.POINTER(_Params)]
+    L.rpa_default_params.restype = None
+    L.rpa_create.argtypes = [C.POINTER(_Taxonomy), C.POINTER(_Params), C.POINTER(C.c_void_p)]
+    L.rpa_create.restype = C.c_int
+    L.rpa_destroy.argtypes = [C.c_void_p]
+    L.rpa_destroy.restype = None
+    L.rpa_last_error.argtypes = [C.c_void_p]
+    L.rpa_last_error.restype = C.c_char_p
+    L.rpa_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.rpa_set_stream.restype = C.c_int
+    L.rpa_store_load.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    L.rpa_store_load.restype = C.c_int
+    L.rpa_predict_batch.argtypes = [C.c_void_p, C.POINTER(_Batch), C.c_void_p, C.c_void_p, C.c_int]
+    L.rpa_predict_batch.restype = C.c_int
+    L.rpa_align_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int]
+    L.rpa_align_pairs.restype = C.c_int
+    L.rpa_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.rpa_profile_enable.restype = C.c_int
+    L.rpa_profile_get.argtypes = [C.c_void_p, C.POINTER(_Profile)]
+    L.rpa_profile_get.restype = C.c_int
+    L.rpa_profile_reset.argtypes = [C.c_void_p]
+    L.rpa_profile_reset.restype = C.c_int
+    if path == LIB_PATH:
+        _lib = L
+    return L
+
+
+def _ptr(a):
+    """numpy array -> host pointer; torch tensor / object with data_ptr() -> device (or host) pointer; int passes."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return int(a)
+
+
+BATCH_FIELDS = (("set_offsets", np.uint32), ("query_seq", np.uint32), ("query_len", np.uint32), ("qstart", np.uint32),
+                ("qstop", np.uint32), ("rstart", np.uint32), ("rstop", np.uint32), ("score", np.float32),
+                ("identities", np.uint32), ("alnlen", np.uint32), ("ref_seq", np.uint32), ("node", np.uint32))
+
+
+class RPAPredictionModel:
+    """One engine on one GPU.
+
+    tax: object with .parent/.left/.right (uint32) and .depth (uint8) arrays, node 0 = root (pruned taxonomy).
+    """
+
+    def __init__(self, tax, alphabet=DNA, exclude_factor=0.5, reeval_bandwidth=0.05, device=0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        parent = np.ascontiguousarray(tax.parent, np.uint32)
+        left = np.ascontiguousarray(tax.left, np.uint32)
+        right = np.ascontiguousarray(tax.right, np.uint32)
+        depth = np.ascontiguousarray(tax.depth, np.uint8)
+        t = _Taxonomy(len(parent), parent.ctypes.data, left.ctypes.data, right.ctypes.data, depth.ctypes.data)
+        p = _Params()
+        self._L.rpa_default_params(C.byref(p))
+        p.alphabet, p.exclude_alignments_factor, p.reeval_bandwidth, p.device = alphabet, exclude_factor, reeval_bandwidth, device
+        rc = self._L.rpa_create(C.byref(t), C.byref(p), C.byref(self._h))
+        if rc:
+            raise RpaError(rc, (self._L.rpa_last_error(None) or b"").decode())
+        self.alphabet = alphabet
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.rpa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise RpaError(rc, (self._L.rpa_last_error(self._h) or b"").decode())
+
+    def set_stream(self, hip_stream):
+        self._check(self._L.rpa_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else 0)))
+
+    def load_store(self, which, letters, offsets, mem_kind=MEM_HOST):
+        """letters: uint8 residue bytes back to back; offsets: uint64 [n_seqs+1] (numpy = host, torch cuda tensor = device)."""
+        n = (len(offsets) if not hasattr(offsets, "numel") else offsets.numel()) - 1
+        if isinstance(letters, np.ndarray):
+            letters = np.ascontiguousarray(letters, np.uint8)
+            offsets = np.ascontiguousarray(offsets, np.uint64)
+        self._keep = (letters, offsets)
+        self._check(self._L.rpa_store_load(self._h, which, n, _ptr(letters), _ptr(offsets), mem_kind))
+        self._keep = None
+
+    def predict(self, batch, mem_kind=MEM_HOST, want_stats=True, out=None, stats=None):
+        """batch: dict with the rpa_batch arrays (numpy for MEM_HOST, torch cuda tensors for MEM_DEVICE).
+        Returns (rows, stats) as numpy structured arrays (host) or fills the given device tensors."""
+        arrs = {}
+        for name, dt in BATCH_FIELDS:
+            a = batch[name]
+            if mem_kind == MEM_HOST:
+                a = np.ascontiguousarray(a, dt)
+            arrs[name] = a
+        filt = batch.get("filtered")
+        if filt is not None and mem_kind == MEM_HOST:
+            filt = np.ascontiguousarray(filt, np.uint8)
+        so = arrs["set_offsets"]
+        n_sets = (len(so) if isinstance(so, np.ndarray) else so.numel()) - 1
+        qs = arrs["qstart"]
+        n_rec = len(qs) if isinstance(qs, np.ndarray) else qs.numel()
+        b = _Batch(n_sets, n_rec, *[_ptr(arrs[name]) for name, _ in BATCH_FIELDS], _ptr(filt), mem_kind)
+        if mem_kind == MEM_HOST or out is None:
+            rows = np.zeros(n_sets, PRED_DTYPE)
+            st = np.zeros(n_sets, STATS_DTYPE) if want_stats else None
+            self._check(self._L.rpa_predict_batch(self._h, C.byref(b), rows.ctypes.data, st.ctypes.data if want_stats else None, MEM_HOST))
+            return rows, st
+        self._check(self._L.rpa_predict_batch(self._h, C.byref(b), _ptr(out), _ptr(stats), MEM_DEVICE))
+        return out, stats
+
+    def align_pairs(self, letters, offsets, pair_a, pair_b):
+        """getAlignment(A, B) for explicit pairs of the sequences in (letters, offsets).  Host arrays in, numpy out."""
+        letters = np.ascontiguousarray(letters, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        pair_a = np.ascontiguousarray(pair_a, np.uint32)
+        pair_b = np.ascontiguousarray(pair_b, np.uint32)
+        out = np.zeros(len(pair_a), ALN_DTYPE)
+        self._check(self._L.rpa_align_pairs(self._h, len(offsets) - 1, letters.ctypes.data, offsets.ctypes.data, len(pair_a),
+                                            pair_a.ctypes.data, pair_b.ctypes.data, out.ctypes.data, MEM_HOST))
+        return out
+
+    def profile(self, enable=None, reset=False):
+        if enable is not None:
+            self._check(self._L.rpa_profile_enable(self._h, 1 if enable else 0))
+        if reset:
+            self._check(self._L.rpa_profile_reset(self._h))
+        p = _Profile()
+        self._check(self._L.rpa_profile_get(self._h, C.byref(p)))
+        return {f: getattr(p, f) for f, _ in _Profile._fields_}

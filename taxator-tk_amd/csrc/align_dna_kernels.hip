@@ -1,0 +1,276 @@
+// taxator-tk_amd/csrc/align_dna_kernels.hip -- nucleotide re-alignment kernels for gfx950 (K1 short, K2 long).
+//
+// What they replace: getAlignmentDNA (core/src/taxonpredictionmodelsequence.hh:133-171) and the SeqAn routine it
+// calls, _globalAlignmentScore(..., MyersBitVector) (seqan/align/global_alignment_myers_impl.h:62-196): the
+// unit-cost global edit distance of two Dna5 strings (N matches only N), from which the reference derives
+//   distance = d, gaps = |len difference|, mismatches = d - gaps, matches = len_short - mismatches (= len_long - d).
+// The reference keeps VP/VN/Peq in heap arrays of 32-bit blocks and walks them block by block per text character.
+//
+// K1 (pattern <= 256 nt): ONE ALIGNMENT PER LANE.  The delta vectors VP/VN of the shorter sequence live in NW
+// 32-bit VGPRs each (NW = ceil(m/32) is a template parameter; pairs are binned by NW so a wave runs one shape);
+// the match masks Peq[5][NW] live in LDS, laid out [symbol][word][lane] so that a lane always hits bank (lane % 32)
+// whatever its text symbol is -> conflict-free ds_read_b32 with an immediate word offset.  The text is streamed from
+// the lane's 16-byte aligned segment slot with dwordx4 loads (32 nt per load).  Integer VALU bound (~13 ops per
+// 32-bit word per column); HBM traffic is the algorithmic minimum (each segment byte is read once per pair).
+// No MFMA: this is bit-parallel integer DP, not a contraction.
+//
+// K2 (pattern 257..16384 nt): ONE ALIGNMENT PER WAVE, words striped over lanes, anti-diagonal (skewed) schedule with
+// the three inter-word carries handed lane to lane by DPP shifts.  See below.
+#include "rpa_device.h"
+
+namespace rpa {
+
+// Compress the bit `b` of each of the 8 nibbles of x into 8 contiguous bits (nibble k -> bit k).
+__device__ __forceinline__ uint32_t nibble_plane(uint32_t x, int b) {
+  uint32_t t = (x >> b) & 0x11111111u;        // bit at 4k
+  t = (t | (t >> 3)) & 0x03030303u;           // per byte: 2 bits at positions 0,1
+  return (t * 0x01041040u) >> 24;             // gather the four 2-bit fields: b0 | b1<<2 | b2<<4 | b3<<6
+}
+
+// Bit planes (32 residues per word) of four packed dwords.
+__device__ __forceinline__ void planes32(const uint4 x, uint32_t& p0, uint32_t& p1, uint32_t& pn) {
+  p0 = nibble_plane(x.x, 0) | (nibble_plane(x.y, 0) << 8) | (nibble_plane(x.z, 0) << 16) | (nibble_plane(x.w, 0) << 24);
+  p1 = nibble_plane(x.x, 1) | (nibble_plane(x.y, 1) << 8) | (nibble_plane(x.z, 1) << 16) | (nibble_plane(x.w, 1) << 24);
+  pn = nibble_plane(x.x, 2) | (nibble_plane(x.y, 2) << 8) | (nibble_plane(x.z, 2) << 16) | (nibble_plane(x.w, 2) << 24);
+}
+
+__device__ __forceinline__ void profile_add(unsigned long long* acc, bool active, uint32_t la, uint32_t lb) {
+  // block-level reduction, then 3 atomics per workgroup (only when profiling is on)
+  __shared__ unsigned long long red[3][kBlock / 64];
+  unsigned long long v0 = active ? 1ull : 0ull, v1 = active ? (unsigned long long)la + lb + 8ull : 0ull,
+                     v2 = active ? (unsigned long long)la * lb : 0ull;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    v0 += __shfl_down(v0, d, 64);
+    v1 += __shfl_down(v1, d, 64);
+    v2 += __shfl_down(v2, d, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = v0; red[1][wave] = v1; red[2][wave] = v2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long s = 0;
+    for (int k = 0; k < kBlock / 64; ++k) s += red[threadIdx.x][k];
+    atomicAdd(&acc[threadIdx.x], s);
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restrict__ list, uint32_t n_list, WorkDev w,
+                                                         unsigned long long* prof_acc) {
+  extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
+  const int tid = threadIdx.x;
+  const uint32_t t = blockIdx.x * kBlock + tid;
+  const bool active = t < n_list;
+  uint32_t slot = 0, m = 0, n = 0;
+  const uint4* __restrict__ pat = nullptr;
+  const uint4* __restrict__ txt = nullptr;
+  if (active) {
+    slot = list[t];
+    uint32_t a = w.pair_a[slot], b = w.pair_b[slot];
+    uint32_t la = w.seg_len[a], lb = w.seg_len[b];
+    if (la < lb) { uint32_t x = a; a = b; b = x; x = la; la = lb; lb = x; }  // a = long (text), b = short (pattern), :144-147
+    n = la; m = lb;
+    txt = reinterpret_cast<const uint4*>(w.arena + (size_t)w.seg_off16[a] * 4);
+    pat = reinterpret_cast<const uint4*>(w.arena + (size_t)w.seg_off16[b] * 4);
+  }
+  if (prof_acc) profile_add(prof_acc, active, n, m);
+
+  // ---- Peq build (bit planes -> five match masks per 32-residue word) ----
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) {
+    uint32_t A = 0, C = 0, G = 0, T = 0, N = 0;
+    if (active && (uint32_t)wi * 32u < m) {
+      const uint4 x = pat[wi];
+      uint32_t p0, p1, pn;
+      planes32(x, p0, p1, pn);
+      const uint32_t rem = m - wi * 32u;
+      const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);  // slot tail is zero = 'A': mask it out
+      N = pn & vm;
+      T = p1 & p0 & vm;
+      G = p1 & ~p0 & vm;
+      C = p0 & ~p1 & ~pn & vm;
+      A = ~(p0 | p1 | pn) & vm;
+    }
+    peq[(0 * NW + wi) * kBlock + tid] = A;
+    peq[(1 * NW + wi) * kBlock + tid] = C;
+    peq[(2 * NW + wi) * kBlock + tid] = G;
+    peq[(3 * NW + wi) * kBlock + tid] = T;
+    peq[(4 * NW + wi) * kBlock + tid] = N;
+  }
+  if (!active) return;
+
+  uint32_t VP[NW], VN[NW];
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
+  int32_t dist = (int32_t)m;  // D[m][0]
+  const uint32_t lastbit = (m - 1u) & 31u;  // m >= 1 (zero-length segments are range errors upstream)
+
+  for (uint32_t base = 0; base < n; base += 32) {
+    const uint4 tx = txt[base >> 5];
+    const uint32_t td[4] = {tx.x, tx.y, tx.z, tx.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t col = base + q * 8 + k;
+        if (col < n) {
+          const uint32_t c = (td[q] >> (4 * k)) & 7u;
+          const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
+          uint32_t carry = 0, hp_prev = 0x80000000u /* global alignment: +1 enters row 0 */, hn_prev = 0, HP = 0, HN = 0;
+#pragma unroll
+          for (int wi = 0; wi < NW; ++wi) {
+            const uint32_t vp = VP[wi], vn = VN[wi];
+            const uint32_t X = e[wi * kBlock] | vn;
+            const uint64_t s = (uint64_t)vp + (uint64_t)(X & vp) + carry;
+            carry = (uint32_t)(s >> 32);
+            const uint32_t D0 = ((uint32_t)s ^ vp) | X;
+            HN = vp & D0;
+            HP = vn | ~(vp | D0);
+            const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);  // (HP << 1) | (hp_prev >> 31)
+            const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+            hp_prev = HP;
+            hn_prev = HN;
+            VN[wi] = Xs & D0;
+            VP[wi] = Hs | ~(Xs | D0);
+          }
+          dist += (int32_t)((HP >> lastbit) & 1u) - (int32_t)((HN >> lastbit) & 1u);
+        }
+      }
+    }
+  }
+  // distance, similarity = matches = len_short - (d - lendiff) = len_long - d   (:154-164)
+  w.pair_res[slot] = make_float2((float)dist, (float)((int32_t)n - dist));
+  if (w.pair_ext) w.pair_ext[slot] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);  // match+mismatch = m, + gap = n
+}
+
+hipError_t launch_align_dna_short(hipStream_t st, int words, const uint32_t* list, uint32_t n, const WorkDev& w,
+                                  unsigned long long* prof_acc) {
+  if (n == 0) return hipSuccess;
+  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+  const size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
+#define RPA_LAUNCH_MYERS(NWV) \
+  case NWV: hipLaunchKernelGGL(k_myers_short<NWV>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, prof_acc); break;
+  switch (words) {
+    RPA_LAUNCH_MYERS(1) RPA_LAUNCH_MYERS(2) RPA_LAUNCH_MYERS(3) RPA_LAUNCH_MYERS(4)
+    RPA_LAUNCH_MYERS(5) RPA_LAUNCH_MYERS(6) RPA_LAUNCH_MYERS(7) RPA_LAUNCH_MYERS(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef RPA_LAUNCH_MYERS
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2: pattern longer than 256 nt (up to 16384 nt) -- ONE ALIGNMENT PER WAVEFRONT.
+// The pattern's 32-bit words are dealt to lanes in contiguous runs of WPL words (lane l owns words
+// [l*WPL, (l+1)*WPL), WPL = ceil(words/64) is a template parameter, pairs are binned by it); at step t lane l
+// processes text column t - l for its run, so the words of one column are computed on an anti-diagonal across
+// lanes.  What crosses lanes per column is the add carry and the two shift carries (HP/HN top bits) out of a run,
+// plus the text symbol: they travel together in one register, one lane to the right per step (__shfl_up by 1, a
+// DPP wave shift) -- the wave itself is the systolic array, no LDS and no barrier.  Peq of the lane's run stays in
+// registers as three bit planes (the symbol differs per lane, so a shared table would not help); the pattern is
+// read from HBM once, the text once (64 dwords per coalesced prefetch, double buffered, handed to lane 0 by
+// v_readlane).  Reference: the multi-block branch of the same SeqAn routine (global_alignment_myers_impl.h:129-191).
+// ------------------------------------------------------------------------------------------------------------
+template <int WPL>
+__global__ __launch_bounds__(64) void k_myers_long(const uint32_t* __restrict__ list, uint32_t n_list, WorkDev w,
+                                                    unsigned long long* prof_acc) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_list) return;
+  const int lane = threadIdx.x;
+  const uint32_t slot = list[t];
+  uint32_t a = w.pair_a[slot], b = w.pair_b[slot];
+  uint32_t la = w.seg_len[a], lb = w.seg_len[b];
+  if (la < lb) { uint32_t x = a; a = b; b = x; x = la; la = lb; lb = x; }
+  const uint32_t n = la, m = lb;
+  if (prof_acc && lane == 0) {
+    atomicAdd(&prof_acc[0], 1ull);
+    atomicAdd(&prof_acc[1], (unsigned long long)la + lb + 8ull);
+    atomicAdd(&prof_acc[2], (unsigned long long)la * lb);
+  }
+  const uint32_t* __restrict__ txt = w.arena + (size_t)w.seg_off16[a] * 4;
+  const uint32_t txt_words = w.seg_cap16[a] * 4;
+  const uint4* __restrict__ pat = reinterpret_cast<const uint4*>(w.arena + (size_t)w.seg_off16[b] * 4);
+  const uint32_t total_words = (m + 31u) / 32u;  // <= 64 * WPL by binning
+  const uint32_t w0 = (uint32_t)lane * WPL;
+  const uint32_t last_word = total_words - 1u;
+  const uint32_t lastbit = (m - 1u) & 31u;
+  const uint32_t lanes_used = (total_words + WPL - 1u) / WPL;
+  int32_t dist = (int32_t)m;
+
+  uint32_t P0[WPL], P1[WPL], PN[WPL], VM[WPL], VP[WPL], VN[WPL];
+#pragma unroll
+  for (int k = 0; k < WPL; ++k) {
+    const uint32_t wi = w0 + k;
+    P0[k] = P1[k] = PN[k] = VM[k] = 0;
+    if (wi < total_words) {
+      planes32(pat[wi], P0[k], P1[k], PN[k]);
+      const uint32_t rem = m - wi * 32u;
+      VM[k] = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+    }
+    VP[k] = 0xFFFFFFFFu;
+    VN[k] = 0u;
+  }
+  const uint32_t steps = n + lanes_used - 1u;
+  uint32_t msg = 0;  // bits 0..2: carries out of my run for my column; bits 4..6: text symbol; bit 8: valid
+  uint32_t tx_cur = (uint32_t)lane < txt_words ? txt[lane] : 0u;  // text dwords [0,64)
+  uint32_t tx_nxt = 64u + lane < txt_words ? txt[64 + lane] : 0u;
+  for (uint32_t step = 0; step < steps; ++step) {
+    if ((step & 511u) == 0u && step) {  // 512 columns = 64 dwords consumed: rotate the prefetch buffers
+      tx_cur = tx_nxt;
+      const uint32_t idx = ((step >> 9) + 1u) * 64u + lane;
+      tx_nxt = idx < txt_words ? txt[idx] : 0u;
+    }
+    const uint32_t dword = __shfl(tx_cur, (int)((step >> 3) & 63u), 64);
+    uint32_t in = __shfl_up(msg, 1, 64);
+    if (lane == 0) in = step < n ? (2u /* add carry 0, HP carry 1 (global), HN carry 0 */ | (((dword >> ((step & 7u) * 4u)) & 7u) << 4) | 0x100u) : 0u;
+    uint32_t out = 0;
+    if ((in & 0x100u) && (uint32_t)lane < lanes_used) {
+      const uint32_t c = (in >> 4) & 7u;
+      const uint32_t m0 = (c & 1u) ? 0xFFFFFFFFu : 0u, m1 = (c & 2u) ? 0xFFFFFFFFu : 0u, mn = (c & 4u) ? 0xFFFFFFFFu : 0u;
+      uint32_t carry = in & 1u;
+      uint32_t hp_prev = (in & 2u) ? 0x80000000u : 0u, hn_prev = (in & 4u) ? 0x80000000u : 0u;
+#pragma unroll
+      for (int k = 0; k < WPL; ++k) {
+        const uint32_t eq = ~(P0[k] ^ m0) & ~(P1[k] ^ m1) & ~(PN[k] ^ mn) & VM[k];
+        const uint32_t vp = VP[k], vn = VN[k];
+        const uint32_t X = eq | vn;
+        const uint64_t s = (uint64_t)vp + (uint64_t)(X & vp) + carry;
+        carry = (uint32_t)(s >> 32);
+        const uint32_t D0 = ((uint32_t)s ^ vp) | X;
+        const uint32_t HN = vp & D0;
+        const uint32_t HP = vn | ~(vp | D0);
+        const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
+        const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+        hp_prev = HP;
+        hn_prev = HN;
+        VN[k] = Xs & D0;
+        VP[k] = Hs | ~(Xs | D0);
+        if (w0 + k == last_word) dist += (int32_t)((HP >> lastbit) & 1u) - (int32_t)((HN >> lastbit) & 1u);
+      }
+      out = carry | ((hp_prev >> 31) << 1) | ((hn_prev >> 31) << 2) | (c << 4) | 0x100u;
+    }
+    msg = out;
+  }
+  dist = __shfl(dist, (int)(last_word / WPL), 64);  // the lane that owns the last word holds the distance
+  if (lane == 0) {
+    w.pair_res[slot] = make_float2((float)dist, (float)((int32_t)n - dist));
+    if (w.pair_ext) w.pair_ext[slot] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
+  }
+}
+
+hipError_t launch_align_dna_long(hipStream_t st, int wpl, const uint32_t* list, uint32_t n, const WorkDev& w,
+                                 unsigned long long* prof_acc) {
+  if (n == 0) return hipSuccess;
+#define RPA_LAUNCH_LONG(V) \
+  case V: hipLaunchKernelGGL(k_myers_long<V>, dim3(n), dim3(64), 0, st, list, n, w, prof_acc); break;
+  switch (wpl) {
+    RPA_LAUNCH_LONG(1) RPA_LAUNCH_LONG(2) RPA_LAUNCH_LONG(3) RPA_LAUNCH_LONG(4)
+    RPA_LAUNCH_LONG(5) RPA_LAUNCH_LONG(6) RPA_LAUNCH_LONG(7) RPA_LAUNCH_LONG(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef RPA_LAUNCH_LONG
+  return hipGetLastError();
+}
+
+}  // namespace rpa

@@ -1,0 +1,164 @@
+// taxator-tk_amd/csrc/rpa_device.h -- shared declarations of the gfx950 RPA engine (device views + kernel launchers).
+// Hand-written HIP for CDNA4 only; no CPU fallback exists behind these functions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rpa {
+
+constexpr int kBlock = 256;          // 4 wave64 per workgroup everywhere
+constexpr uint32_t kRoot = 0;        // taxonomy node 0 is the root
+constexpr uint32_t kQueryTag = 0xFFFFFFFFu;  // pair_i value of an (anchor, query) pair
+constexpr int kShortWords = 8;       // per-lane Myers kernel: pattern <= 8*32 = 256 residues
+constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel: pattern <= 64 lanes * 8 words * 32 = 16384 residues
+constexpr int kNumBins = kShortWords + kLongMaxWPL;  // bins 0..7: short, words = bin+1 ; bins 8..15: long, words per lane = bin-7
+constexpr uint32_t kMaxPattern = 64u * kLongMaxWPL * 32u;
+constexpr int kMaxDepth = 31;         // deepest taxonomy level the placement kernel's rank table holds (NCBI pruned: 8)
+
+// error codes mirror include/taxator_rpa.h
+enum { kOk = 0, kErrInvalid = 1, kErrDevice = 2, kErrRange = 3, kErrSeqId = 4, kErrAssert = 5, kErrUnsupported = 6 };
+
+// Flattened taxonomy (reference: Taxon::leftvalue/rightvalue/root_pathlength, core/src/taxontree.hh:64-66).
+struct TaxDev {
+  const uint32_t* parent;
+  const uint32_t* left;
+  const uint32_t* right;
+  const uint8_t* depth;
+  uint32_t n_nodes;
+};
+
+// Resident sequence store: residues packed little-endian into 32-bit words, 4 bit (DNA) or 8 bit (protein) each.
+struct StoreDev {
+  const uint32_t* words;
+  const uint64_t* offsets;  // residue index of sequence i = offsets[i]; n_seqs+1 entries
+  uint32_t n_seqs;
+};
+
+// Batch (device pointers), same meaning as rpa_batch in include/taxator_rpa.h.
+struct BatchDev {
+  uint32_t n_sets, n_records;
+  const uint32_t* set_offsets;
+  const uint32_t* query_seq;
+  const uint32_t* query_len;
+  const uint32_t *qstart, *qstop, *rstart, *rstop;
+  const float* score;
+  const uint32_t *identities, *alnlen, *ref_seq, *node;
+  const uint8_t* filtered;  // may be null
+};
+
+enum Phase : uint32_t { kDone = 0, kPass0Wait = 1, kPass1Wait = 2, kPass2Wait = 3, kPass1Select = 4, kPass2Select = 5 };
+
+// Per record-set state carried between rounds (one thread owns one set).
+struct SetState {
+  uint32_t phase;
+  uint32_t n;        // active (unmasked) records
+  uint32_t L;        // qrlength
+  uint32_t qrstart, qrstop;
+  uint32_t support;  // anchors_support
+  uint32_t lca_all;  // lca_allnodes
+  uint32_t rtax;
+  uint32_t lnode_g, unode_g;
+  float ival_g;
+  float bf_max;
+  uint32_t lrd_min;  // lca_root_dist_min
+  uint32_t anchor;
+  uint32_t cnt0, cnt1, cnt2;
+  uint32_t n_emitted;  // pairs emitted for the round in flight
+};
+
+// Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
+struct WorkDev {
+  SetState* state;      // S
+  uint32_t* rec_set;    // H   record -> set
+  uint32_t* order;      // H   sorted position (set_off+i) -> record index
+  float* qd;            // H   querydistance  (sorted position)
+  float* qs;            // H   querysimilarity
+  uint8_t* flags;       // H   bit0 qgroup, bit1 outgroup
+  // segments: id r in [0,H) = reference segment of record r, id H+s = query range of set s
+  uint32_t* seg_len;    // T   residues (0 if never planned)
+  uint32_t* seg_cap16;  // T   slot size in 16-byte units
+  uint32_t* seg_off16;  // T   slot offset in 16-byte units (exclusive scan of seg_cap16)
+  uint64_t* seg_src;    // T   first source residue (global residue index in the store)
+  uint8_t* seg_info;    // T   bit0 reverse-complement, bit1 from query store, bits 4-7 error code
+  uint32_t* arena;      // packed segments
+  // pairs of the round in flight: slot region of set s = [set_off[s]+s, set_off[s+1]+s+1)
+  uint32_t* pair_a;     // T   segment id
+  uint32_t* pair_b;     // T
+  uint32_t* pair_i;     // T   hit index i the result belongs to (kQueryTag for anchor<->query)
+  float2* pair_res;     // T   (distance, similarity)
+  uint4* pair_ext;      // optional (rpa_align_pairs only): matches, mismatches, gaps, length
+  uint32_t* bin_list;   // kNumBins * T2
+  uint32_t* counters;   // kNumCounters words, layout below
+  // pass-1 scratch (per set region like the pair slots)
+  float* bf_dist;       // T
+  uint32_t* bf_node;    // T
+  uint32_t* og_idx;     // T
+  int32_t* og_dist;     // T
+  uint32_t T;    // number of segments
+  uint32_t T2;   // number of pair slots = stride of each bin list
+};
+// counters: [0..kNumBins) pairs per bin | live sets | longest horizontal sequence among emitted pairs | error code | error set/pair
+constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrErr = kNumBins + 2, kCtrErrSet = kNumBins + 3,
+              kNumCounters = kNumBins + 4, kNumRoundCounters = kNumBins + 2;  // the first kNumRoundCounters are reset every round
+
+struct Params {
+  int alphabet;
+  float exclude_factor;   // exclude_alignments_factor_
+  float reeval_factor;    // reeval_bandwidth_factor_ = (float)(1. - reeval_bandwidth)
+};
+
+struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells
+  unsigned long long* acc;
+};
+
+// ---- launchers (each enqueues on `st`, returns the hipError of the launch) ----
+hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* letters, uint64_t n_residues, uint32_t* words);
+hipError_t launch_exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums,
+                                     uint32_t* total_out);
+size_t scan_workspace_elems(uint32_t n);
+
+hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w);
+hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
+                            const StoreDev& db, const Params& p, void* out_rows, void* out_stats);
+hipError_t launch_materialize(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& q, const StoreDev& db);
+hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
+                         void* out_rows, void* out_stats, unsigned long long* prof_acc);
+
+// pair-level entry (rpa_align_pairs): segments straight from an arena-shaped store, explicit pair list
+hipError_t launch_plan_plain_segments(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& store);
+hipError_t launch_bin_pairs(hipStream_t st, int alphabet, const WorkDev& w, uint32_t n_pairs);
+hipError_t launch_export_alignments(hipStream_t st, const WorkDev& w, uint32_t n_pairs, void* out);
+
+// alignment kernels over one bin list
+hipError_t launch_align_dna_short(hipStream_t st, int words, const uint32_t* list, uint32_t n, const WorkDev& w,
+                                  unsigned long long* prof_acc);
+hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint32_t* list, uint32_t n, const WorkDev& w,
+                                 unsigned long long* prof_acc);
+hipError_t launch_align_protein(hipStream_t st, const uint32_t* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
+                                size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
+size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
+
+// bin of a pair whose shorter sequence has m residues (DNA); kNumBins = too long
+__host__ __device__ __forceinline__ int dna_bin(uint32_t m) {
+  const uint32_t words = (m + 31u) / 32u;
+  if (words <= (uint32_t)kShortWords) return words ? (int)words - 1 : 0;
+  const uint32_t wpl = (words + 63u) / 64u;
+  return wpl <= (uint32_t)kLongMaxWPL ? kShortWords + (int)wpl - 1 : kNumBins;
+}
+
+// ---- small device helpers shared by the placement kernels ----
+__device__ __forceinline__ bool d_is_parent_of(const TaxDev& t, uint32_t a, uint32_t b) {
+  // TaxonomyInterface::isParentOf, core/src/taxonomyinterface.cpp:52-55
+  return t.right[a] > t.left[b] && t.left[a] < t.left[b];
+}
+__device__ __forceinline__ uint32_t d_lca(const TaxDev& t, uint32_t a, uint32_t b) {
+  // TaxonomyInterface::getLCA, core/src/taxonomyinterface.cpp:67-77 (its min(A.left, B.right) kept as is)
+  const uint32_t la = t.left[a], ra = t.right[a], rb = t.right[b];
+  const uint32_t left_min = la < rb ? la : rb;
+  const uint32_t right_max = ra > rb ? ra : rb;
+  uint32_t lca = a;
+  while (t.left[lca] > left_min || t.right[lca] < right_max) lca = t.parent[lca];
+  return lca;
+}
+
+}  // namespace rpa

@@ -1,0 +1,534 @@
+// taxator-tk_amd/csrc/rpa_engine.hip -- host side of the C ABI (include/taxator_rpa.h) for the gfx950 RPA engine.
+//
+// One engine = one GPU = one RPAPredictionModel instance of the reference (core/src/taxonpredictionmodelsequence.hh:326-339)
+// plus its two sequence stores (core/taxator.cpp:230-249), resident in HBM.  rpa_predict_batch drives the rounds
+//   rank -> plan -> scan -> materialise -> { align bins -> decide }*      (kernels: place_/seq_/align_*_kernels.hip)
+// on one HIP stream.  The host reads one small counter block per round (pairs per bin, live sets, error word).
+// There is no CPU compute path: every entry point fails with RPA_ERR_DEVICE when no gfx950 device answers.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/taxator_rpa.h"
+#include "rpa_device.h"
+
+using namespace rpa;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    size_t want = bytes + bytes / 8 + 256;  // a little slack so a slightly bigger next batch does not reallocate
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Store {
+  DevBuf words, offsets;
+  uint32_t n_seqs = 0;
+  uint64_t n_residues = 0;
+  bool loaded = false;
+  StoreDev view() const { return StoreDev{words.as<const uint32_t>(), offsets.as<const uint64_t>(), n_seqs}; }
+};
+
+}  // namespace
+
+struct rpa_engine {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  Params params{};
+  DevBuf tax_parent, tax_left, tax_right, tax_depth;
+  TaxDev tax{};
+  Store stores[2];
+  std::string err;
+  // batch staging (host batches) and working set
+  DevBuf in_u32[11], in_f32, in_u8;
+  DevBuf state, rec_set, order, qd, qs, flags, seg_len, seg_cap16, seg_off16, seg_src, seg_info, arena, pair_a, pair_b, pair_i,
+      pair_res, pair_ext, bin_list, counters, bf_dist, bf_node, og_idx, og_dist, scan_ws, out_rows, out_stats, tmp_letters,
+      tmp_words, tmp_offsets, protein_ws;
+  uint32_t* h_counters = nullptr;  // pinned
+  // profiling
+  bool profiling = false;
+  DevBuf prof_acc;
+  rpa_profile prof{};
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<std::pair<size_t, size_t>> ev_align;  // (start, stop) indices
+  hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
+  std::mutex mu;  // submit is serialised per engine (SURVEY 8b threading)
+};
+
+namespace {
+
+int fail(rpa_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                                      \
+  do {                                                                                                        \
+    hipError_t _err = (call);                                                                                 \
+    if (_err != hipSuccess) return fail(e, RPA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(_err)); \
+  } while (0)
+
+hipEvent_t get_event(rpa_engine* e) {
+  if (e->ev_used == e->ev_pool.size()) {
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    e->ev_pool.push_back(ev);
+  }
+  return e->ev_pool[e->ev_used++];
+}
+
+const char* kernel_error_text(uint32_t code) {
+  switch (code) {
+    case kErrRange: return "sequence range error: segment start lies beyond the end of the sequence (SequenceRangeError)";
+    case kErrSeqId: return "sequence index outside the store (SequenceNotFound)";
+    case kErrAssert: return "a reference assert would abort here (reverse reference coordinates in protein mode, empty best-reference group or inconsistent node range)";
+    case kErrUnsupported: return "sequence pair longer than this build supports (pattern > 16384 residues)";
+    default: return "inconsistent batch";
+  }
+}
+
+// Launch the alignment kernels for every non-empty bin list (counts come from the host copy of the counters).
+int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts) {
+  unsigned long long* acc = e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr;
+  for (int bin = 0; bin < kNumBins; ++bin) {
+    const uint32_t n = counts[bin];
+    if (!n) continue;
+    const uint32_t* list = w.bin_list + (size_t)bin * w.T2;
+    size_t i0 = 0, i1 = 0;
+    if (e->profiling) {
+      hipEvent_t a = get_event(e), b = get_event(e);
+      if (!a || !b) return fail(e, RPA_ERR_DEVICE, "hipEventCreate failed");
+      i0 = e->ev_used - 2; i1 = e->ev_used - 1;
+      HIP_TRY(e, hipEventRecord(a, e->stream));
+    }
+    if (e->params.alphabet == RPA_DNA) {
+      if (bin < kShortWords) HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, w, acc));
+      else HIP_TRY(e, launch_align_dna_long(e->stream, bin - kShortWords + 1, list, n, w, acc));
+    } else {
+      const uint32_t max_len = counts[kCtrMaxLen];
+      HIP_TRY(e, e->protein_ws.ensure(protein_scratch_words(n, max_len) * 4));
+      HIP_TRY(e, launch_align_protein(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
+    }
+    if (e->profiling) {
+      HIP_TRY(e, hipEventRecord(e->ev_pool[i1], e->stream));
+      e->ev_align.emplace_back(i0, i1);
+      e->prof.launches += 1;
+    }
+  }
+  return RPA_OK;
+}
+
+int profile_begin(rpa_engine* e) {
+  if (!e->profiling) return RPA_OK;
+  e->ev_used = 0;
+  e->ev_align.clear();
+  if (!e->ev_total0) { HIP_TRY(e, hipEventCreate(&e->ev_total0)); HIP_TRY(e, hipEventCreate(&e->ev_total1)); }
+  HIP_TRY(e, hipEventRecord(e->ev_total0, e->stream));
+  return RPA_OK;
+}
+
+int profile_end(rpa_engine* e) {
+  if (!e->profiling) return RPA_OK;
+  HIP_TRY(e, hipEventRecord(e->ev_total1, e->stream));
+  HIP_TRY(e, hipEventSynchronize(e->ev_total1));
+  float ms = 0.f;
+  HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_total0, e->ev_total1));
+  e->prof.total_ms += ms;
+  for (auto& pr : e->ev_align) {
+    HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_pool[pr.first], e->ev_pool[pr.second]));
+    e->prof.align_ms += ms;
+  }
+  unsigned long long acc[4];
+  HIP_TRY(e, hipMemcpy(acc, e->prof_acc.p, sizeof(acc), hipMemcpyDeviceToHost));
+  e->prof.pairs = acc[0]; e->prof.residue_bytes = acc[1]; e->prof.cells = acc[2]; e->prof.demanded = acc[3];
+  return RPA_OK;
+}
+
+// Working-set allocation shared by predict and align_pairs.  T = segments, T2 = pair slots.
+int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, bool want_ext, WorkDev* w) {
+  HIP_TRY(e, e->state.ensure((size_t)(S ? S : 1) * sizeof(SetState)));
+  HIP_TRY(e, e->rec_set.ensure((size_t)(H ? H : 1) * 4));
+  HIP_TRY(e, e->order.ensure((size_t)(H ? H : 1) * 4));
+  HIP_TRY(e, e->qd.ensure((size_t)(H ? H : 1) * 4));
+  HIP_TRY(e, e->qs.ensure((size_t)(H ? H : 1) * 4));
+  HIP_TRY(e, e->flags.ensure((size_t)(H ? H : 1)));
+  HIP_TRY(e, e->seg_len.ensure((size_t)(T ? T : 1) * 4));
+  HIP_TRY(e, e->seg_cap16.ensure((size_t)(T ? T : 1) * 4));
+  HIP_TRY(e, e->seg_off16.ensure((size_t)(T ? T : 1) * 4));
+  HIP_TRY(e, e->seg_src.ensure((size_t)(T ? T : 1) * 8));
+  HIP_TRY(e, e->seg_info.ensure((size_t)(T ? T : 1)));
+  HIP_TRY(e, e->pair_a.ensure((size_t)(T2 ? T2 : 1) * 4));
+  HIP_TRY(e, e->pair_b.ensure((size_t)(T2 ? T2 : 1) * 4));
+  HIP_TRY(e, e->pair_i.ensure((size_t)(T2 ? T2 : 1) * 4));
+  HIP_TRY(e, e->pair_res.ensure((size_t)(T2 ? T2 : 1) * 8));
+  if (want_ext) HIP_TRY(e, e->pair_ext.ensure((size_t)(T2 ? T2 : 1) * 16));
+  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * 4 * kNumBins));
+  HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
+  HIP_TRY(e, e->bf_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
+  HIP_TRY(e, e->bf_node.ensure((size_t)(T2 ? T2 : 1) * 4));
+  HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
+  HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
+  HIP_TRY(e, e->scan_ws.ensure(scan_workspace_elems(T) * 4));
+  w->state = e->state.as<SetState>(); w->rec_set = e->rec_set.as<uint32_t>(); w->order = e->order.as<uint32_t>();
+  w->qd = e->qd.as<float>(); w->qs = e->qs.as<float>(); w->flags = e->flags.as<uint8_t>();
+  w->seg_len = e->seg_len.as<uint32_t>(); w->seg_cap16 = e->seg_cap16.as<uint32_t>(); w->seg_off16 = e->seg_off16.as<uint32_t>();
+  w->seg_src = e->seg_src.as<uint64_t>(); w->seg_info = e->seg_info.as<uint8_t>(); w->arena = nullptr;
+  w->pair_a = e->pair_a.as<uint32_t>(); w->pair_b = e->pair_b.as<uint32_t>(); w->pair_i = e->pair_i.as<uint32_t>();
+  w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
+  w->bin_list = e->bin_list.as<uint32_t>(); w->counters = e->counters.as<uint32_t>();
+  w->bf_dist = e->bf_dist.as<float>(); w->bf_node = e->bf_node.as<uint32_t>(); w->og_idx = e->og_idx.as<uint32_t>();
+  w->og_dist = e->og_dist.as<int32_t>();
+  w->T = T; w->T2 = T2;
+  return RPA_OK;
+}
+
+// seg_cap16 -> seg_off16, allocate the arena, materialise the segments.
+int build_arena(rpa_engine* e, WorkDev* w, const StoreDev& q, const StoreDev& db) {
+  uint32_t* total_dev = w->counters + kNumCounters;
+  HIP_TRY(e, launch_exclusive_scan_u32(e->stream, w->seg_cap16, w->seg_off16, w->T, e->scan_ws.as<uint32_t>(), total_dev));
+  HIP_TRY(e, hipMemcpyAsync(e->h_counters, total_dev, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  const uint64_t total16 = e->h_counters[0];
+  if (total16 >= 0xFFFFFFF0ull) return fail(e, RPA_ERR_UNSUPPORTED, "segment arena exceeds 64 GiB; split the batch");
+  HIP_TRY(e, e->arena.ensure((size_t)(total16 + 64) * 16));  // + slack: the long kernel prefetches up to 512 B past a slot
+  w->arena = e->arena.as<uint32_t>();
+  HIP_TRY(e, launch_materialize(e->stream, e->params.alphabet, *w, q, db));
+  return RPA_OK;
+}
+
+int check_device_error(rpa_engine* e, const uint32_t* c) {
+  if (c[kCtrErr] == 0) return RPA_OK;
+  const uint32_t code = c[kCtrErr];
+  int rc = code == kErrRange ? RPA_ERR_RANGE : code == kErrSeqId ? RPA_ERR_SEQ_ID : code == kErrAssert ? RPA_ERR_ASSERT
+           : code == kErrUnsupported ? RPA_ERR_UNSUPPORTED : RPA_ERR_INVALID;
+  return fail(e, rc, "%s (record set / pair %u)", kernel_error_text(code), c[kCtrErrSet]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpa_abi_version(void) { return RPA_ABI_VERSION; }
+
+void rpa_default_params(rpa_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->alphabet = RPA_DNA;
+  p->exclude_alignments_factor = 0.5f;  // taxator.cpp:286
+  p->reeval_bandwidth = 0.05f;          // taxator.cpp:287
+  p->device = 0;
+}
+
+const char* rpa_last_error(const rpa_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** out) {
+  if (!tax || !params || !out) return fail(nullptr, RPA_ERR_INVALID, "rpa_create: null argument");
+  *out = nullptr;
+  if (tax->n_nodes == 0 || !tax->parent || !tax->left || !tax->right || !tax->depth)
+    return fail(nullptr, RPA_ERR_INVALID, "rpa_create: empty taxonomy");
+  if (params->alphabet != RPA_DNA && params->alphabet != RPA_PROTEIN) return fail(nullptr, RPA_ERR_INVALID, "rpa_create: bad alphabet");
+  if (tax->parent[0] != 0 || tax->depth[0] != 0) return fail(nullptr, RPA_ERR_INVALID, "rpa_create: node 0 must be the root");
+  for (uint32_t i = 0; i < tax->n_nodes; ++i) {
+    if (tax->depth[i] > kMaxDepth) return fail(nullptr, RPA_ERR_UNSUPPORTED, "rpa_create: taxonomy deeper than %d levels", kMaxDepth);
+    if (tax->parent[i] >= tax->n_nodes) return fail(nullptr, RPA_ERR_INVALID, "rpa_create: parent index out of range");
+    if (i && !(tax->left[tax->parent[i]] < tax->left[i] && tax->right[tax->parent[i]] > tax->right[i]))
+      return fail(nullptr, RPA_ERR_INVALID, "rpa_create: nested-set values of node %u are not inside its parent's", i);
+  }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(nullptr, RPA_ERR_DEVICE, "rpa_create: no HIP device visible (this engine has no CPU path)");
+  if (params->device < 0 || params->device >= n_dev) return fail(nullptr, RPA_ERR_DEVICE, "rpa_create: device %d of %d", params->device, n_dev);
+  rpa_engine* e = new (std::nothrow) rpa_engine();
+  if (!e) return fail(nullptr, RPA_ERR_DEVICE, "rpa_create: out of host memory");
+  e->device = params->device;
+  e->params.alphabet = params->alphabet;
+  e->params.exclude_factor = params->exclude_alignments_factor;
+  e->params.reeval_factor = (float)(1. - params->reeval_bandwidth);  // reeval_bandwidth_factor_(1. - reeval_bandwidth), :334
+  auto bail = [&](int code) { g_create_error = e->err; rpa_destroy(e); return code; };
+#define CREATE_TRY(call)                                                                                  \
+  do {                                                                                                    \
+    hipError_t _err = (call);                                                                             \
+    if (_err != hipSuccess) { fail(e, RPA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(_err)); return bail(RPA_ERR_DEVICE); } \
+  } while (0)
+  CREATE_TRY(hipSetDevice(e->device));
+  hipDeviceProp_t prop;
+  CREATE_TRY(hipGetDeviceProperties(&prop, e->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fail(e, RPA_ERR_DEVICE, "rpa_create: device %d is %s; this library carries gfx950 code only", e->device, prop.gcnArchName);
+    return bail(RPA_ERR_DEVICE);
+  }
+  CREATE_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+  e->stream = e->own_stream;
+  CREATE_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault));
+  const size_t n = tax->n_nodes;
+  CREATE_TRY(e->tax_parent.ensure(n * 4)); CREATE_TRY(e->tax_left.ensure(n * 4)); CREATE_TRY(e->tax_right.ensure(n * 4));
+  CREATE_TRY(e->tax_depth.ensure(n));
+  CREATE_TRY(hipMemcpy(e->tax_parent.p, tax->parent, n * 4, hipMemcpyHostToDevice));
+  CREATE_TRY(hipMemcpy(e->tax_left.p, tax->left, n * 4, hipMemcpyHostToDevice));
+  CREATE_TRY(hipMemcpy(e->tax_right.p, tax->right, n * 4, hipMemcpyHostToDevice));
+  CREATE_TRY(hipMemcpy(e->tax_depth.p, tax->depth, n, hipMemcpyHostToDevice));
+  e->tax = TaxDev{e->tax_parent.as<const uint32_t>(), e->tax_left.as<const uint32_t>(), e->tax_right.as<const uint32_t>(),
+                  e->tax_depth.as<const uint8_t>(), tax->n_nodes};
+  CREATE_TRY(e->prof_acc.ensure(4 * sizeof(unsigned long long)));
+  CREATE_TRY(hipMemset(e->prof_acc.p, 0, 4 * sizeof(unsigned long long)));
+#undef CREATE_TRY
+  *out = e;
+  return RPA_OK;
+}
+
+void rpa_destroy(rpa_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->in_f32, &e->in_u8, &e->state, &e->rec_set,
+                    &e->order, &e->qd, &e->qs, &e->flags, &e->seg_len, &e->seg_cap16, &e->seg_off16, &e->seg_src, &e->seg_info,
+                    &e->arena, &e->pair_a, &e->pair_b, &e->pair_i, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
+                    &e->bf_dist, &e->bf_node, &e->og_idx, &e->og_dist, &e->scan_ws, &e->out_rows, &e->out_stats, &e->tmp_letters,
+                    &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc};
+  for (DevBuf* b : bufs) b->release();
+  for (auto& b : e->in_u32) b.release();
+  for (auto& s : e->stores) { s.words.release(); s.offsets.release(); }
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  if (e->ev_total0) (void)hipEventDestroy(e->ev_total0);
+  if (e->ev_total1) (void)hipEventDestroy(e->ev_total1);
+  if (e->h_counters) (void)hipHostFree(e->h_counters);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+int rpa_set_stream(rpa_engine* e, void* hip_stream) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return RPA_OK;
+}
+
+static int pack_store(rpa_engine* e, Store* st, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, int mem_kind,
+                      DevBuf* letters_buf) {
+  // offsets -> host copy of the total, device copy of the table
+  uint64_t total = 0;
+  HIP_TRY(e, st->offsets.ensure((size_t)(n_seqs + 1) * 8));
+  if (mem_kind == RPA_MEM_HOST) {
+    for (uint32_t i = 0; i < n_seqs; ++i)
+      if (offsets[i + 1] < offsets[i]) return fail(e, RPA_ERR_INVALID, "store offsets must be non-decreasing (sequence %u)", i);
+    if (offsets[0] != 0) return fail(e, RPA_ERR_INVALID, "store offsets[0] must be 0");
+    total = offsets[n_seqs];
+    HIP_TRY(e, hipMemcpyAsync(st->offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, e->stream));
+  } else {
+    HIP_TRY(e, hipMemcpyAsync(st->offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&total, offsets + n_seqs, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  const int bits = e->params.alphabet == RPA_DNA ? 4 : 8;
+  const uint64_t n_words = (total * bits + 31) / 32;
+  HIP_TRY(e, st->words.ensure((size_t)(n_words + 4) * 4));
+  const uint8_t* dev_letters = letters;
+  if (mem_kind == RPA_MEM_HOST && total) {
+    HIP_TRY(e, letters_buf->ensure((size_t)total + 8));
+    HIP_TRY(e, hipMemcpyAsync(letters_buf->p, letters, (size_t)total, hipMemcpyHostToDevice, e->stream));
+    dev_letters = letters_buf->as<const uint8_t>();
+  } else if (total && ((uintptr_t)letters & 7u)) {
+    return fail(e, RPA_ERR_INVALID, "device letter buffer must be 8-byte aligned");
+  }
+  HIP_TRY(e, launch_pack_letters(e->stream, e->params.alphabet, dev_letters, total, st->words.as<uint32_t>()));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  st->n_seqs = n_seqs; st->n_residues = total; st->loaded = true;
+  return RPA_OK;
+}
+
+int rpa_store_load(rpa_engine* e, int which, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, int mem_kind) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_load: bad store id");
+  if (!offsets || (n_seqs && !letters)) return fail(e, RPA_ERR_INVALID, "rpa_store_load: null argument");
+  if (mem_kind != RPA_MEM_HOST && mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_store_load: bad mem_kind");
+  HIP_TRY(e, hipSetDevice(e->device));
+  int rc = pack_store(e, &e->stores[which], n_seqs, letters, offsets, mem_kind, &e->tmp_letters);
+  e->tmp_letters.release();  // the raw letters are not kept: the packed store is the resident copy
+  return rc;
+}
+
+int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!batch || !out) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: null argument");
+  if (!e->stores[0].loaded || !e->stores[1].loaded) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: load both sequence stores first");
+  const uint32_t S = batch->n_sets, H = batch->n_records;
+  if (S == 0) return RPA_OK;
+  if (!batch->set_offsets || !batch->query_seq || !batch->query_len ||
+      (H && (!batch->qstart || !batch->qstop || !batch->rstart || !batch->rstop || !batch->score || !batch->identities ||
+             !batch->alnlen || !batch->ref_seq || !batch->node)))
+    return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: null array in batch");
+  if ((uint64_t)S + H >= 0xFFFFFFF0ull) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: batch too large");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint32_t T = H + S;
+  BatchDev b{};
+  b.n_sets = S; b.n_records = H;
+  if (batch->mem_kind == RPA_MEM_HOST) {
+    if (batch->set_offsets[0] != 0 || batch->set_offsets[S] != H) return fail(e, RPA_ERR_INVALID, "set_offsets must run from 0 to n_records");
+    const void* src_u32[11] = {batch->set_offsets, batch->query_seq, batch->query_len, batch->qstart, batch->qstop, batch->rstart,
+                               batch->rstop, batch->identities, batch->alnlen, batch->ref_seq, batch->node};
+    const size_t cnt[11] = {(size_t)S + 1, S, S, H, H, H, H, H, H, H, H};
+    for (int k = 0; k < 11; ++k) {
+      HIP_TRY(e, e->in_u32[k].ensure((cnt[k] ? cnt[k] : 1) * 4));
+      if (cnt[k]) HIP_TRY(e, hipMemcpyAsync(e->in_u32[k].p, src_u32[k], cnt[k] * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    HIP_TRY(e, e->in_f32.ensure((size_t)(H ? H : 1) * 4));
+    if (H) HIP_TRY(e, hipMemcpyAsync(e->in_f32.p, batch->score, (size_t)H * 4, hipMemcpyHostToDevice, e->stream));
+    if (batch->filtered) {
+      HIP_TRY(e, e->in_u8.ensure(H ? H : 1));
+      if (H) HIP_TRY(e, hipMemcpyAsync(e->in_u8.p, batch->filtered, H, hipMemcpyHostToDevice, e->stream));
+    }
+    b.set_offsets = e->in_u32[0].as<uint32_t>(); b.query_seq = e->in_u32[1].as<uint32_t>(); b.query_len = e->in_u32[2].as<uint32_t>();
+    b.qstart = e->in_u32[3].as<uint32_t>(); b.qstop = e->in_u32[4].as<uint32_t>(); b.rstart = e->in_u32[5].as<uint32_t>();
+    b.rstop = e->in_u32[6].as<uint32_t>(); b.identities = e->in_u32[7].as<uint32_t>(); b.alnlen = e->in_u32[8].as<uint32_t>();
+    b.ref_seq = e->in_u32[9].as<uint32_t>(); b.node = e->in_u32[10].as<uint32_t>();
+    b.score = e->in_f32.as<float>();
+    b.filtered = batch->filtered ? e->in_u8.as<uint8_t>() : nullptr;
+  } else if (batch->mem_kind == RPA_MEM_DEVICE) {
+    b.set_offsets = batch->set_offsets; b.query_seq = batch->query_seq; b.query_len = batch->query_len;
+    b.qstart = batch->qstart; b.qstop = batch->qstop; b.rstart = batch->rstart; b.rstop = batch->rstop; b.score = batch->score;
+    b.identities = batch->identities; b.alnlen = batch->alnlen; b.ref_seq = batch->ref_seq; b.node = batch->node;
+    b.filtered = batch->filtered;
+  } else return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: bad mem_kind");
+
+  WorkDev w{};
+  int rc = alloc_work(e, S, H, T, T, false, &w);
+  if (rc) return rc;
+  void* rows_dev = out;
+  void* stats_dev = stats;
+  if (out_mem_kind == RPA_MEM_HOST) {
+    HIP_TRY(e, e->out_rows.ensure((size_t)S * sizeof(rpa_prediction)));
+    rows_dev = e->out_rows.p;
+    if (stats) { HIP_TRY(e, e->out_stats.ensure((size_t)S * sizeof(rpa_stats))); stats_dev = e->out_stats.p; }
+  } else if (out_mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: bad out_mem_kind");
+
+  rc = profile_begin(e);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * (kNumCounters + 1), e->stream));
+  HIP_TRY(e, hipMemsetAsync(w.seg_len, 0, (size_t)T * 4, e->stream));
+  HIP_TRY(e, hipMemsetAsync(w.seg_cap16, 0, (size_t)T * 4, e->stream));
+  HIP_TRY(e, hipMemsetAsync(w.seg_info, 0, (size_t)T, e->stream));
+  const StoreDev q = e->stores[RPA_STORE_QUERY].view(), db = e->stores[RPA_STORE_DB].view();
+  HIP_TRY(e, launch_rank_records(e->stream, b, w));
+  HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, q, db, e->params, rows_dev, stats_dev));
+  rc = build_arena(e, &w, q, db);
+  if (rc) return rc;
+  uint64_t rounds = 0;
+  for (;;) {
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    rc = check_device_error(e, e->h_counters);
+    if (rc) return rc;
+    if (e->h_counters[kCtrActive] == 0) break;
+    uint32_t counts[kNumRoundCounters];
+    memcpy(counts, e->h_counters, sizeof(counts));
+    rc = run_align_bins(e, w, counts);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kNumRoundCounters, e->stream));  // keep the error words
+    HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev,
+                             e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr));
+    ++rounds;
+    if (rounds > (uint64_t)H + S + 8) return fail(e, RPA_ERR_INVALID, "placement state machine did not terminate");
+  }
+  if (out_mem_kind == RPA_MEM_HOST) {
+    HIP_TRY(e, hipMemcpyAsync(out, rows_dev, (size_t)S * sizeof(rpa_prediction), hipMemcpyDeviceToHost, e->stream));
+    if (stats) HIP_TRY(e, hipMemcpyAsync(stats, stats_dev, (size_t)S * sizeof(rpa_stats), hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->prof.rounds += rounds;
+  return profile_end(e);
+}
+
+int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, uint32_t n_pairs,
+                    const uint32_t* pair_a, const uint32_t* pair_b, rpa_alignment* out, int mem_kind) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!offsets || (n_pairs && (!pair_a || !pair_b || !out))) return fail(e, RPA_ERR_INVALID, "rpa_align_pairs: null argument");
+  if (mem_kind != RPA_MEM_HOST && mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_align_pairs: bad mem_kind");
+  if (n_pairs == 0) return RPA_OK;
+  HIP_TRY(e, hipSetDevice(e->device));
+  Store tmp;
+  tmp.words = e->tmp_words; tmp.offsets = e->tmp_offsets;  // reuse the engine's scratch buffers
+  int rc = pack_store(e, &tmp, n_seqs, letters, offsets, mem_kind, &e->tmp_letters);
+  e->tmp_words = tmp.words; e->tmp_offsets = tmp.offsets;
+  if (rc) return rc;
+  WorkDev w{};
+  rc = alloc_work(e, 1, 1, n_seqs, n_pairs, true, &w);
+  if (rc) return rc;
+  const hipMemcpyKind kind = mem_kind == RPA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  HIP_TRY(e, hipMemcpyAsync(w.pair_a, pair_a, (size_t)n_pairs * 4, kind, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(w.pair_b, pair_b, (size_t)n_pairs * 4, kind, e->stream));
+  HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * (kNumCounters + 1), e->stream));
+  rc = profile_begin(e);
+  if (rc) return rc;
+  const StoreDev sv = tmp.view();
+  HIP_TRY(e, launch_plan_plain_segments(e->stream, e->params.alphabet, w, sv));
+  rc = build_arena(e, &w, sv, sv);
+  if (rc) return rc;
+  HIP_TRY(e, launch_bin_pairs(e->stream, e->params.alphabet, w, n_pairs));
+  HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  rc = check_device_error(e, e->h_counters);
+  if (rc) return rc;
+  uint32_t counts[kNumRoundCounters];
+  memcpy(counts, e->h_counters, sizeof(counts));
+  rc = run_align_bins(e, w, counts);
+  if (rc) return rc;
+  void* out_dev = out;
+  if (mem_kind == RPA_MEM_HOST) { HIP_TRY(e, e->out_rows.ensure((size_t)n_pairs * sizeof(rpa_alignment))); out_dev = e->out_rows.p; }
+  HIP_TRY(e, launch_export_alignments(e->stream, w, n_pairs, out_dev));
+  if (mem_kind == RPA_MEM_HOST) HIP_TRY(e, hipMemcpyAsync(out, out_dev, (size_t)n_pairs * sizeof(rpa_alignment), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return profile_end(e);
+}
+
+int rpa_profile_enable(rpa_engine* e, int on) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->profiling = on != 0;
+  return RPA_OK;
+}
+
+int rpa_profile_reset(rpa_engine* e) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  memset(&e->prof, 0, sizeof(e->prof));
+  HIP_TRY(e, hipMemset(e->prof_acc.p, 0, 4 * sizeof(unsigned long long)));
+  return RPA_OK;
+}
+
+int rpa_profile_get(rpa_engine* e, rpa_profile* out) {
+  if (!e || !out) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  *out = e->prof;
+  return RPA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// taxator-tk_amd/csrc/seq_kernels.hip -- residue packing, segment materialisation, exclusive scan (gfx950).
+//
+// Replaces, on the device, the byte->ordinal conversion and sub-sequence fetch of the reference's sequence stores:
+//   core/src/sequencestorage.hh:341-369 (getSequence / getSequenceReverseComplement of the indexed store),
+//   core/src/faidx.h:315-350 (readRegion: chars -> alphabet ordinals through the SeqAn tables),
+//   core/src/taxonpredictionmodelsequence.hh:856-880 (segment = hit range extended to the query range; RC for rstart>rstop).
+// These kernels are HBM-streaming work (a few bytes in, a few bytes out per residue); no LDS reuse to exploit.
+#include "rpa_device.h"
+#include "rpa_tables.inc"
+
+namespace rpa {
+
+__device__ __constant__ uint8_t c_char_to_dna5[256];
+__device__ __constant__ uint8_t c_char_to_aa27[256];
+static bool g_tables_uploaded[64] = {false};
+
+static hipError_t upload_tables() {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 64 && g_tables_uploaded[dev]) return hipSuccess;
+  e = hipMemcpyToSymbol(HIP_SYMBOL(c_char_to_dna5), RPA_CHAR_TO_DNA5, 256);
+  if (e != hipSuccess) return e;
+  e = hipMemcpyToSymbol(HIP_SYMBOL(c_char_to_aa27), RPA_CHAR_TO_AA27, 256);
+  if (e != hipSuccess) return e;
+  if (dev < 64) g_tables_uploaded[dev] = true;
+  return hipSuccess;
+}
+
+// One thread per output word: 8 letters -> 8 nibbles (DNA) or 4 letters -> 4 bytes (protein).
+// The 256-entry table is staged in LDS (a constant-memory lookup with a per-lane index serialises).
+template <int BITS>
+__global__ __launch_bounds__(kBlock) void k_pack_letters(const uint8_t* __restrict__ letters, uint64_t n_residues,
+                                                          uint32_t* __restrict__ words, uint64_t n_words) {
+  __shared__ uint8_t tab[256];
+  tab[threadIdx.x] = BITS == 4 ? c_char_to_dna5[threadIdx.x] : c_char_to_aa27[threadIdx.x];
+  __syncthreads();
+  constexpr int PER = 32 / BITS;
+  for (uint64_t wi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; wi < n_words; wi += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t r0 = wi * PER;
+    uint32_t out = 0;
+    if (r0 + PER <= n_residues) {
+      if (PER == 8) {
+        const uint2 v = *reinterpret_cast<const uint2*>(letters + r0);  // r0 % 8 == 0 and the base is 8-byte aligned
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out |= (uint32_t)tab[(v.x >> (8 * k)) & 0xFF] << (BITS * k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out |= (uint32_t)tab[(v.y >> (8 * k)) & 0xFF] << (BITS * (k + 4));
+      } else {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(letters + r0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out |= (uint32_t)tab[(v >> (8 * k)) & 0xFF] << (BITS * k);
+      }
+    } else {
+      for (int k = 0; k < PER; ++k)
+        if (r0 + k < n_residues) out |= (uint32_t)tab[letters[r0 + k]] << (BITS * k);
+    }
+    words[wi] = out;
+  }
+}
+
+hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* letters, uint64_t n_residues, uint32_t* words) {
+  hipError_t e = upload_tables();
+  if (e != hipSuccess) return e;
+  if (n_residues == 0) return hipSuccess;
+  const int bits = alphabet == 0 ? 4 : 8;
+  const uint64_t n_words = (n_residues * bits + 31) / 32;
+  uint64_t blocks = (n_words + kBlock - 1) / kBlock;
+  if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond ~64 blocks per CU
+  if (bits == 4)
+    hipLaunchKernelGGL(k_pack_letters<4>, dim3((unsigned)blocks), dim3(kBlock), 0, st, letters, n_residues, words, n_words);
+  else
+    hipLaunchKernelGGL(k_pack_letters<8>, dim3((unsigned)blocks), dim3(kBlock), 0, st, letters, n_residues, words, n_words);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Exclusive scan of u32 (segment slot sizes -> slot offsets).  Three launches: per-block scan + block totals,
+// scan of the totals by one workgroup, add-back.  8 items per thread.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wave_sums[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; ++k) {
+    const uint32_t ws = wave_sums[k];
+    if (k < wave) base += ws;
+    tot += ws;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
+                                                        uint32_t* __restrict__ block_sums) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0u;
+    sum += v[k];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(sum, &total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_block_sums(uint32_t* __restrict__ block_sums, uint32_t n_blocks,
+                                                             uint32_t* __restrict__ total_out) {
+  uint32_t carry = 0;
+  for (uint32_t start = 0; start < n_blocks; start += kBlock) {
+    const uint32_t i = start + threadIdx.x;
+    const uint32_t v = i < n_blocks ? block_sums[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, &total);
+    if (i < n_blocks) block_sums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ block_sums) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  const uint32_t add = block_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n) out[base + k] += add;
+}
+
+size_t scan_workspace_elems(uint32_t n) { return (size_t)(n + kScanTile - 1) / kScanTile + 1; }
+
+hipError_t launch_exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums,
+                                     uint32_t* total_out) {
+  if (n == 0) return hipMemsetAsync(total_out, 0, sizeof(uint32_t), st);
+  const uint32_t blocks = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(blocks), dim3(kBlock), 0, st, in, out, n, block_sums);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(kBlock), 0, st, block_sums, blocks, total_out);
+  hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(kBlock), 0, st, out, n, block_sums);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Segment materialisation: copy [src, src+len) (or its reverse complement) out of the resident store into the
+// segment's 16-byte aligned slot, so that the alignment kernels can stream aligned 16-byte chunks.
+// 32 threads cooperate on one segment, one output word (8 nt / 4 aa) per thread per trip.
+// Reverse complement (seqan::reverseComplement, sequencestorage.hh:364-369): A<->T, C<->G, N stays.
+// ------------------------------------------------------------------------------------------------------------
+template <int BITS>
+__device__ __forceinline__ uint32_t load_residue(const uint32_t* __restrict__ words, uint64_t g) {
+  constexpr int PER = 32 / BITS;
+  constexpr uint32_t MASK = (1u << BITS) - 1u;
+  return (words[g / PER] >> ((uint32_t)(g % PER) * BITS)) & MASK;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kBlock) void k_materialize(WorkDev w, StoreDev q, StoreDev db) {
+  constexpr int PER = 32 / BITS;
+  const uint32_t seg = blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5);
+  if (seg >= w.T) return;
+  const uint32_t len = w.seg_len[seg];
+  if (len == 0) return;
+  const uint8_t info = w.seg_info[seg];
+  if (info >> 4) return;  // fetch error: never read
+  const uint32_t* __restrict__ src_words = (info & 2) ? q.words : db.words;
+  const uint64_t src = w.seg_src[seg];
+  const bool rc = info & 1;
+  uint32_t* __restrict__ dst = w.arena + (size_t)w.seg_off16[seg] * 4;
+  const uint32_t n_words = w.seg_cap16[seg] * 4;  // whole slot, so the tail is zero-filled
+  for (uint32_t wi = threadIdx.x & 31; wi < n_words; wi += 32) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t p = wi * PER + k;
+      if (p < len) {
+        uint32_t c;
+        if (!rc) c = load_residue<BITS>(src_words, src + p);
+        else {
+          c = load_residue<BITS>(src_words, src + (len - 1 - p));
+          if (c < 4) c = 3 - c;
+        }
+        out |= c << (BITS * k);
+      }
+    }
+    dst[wi] = out;
+  }
+}
+
+hipError_t launch_materialize(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& q, const StoreDev& db) {
+  if (w.T == 0) return hipSuccess;
+  const uint32_t blocks = (w.T + (kBlock / 32) - 1) / (kBlock / 32);
+  if (alphabet == 0)
+    hipLaunchKernelGGL(k_materialize<4>, dim3(blocks), dim3(kBlock), 0, st, w, q, db);
+  else
+    hipLaunchKernelGGL(k_materialize<8>, dim3(blocks), dim3(kBlock), 0, st, w, q, db);
+  return hipGetLastError();
+}
+
+}  // namespace rpa

@@ -1,0 +1,79 @@
+"""CPU-side checks of the product boundary: the C-ABI library builds, loads and exports every symbol the header
+declares, and -- with no GPU in this container -- refuses to run instead of falling back to anything."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = graft.load_package()
+    if not os.path.exists(p.LIB_PATH):
+        graft.build()
+    return p
+
+
+def test_header_symbols_are_exported(pkg):
+    header = open(os.path.join(ROOT, "include", "taxator_rpa.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(rpa_\w+)\s*\(", header, re.M))
+    assert declared == set(pkg.ABI_SYMBOLS)
+    lib = pkg.load_library()
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.rpa_abi_version() == 1
+
+
+def test_struct_layouts_match_header(pkg):
+    assert pkg.PRED_DTYPE.itemsize == 32 and pkg.STATS_DTYPE.itemsize == 16 and pkg.ALN_DTYPE.itemsize == 24
+    assert ctypes.sizeof(pkg._Params) == 32
+    assert ctypes.sizeof(pkg._Batch) == 8 + 13 * 8 + 8
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped path may not import, link or call anything under oracle/ (tier rule 3)."""
+    pkgdir = os.path.join(ROOT, "taxator-tk_amd")
+    for base, _, files in os.walk(pkgdir):
+        if os.path.basename(base) == "build":
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", ".inc", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "liboracle" not in text and "rpa_oracle" not in text and "helpers.oracle" not in text, f
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+
+    class T:
+        parent = np.zeros(1, np.uint32)
+        left = np.array([1], np.uint32)
+        right = np.array([2], np.uint32)
+        depth = np.zeros(1, np.uint8)
+
+    with pytest.raises(pkg.RpaError) as ei:
+        pkg.RPAPredictionModel(T())
+    assert ei.value.code == 2 and "no CPU path" in str(ei.value)
+
+
+def test_create_validates_taxonomy(pkg):
+    lib = pkg.load_library()
+    h = ctypes.c_void_p()
+    p = pkg._Params()
+    lib.rpa_default_params(ctypes.byref(p))
+    assert (p.alphabet, p.device) == (0, 0) and abs(p.exclude_alignments_factor - 0.5) < 1e-9 and abs(p.reeval_bandwidth - 0.05) < 1e-9
+    parent = np.array([1, 0], np.uint32)  # node 0 is not its own parent
+    left = np.array([1, 2], np.uint32)
+    right = np.array([4, 3], np.uint32)
+    depth = np.array([0, 1], np.uint8)
+    t = pkg._Taxonomy(2, parent.ctypes.data, left.ctypes.data, right.ctypes.data, depth.ctypes.data)
+    assert lib.rpa_create(ctypes.byref(t), ctypes.byref(p), ctypes.byref(h)) == 1
+    assert b"root" in lib.rpa_last_error(None)

@@ -1,0 +1,330 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the committed golden fixtures.
+Run on the MI355X box: python -m pytest tests -m gpu.  Bit-exact bar: integer scores, node indices, supports,
+feature coordinates, alignment counters AND the float32 bit patterns of distances / ival."""
+import gzip
+import importlib
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+from helpers import refio as R
+
+pytestmark = pytest.mark.gpu
+
+LETTERS_DNA = np.frombuffer(b"ACGTN", np.uint8)
+LETTERS_AA = np.frombuffer(R.AA_LETTERS.encode(), np.uint8)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = graft.load_package()
+    p.load_library()  # must exist: no fallback
+    return p
+
+
+@pytest.fixture(scope="module")
+def synth(pkg):
+    return importlib.import_module("taxator_tk_amd.synth")
+
+
+class OneNodeTax:
+    parent = np.zeros(1, np.uint32)
+    left = np.array([1], np.uint32)
+    right = np.array([2], np.uint32)
+    depth = np.zeros(1, np.uint8)
+
+
+def _pack(seqs):
+    offsets = np.zeros(len(seqs) + 1, np.uint64)
+    offsets[1:] = np.cumsum([len(s) for s in seqs])
+    return np.concatenate(seqs) if seqs else np.zeros(0, np.uint8), offsets
+
+
+def _check_dna(oracle, out, a_codes, b_codes):
+    for k in range(len(out)):
+        o = oracle.align_dna(a_codes[k], b_codes[k])
+        got = out[k]
+        assert (got["matches"], got["mismatches"], got["gaps"], got["length"]) == (o["matches"], o["mismatches"], o["gaps"], o["length"]), k
+        assert np.float32(got["distance"]).tobytes() == np.float32(o["distance"]).tobytes(), k
+        assert np.float32(got["similarity"]).tobytes() == np.float32(o["similarity"]).tobytes(), k
+
+
+def test_dna_pairs_golden(pkg, oracle, golden_dir):
+    vec = json.load(open(os.path.join(golden_dir, "pairs_dna.json")))
+    m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
+    seqs, pa, pb = [], [], []
+    for v in vec:
+        seqs += [np.frombuffer(v["a"].encode(), np.uint8), np.frombuffer(v["b"].encode(), np.uint8)]
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+    letters, offsets = _pack(seqs)
+    out = m.align_pairs(letters, offsets, pa, pb)
+    for v, got in zip(vec, out):
+        assert (int(got["distance"]), got["matches"], got["mismatches"], got["gaps"], got["length"]) == (
+            v["dist"], v["match"], v["mismatch"], v["gap"], v["length"]), (len(v["a"]), len(v["b"]))
+
+
+def test_dna_pairs_random_all_bins(pkg, oracle):
+    rng = np.random.default_rng(42)
+    m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
+    a_codes, b_codes = [], []
+    lens = list(range(1, 70)) + [95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 223, 224, 225, 255, 256] * 3
+    lens += [257, 300, 511, 512, 513, 1000, 2047, 2048, 2049, 3000, 4097, 6000, 8192, 10000, 12289, 16384]
+    for la in lens:
+        for mode in range(3):
+            a = rng.integers(0, 5 if mode else 4, la).astype(np.uint8)
+            if mode == 0:
+                b = a.copy()
+                mm = rng.random(la) < 0.1
+                b[mm] = rng.integers(0, 4, int(mm.sum()))
+                for _ in range(min(4, la // 8)):
+                    b = np.delete(b, rng.integers(0, len(b))) if rng.random() < 0.5 else np.insert(b, rng.integers(0, len(b)), rng.integers(0, 4))
+            elif mode == 1:
+                b = rng.integers(0, 5, max(1, int(la * rng.uniform(0.5, 1.5)))).astype(np.uint8)
+            else:
+                b = a[::-1].copy()
+            a_codes.append(a)
+            b_codes.append(b.astype(np.uint8))
+    seqs = [LETTERS_DNA[x] for pair in zip(a_codes, b_codes) for x in pair]
+    letters, offsets = _pack(seqs)
+    n = len(a_codes)
+    out = m.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    _check_dna(oracle, out, a_codes, b_codes)
+    # argument order must not matter for DNA (getAlignmentDNA orders by length itself)
+    out2 = m.align_pairs(letters, offsets, np.arange(n) * 2 + 1, np.arange(n) * 2)
+    assert out.tobytes() == out2.tobytes()
+
+
+def test_dna_pairs_many_200bp(pkg, oracle):
+    """The benchmark shape: 200 bp x 200 bp, ~10 % divergence, checked against the oracle on a sample and through
+    a size-independent property on all of them: d(a,b) == d(b,a) and |len diff| <= d <= max len."""
+    rng = np.random.default_rng(7)
+    m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
+    n = 20000
+    base = rng.integers(0, 4, (n, 200)).astype(np.uint8)
+    mut = base.copy()
+    mm = rng.random((n, 200)) < rng.uniform(0, 0.3, (n, 1))
+    mut[mm] = rng.integers(0, 4, int(mm.sum()))
+    cut = rng.integers(190, 201, n)
+    seqs = []
+    for k in range(n):
+        seqs.append(LETTERS_DNA[base[k]])
+        seqs.append(LETTERS_DNA[mut[k, :cut[k]]])
+    letters, offsets = _pack(seqs)
+    out = m.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    rev = m.align_pairs(letters, offsets, np.arange(n) * 2 + 1, np.arange(n) * 2)
+    assert out.tobytes() == rev.tobytes()
+    d = out["distance"]
+    assert ((d >= 200 - cut) & (d <= 200)).all()
+    assert (out["matches"] + out["mismatches"] + out["gaps"] == out["length"]).all()
+    idx = rng.choice(n, 600, replace=False)
+    _check_dna(oracle, out[idx], [base[k] for k in idx], [mut[k, :cut[k]] for k in idx])
+
+
+def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir):
+    vec = json.load(open(os.path.join(golden_dir, "pairs_protein.json")))
+    m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.PROTEIN)
+    seqs = []
+    for v in vec:
+        seqs += [np.frombuffer(v["a"].encode(), np.uint8), np.frombuffer(v["b"].encode(), np.uint8)]
+    letters, offsets = _pack(seqs)
+    n = len(vec)
+    out = m.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    for v, got in zip(vec, out):
+        assert (got["matches"], got["mismatches"], got["gaps"], got["length"]) == (v["match"], v["mismatch"], v["gap"], v["length"])
+        d_ref = np.array([v["distance_bits"]], np.uint32).view(np.float32)[0]
+        if v["selfscore"] >= v["mutual"] and d_ref >= 0:
+            assert int(np.float32(got["distance"]).view(np.uint32)) == v["distance_bits"]
+        else:
+            assert np.isnan(got["distance"])  # a live assert of the reference build: flagged, raised only if consumed
+        assert int(np.float32(got["similarity"]).view(np.uint32)) == v["similarity_bits"]
+    rng = np.random.default_rng(3)
+    a_codes, b_codes = [], []
+    for la in [1, 2, 3, 31, 32, 33, 63, 64, 65, 66, 67, 68, 96, 97, 130, 200, 333]:
+        for mode in range(3):
+            a = rng.integers(0, 20, la).astype(np.uint8)
+            if mode == 0:
+                b = a.copy()
+                mm = rng.random(la) < 0.3
+                b[mm] = rng.integers(0, 20, int(mm.sum()))
+                if la > 8:
+                    b = np.delete(b, rng.integers(0, la, 3))
+            elif mode == 1:
+                b = rng.integers(0, 20, max(1, int(la * rng.uniform(0.6, 1.4)))).astype(np.uint8)
+            else:
+                b = a.copy()
+            a_codes.append(a)
+            b_codes.append(b.astype(np.uint8))
+    seqs = [LETTERS_AA[x] for pair in zip(a_codes, b_codes) for x in pair]
+    letters, offsets = _pack(seqs)
+    n = len(a_codes)
+    out = m.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    for k in range(n):
+        rc, o = oracle.align_protein(a_codes[k], b_codes[k])
+        got = out[k]
+        assert (got["matches"], got["mismatches"], got["gaps"], got["length"]) == (o["matches"], o["mismatches"], o["gaps"], o["length"]), k
+        if rc == 0:
+            assert np.float32(got["distance"]).tobytes() == np.float32(o["distance"]).tobytes(), k
+        assert np.float32(got["similarity"]).tobytes() == np.float32(o["similarity"]).tobytes(), k
+
+
+def _engine_vs_oracle(pkg, oracle, synth, ds, alphabet):
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    rows, stats = model.predict(ds.batch)
+    tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    q = oracle.StoreArrays(synth.encode(ds.query_letters, alphabet), ds.query_offsets)
+    db = oracle.StoreArrays(synth.encode(ds.ref_letters, alphabet), ds.ref_offsets)
+    rc, exp, est = oracle.predict_batch(tax, q, db, alphabet, ds.batch["set_offsets"], ds.batch["query_seq"],
+                                        ds.batch["query_len"], synth.records_aos(ds.batch, oracle.RECORD_DTYPE))
+    assert rc == 0
+    for f in ("lower", "upper", "rtax", "support", "begin", "end", "flags"):
+        bad = np.nonzero(rows[f] != exp[f])[0]
+        assert len(bad) == 0, (f, bad[:5], rows[bad[:5]], exp[bad[:5]])
+    assert rows["ival"].tobytes() == exp["ival"].tobytes()
+    for f in ("n", "pass0", "pass1", "pass2"):
+        assert (stats[f] == est[f]).all(), f
+    return rows, stats
+
+
+def test_predict_config1_plumbing(pkg, oracle, synth):
+    """BASELINE config 1: 100 segments x 10 hits x 200 bp, b=2 mock taxonomy (128 nodes)."""
+    ds = synth.make_dataset(n_sets=100, n_hits=10, seg_len=200, branching=2, genome_len=2000, seed=1)
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    assert int(stats["pass0"].sum() + stats["pass1"].sum() + stats["pass2"].sum()) > 500
+
+
+@pytest.mark.parametrize("seed", [2, 3])
+def test_predict_dna_variety(pkg, oracle, synth, seed):
+    ds = synth.make_dataset(n_sets=3000, n_hits=20, seg_len=200, branching=4, genome_len=3000, seed=seed, variety=True)
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    assert (rows["flags"] & 1).any() and (rows["flags"] & 2).any() and (rows["flags"] & 4).any()
+
+
+def test_predict_dna_ragged_sets_and_lengths(pkg, oracle, synth):
+    """Record sets of different sizes (1..40 records) and segment lengths from 40 to 700 bp in one batch."""
+    parts = [synth.make_dataset(n_sets=150, n_hits=h, seg_len=L, branching=3, genome_len=2500, seed=10 + k, variety=True)
+             for k, (h, L) in enumerate([(3, 40), (7, 90), (20, 200), (40, 256), (12, 300), (9, 700)])]
+    # all parts share nothing: run each through its own engine, plus one merged batch against a common taxonomy
+    for ds in parts:
+        _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+
+
+def test_predict_protein(pkg, oracle, synth):
+    ds = synth.make_dataset(n_sets=400, n_hits=20, seg_len=67, branching=3, genome_len=1500, seed=4, alphabet=1,
+                            level_rate=0.06, query_rate=0.08, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 1)
+    ds = synth.make_dataset(n_sets=60, n_hits=10, seg_len=200, branching=2, genome_len=1500, seed=5, alphabet=1,
+                            level_rate=0.06, query_rate=0.08)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 1)
+
+
+def test_predict_long_contigs(pkg, oracle, synth):
+    """BASELINE config 5 shape at a size the oracle finishes in seconds: 10 kbp x 10 kbp, 12 hits."""
+    ds = synth.make_dataset(n_sets=6, n_hits=12, seg_len=10000, branching=2, genome_len=30000, seed=6)
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    assert int(stats["pass1"].sum()) > 0
+
+
+def _load_survey(folder, alphabet, tmp_path, **kw):
+    ext = ".fna" if alphabet == 0 else ".faa"
+    gz = os.path.join(folder, "ref" + ext + ".gz")
+    if os.path.exists(gz):
+        work = tmp_path / os.path.basename(folder)
+        shutil.copytree(folder, work)
+        with gzip.open(gz, "rb") as f, open(work / ("ref" + ext), "wb") as g:
+            g.write(f.read())
+        folder = str(work)
+    return R.Dataset(folder, alphabet, **kw)
+
+
+def _letters(fasta, alphabet):
+    return (LETTERS_DNA if alphabet == 0 else LETTERS_AA)[fasta.residues]
+
+
+@pytest.mark.parametrize("name,alphabet", [("survey_dna", 0), ("survey_protein", 1)])
+def test_gff3_matches_reference_output(pkg, golden_dir, tmp_path, name, alphabet):
+    """Through the engine, the GFF3 the reference code printed for the same input files (secondary evidence,
+    tests/golden/make_survey_fixture.py)."""
+    ds = _load_survey(os.path.join(golden_dir, name), alphabet, tmp_path)
+    b = ds.batch()
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
+    model.load_store(pkg.STORE_QUERY, _letters(ds.query, alphabet), ds.query.offsets)
+    model.load_store(pkg.STORE_DB, _letters(ds.ref, alphabet), ds.ref.offsets)
+    recs = b["recs"]
+    batch = dict(set_offsets=b["offsets"], query_seq=b["qseq"], query_len=b["qlen"], filtered=recs["filtered"].astype(np.uint8))
+    for f in ("qstart", "qstop", "rstart", "rstop", "score", "identities", "alnlen", "ref_seq", "node"):
+        batch[f] = recs[f]
+    rows, stats = model.predict(batch)
+    assert ds.gff3(rows, b["qids"], b["qlen"]) == open(os.path.join(golden_dir, name, "out.gff3")).read()
+
+
+def test_edge_sets_and_errors(pkg, oracle, golden_dir):
+    folder = os.path.join(golden_dir, "survey_edge")
+    ds = R.Dataset(folder, 0, query_name="query_edge.fna", aln_name="aln_edge.tsv")
+    b = ds.batch()
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+    model.load_store(pkg.STORE_QUERY, _letters(ds.query, 0), ds.query.offsets)
+    model.load_store(pkg.STORE_DB, _letters(ds.ref, 0), ds.ref.offsets)
+    recs = b["recs"]
+    batch = dict(set_offsets=b["offsets"], query_seq=b["qseq"], query_len=b["qlen"], filtered=recs["filtered"].astype(np.uint8))
+    for f in ("qstart", "qstop", "rstart", "rstop", "score", "identities", "alnlen", "ref_seq", "node"):
+        batch[f] = recs[f].copy()
+    rows, stats = model.predict(batch)
+    tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    q = oracle.StoreArrays(ds.query.residues, ds.query.offsets)
+    db = oracle.StoreArrays(ds.ref.residues, ds.ref.offsets)
+    rc, exp, est = oracle.predict_batch(tax, q, db, 0, b["offsets"], b["qseq"], b["qlen"], recs)
+    assert rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes()
+    exp_json = json.load(open(os.path.join(folder, "expected_edge.json")))
+    assert [int(s) for s in stats["pass1"]] == [e["stats"][1] for e in exp_json]
+    # empty batch, then a hit that starts beyond the end of its reference: SequenceRangeError, like the reference
+    bad = dict(batch)
+    bad["rstart"] = batch["rstart"].copy()
+    bad["rstop"] = batch["rstop"].copy()
+    k = int(b["offsets"][3])  # first record of e3 (3 active records -> alignments happen)
+    bad["rstart"][k] = 10 ** 8
+    bad["rstop"][k] = 10 ** 8 + 150
+    with pytest.raises(pkg.RpaError) as ei:
+        model.predict(bad)
+    assert ei.value.code == 3
+    # engine still usable afterwards
+    rows2, _ = model.predict(batch)
+    assert rows2.tobytes() == rows.tobytes()
+    # protein engine: reverse reference coordinates are an assert in the reference build
+    pm = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.PROTEIN)
+    pm.load_store(pkg.STORE_QUERY, _letters(ds.query, 0), ds.query.offsets)
+    pm.load_store(pkg.STORE_DB, _letters(ds.ref, 0), ds.ref.offsets)
+    with pytest.raises(pkg.RpaError) as ei:
+        pm.predict(batch)
+    assert ei.value.code == 5
+
+
+def test_device_resident_batch_and_profile(pkg, oracle, synth):
+    """The bench path: batch arrays already in HBM (torch tensors), results left on the device, live kernel timing."""
+    import torch
+    ds = synth.make_dataset(n_sets=2000, n_hits=20, seg_len=200, branching=4, genome_len=3000, seed=9)
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    host_rows, host_stats = model.predict(ds.batch)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).cuda()
+           for k, v in ds.batch.items()}
+    out = torch.zeros(ds.n_sets * 8, dtype=torch.int32, device="cuda")
+    st = torch.zeros(ds.n_sets * 4, dtype=torch.int32, device="cuda")
+    model.profile(enable=True, reset=True)
+    model.set_stream(torch.cuda.current_stream().cuda_stream)
+    model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=out, stats=st)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == host_rows.tobytes()
+    assert st.cpu().numpy().tobytes() == host_stats.tobytes()
+    prof = model.profile()
+    demanded = int(host_stats["pass0"].sum() + host_stats["pass1"].sum() + host_stats["pass2"].sum())
+    assert prof["demanded"] == demanded and prof["pairs"] >= demanded and prof["launches"] >= 3
+    assert 0 < prof["align_ms"] <= prof["total_ms"]
+    assert prof["residue_bytes"] > prof["pairs"] * 300 and prof["cells"] > prof["pairs"] * 150 * 150
