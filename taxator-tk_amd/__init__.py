@@ -72,6 +72,13 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  If
+    # torch is going to be used in this process (bench.py, torch.distributed) it has to be loaded FIRST so that this
+    # library binds to the runtime that is already resident; two runtimes in one process fight over the device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError("%s not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()')" % path)
     L = C.CDLL(path)
