@@ -1,0 +1,113 @@
+// taxator-tk_amd/host/taxonomy.cpp -- see taxonomy.hh.
+#include "taxonomy.hh"
+
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <set>
+#include <sys/stat.h>
+
+#include "exception.hh"
+
+namespace taxator {
+
+const std::vector<std::string> default_ranks = {"superkingdom", "phylum", "class", "order", "family", "genus", "species"};
+const char* const ENVVAR_TAXONOMY_NCBI = "TAXATORTK_TAXONOMY_NCBI";
+
+static bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+// fields separated by "\t|\t" (ncbidata.cpp:42,59)
+static void split_dmp(const std::string& line, std::vector<std::string>& out, size_t max_fields) {
+  out.clear();
+  size_t pos = 0;
+  while (out.size() + 1 < max_fields) {
+    size_t e = line.find("\t|\t", pos);
+    if (e == std::string::npos) break;
+    out.emplace_back(line, pos, e - pos);
+    pos = e + 3;
+  }
+  out.emplace_back(line, pos);
+}
+
+uint32_t Taxonomy::getNode(const TaxonID& id) const {
+  auto it = index_.find(id);
+  if (it == index_.end()) throw TaxonNotFound("taxid " + id);
+  return it->second;
+}
+
+Taxonomy* parseNCBIFlatFiles(const std::string& nodes_filename, const std::string& names_filename,
+                             const std::vector<std::string>* ranks_to_mark, bool delete_unmarked) {
+  std::unordered_map<TaxonID, std::vector<TaxonID>> children;
+  std::unordered_map<TaxonID, std::string> rank_of, name_of;
+  std::vector<std::string> f;
+  std::string line;
+  {
+    std::ifstream nodes(nodes_filename);
+    if (!nodes) throw FileNotFound(nodes_filename);
+    while (std::getline(nodes, line)) {
+      split_dmp(line, f, 4);
+      if (f.size() < 3) continue;
+      rank_of[f[0]] = f[2];
+      if (!(f[0] == "1" && f[1] == "1")) children[f[1]].push_back(f[0]);  // root self-link removed (:78-83)
+    }
+  }
+  {
+    std::ifstream names(names_filename);
+    if (names) {
+      while (std::getline(names, line)) {
+        split_dmp(line, f, 5);
+        if (f.size() >= 4 && f[3].compare(0, 15, "scientific name") == 0) name_of[f[0]] = f[1];  // :60
+      }
+    }
+  }
+  std::set<std::string> keep;
+  if (ranks_to_mark) keep.insert(ranks_to_mark->begin(), ranks_to_mark->end());
+  const bool prune = delete_unmarked && ranks_to_mark;
+
+  Taxonomy* tax = new Taxonomy;
+  uint32_t counter = 0;
+  struct Frame { TaxonID id; int32_t kept_parent; uint8_t depth; bool closing; uint32_t idx; };
+  std::vector<Frame> stack;
+  stack.push_back({"1", -1, 0, false, 0});
+  while (!stack.empty()) {
+    Frame fr = stack.back();
+    stack.pop_back();
+    if (fr.closing) { tax->right[fr.idx] = ++counter; continue; }
+    const bool is_kept = fr.id == "1" || !prune || keep.count(rank_of[fr.id]);
+    int32_t kp = fr.kept_parent;
+    uint8_t kd = fr.depth;
+    if (is_kept) {
+      const uint32_t idx = (uint32_t)tax->parent.size();
+      tax->index_[fr.id] = idx;
+      tax->taxid.push_back(fr.id);
+      tax->name.push_back(name_of.count(fr.id) ? name_of[fr.id] : std::string());
+      tax->parent.push_back(fr.kept_parent >= 0 ? (uint32_t)fr.kept_parent : 0u);
+      tax->depth.push_back(fr.depth);
+      tax->left.push_back(++counter);
+      tax->right.push_back(0);
+      stack.push_back({fr.id, fr.kept_parent, fr.depth, true, idx});
+      kp = (int32_t)idx;
+      kd = (uint8_t)(fr.depth + 1);
+    }
+    auto it = children.find(fr.id);
+    if (it != children.end())
+      for (auto c = it->second.rbegin(); c != it->second.rend(); ++c) stack.push_back({*c, kp, kd, false, 0});
+  }
+  return tax;
+}
+
+Taxonomy* loadTaxonomyFromEnvironment(const std::vector<std::string>* ranks_to_mark, bool delete_unmarked) {
+  const char* env = getenv(ENVVAR_TAXONOMY_NCBI);
+  if (!env) {
+    std::cerr << "Specify the folder containing the NCBI taxonomy dump files as " << ENVVAR_TAXONOMY_NCBI
+              << " environment variable" << std::endl;  // ncbidata.cpp:173-176
+    return nullptr;
+  }
+  const std::string folder = env;
+  const std::string nodes = folder + "/nodes.dmp", names = folder + "/names.dmp";
+  if (!file_exists(nodes)) { std::cerr << " \"" << nodes << "\" not found" << std::endl; return nullptr; }
+  if (!file_exists(names)) { std::cerr << " \"" << names << "\" not found" << std::endl; return nullptr; }
+  return parseNCBIFlatFiles(nodes, names, ranks_to_mark, delete_unmarked);
+}
+
+}  // namespace taxator

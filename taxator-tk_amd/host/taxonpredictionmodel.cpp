@@ -1,0 +1,80 @@
+// taxator-tk_amd/host/taxonpredictionmodel.cpp -- see taxonpredictionmodel.hh.
+#include "taxonpredictionmodel.hh"
+
+#include "exception.hh"
+
+namespace taxator {
+
+static void check(rpa_engine* e, int rc) {
+  if (rc == RPA_OK) return;
+  const std::string msg = rpa_last_error(e);
+  switch (rc) {  // back to the reference's exception kinds (core/src/exception.hh:29-73)
+    case RPA_ERR_RANGE: throw SequenceRangeError(msg);
+    case RPA_ERR_SEQ_ID: throw SequenceNotFound(msg);
+    case RPA_ERR_DEVICE: throw DeviceError(msg);
+    default: throw GeneralError(msg);
+  }
+}
+
+RPAPredictionModel::RPAPredictionModel(const Taxonomy* tax, const SequenceStore& q_storage, const SequenceStore& db_storage,
+                                       float exclude_factor, float reeval_bandwidth, bool protein, int device)
+    : TaxonPredictionModel(tax), query_sequences_(q_storage) {
+  rpa_taxonomy t{(uint32_t)tax->size(), tax->parent.data(), tax->left.data(), tax->right.data(), tax->depth.data()};
+  rpa_params p;
+  rpa_default_params(&p);
+  p.alphabet = protein ? RPA_PROTEIN : RPA_DNA;
+  p.exclude_alignments_factor = exclude_factor;
+  p.reeval_bandwidth = reeval_bandwidth;
+  p.device = device;
+  int rc = rpa_create(&t, &p, &engine_);
+  if (rc != RPA_OK) throw DeviceError(rpa_last_error(nullptr));
+  check(engine_, rpa_store_load(engine_, RPA_STORE_QUERY, q_storage.size(), q_storage.letters().data(), q_storage.offsets().data(), RPA_MEM_HOST));
+  check(engine_, rpa_store_load(engine_, RPA_STORE_DB, db_storage.size(), db_storage.letters().data(), db_storage.offsets().data(), RPA_MEM_HOST));
+}
+
+RPAPredictionModel::~RPAPredictionModel() { rpa_destroy(engine_); }
+
+void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, std::vector<PredictionRecord>& precs, std::ostream&) {
+  const size_t S = recordsets.size();
+  if (precs.size() < S) precs.resize(S, PredictionRecord(tax_));
+  set_offsets_.assign(1, 0);
+  query_seq_.clear(); query_len_.clear();
+  qstart_.clear(); qstop_.clear(); rstart_.clear(); rstop_.clear(); identities_.clear(); alnlen_.clear(); ref_seq_.clear();
+  node_.clear(); score_.clear(); filtered_.clear();
+  for (const RecordSetType& rset : recordsets) {
+    if (rset.empty()) throw GeneralError("empty record set");
+    const AlignmentRecordTaxonomy& front = rset.front();  // initPredictionRecord: id and length of the first record
+    query_seq_.push_back(query_sequences_.getIndex(front.getQueryIdentifier()));
+    query_len_.push_back(front.getQueryLength());
+    for (const AlignmentRecordTaxonomy& r : rset) {
+      qstart_.push_back(r.getQueryStart()); qstop_.push_back(r.getQueryStop());
+      rstart_.push_back(r.getReferenceStart()); rstop_.push_back(r.getReferenceStop());
+      score_.push_back(r.getScore()); identities_.push_back(r.getIdentities()); alnlen_.push_back(r.getAlignmentLength());
+      ref_seq_.push_back(r.reference_seq); node_.push_back(r.getReferenceNode()); filtered_.push_back(r.isFiltered() ? 1 : 0);
+    }
+    set_offsets_.push_back((uint32_t)qstart_.size());
+  }
+  rpa_batch b;
+  b.n_sets = (uint32_t)S; b.n_records = (uint32_t)qstart_.size();
+  b.set_offsets = set_offsets_.data(); b.query_seq = query_seq_.data(); b.query_len = query_len_.data();
+  b.qstart = qstart_.data(); b.qstop = qstop_.data(); b.rstart = rstart_.data(); b.rstop = rstop_.data(); b.score = score_.data();
+  b.identities = identities_.data(); b.alnlen = alnlen_.data(); b.ref_seq = ref_seq_.data(); b.node = node_.data();
+  b.filtered = filtered_.data(); b.mem_kind = RPA_MEM_HOST;
+  rows_.resize(S);
+  stats_.resize(S);
+  check(engine_, rpa_predict_batch(engine_, &b, rows_.data(), stats_.data(), RPA_MEM_HOST));
+  for (size_t s = 0; s < S; ++s) {
+    const rpa_prediction& r = rows_[s];
+    PredictionRecord& prec = precs[s];
+    prec.initialize(recordsets[s].front().getQueryIdentifier(), recordsets[s].front().getQueryLength());
+    prec.setQueryFeatureBegin(r.begin);
+    prec.setQueryFeatureEnd(r.end);
+    if (!(r.flags & RPA_FLAG_IVAL_UNTOUCHED)) stale_ival_ = r.ival;
+    prec.setInterpolationValue(stale_ival_);
+    prec.setSignalStrength(0.f);  // anchors_taxsig ends at 0 on every path that sets it (:722-725,828); printed as "0"
+    prec.setNodeRange(r.lower, r.upper, r.support);
+    prec.setBestReferenceTaxon(r.rtax);
+  }
+}
+
+}  // namespace taxator

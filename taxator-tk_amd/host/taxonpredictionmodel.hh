@@ -1,0 +1,49 @@
+// taxator-tk_amd/host/taxonpredictionmodel.hh -- the plugin seam, batched.
+// Mirrors TaxonPredictionModel<ContainerT> (core/src/taxonpredictionmodel.hh:36-52) and RPAPredictionModel
+// (core/src/taxonpredictionmodelsequence.hh:326-881).  The reference calls predict(recordset, prec, logsink) once per
+// record set; the MI355X engine wants thousands of record sets at a time, so predict() here takes a span of record sets
+// and fills one PredictionRecord per set, in input order (what the reference's serial loop prints, taxator.cpp:69-74).
+// All computation happens behind the C ABI (include/taxator_rpa.h) in hand-written HIP; there is no CPU path.
+#pragma once
+#include <ostream>
+#include <vector>
+
+#include "../../include/taxator_rpa.h"
+#include "alignmentrecord.hh"
+#include "predictionrecord.hh"
+#include "sequencestorage.hh"
+#include "taxonomy.hh"
+
+namespace taxator {
+
+class TaxonPredictionModel {
+ public:
+  explicit TaxonPredictionModel(const Taxonomy* tax) : tax_(tax) {}
+  virtual ~TaxonPredictionModel() {}
+  // one PredictionRecord per record set; precs must hold recordsets.size() records (they are reused between calls)
+  virtual void predict(const std::vector<RecordSetType>& recordsets, std::vector<PredictionRecord>& precs, std::ostream& logsink) = 0;
+ protected:
+  const Taxonomy* tax_;
+};
+
+class RPAPredictionModel : public TaxonPredictionModel {
+ public:
+  // same argument meaning as the reference ctor (:329): exclude_factor = -x, reeval_bandwidth = -t
+  RPAPredictionModel(const Taxonomy* tax, const SequenceStore& q_storage, const SequenceStore& db_storage, float exclude_factor,
+                     float reeval_bandwidth = .1f, bool protein = false, int device = 0);
+  ~RPAPredictionModel() override;
+  void predict(const std::vector<RecordSetType>& recordsets, std::vector<PredictionRecord>& precs, std::ostream& logsink) override;
+  const std::vector<rpa_stats>& lastStats() const { return stats_; }
+ private:
+  const SequenceStore& query_sequences_;
+  rpa_engine* engine_ = nullptr;
+  float stale_ival_ = -1.f;  // PredictionRecord is reused across calls in the reference (taxator.cpp:66): n==0 keeps the last ival
+  std::vector<rpa_stats> stats_;
+  std::vector<rpa_prediction> rows_;
+  // SoA staging
+  std::vector<uint32_t> set_offsets_, query_seq_, query_len_, qstart_, qstop_, rstart_, rstop_, identities_, alnlen_, ref_seq_, node_;
+  std::vector<float> score_;
+  std::vector<uint8_t> filtered_;
+};
+
+}  // namespace taxator

@@ -1,0 +1,80 @@
+"""End-to-end through the host C++ mirror: alignments TSV on stdin -> `taxator` -> C ABI -> HIP -> GFF3 on stdout."""
+import gzip
+import importlib
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+from helpers import refio as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "taxator-tk_amd", "bin", "taxator")
+
+
+def _run(folder, ext, extra=(), aln="aln.tsv", query=None, log=None):
+    env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
+    cmd = [BIN, "-g", os.path.join(folder, "mapping.tax"), "-q", os.path.join(folder, query or ("query" + ext)), "-f",
+           os.path.join(folder, "ref" + ext), "-i", os.path.join(folder, "ref" + ext + ".fai"), "-p", "0"] + list(extra)
+    if log:
+        cmd += ["-l", log]
+    return subprocess.run(cmd, stdin=open(os.path.join(folder, aln)), capture_output=True, text=True, env=env)
+
+
+def _unpack(golden_dir, name, ext, tmp_path):
+    work = tmp_path / name
+    shutil.copytree(os.path.join(golden_dir, name), work)
+    with gzip.open(work / ("ref" + ext + ".gz"), "rb") as f, open(work / ("ref" + ext), "wb") as g:
+        g.write(f.read())
+    return str(work)
+
+
+@pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])
+def test_cli_reproduces_reference_gff3(golden_dir, tmp_path, name, ext, extra):
+    folder = _unpack(golden_dir, name, ext, tmp_path)
+    r = _run(folder, ext, extra + ["--batch", "97"])  # several batches: the stale-ival state must carry across them
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(os.path.join(folder, "out.gff3")).read()
+
+
+def test_cli_config1_plumbing(oracle, tmp_path):
+    """BASELINE config 1 through files: 100 segments x 10 hits, b=2 taxonomy; GFF3 equals the oracle's."""
+    graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    ds = synth.make_dataset(n_sets=100, n_hits=10, seg_len=200, branching=2, genome_len=2000, seed=1, variety=True)
+    folder = str(tmp_path / "c1")
+    synth.write_files(ds, folder)
+    log = str(tmp_path / "log.txt")
+    r = _run(folder, ".fna", log=log)
+    assert r.returncode == 0, r.stderr
+    fds = R.Dataset(folder, 0)
+    b = fds.batch()
+    tax = oracle.TaxArrays(fds.tax.parent, fds.tax.left, fds.tax.right, fds.tax.depth)
+    q = oracle.StoreArrays(fds.query.residues, fds.query.offsets)
+    db = oracle.StoreArrays(fds.ref.residues, fds.ref.offsets)
+    rc, out, st = oracle.predict_batch(tax, q, db, 0, b["offsets"], b["qseq"], b["qlen"], b["recs"])
+    assert rc == 0
+    assert r.stdout == fds.gff3(out, b["qids"], b["qlen"])
+    stats_lines = [l.split("\t") for l in open(log) if l.startswith("STATS")]
+    assert [int(l[3]) + int(l[4]) + int(l[5]) for l in stats_lines] == [int(x) for x in st["pass0"] + st["pass1"] + st["pass2"]]
+
+
+def test_cli_errors_like_the_reference(golden_dir, tmp_path):
+    folder = os.path.join(golden_dir, "survey_edge")
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("e0\t1\t200\t200\tnope\t101\t300\t400\t0\t200\t200\n")
+    work = tmp_path / "w"
+    shutil.copytree(folder, work)
+    shutil.copy(bad, work / "aln_bad.tsv")
+    r = _run(str(work), ".fna", aln="aln_bad.tsv", query="query_edge.fna")
+    assert r.returncode == 1 and "bad taxon mapping for alignment reference sequence" in r.stderr  # alignmentrecord.hh:214-219
+    (work / "aln_bad.tsv").write_text("e0\t200\t1\t200\tref3\t101\t300\t400\t0\t200\t200\n")
+    r = _run(str(work), ".fna", aln="aln_bad.tsv", query="query_edge.fna")
+    assert r.returncode == 1 and "reverse query positions not allowed" in r.stderr               # alignmentrecord.hh:114
+    (work / "aln_bad.tsv").write_text("e0\t1\t200\t200\tref3\t99999101\t99999300\t400\t0\t150\t200\ne0\t1\t200\t200\tref2\t101\t300\t300\t0\t180\t200\n")
+    r = _run(str(work), ".fna", aln="aln_bad.tsv", query="query_edge.fna")
+    assert r.returncode == 1 and "SequenceRangeError" in r.stderr
