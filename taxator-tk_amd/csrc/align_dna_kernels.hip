@@ -106,37 +106,56 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restri
   int32_t dist = (int32_t)m;  // D[m][0]
   const uint32_t lastbit = (m - 1u) & 31u;  // m >= 1 (zero-length segments are range errors upstream)
 
-  for (uint32_t base = 0; base < n; base += 32) {
-    const uint4 tx = txt[base >> 5];
+  // One text column: NW chained word updates (add carry in VCC via v_addc_co, shift carries via v_alignbit).
+  auto column = [&](uint32_t c) {
+    const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
+    uint32_t carry = 0, hp_prev = 0x80000000u /* global alignment: +1 enters row 0 */, hn_prev = 0, HP = 0, HN = 0;
+#pragma unroll
+    for (int wi = 0; wi < NW; ++wi) {
+      // 10 VALU ops per word: or, and, addc, 3x v_bitop3 (gfx950 three-input boolean), 2x and, 2x alignbit.
+      // Truth tables use a=0xF0, b=0xCC, c=0xAA.
+      const uint32_t vp = VP[wi], vn = VN[wi];
+      const uint32_t X = e[wi * kBlock] | vn;
+      uint32_t cout;
+      const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
+      carry = cout;
+      const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);   // (sum ^ vp) | X
+      HN = vp & D0;
+      HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);                  // vn | ~(vp | D0)
+      const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);      // (HP << 1) | (hp_prev >> 31)
+      const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+      hp_prev = HP;
+      hn_prev = HN;
+      VN[wi] = Xs & D0;
+      VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);              // Hs | ~(Xs | D0)
+    }
+    dist += (int32_t)((HP >> lastbit) & 1u) - (int32_t)((HN >> lastbit) & 1u);
+  };
+
+  // Whole dwords (8 columns) need no per-column bound check; only the last partial dword of a lane does.
+  const uint32_t full_dwords = n >> 3;
+  uint32_t dw = 0;
+  for (; dw + 4 <= full_dwords; dw += 4) {
+    const uint4 tx = txt[dw >> 2];
     const uint32_t td[4] = {tx.x, tx.y, tx.z, tx.w};
-#pragma unroll
+#pragma unroll 1
     for (int q = 0; q < 4; ++q) {
+      const uint32_t d = td[q];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t col = base + q * 8 + k;
-        if (col < n) {
-          const uint32_t c = (td[q] >> (4 * k)) & 7u;
-          const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
-          uint32_t carry = 0, hp_prev = 0x80000000u /* global alignment: +1 enters row 0 */, hn_prev = 0, HP = 0, HN = 0;
-#pragma unroll
-          for (int wi = 0; wi < NW; ++wi) {
-            const uint32_t vp = VP[wi], vn = VN[wi];
-            const uint32_t X = e[wi * kBlock] | vn;
-            const uint64_t s = (uint64_t)vp + (uint64_t)(X & vp) + carry;
-            carry = (uint32_t)(s >> 32);
-            const uint32_t D0 = ((uint32_t)s ^ vp) | X;
-            HN = vp & D0;
-            HP = vn | ~(vp | D0);
-            const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);  // (HP << 1) | (hp_prev >> 31)
-            const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
-            hp_prev = HP;
-            hn_prev = HN;
-            VN[wi] = Xs & D0;
-            VP[wi] = Hs | ~(Xs | D0);
-          }
-          dist += (int32_t)((HP >> lastbit) & 1u) - (int32_t)((HN >> lastbit) & 1u);
-        }
-      }
+      for (int k = 0; k < 8; ++k) column((d >> (4 * k)) & 7u);
+    }
+  }
+  {  // tail: up to 3 full dwords + one partial
+    const uint4 tx = txt[dw >> 2];
+    const uint32_t td[4] = {tx.x, tx.y, tx.z, tx.w};
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t d = td[q];
+      const uint32_t col0 = (dw + q) * 8u;
+      if (col0 >= n) break;
+#pragma unroll 1
+      for (int k = 0; k < 8; ++k)
+        if (col0 + k < n) column((d >> (4 * k)) & 7u);
     }
   }
   // distance, similarity = matches = len_short - (d - lendiff) = len_long - d   (:154-164)

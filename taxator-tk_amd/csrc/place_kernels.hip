@@ -32,47 +32,12 @@ struct OutStats {  // = rpa_stats
   uint32_t n, pass0, pass1, pass2;
 };
 constexpr uint32_t kFlagIvalUntouched = 1u, kFlagShortcut = 2u, kFlagSingle = 4u;
-constexpr uint8_t kQGroup = 1, kOutGroup = 2;
+constexpr uint32_t kQGroup = 1, kOutGroup = 2;
 
 __device__ __forceinline__ bool rec_filtered(const BatchDev& b, uint32_t r) { return b.filtered && b.filtered[r]; }
 
 __device__ __forceinline__ void raise_error(const WorkDev& w, uint32_t code, uint32_t set) {
   if (atomicCAS(&w.counters[kCtrErr], 0u, code) == 0u) w.counters[kCtrErrSet] = set;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Rank sort: one thread per record computes its position in SortFilter order (score desc, identities desc, input
-// order on full ties = what a stable list::sort gives) among the unmasked records of its set.
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w) {
-  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
-  if (r >= b.n_records) return;
-  uint32_t lo = 0, hi = b.n_sets;  // largest s with set_offsets[s] <= r
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (b.set_offsets[mid] <= r) lo = mid; else hi = mid;
-  }
-  const uint32_t s = lo;
-  w.rec_set[r] = s;
-  if (rec_filtered(b, r)) return;
-  const uint32_t beg = b.set_offsets[s], end = b.set_offsets[s + 1];
-  const float sc = b.score[r];
-  const uint32_t id = b.identities[r];
-  uint32_t rank = 0;
-  for (uint32_t j = beg; j < end; ++j) {
-    if (rec_filtered(b, j)) continue;
-    const float sj = b.score[j];
-    const uint32_t ij = b.identities[j];
-    const bool before = (sj > sc) || (sj == sc && (ij > id || (ij == id && j < r)));
-    rank += before ? 1u : 0u;
-  }
-  w.order[beg + rank] = r;
-}
-
-hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w) {
-  if (b.n_records == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_rank_records, dim3((b.n_records + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, w);
-  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -101,6 +66,68 @@ __device__ __forceinline__ void plan_segment(const WorkDev& w, uint32_t seg, con
   w.seg_cap16[seg] = (len + per16 - 1) / per16;
   w.seg_src[seg] = src;
   w.seg_info[seg] = (uint8_t)((rc ? 1u : 0u) | (from_query ? 2u : 0u) | (err << 4));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Rank + gather: one thread per record.  It scans the records of its own set once (neighbouring lanes read the same
+// few cache lines) to get (a) its position in SortFilter order (score desc, identities desc, input order on full ties
+// = what a stable list::sort gives) among the unmasked records, and (b) the set's n / query range (:391-404).  It
+// then writes its HitRow at that sorted position -- from here on a set's hits are one contiguous 32-byte-per-hit
+// array that the per-set threads walk sequentially -- and plans its own reference segment; the thread of a set's
+// first record also plans the query-range segment and writes the set header.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, StoreDev qstore, StoreDev dbstore, Params p) {
+  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= b.n_records) return;
+  uint32_t lo = 0, hi = b.n_sets;  // largest s with set_offsets[s] <= r  (empty sets share an offset: take the last one)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (b.set_offsets[mid] <= r) lo = mid; else hi = mid;
+  }
+  const uint32_t s = lo;
+  const uint32_t beg = b.set_offsets[s], end = b.set_offsets[s + 1];
+  const bool me_filtered = rec_filtered(b, r);
+  const float sc = b.score[r];
+  const uint32_t id = b.identities[r];
+  uint32_t rank = 0, n = 0, qrstart = 0xFFFFFFFFu, qrstop = 0;
+  for (uint32_t j = beg; j < end; ++j) {
+    if (rec_filtered(b, j)) continue;
+    ++n;
+    qrstart = min(qrstart, b.qstart[j]);
+    qrstop = max(qrstop, b.qstop[j]);
+    const float sj = b.score[j];
+    const uint32_t ij = b.identities[j];
+    const bool before = (sj > sc) || (sj == sc && (ij > id || (ij == id && j < r)));
+    rank += before ? 1u : 0u;
+  }
+  const int bits = p.alphabet == 0 ? 4 : 8;
+  if (r == beg) {
+    w.set_info[s] = make_uint4(n, qrstart, qrstop, 0u);
+    if (n >= 2) plan_segment(w, b.n_records + s, qstore, true, b.query_seq[s], qrstart, qrstop, false, bits);  // :415
+  }
+  if (me_filtered) return;
+  HitRow h;
+  h.score = sc; h.ident = id; h.alnlen = b.alnlen[r]; h.node = b.node[r]; h.rec = r;
+  h.qd = FLT_MAX; h.qs = 0.f; h.flags = 0;  // :475-476
+  if (n == 1) { h.qd = __uint_as_float(b.qstart[r]); h.qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
+  w.hits[beg + rank] = h;
+  if (n < 2) return;
+  const uint32_t left_ext = b.qstart[r] - qrstart, right_ext = qrstop - b.qstop[r];  // :523
+  const uint32_t start = b.rstart[r], stop = b.rstop[r];
+  if (start <= stop) {
+    plan_segment(w, r, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false, bits);
+  } else if (p.alphabet != 0) {
+    w.seg_len[r] = 0; w.seg_cap16[r] = 0; w.seg_src[r] = 0; w.seg_info[r] = (uint8_t)(kErrAssert << 4);
+  } else {
+    plan_segment(w, r, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true, bits);
+  }
+}
+
+hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const StoreDev& q, const StoreDev& db,
+                               const Params& p) {
+  if (b.n_records == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rank_records, dim3((b.n_records + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, w, q, db, p);
+  return hipGetLastError();
 }
 
 // Pair emission bookkeeping: a thread first counts what it will emit per bin, reserves list space with one atomic
@@ -137,38 +164,37 @@ struct Emit {  // what a set wants aligned next
 template <typename F>
 __device__ __forceinline__ void for_each_pair(const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                                               const SetState& st, uint32_t s, const Emit& em, F&& f) {
-  const uint32_t lo = b.set_offsets[s];
+  const HitRow* __restrict__ hits = w.hits + b.set_offsets[s];
   const uint32_t n = st.n;
   const uint32_t qseg = b.n_records + s;
   if (em.mode == 1) {  // pass 0: every non-perfect hit within the re-evaluation band against the query range (:511-534)
-    const float thr = p.reeval_factor * b.score[w.order[lo]];
+    const float thr = p.reeval_factor * hits[0].score;
     for (uint32_t i = 0; i < n; ++i) {
-      const uint32_t r = w.order[lo + i];
-      if (b.alnlen[r] == st.L && b.identities[r] == st.L) continue;
-      if (b.score[r] >= thr) f(i, r, qseg);
+      const HitRow h = hits[i];
+      if (h.alnlen == st.L && h.ident == st.L) continue;
+      if (h.score >= thr) f(i, h.rec, qseg);
     }
   } else if (em.mode == 2) {  // pass 1: everything the anchor loop can reach (:604-638)
-    const uint32_t ra = w.order[lo + em.anchor];
+    const uint32_t ra = hits[em.anchor].rec;
     for (uint32_t i = 0; i < n; ++i) {
-      if (i == em.anchor || w.qd[lo + i] == 0.f) continue;
-      f(i, w.order[lo + i], ra);
+      if (i == em.anchor || hits[i].qd == 0.f) continue;
+      f(i, hits[i].rec, ra);
     }
   } else if (em.mode == 3) {  // pass 2 (:750-797)
     const uint32_t a = em.anchor;
-    const uint32_t ra = w.order[lo + a];
-    if (w.qd[lo + a] == FLT_MAX) f(kQueryTag, ra, qseg);
-    const double qpid_anchor = (double)w.qs[lo + a] / st.L;
+    const HitRow ha = hits[a];
+    if (ha.qd == FLT_MAX) f(kQueryTag, ha.rec, qseg);
+    const double qpid_anchor = (double)ha.qs / st.L;
     const double g = qpid_anchor * 2. - 1., h = qpid_anchor * p.exclude_factor;
     const double qpid_thresh = g < h ? h : g;
-    const float scut = b.score[ra] * p.exclude_factor;
+    const float scut = ha.score * p.exclude_factor;
     for (uint32_t i = 0; i < n; ++i) {
-      const uint32_t r = w.order[lo + i];
-      if (!(b.score[r] >= scut)) break;
+      const HitRow hi = hits[i];
+      if (!(hi.score >= scut)) break;
       if (i == a) continue;
-      if (!((double)w.qs[lo + i] / st.L >= qpid_thresh)) continue;
-      const uint32_t cnode = b.node[r];
-      if (d_is_parent_of(tax, st.unode_g, cnode) || cnode == st.unode_g) continue;
-      f(i, r, ra);
+      if (!((double)hi.qs / st.L >= qpid_thresh)) continue;
+      if (d_is_parent_of(tax, st.unode_g, hi.node) || hi.node == st.unode_g) continue;
+      f(i, hi.rec, ha.rec);
     }
   }
 }
@@ -223,11 +249,12 @@ __device__ __forceinline__ void emit_pairs(const BatchDev& b, const WorkDev& w, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Plan: one thread per record set.  Handles everything predict() decides before any alignment
-// (:341-472): masking, n == 0, n == 1, query range, perfect-best-hit shortcut; plans the segments; emits pass 0.
+// Plan: one thread per record set.  Handles everything predict() decides before any alignment (:341-472): n == 0,
+// n == 1, perfect-best-hit shortcut; otherwise emits pass 0.  (Masking, query range, sorting and segment plans were
+// done per record by k_rank_records.)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, TaxDev tax, StoreDev qstore, StoreDev dbstore,
-                                                       Params p, OutRow* __restrict__ rows, OutStats* __restrict__ stats) {
+__global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
+                                                       OutStats* __restrict__ stats) {
   const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
   const bool live = s < b.n_sets;
   SetState st;
@@ -235,13 +262,10 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
   Emit em{0, 0};
   if (live) {
     const uint32_t lo = b.set_offsets[s], hi = b.set_offsets[s + 1];
-    uint32_t n = 0, qrstart = 0xFFFFFFFFu, qrstop = 0;
-    for (uint32_t r = lo; r < hi; ++r) {
-      if (rec_filtered(b, r)) continue;
-      ++n;
-      qrstart = min(qrstart, b.qstart[r]);
-      qrstop = max(qrstop, b.qstop[r]);
-    }
+    uint4 info = make_uint4(0u, 0u, 0u, 0u);
+    if (hi > lo) info = w.set_info[s];
+    const uint32_t n = info.x, qrstart = info.y, qrstop = info.z;
+    const HitRow* __restrict__ hits = w.hits + lo;
     st.n = n; st.qrstart = qrstart; st.qrstop = qrstop; st.L = qrstop - qrstart + 1;
     st.support = 0; st.lca_all = kRoot; st.rtax = kRoot; st.lnode_g = st.unode_g = kRoot; st.ival_g = 0.f; st.bf_max = 1.f;
     st.lrd_min = 255; st.anchor = 0; st.cnt0 = st.cnt1 = st.cnt2 = 0; st.n_emitted = 0;
@@ -252,24 +276,24 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
     if (n == 0) {  // :359-368
       row.flags = kFlagIvalUntouched;
     } else if (n == 1) {  // :371-388
-      const uint32_t r = w.order[lo];
-      row.begin = b.qstart[r]; row.end = b.qstop[r]; row.ival = 1.f;
-      row.lower = b.node[r]; row.upper = kRoot; row.support = b.identities[r]; row.rtax = b.node[r];
+      const HitRow h = hits[0];
+      row.begin = __float_as_uint(h.qd); row.end = __float_as_uint(h.qs); row.ival = 1.f;
+      row.lower = h.node; row.upper = kRoot; row.support = h.ident; row.rtax = h.node;
       row.flags = kFlagSingle;
     } else {
-      const uint32_t r0 = w.order[lo];
+      const HitRow h0 = hits[0];
       const uint32_t L = st.L;
-      if (b.alnlen[r0] == L && b.identities[r0] == L) {  // :431-472
-        const float best = b.score[r0];
-        uint32_t lnode = b.node[r0], unode = kRoot;
+      if (h0.alnlen == L && h0.ident == L) {  // :431-472
+        const float best = h0.score;
+        uint32_t lnode = h0.node, unode = kRoot;
         uint32_t i = 1;
         for (;;) {
           if (i == n) { unode = kRoot; break; }
-          const float sc = b.score[w.order[lo + i]];
-          if (sc == best) lnode = d_lca(tax, lnode, b.node[w.order[lo + i]]);
+          const float sc = hits[i].score;
+          if (sc == best) lnode = d_lca(tax, lnode, hits[i].node);
           else {
             unode = lnode;
-            do { unode = d_lca(tax, unode, b.node[w.order[lo + i]]); } while (++i < n && b.score[w.order[lo + i]] == sc);
+            do { unode = d_lca(tax, unode, hits[i].node); } while (++i < n && hits[i].score == sc);
             break;
           }
           ++i;
@@ -278,21 +302,6 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
         row.lower = lnode; row.upper = unode; row.support = L; row.rtax = lnode; row.flags = kFlagShortcut;
       } else {
         done = false;
-        const int bits = p.alphabet == 0 ? 4 : 8;
-        // query range sequence (:415) and the reference segment of every active record (:523)
-        plan_segment(w, b.n_records + s, qstore, true, b.query_seq[s], qrstart, qrstop, false, bits);
-        for (uint32_t i = 0; i < n; ++i) {
-          const uint32_t r = w.order[lo + i];
-          const uint32_t left_ext = b.qstart[r] - qrstart, right_ext = qrstop - b.qstop[r];
-          const uint32_t start = b.rstart[r], stop = b.rstop[r];
-          if (start <= stop) {
-            plan_segment(w, r, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false, bits);
-          } else if (p.alphabet != 0) {
-            w.seg_len[r] = 0; w.seg_cap16[r] = 0; w.seg_src[r] = 0; w.seg_info[r] = (uint8_t)(kErrAssert << 4);
-          } else {
-            plan_segment(w, r, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true, bits);
-          }
-        }
         st.phase = kPass0Wait;
         em.mode = 1;
       }
@@ -308,58 +317,59 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
   if (live) w.state[s] = st;
 }
 
-hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
-                            const StoreDev& db, const Params& p, void* out_rows, void* out_stats) {
+hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
+                            void* out_rows, void* out_stats) {
   if (b.n_sets == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_plan_sets, dim3((b.n_sets + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, w, tax, q, db, p,
+  hipLaunchKernelGGL(k_plan_sets, dim3((b.n_sets + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, w, tax, p,
                      (OutRow*)out_rows, (OutStats*)out_stats);
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// BandFactor (:259-323) over the (dist, node) entries gathered in this set's scratch region.  entries[0] is the
-// anchor.  The reference sorts [1..] by distance with std::sort; the factor does not depend on the order of equal
-// distances, so entries are visited here in (distance, insertion index) order by repeated
-// selection -- O(k^2) for k entries, k <= n + 1.
+// BandFactor (:259-323) without the sort.  The reference sorts the (distance, node) entries by distance and walks
+// them, remembering per taxonomic rank (= depth of LCA(node, anchor)) the distance at which that rank was first
+// reached ("worst[rank]", only while ranks keep decreasing) and, for every entry whose rank is higher than the lowest
+// rank seen so far ("disorder"), taking max(distance / worst[r]) over the remembered lower ranks r.  Because
+// x -> fl(x / y) is monotone, that maximum only needs, per rank, the smallest (fmin) and the largest (dmax) distance:
+//   rank rho is remembered  <=>  rho < rank(anchor) and fmin[rho] < fmin[rho'] for every rho' < rho,
+//   factor = max(1, max over remembered rho with fmin[rho] != 0 of  (max_{r > rho} dmax[r]) / fmin[rho]),
+// and ties (equal distances) only ever contribute ratios <= 1, which is why the reference's unstable std::sort cannot
+// change the result either.  tests/test_oracle_placement.py checks this formulation against the
+// sorted walk of the oracle on random inputs.  The accumulators live in LDS, [rank][thread] (bank = thread).
 // ------------------------------------------------------------------------------------------------------------
-__device__ float band_factor(const TaxDev& tax, const float* __restrict__ dist, const uint32_t* __restrict__ node, uint32_t k) {
-  float bandfactor = 1.f;
-  float worst[kMaxDepth + 1];  // std::map<rank, score> of the reference; depth <= kMaxDepth is checked at rpa_create
-  uint32_t have = 0;           // bit r: worst[r] recorded
-  const uint32_t anchor = node[0];
-  uint32_t last_rank = tax.depth[anchor];
-  worst[last_rank] = dist[0];
-  have |= 1u << last_rank;
-  float prev_d = -1.f;
-  uint32_t prev_i = 0;
-  for (uint32_t e = 1; e < k; ++e) {
-    // next entry in (dist, index) order after (prev_d, prev_i)
-    uint32_t best = 0;
-    float best_d = FLT_MAX;
-    bool found = false;
-    for (uint32_t j = 1; j < k; ++j) {
-      const float d = dist[j];
-      const bool after = (d > prev_d) || (d == prev_d && j > prev_i);
-      if (after && (!found || d < best_d)) { best = j; best_d = d; found = true; }
-    }
-    prev_d = best_d; prev_i = best;
-    const float score = best_d;
-    const uint32_t rank = tax.depth[d_lca(tax, node[best], anchor)];
-    if (rank == last_rank) {
-    } else if (rank < last_rank) {  // :295-297
-      worst[rank] = score; have |= 1u << rank;
-      last_rank = rank;
-    } else {  // disorder, :298-308
-      for (int r = (int)rank - 1; r >= 0; --r) {
-        if (have & (1u << r)) {
-          const float refscore = worst[r];
-          if (refscore != 0.f) { const float q = score / refscore; bandfactor = bandfactor < q ? q : bandfactor; }
-        }
-      }
-    }
+struct BandAcc {
+  float* fmin;  // this thread's column of s_fmin: element rank at fmin[rank * kBlock]
+  float* dmax;
+  uint32_t anchor_rank;
+  __device__ void reset(uint32_t ra) {
+    anchor_rank = ra;
+    for (uint32_t r = 0; r <= ra; ++r) { fmin[r * kBlock] = FLT_MAX; dmax[r * kBlock] = -1.f; }
   }
-  return sqrtf(bandfactor);
-}
+  __device__ void add(float dist, uint32_t rank) {  // BandFactor::addSequence (:267-269), rank = depth(LCA(node, anchor)) (:292-293)
+    const float f = fmin[rank * kBlock], d = dmax[rank * kBlock];
+    if (dist < f) fmin[rank * kBlock] = dist;
+    if (dist > d) dmax[rank * kBlock] = dist;
+  }
+  __device__ float factor() const {  // getFactor (:271-277)
+    float bandfactor = 1.f;
+    uint32_t remembered = 0;
+    float lowmin = FLT_MAX;
+    for (uint32_t r = 0; r < anchor_rank; ++r) {
+      const float f = fmin[r * kBlock];
+      if (f < lowmin) { remembered |= 1u << r; lowmin = f; }
+    }
+    float dsuf = dmax[anchor_rank * kBlock];
+    for (int r = (int)anchor_rank - 1; r >= 0; --r) {
+      const float f = fmin[r * kBlock];
+      if ((remembered >> r) & 1u) {
+        if (f != 0.f && dsuf >= 0.f) { const float q = dsuf / f; bandfactor = bandfactor < q ? q : bandfactor; }
+      }
+      const float d = dmax[r * kBlock];
+      dsuf = dsuf < d ? d : dsuf;
+    }
+    return sqrtf(bandfactor);
+  }
+};
 
 // ------------------------------------------------------------------------------------------------------------
 // Decide: one thread per record set, one call per round.
@@ -387,6 +397,8 @@ __device__ __forceinline__ bool seg_ok(const WorkDev& w, uint32_t s, uint32_t sa
 
 __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
                                                     OutStats* __restrict__ stats, unsigned long long* prof_acc) {
+  __shared__ float s_fmin[kMaxDepth + 1][kBlock];
+  __shared__ float s_dmax[kMaxDepth + 1][kBlock];
   const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
   bool live = s < b.n_sets;
   SetState st;
@@ -398,54 +410,53 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
     const uint32_t lo = b.set_offsets[s];
     const uint32_t n = st.n, L = st.L;
     const uint32_t slot0 = lo + s;
-    float* __restrict__ qd = w.qd + lo;
-    float* __restrict__ qs = w.qs + lo;
-    uint8_t* __restrict__ fl = w.flags + lo;
+    HitRow* __restrict__ hits = w.hits + lo;  // this set's hits in SortFilter order, 32 B each, contiguous
     const float X = p.exclude_factor;
     ResultCursor cur{w, slot0, slot0 + st.n_emitted};
     bool failed = false;
-#define REC(i) (w.order[lo + (i)])
 
     if (st.phase == kPass0Wait) {  // ---- pass 0, :497-566 ----
-      const float thr = p.reeval_factor * b.score[REC(0)];  // :499
+      const float thr = p.reeval_factor * hits[0].score;  // :499
       uint32_t index_best = 0;
+      float best_d = 0.f, best_s = 0.f, best_sc = 0.f;
       uint32_t support = 0;
-      uint32_t lca_all = b.node[REC(0)];
-      for (uint32_t i = 0; i < n && !failed; ++i) {
-        const uint32_t r = REC(i);
+      uint32_t lca_all = hits[0].node;
+      for (uint32_t i = 0; i < n; ++i) {
+        const HitRow h = hits[i];
         float dist, sim;
-        uint8_t flag = 0;
-        if (b.alnlen[r] == L && b.identities[r] == L) {  // :511-517
-          flag = kQGroup; dist = 0.f; sim = (float)b.identities[r];
-        } else if (b.score[r] >= thr) {  // :518-534
+        uint32_t flag = 0;
+        if (h.alnlen == L && h.ident == L) {  // :511-517
+          flag = kQGroup; dist = 0.f; sim = (float)h.ident;
+        } else if (h.score >= thr) {  // :518-534
           flag = kQGroup;
           float2 res; uint32_t sa, sb;
           if (!cur.find(i, res, sa, sb)) { raise_error(w, kErrInvalid, s); failed = true; break; }
           if (!seg_ok(w, s, sa, sb, res.x)) { failed = true; break; }
           dist = res.x;
           ++st.cnt0;
-          const float idf = (float)b.identities[r];
+          const float idf = (float)h.ident;
           sim = res.y < idf ? idf : res.y;  // std::max(similarity, identities), :531
         } else {
-          dist = FLT_MAX; sim = (float)b.identities[r];
+          dist = FLT_MAX; sim = (float)h.ident;
         }
-        qd[i] = dist; qs[i] = sim; fl[i] = flag;
-        if (dist < qd[index_best]) index_best = i;  // :542-546
-        else if (dist == qd[index_best]) {
-          if (sim > qs[index_best]) index_best = i;
-          else if (sim == qs[index_best] && b.score[r] > b.score[REC(index_best)]) index_best = i;
+        hits[i].qd = dist; hits[i].qs = sim; hits[i].flags = flag;
+        if (i == 0) { best_d = dist; best_s = sim; best_sc = h.score; }  // index_best starts at 0 (:500)
+        else if (dist < best_d) { index_best = i; best_d = dist; best_s = sim; best_sc = h.score; }  // :542-546
+        else if (dist == best_d) {
+          if (sim > best_s) { index_best = i; best_s = sim; best_sc = h.score; }
+          else if (sim == best_s && h.score > best_sc) { index_best = i; best_sc = h.score; }
         }
-        support = max(support, (uint32_t)sim);          // :547
-        lca_all = d_lca(tax, lca_all, b.node[r]);        // :548
+        support = max(support, (uint32_t)sim);     // :547
+        lca_all = d_lca(tax, lca_all, h.node);      // :548
       }
       if (!failed) {
-        uint32_t rtax = b.node[REC(index_best)];
+        uint32_t rtax = hits[index_best].node;
         bool any = false;
-        const float bd = qd[index_best], bs = qs[index_best], bsc = b.score[REC(index_best)];
         for (uint32_t i = 0; i < n; ++i) {  // :554-562
-          if (!(fl[i] & kQGroup)) continue;
-          if (qd[i] != bd || qs[i] != bs || b.score[REC(i)] != bsc) fl[i] = 0;
-          else { rtax = d_lca(tax, rtax, b.node[REC(i)]); any = true; }
+          const HitRow h = hits[i];
+          if (!(h.flags & kQGroup)) continue;
+          if (h.qd != best_d || h.qs != best_s || h.score != best_sc) hits[i].flags = 0;
+          else { rtax = d_lca(tax, rtax, h.node); any = true; }
         }
         if (!any) { raise_error(w, kErrAssert, s); failed = true; }  // assert(!qgroup.empty()), :563
         st.support = support; st.lca_all = lca_all; st.rtax = rtax;
@@ -454,28 +465,28 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
       }
     } else if (st.phase == kPass1Wait) {  // ---- pass 1 for one anchor, :580-728 ----
       const uint32_t a = st.anchor;
-      const float qdist = qd[a];
-      const uint32_t rnode = b.node[REC(a)];
-      float* __restrict__ bfd = w.bf_dist + slot0;
-      uint32_t* __restrict__ bfn = w.bf_node + slot0;
+      const float qdist = hits[a].qd;
+      const uint32_t rnode = hits[a].node;
       uint32_t* __restrict__ ogi = w.og_idx + slot0;
       int32_t* __restrict__ ogd = w.og_dist + slot0;
-      uint32_t nbf = 0, nog = 0;
-      bfd[0] = 0.f; bfn[0] = rnode; nbf = 1;  // :586
+      uint32_t nog = 0;
+      BandAcc band{&s_fmin[0][threadIdx.x], &s_dmax[0][threadIdx.x], 0};
+      band.reset(tax.depth[rnode]);  // BandFactor(...); addSequence(0, rnode) (:581,586): the anchor entry only sets the start rank
       uint32_t lnode = st.rtax;
       float ldist = 0.f, udist = FLT_MAX;
       double qpid_upper = 0., cut_g = 0., cut_h = 0.;  // :599-601
       int scut = 0;                                     // :602 (int!)
-      for (uint32_t i = 0; lnode != kRoot && i < n && b.score[REC(i)] >= (float)scut; ++i) {  // :604
-        const uint32_t r = REC(i);
-        const uint32_t cnode = b.node[r];
-        const double qsearchpid = (double)b.identities[r] / L;
-        const double qpid = (double)qs[i] / L;
+      for (uint32_t i = 0; lnode != kRoot && i < n; ++i) {  // :604
+        const HitRow h = hits[i];
+        if (!(h.score >= (float)scut)) break;
+        const uint32_t cnode = h.node;
+        const double qsearchpid = (double)h.ident / L;
+        const double qpid = (double)h.qs / L;
         const double qpid_thresh = cut_g < cut_h ? cut_h : cut_g;
         if (!(qpid >= qpid_thresh)) continue;  // :612
         float dist;
         if (i == a) dist = 0.f;
-        else if (qd[i] == 0.f) dist = qd[a];  // :620-621
+        else if (h.qd == 0.f) dist = qdist;  // :620-621
         else {
           float2 res; uint32_t sa, sb;
           if (!cur.find(i, res, sa, sb)) { raise_error(w, kErrInvalid, s); failed = true; break; }
@@ -483,8 +494,8 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
           dist = res.x;
           ++st.cnt1;
         }
-        bfd[nbf] = dist; bfn[nbf] = cnode; ++nbf;  // :641
-        if (dist == 0.f) fl[i] &= (uint8_t)~kQGroup;  // :644
+        band.add(dist, tax.depth[d_lca(tax, cnode, rnode)]);  // :641
+        if (dist == 0.f) hits[i].flags = h.flags & ~(uint32_t)kQGroup;  // :644
         else if (dist <= qdist) {  // :646-650
           lnode = d_lca(tax, lnode, cnode);
           if (dist > ldist) ldist = dist;
@@ -496,13 +507,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
               cut_g = qsearchpid * 2. - 1.;
               cut_h = qsearchpid * X;
             }
-            if (!scut) scut = (int)(b.score[r] * X);
+            if (!scut) scut = (int)(h.score * X);
           }
           ogi[nog] = i; ogd[nog] = (int)dist; ++nog;
         }
       }
       if (!failed) {
-        const float bandfactor = band_factor(tax, bfd, bfn, nbf);  // :667
+        const float bandfactor = band.factor();  // :667
         st.bf_max = st.bf_max < bandfactor ? bandfactor : st.bf_max;
         const float qdist_ex = qdist * bandfactor;  // :669
         float min_upper_dist = (float)INT_MAX;       // :670
@@ -524,16 +535,16 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
         for (uint32_t k = 0; k < nog; ++k) {  // :691-711
           const uint32_t i = ogi[k];
           const float dist = (float)ogd[k];
-          const uint32_t cnode = b.node[REC(i)];
+          const uint32_t cnode = hits[i].node;
           if (dist > min_upper_dist) continue;
           unode = d_lca(tax, cnode, unode);
           const uint32_t lca_root_dist = tax.depth[d_lca(tax, cnode, st.rtax)];
           if (lca_root_dist > st.lrd_min) continue;
           if (lca_root_dist < st.lrd_min) {
             st.lrd_min = lca_root_dist;
-            for (uint32_t j = 0; j < n; ++j) fl[j] &= (uint8_t)~kOutGroup;
+            for (uint32_t j = 0; j < n; ++j) hits[j].flags &= ~(uint32_t)kOutGroup;
           }
-          fl[i] |= kOutGroup;
+          hits[i].flags |= kOutGroup;
         }
         float ival = 0.f;  // :714-719
         if (unode != lnode && ldist < qdist) ival = (qdist - ldist) / (udist - ldist);
@@ -541,16 +552,17 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
         st.unode_g = d_lca(tax, st.unode_g, unode);               // :726
         st.lnode_g = d_lca(tax, st.lnode_g, lnode);               // :727
         bool more = false;
-        for (uint32_t j = 0; j < n; ++j) more |= (fl[j] & kQGroup) != 0;
+        for (uint32_t j = 0; j < n; ++j) more |= (hits[j].flags & kQGroup) != 0;
         st.phase = (more && st.lnode_g != kRoot) ? kPass1Select : kPass2Select;  // :729
       }
     } else if (st.phase == kPass2Wait) {  // ---- pass 2 for one anchor, :750-820 ----
       const uint32_t a = st.anchor;
-      const uint32_t ra = REC(a);
-      const double qpid_anchor = (double)qs[a] / L;
-      const double g = qpid_anchor * 2. - 1., h = qpid_anchor * X;
-      const double qpid_thresh = g < h ? h : g;
-      const float scut = b.score[ra] * X;  // :754 (float here)
+      const HitRow ha = hits[a];
+      float qd_a = ha.qd, qs_a = ha.qs;
+      const double qpid_anchor = (double)qs_a / L;
+      const double g = qpid_anchor * 2. - 1., h2 = qpid_anchor * X;
+      const double qpid_thresh = g < h2 ? h2 : g;
+      const float scut = ha.score * X;  // :754 (float here)
       // the (anchor, query) pair, if emitted, sits in the first slot
       float2 qres = make_float2(0.f, 0.f);
       bool have_q = false;
@@ -560,10 +572,12 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
         ++cur.slot;
       }
       const uint32_t qslot = slot0;
-      for (uint32_t i = 0; i < n && b.score[REC(i)] >= scut; ++i) {  // :757
-        const double qpid = (double)qs[i] / L;
+      for (uint32_t i = 0; i < n; ++i) {  // :757
+        const HitRow h = hits[i];
+        if (!(h.score >= scut)) break;
+        const double qpid = (double)(i == a ? qs_a : h.qs) / L;
         if (!(qpid >= qpid_thresh)) continue;
-        const uint32_t cnode = b.node[REC(i)];
+        const uint32_t cnode = h.node;
         float dist;
         if (i == a) dist = 0.f;
         else {
@@ -573,20 +587,21 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
           if (!seg_ok(w, s, sa, sb, res.x)) { failed = true; break; }
           dist = res.x;
           ++st.cnt2;
-          qd[i] = dist;  // :785
+          hits[i].qd = dist;  // :785
         }
-        if (dist == 0.f) fl[i] &= (uint8_t)~kOutGroup;  // :789
+        if (dist == 0.f) hits[i].flags = h.flags & ~(uint32_t)kOutGroup;  // :789
         else {
           float qdist_ex;
-          if (qd[a] == FLT_MAX) {  // :792-808
+          if (qd_a == FLT_MAX) {  // :792-808
             if (!have_q) { raise_error(w, kErrInvalid, s); failed = true; break; }
             if (!seg_ok(w, s, w.pair_a[qslot], w.pair_b[qslot], qres.x)) { failed = true; break; }
             const float d2 = qres.x;
-            const float s2 = qres.y < qs[a] ? qs[a] : qres.y;
-            qd[a] = d2; qs[a] = s2;
+            const float s2 = qres.y < qs_a ? qs_a : qres.y;
+            qd_a = d2; qs_a = s2;
+            hits[a].qd = d2; hits[a].qs = s2;
             qdist_ex = d2 * st.bf_max;
             ++st.cnt2;
-          } else qdist_ex = qd[a] * st.bf_max;  // :809
+          } else qdist_ex = qd_a * st.bf_max;  // :809
           if (dist <= qdist_ex) st.unode_g = d_lca(tax, st.unode_g, cnode);  // :811-813
         }
       }
@@ -596,14 +611,15 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
     // ---- choose what to align next ----
     if (!failed && st.phase == kPass1Select) {  // :582-583
       uint32_t a = 0;
-      while (a < n && !(fl[a] & kQGroup)) ++a;
-      fl[a] &= (uint8_t)~kQGroup;
+      while (a < n && !(hits[a].flags & kQGroup)) ++a;
+      hits[a].flags &= ~(uint32_t)kQGroup;
       st.anchor = a; st.phase = kPass1Wait; em.mode = 2; em.anchor = a;
     } else if (!failed && st.phase == kPass2Select) {  // :739-747
       bool found = false;
       for (uint32_t a = 0; a < n; ++a) {
-        if (!(fl[a] & kOutGroup)) continue;
-        fl[a] &= (uint8_t)~kOutGroup;
+        const uint32_t f = hits[a].flags;
+        if (!(f & kOutGroup)) continue;
+        hits[a].flags = f & ~(uint32_t)kOutGroup;
         if (st.unode_g == st.lca_all) continue;
         st.anchor = a; st.phase = kPass2Wait; em.mode = 3; em.anchor = a; found = true;
         break;
@@ -622,7 +638,6 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
     }
     if (failed) st.phase = kDone;
     if (st.phase != kDone) atomicAdd(&w.counters[kCtrActive], 1u);
-#undef REC
   }
   emit_pairs(b, w, tax, p, st, s, live, em);
   if (live) w.state[s] = st;

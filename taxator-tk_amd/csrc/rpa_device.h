@@ -13,7 +13,7 @@ constexpr int kShortWords = 8;       // per-lane Myers kernel: pattern <= 8*32 =
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel: pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr int kNumBins = kShortWords + kLongMaxWPL;  // bins 0..7: short, words = bin+1 ; bins 8..15: long, words per lane = bin-7
 constexpr uint32_t kMaxPattern = 64u * kLongMaxWPL * 32u;
-constexpr int kMaxDepth = 31;         // deepest taxonomy level the placement kernel's rank table holds (NCBI pruned: 8)
+constexpr int kMaxDepth = 15;         // deepest taxonomy level the placement kernel's per-rank LDS tables hold (NCBI pruned: 8)
 
 // error codes mirror include/taxator_rpa.h
 enum { kOk = 0, kErrInvalid = 1, kErrDevice = 2, kErrRange = 3, kErrSeqId = 4, kErrAssert = 5, kErrUnsupported = 6 };
@@ -66,14 +66,23 @@ struct SetState {
   uint32_t n_emitted;  // pairs emitted for the round in flight
 };
 
+// One hit of a record set at its SortFilter position: everything the per-set threads read per hit, contiguous (32 B).
+struct HitRow {
+  float score;       // getScore()
+  uint32_t ident;    // getIdentities()
+  uint32_t alnlen;   // getAlignmentLength()
+  uint32_t node;     // getReferenceNode()
+  uint32_t rec;      // record index in the batch = segment id of the hit's reference segment
+  float qd;          // querydistance[i]
+  float qs;          // querysimilarity[i]
+  uint32_t flags;    // bit0 member of qgroup, bit1 member of outgroup
+};
+
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
 struct WorkDev {
   SetState* state;      // S
-  uint32_t* rec_set;    // H   record -> set
-  uint32_t* order;      // H   sorted position (set_off+i) -> record index
-  float* qd;            // H   querydistance  (sorted position)
-  float* qs;            // H   querysimilarity
-  uint8_t* flags;       // H   bit0 qgroup, bit1 outgroup
+  HitRow* hits;         // H   hits of set s at [set_off[s], set_off[s]+n) in sorted order
+  uint4* set_info;      // S   (n active, qrstart, qrstop, -)
   // segments: id r in [0,H) = reference segment of record r, id H+s = query range of set s
   uint32_t* seg_len;    // T   residues (0 if never planned)
   uint32_t* seg_cap16;  // T   slot size in 16-byte units
@@ -90,8 +99,6 @@ struct WorkDev {
   uint32_t* bin_list;   // kNumBins * T2
   uint32_t* counters;   // kNumCounters words, layout below
   // pass-1 scratch (per set region like the pair slots)
-  float* bf_dist;       // T
-  uint32_t* bf_node;    // T
   uint32_t* og_idx;     // T
   int32_t* og_dist;     // T
   uint32_t T;    // number of segments
@@ -117,9 +124,10 @@ hipError_t launch_exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_
                                      uint32_t* total_out);
 size_t scan_workspace_elems(uint32_t n);
 
-hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w);
-hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
-                            const StoreDev& db, const Params& p, void* out_rows, void* out_stats);
+hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const StoreDev& q, const StoreDev& db,
+                               const Params& p);
+hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
+                            void* out_rows, void* out_stats);
 hipError_t launch_materialize(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& q, const StoreDev& db);
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc);

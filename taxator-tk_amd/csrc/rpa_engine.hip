@@ -60,8 +60,8 @@ struct rpa_engine {
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8;
-  DevBuf state, rec_set, order, qd, qs, flags, seg_len, seg_cap16, seg_off16, seg_src, seg_info, arena, pair_a, pair_b, pair_i,
-      pair_res, pair_ext, bin_list, counters, bf_dist, bf_node, og_idx, og_dist, scan_ws, out_rows, out_stats, tmp_letters,
+  DevBuf state, hits, set_info, seg_len, seg_cap16, seg_off16, seg_src, seg_info, arena, pair_a, pair_b, pair_i,
+      pair_res, pair_ext, bin_list, counters, og_idx, og_dist, scan_ws, out_rows, out_stats, tmp_letters,
       tmp_words, tmp_offsets, protein_ws;
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
@@ -172,11 +172,8 @@ int profile_end(rpa_engine* e) {
 // Working-set allocation shared by predict and align_pairs.  T = segments, T2 = pair slots.
 int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, bool want_ext, WorkDev* w) {
   HIP_TRY(e, e->state.ensure((size_t)(S ? S : 1) * sizeof(SetState)));
-  HIP_TRY(e, e->rec_set.ensure((size_t)(H ? H : 1) * 4));
-  HIP_TRY(e, e->order.ensure((size_t)(H ? H : 1) * 4));
-  HIP_TRY(e, e->qd.ensure((size_t)(H ? H : 1) * 4));
-  HIP_TRY(e, e->qs.ensure((size_t)(H ? H : 1) * 4));
-  HIP_TRY(e, e->flags.ensure((size_t)(H ? H : 1)));
+  HIP_TRY(e, e->hits.ensure((size_t)(H ? H : 1) * sizeof(HitRow)));
+  HIP_TRY(e, e->set_info.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
   HIP_TRY(e, e->seg_len.ensure((size_t)(T ? T : 1) * 4));
   HIP_TRY(e, e->seg_cap16.ensure((size_t)(T ? T : 1) * 4));
   HIP_TRY(e, e->seg_off16.ensure((size_t)(T ? T : 1) * 4));
@@ -189,19 +186,16 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   if (want_ext) HIP_TRY(e, e->pair_ext.ensure((size_t)(T2 ? T2 : 1) * 16));
   HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * 4 * kNumBins));
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
-  HIP_TRY(e, e->bf_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
-  HIP_TRY(e, e->bf_node.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->scan_ws.ensure(scan_workspace_elems(T) * 4));
-  w->state = e->state.as<SetState>(); w->rec_set = e->rec_set.as<uint32_t>(); w->order = e->order.as<uint32_t>();
-  w->qd = e->qd.as<float>(); w->qs = e->qs.as<float>(); w->flags = e->flags.as<uint8_t>();
+  w->state = e->state.as<SetState>(); w->hits = e->hits.as<HitRow>(); w->set_info = e->set_info.as<uint4>();
   w->seg_len = e->seg_len.as<uint32_t>(); w->seg_cap16 = e->seg_cap16.as<uint32_t>(); w->seg_off16 = e->seg_off16.as<uint32_t>();
   w->seg_src = e->seg_src.as<uint64_t>(); w->seg_info = e->seg_info.as<uint8_t>(); w->arena = nullptr;
   w->pair_a = e->pair_a.as<uint32_t>(); w->pair_b = e->pair_b.as<uint32_t>(); w->pair_i = e->pair_i.as<uint32_t>();
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
   w->bin_list = e->bin_list.as<uint32_t>(); w->counters = e->counters.as<uint32_t>();
-  w->bf_dist = e->bf_dist.as<float>(); w->bf_node = e->bf_node.as<uint32_t>(); w->og_idx = e->og_idx.as<uint32_t>();
+  w->og_idx = e->og_idx.as<uint32_t>();
   w->og_dist = e->og_dist.as<int32_t>();
   w->T = T; w->T2 = T2;
   return RPA_OK;
@@ -305,10 +299,10 @@ void rpa_destroy(rpa_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->in_f32, &e->in_u8, &e->state, &e->rec_set,
-                    &e->order, &e->qd, &e->qs, &e->flags, &e->seg_len, &e->seg_cap16, &e->seg_off16, &e->seg_src, &e->seg_info,
+  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->in_f32, &e->in_u8, &e->state, &e->hits,
+                    &e->set_info, &e->seg_len, &e->seg_cap16, &e->seg_off16, &e->seg_src, &e->seg_info,
                     &e->arena, &e->pair_a, &e->pair_b, &e->pair_i, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
-                    &e->bf_dist, &e->bf_node, &e->og_idx, &e->og_dist, &e->scan_ws, &e->out_rows, &e->out_stats, &e->tmp_letters,
+                    &e->og_idx, &e->og_dist, &e->scan_ws, &e->out_rows, &e->out_stats, &e->tmp_letters,
                     &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
@@ -435,8 +429,8 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
   HIP_TRY(e, hipMemsetAsync(w.seg_cap16, 0, (size_t)T * 4, e->stream));
   HIP_TRY(e, hipMemsetAsync(w.seg_info, 0, (size_t)T, e->stream));
   const StoreDev q = e->stores[RPA_STORE_QUERY].view(), db = e->stores[RPA_STORE_DB].view();
-  HIP_TRY(e, launch_rank_records(e->stream, b, w));
-  HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, q, db, e->params, rows_dev, stats_dev));
+  HIP_TRY(e, launch_rank_records(e->stream, b, w, q, db, e->params));
+  HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev));
   rc = build_arena(e, &w, q, db);
   if (rc) return rc;
   uint64_t rounds = 0;

@@ -186,19 +186,34 @@ __global__ __launch_bounds__(kBlock) void k_materialize(WorkDev w, StoreDev q, S
   uint32_t* __restrict__ dst = w.arena + (size_t)w.seg_off16[seg] * 4;
   const uint32_t n_words = w.seg_cap16[seg] * 4;  // whole slot, so the tail is zero-filled
   for (uint32_t wi = threadIdx.x & 31; wi < n_words; wi += 32) {
+    const uint32_t p0 = wi * PER;  // first residue of this output word
     uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const uint32_t p = wi * PER + k;
-      if (p < len) {
-        uint32_t c;
-        if (!rc) c = load_residue<BITS>(src_words, src + p);
-        else {
-          c = load_residue<BITS>(src_words, src + (len - 1 - p));
-          if (c < 4) c = 3 - c;
+    if (p0 < len) {
+      const uint32_t rem = len - p0;
+      if (!rc) {
+        // PER residues starting at source residue src+p0: two adjacent store words, funnel-shifted (v_alignbit)
+        const uint64_t g = src + p0;
+        const uint64_t widx = g / PER;
+        const uint32_t sh = (uint32_t)(g % PER) * BITS;
+        out = __builtin_amdgcn_alignbit(src_words[widx + 1], src_words[widx], sh);  // the store has slack words at its end
+      } else if (BITS == 4) {
+        // output residue p <- complement of source residue src+len-1-p: fetch the 8 source nibbles [gs, gs+7] that end
+        // at src+len-1-p0, reverse the nibble order, complement (A<->T, C<->G, N stays)
+        const int64_t gs = (int64_t)(src + len - 1 - p0) - 7;
+        uint32_t x;
+        if (gs >= 0) {
+          const uint64_t widx = (uint64_t)gs / 8;
+          const uint32_t sh = (uint32_t)((uint64_t)gs % 8) * 4;
+          x = __builtin_amdgcn_alignbit(src_words[widx + 1], src_words[widx], sh);
+        } else {  // within 7 residues of the very start of the store: shift the first word up instead
+          x = src_words[0] << (uint32_t)(-gs * 4);
         }
-        out |= c << (BITS * k);
+        x = __builtin_bswap32(x);
+        x = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);
+        const uint32_t lt4 = (~x >> 2) & 0x11111111u;  // 1 per nibble whose code is < 4
+        out = x ^ (lt4 * 3u);
       }
+      if (rem < (uint32_t)PER) out &= (1u << (rem * BITS)) - 1u;  // zero the slot tail
     }
     dst[wi] = out;
   }

@@ -203,3 +203,41 @@ def test_segment_fetch_rules(oracle):
     assert rc == 1                                              # start beyond the sequence: range error
     rc, s = st.segment(1, 0, 6, 3)
     assert rc == 3                                              # protein + reverse coordinates: live assert (:864)
+
+
+def test_bandfactor_sort_free_formulation(oracle, golden_dir):
+    """The device computes BandFactor from per-rank (min, max) distances instead of sorting (place_kernels.hip);
+    this is that formulation in numpy against the oracle's sorted walk, bit for bit."""
+    ds = R.Dataset(os.path.join(golden_dir, "survey_edge"), 0)
+    tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    depth = ds.tax.depth
+    rng = np.random.default_rng(1)
+
+    def sort_free(dist, node):
+        anchor = int(node[0])
+        ra = int(depth[anchor])
+        fmin = np.full(ra + 1, np.float32(np.finfo(np.float32).max), np.float32)
+        dmax = np.full(ra + 1, np.float32(-1), np.float32)
+        for d, nd in zip(dist[1:], node[1:]):
+            r = int(depth[tax.lca(int(nd), anchor)])
+            fmin[r] = min(fmin[r], d)
+            dmax[r] = max(dmax[r], d)
+        bf = np.float32(1)
+        remembered, lowmin = [], np.float32(np.finfo(np.float32).max)
+        for r in range(ra):
+            if fmin[r] < lowmin:
+                remembered.append(r)
+                lowmin = fmin[r]
+        dsuf = dmax[ra]
+        for r in range(ra - 1, -1, -1):
+            if r in remembered and fmin[r] != 0 and dsuf >= 0:
+                bf = max(bf, np.float32(dsuf) / np.float32(fmin[r]))
+            dsuf = max(dsuf, dmax[r])
+        return np.sqrt(np.float32(bf))
+
+    for _ in range(4000):
+        n = int(rng.integers(1, 25))
+        node = rng.integers(0, len(depth), n)
+        dist = (rng.integers(0, 7, n).astype(np.float32) * np.float32(rng.choice([1.0, 0.37, 2.5]))).astype(np.float32)
+        dist[0] = 0
+        assert np.float32(tax.bandfactor(dist, node)).tobytes() == np.float32(sort_free(dist, node)).tobytes()
