@@ -51,7 +51,7 @@ __device__ __forceinline__ void profile_add(unsigned long long* acc, bool active
   if (threadIdx.x < 3) {
     unsigned long long s = 0;
     for (int k = 0; k < kBlock / 64; ++k) s += red[threadIdx.x][k];
-    atomicAdd(&acc[threadIdx.x], s);
+    atomicAdd(&acc[(blockIdx.x & (kProfParts - 1)) * 4 + threadIdx.x], s);  // partitioned: same-address atomics serialise
   }
 }
 
@@ -62,12 +62,12 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restri
   const int tid = threadIdx.x;
   const uint32_t t = blockIdx.x * kBlock + tid;
   const bool active = t < n_list;
-  uint32_t slot = 0, m = 0, n = 0;
+  uint32_t dst = 0, m = 0, n = 0;
   const uint4* __restrict__ pat = nullptr;
   const uint4* __restrict__ txt = nullptr;
   if (active) {
-    slot = list[t];
-    uint32_t a = w.pair_a[slot], b = w.pair_b[slot];
+    uint32_t a, b;
+    resolve_pair(w, list[t], a, b, dst);
     uint32_t la = w.seg_len[a], lb = w.seg_len[b];
     if (la < lb) { uint32_t x = a; a = b; b = x; x = la; la = lb; lb = x; }  // a = long (text), b = short (pattern), :144-147
     n = la; m = lb;
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restri
     }
   }
   // distance, similarity = matches = len_short - (d - lendiff) = len_long - d   (:154-164)
-  w.pair_res[slot] = make_float2((float)dist, (float)((int32_t)n - dist));
-  if (w.pair_ext) w.pair_ext[slot] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);  // match+mismatch = m, + gap = n
+  w.pair_res[dst] = make_float2((float)dist, (float)((int32_t)n - dist));
+  if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);  // match+mismatch = m, + gap = n
 }
 
 hipError_t launch_align_dna_short(hipStream_t st, int words, const uint32_t* list, uint32_t n, const WorkDev& w,
@@ -197,15 +197,16 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint32_t* __restrict__ 
   const uint32_t t = blockIdx.x;
   if (t >= n_list) return;
   const int lane = threadIdx.x;
-  const uint32_t slot = list[t];
-  uint32_t a = w.pair_a[slot], b = w.pair_b[slot];
+  uint32_t a, b, dst;
+  resolve_pair(w, list[t], a, b, dst);
   uint32_t la = w.seg_len[a], lb = w.seg_len[b];
   if (la < lb) { uint32_t x = a; a = b; b = x; x = la; la = lb; lb = x; }
   const uint32_t n = la, m = lb;
   if (prof_acc && lane == 0) {
-    atomicAdd(&prof_acc[0], 1ull);
-    atomicAdd(&prof_acc[1], (unsigned long long)la + lb + 8ull);
-    atomicAdd(&prof_acc[2], (unsigned long long)la * lb);
+    unsigned long long* acc = prof_acc + (blockIdx.x & (kProfParts - 1)) * 4;
+    atomicAdd(&acc[0], 1ull);
+    atomicAdd(&acc[1], (unsigned long long)la + lb + 8ull);
+    atomicAdd(&acc[2], (unsigned long long)la * lb);
   }
   const uint32_t* __restrict__ txt = w.arena + (size_t)w.seg_off16[a] * 4;
   const uint32_t txt_words = w.seg_cap16[a] * 4;
@@ -273,8 +274,8 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint32_t* __restrict__ 
   }
   dist = __shfl(dist, (int)(last_word / WPL), 64);  // the lane that owns the last word holds the distance
   if (lane == 0) {
-    w.pair_res[slot] = make_float2((float)dist, (float)((int32_t)n - dist));
-    if (w.pair_ext) w.pair_ext[slot] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
+    w.pair_res[dst] = make_float2((float)dist, (float)((int32_t)n - dist));
+    if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
   }
 }
 

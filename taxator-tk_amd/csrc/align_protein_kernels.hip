@@ -65,12 +65,12 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint32_t* __restric
 
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   const bool active = t < n_list;
-  uint32_t slot = 0, la = 0, lb = 0;
+  uint32_t dst = 0, la = 0, lb = 0;
   const uint8_t* __restrict__ pa = nullptr;
   const uint8_t* __restrict__ pb = nullptr;
   if (active) {
-    slot = list[t];
-    const uint32_t sa = w.pair_a[slot], sb = w.pair_b[slot];
+    uint32_t sa, sb;
+    resolve_pair(w, list[t], sa, sb, dst);
     la = w.seg_len[sa]; lb = w.seg_len[sb];
     pa = reinterpret_cast<const uint8_t*>(w.arena + (size_t)w.seg_off16[sa] * 4);
     pb = reinterpret_cast<const uint8_t*>(w.arena + (size_t)w.seg_off16[sb] * 4);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint32_t* __restric
     if (threadIdx.x < 3) {
       unsigned long long s = 0;
       for (int k = 0; k < kBlock / 64; ++k) s += red[threadIdx.x][k];
-      atomicAdd(&prof_acc[threadIdx.x], s);
+      atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * 4 + threadIdx.x], s);
     }
   }
   if (!active) return;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint32_t* __restric
   float distance = (float)(selfscore - 2 * mutual) * normfactor;      // :232
   const float similarity = (float)(2 * mutual) * normfactor;          // :233
   if (!(selfscore >= mutual) || !(distance >= 0.f)) distance = __builtin_nanf("");  // live asserts :205,:240 -> flagged, raised if consumed
-  w.pair_res[slot] = make_float2(distance, similarity);
-  if (w.pair_ext) w.pair_ext[slot] = make_uint4(nmatch, mismatch, gap, len);
+  w.pair_res[dst] = make_float2(distance, similarity);
+  if (w.pair_ext) w.pair_ext[dst] = make_uint4(nmatch, mismatch, gap, len);
 }
 
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len) {

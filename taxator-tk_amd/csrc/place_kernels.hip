@@ -11,8 +11,17 @@
 // its early exits, so an alignment that was computed speculatively but that the reference would not have reached is
 // neither read nor counted -- and (2) emits the pairs the next loop may need (a superset: everything the loop could
 // reach given what is known before it starts).  Between rounds all emitted pairs of all record sets are aligned by
-// the batched kernels of align_*_kernels.hip.  One thread per set keeps the data-dependent control flow out of the
-// wave-parallel alignment kernels; the work here is O(n) scalar logic plus <= 8-step LCA walks per set and round.
+// the batched kernels of align_*_kernels.hip.
+//
+// Memory shape (this is what makes a thread-per-set kernel viable on a GPU): a set's hits are ONE contiguous array of
+// fixed-size rows in SortFilter order; a row carries everything the loops read per hit, including the hit's taxon
+// PATH (its ancestors at depth 1..P from the flattened parent-pointer taxonomy, copied once per hit from a
+// per-node table).  Every node predict() ever forms -- rtax, lnode, unode, lca_allnodes and their global versions -- is
+// an LCA that includes the best reference's taxon, i.e. a point on the best hit's root path, so the state machine
+// keeps DEPTHS on that path instead of nodes, and every getLCA / isParentOf of the reference becomes
+//     common(x, i) = length of the common prefix of two paths,   LCA(point d on x's path, node_i) = min(d, common(x, i)),
+// pure register arithmetic with no dependent walks over the taxonomy arrays.  Alignment results come back in a per-hit
+// array parallel to the rows, so a round reads ~72 contiguous bytes per hit.
 //
 // Float discipline (bit-exact decisions): f32 distances/similarities/scores, f64 percent identities, int truncations
 // exactly where the reference has them (:592,602,659,661); compiled with -ffp-contract=off and IEEE divide/sqrt.
@@ -32,7 +41,6 @@ struct OutStats {  // = rpa_stats
   uint32_t n, pass0, pass1, pass2;
 };
 constexpr uint32_t kFlagIvalUntouched = 1u, kFlagShortcut = 2u, kFlagSingle = 4u;
-constexpr uint32_t kQGroup = 1, kOutGroup = 2;
 
 __device__ __forceinline__ bool rec_filtered(const BatchDev& b, uint32_t r) { return b.filtered && b.filtered[r]; }
 
@@ -40,14 +48,62 @@ __device__ __forceinline__ void raise_error(const WorkDev& w, uint32_t code, uin
   if (atomicCAS(&w.counters[kCtrErr], 0u, code) == 0u) w.counters[kCtrErrSet] = set;
 }
 
+// ---- hit rows -------------------------------------------------------------------------------------------------
+template <int P4>
+__device__ __forceinline__ const uint4* hit_ptr(const WorkDev& w, uint32_t pos) {
+  return reinterpret_cast<const uint4*>(w.hits) + (size_t)pos * (2 + P4);
+}
+__device__ __forceinline__ HitCore load_core(const uint4* p) {
+  const uint4 a = p[0], b = p[1];
+  HitCore c;
+  c.score = __uint_as_float(a.x); c.ident = a.y; c.node = a.z; c.rec = a.w;
+  c.qd = __uint_as_float(b.x); c.qs = __uint_as_float(b.y); c.seglen = b.z; c.meta = b.w;
+  return c;
+}
+template <int P4>
+__device__ __forceinline__ void load_path(const uint4* p, uint32_t (&path)[4 * P4]) {
+#pragma unroll
+  for (int k = 0; k < P4; ++k) {
+    const uint4 v = p[2 + k];
+    path[4 * k] = v.x; path[4 * k + 1] = v.y; path[4 * k + 2] = v.z; path[4 * k + 3] = v.w;
+  }
+}
+// mutable fields of a row (qd, qs, meta) live in its second 16-byte half
+__device__ __forceinline__ void store_dyn(const WorkDev& w, int stride4, uint32_t pos, float qd, float qs, uint32_t seglen, uint32_t meta) {
+  reinterpret_cast<uint4*>(w.hits)[(size_t)pos * stride4 + 1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), seglen, meta);
+}
+__device__ __forceinline__ uint32_t meta_depth(uint32_t meta) { return (meta >> kMetaDepthShift) & 0xFFu; }
+__device__ __forceinline__ uint32_t meta_err(uint32_t meta) { return (meta >> kMetaErrShift) & 0xFu; }
+
+// length of the common prefix of two root paths = depth of the LCA of the two nodes
+template <int P4>
+__device__ __forceinline__ uint32_t common(const uint32_t (&a)[4 * P4], uint32_t da, const uint32_t (&b)[4 * P4], uint32_t db) {
+  uint32_t c = 0;
+  bool run = true;
+#pragma unroll
+  for (int d = 0; d < 4 * P4; ++d) {
+    run = run && (a[d] == b[d]);
+    c += run ? 1u : 0u;
+  }
+  return min(c, min(da, db));
+}
+template <int P4>
+__device__ __forceinline__ uint32_t node_at(const uint32_t (&path)[4 * P4], uint32_t depth) {  // point `depth` on a path
+  uint32_t v = kRoot;
+#pragma unroll
+  for (int d = 0; d < 4 * P4; ++d)
+    if ((uint32_t)d + 1 == depth) v = path[d];
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Segment planning (a7).  store.getSequence(id, start, stop): stop clipped to the sequence length, start beyond it is
 // a range error (sequencestorage.hh:341-362); getSequenceDNA (:870-880): forward [rstart-left_ext, rstop+right_ext]
 // with the start floored at 1; reverse (rstart > rstop) [rstop-right_ext, rstart+left_ext] reverse-complemented.
-// Protein with reverse coordinates trips a live assert in the reference (:864).
+// Protein with reverse coordinates trips a live assert in the reference (:864).  Returns (length, error code).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void plan_segment(const WorkDev& w, uint32_t seg, const StoreDev& store, bool from_query,
-                                             uint32_t seq, uint32_t start, uint32_t stop, bool rc, int bits) {
+__device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, const StoreDev& store, bool from_query,
+                                              uint32_t seq, uint32_t start, uint32_t stop, bool rc, int bits) {
   uint32_t err = 0, len = 0;
   uint64_t src = 0;
   if (seq >= store.n_seqs) err = kErrSeqId;
@@ -66,17 +122,19 @@ __device__ __forceinline__ void plan_segment(const WorkDev& w, uint32_t seg, con
   w.seg_cap16[seg] = (len + per16 - 1) / per16;
   w.seg_src[seg] = src;
   w.seg_info[seg] = (uint8_t)((rc ? 1u : 0u) | (from_query ? 2u : 0u) | (err << 4));
+  return make_uint2(len, err);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // Rank + gather: one thread per record.  It scans the records of its own set once (neighbouring lanes read the same
 // few cache lines) to get (a) its position in SortFilter order (score desc, identities desc, input order on full ties
 // = what a stable list::sort gives) among the unmasked records, and (b) the set's n / query range (:391-404).  It
-// then writes its HitRow at that sorted position -- from here on a set's hits are one contiguous 32-byte-per-hit
-// array that the per-set threads walk sequentially -- and plans its own reference segment; the thread of a set's
-// first record also plans the query-range segment and writes the set header.
+// plans its own reference segment, then writes its row -- core fields plus the taxon path copied from the per-node
+// ancestor table -- at the sorted position.  The thread of a set's first record also plans the query-range segment
+// and writes the set header.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, StoreDev qstore, StoreDev dbstore, Params p) {
+template <int P4>
+__global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, TaxDev tax, StoreDev qstore, StoreDev dbstore, Params p) {
   const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
   if (r >= b.n_records) return;
   uint32_t lo = 0, hi = b.n_sets;  // largest s with set_offsets[s] <= r  (empty sets share an offset: take the last one)
@@ -85,6 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     if (b.set_offsets[mid] <= r) lo = mid; else hi = mid;
   }
   const uint32_t s = lo;
+  w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
   const uint32_t beg = b.set_offsets[s], end = b.set_offsets[s + 1];
   const bool me_filtered = rec_filtered(b, r);
   const float sc = b.score[r];
@@ -102,32 +161,37 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   }
   const int bits = p.alphabet == 0 ? 4 : 8;
   if (r == beg) {
+    uint2 qp = make_uint2(0u, 0u);
+    if (n >= 2) qp = plan_segment(w, b.n_records + s, qstore, true, b.query_seq[s], qrstart, qrstop, false, bits);  // :415
     w.set_info[s] = make_uint4(n, qrstart, qrstop, 0u);
-    if (n >= 2) plan_segment(w, b.n_records + s, qstore, true, b.query_seq[s], qrstart, qrstop, false, bits);  // :415
+    w.set_qseg[s] = qp;
   }
   if (me_filtered) return;
-  HitRow h;
-  h.score = sc; h.ident = id; h.alnlen = b.alnlen[r]; h.node = b.node[r]; h.rec = r;
-  h.qd = FLT_MAX; h.qs = 0.f; h.flags = 0;  // :475-476
-  if (n == 1) { h.qd = __uint_as_float(b.qstart[r]); h.qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
-  w.hits[beg + rank] = h;
-  if (n < 2) return;
-  const uint32_t left_ext = b.qstart[r] - qrstart, right_ext = qrstop - b.qstop[r];  // :523
-  const uint32_t start = b.rstart[r], stop = b.rstop[r];
-  if (start <= stop) {
-    plan_segment(w, r, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false, bits);
-  } else if (p.alphabet != 0) {
-    w.seg_len[r] = 0; w.seg_cap16[r] = 0; w.seg_src[r] = 0; w.seg_info[r] = (uint8_t)(kErrAssert << 4);
-  } else {
-    plan_segment(w, r, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true, bits);
+  uint2 sp = make_uint2(0u, 0u);
+  if (n >= 2) {
+    const uint32_t left_ext = b.qstart[r] - qrstart, right_ext = qrstop - b.qstop[r];  // :523
+    const uint32_t start = b.rstart[r], stop = b.rstop[r];
+    if (start <= stop) {
+      sp = plan_segment(w, r, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false, bits);
+    } else if (p.alphabet != 0) {
+      w.seg_len[r] = 0; w.seg_cap16[r] = 0; w.seg_src[r] = 0; w.seg_info[r] = (uint8_t)(kErrAssert << 4);
+      sp = make_uint2(0u, (uint32_t)kErrAssert);
+    } else {
+      sp = plan_segment(w, r, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true, bits);
+    }
   }
-}
-
-hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const StoreDev& q, const StoreDev& db,
-                               const Params& p) {
-  if (b.n_records == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_rank_records, dim3((b.n_records + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, w, q, db, p);
-  return hipGetLastError();
+  const uint32_t node = b.node[r];
+  const uint32_t L = qrstop - qrstart + 1;
+  const bool perfect = b.alnlen[r] == L && id == L;  // :431,511
+  const uint32_t meta = (perfect ? kMetaPerfect : 0u) | (sp.y << kMetaErrShift) | ((uint32_t)tax.depth[node] << kMetaDepthShift);
+  float qd = FLT_MAX, qs = 0.f;  // :475-476
+  if (n == 1) { qd = __uint_as_float(b.qstart[r]); qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
+  uint4* row = reinterpret_cast<uint4*>(w.hits) + (size_t)(beg + rank) * (2 + P4);
+  row[0] = make_uint4(__float_as_uint(sc), id, node, r);
+  row[1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta);
+  const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
+#pragma unroll
+  for (int k = 0; k < P4; ++k) row[2 + k] = anc[k];
 }
 
 // Pair emission bookkeeping: a thread first counts what it will emit per bin, reserves list space with one atomic
@@ -155,97 +219,99 @@ __device__ __forceinline__ void wave_max_to(uint32_t* counter, uint32_t v) {
   if ((threadIdx.x & 63) == 0 && v) atomicMax(counter, v);
 }
 
-struct Emit {  // what a set wants aligned next
-  uint32_t mode;   // 0 nothing, 1 pass 0, 2 pass 1 (anchor), 3 pass 2 (anchor)
-  uint32_t anchor;
-};
-
-// Enumerate the pairs of an emission in loop order; F(i_or_tag, segA, segB) is called for each.
-template <typename F>
-__device__ __forceinline__ void for_each_pair(const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
-                                              const SetState& st, uint32_t s, const Emit& em, F&& f) {
-  const HitRow* __restrict__ hits = w.hits + b.set_offsets[s];
-  const uint32_t n = st.n;
-  const uint32_t qseg = b.n_records + s;
-  if (em.mode == 1) {  // pass 0: every non-perfect hit within the re-evaluation band against the query range (:511-534)
-    const float thr = p.reeval_factor * hits[0].score;
-    for (uint32_t i = 0; i < n; ++i) {
-      const HitRow h = hits[i];
-      if (h.alnlen == st.L && h.ident == st.L) continue;
-      if (h.score >= thr) f(i, h.rec, qseg);
-    }
-  } else if (em.mode == 2) {  // pass 1: everything the anchor loop can reach (:604-638)
-    const uint32_t ra = hits[em.anchor].rec;
-    for (uint32_t i = 0; i < n; ++i) {
-      if (i == em.anchor || hits[i].qd == 0.f) continue;
-      f(i, hits[i].rec, ra);
-    }
-  } else if (em.mode == 3) {  // pass 2 (:750-797)
-    const uint32_t a = em.anchor;
-    const HitRow ha = hits[a];
-    if (ha.qd == FLT_MAX) f(kQueryTag, ha.rec, qseg);
-    const double qpid_anchor = (double)ha.qs / st.L;
-    const double g = qpid_anchor * 2. - 1., h = qpid_anchor * p.exclude_factor;
-    const double qpid_thresh = g < h ? h : g;
-    const float scut = ha.score * p.exclude_factor;
-    for (uint32_t i = 0; i < n; ++i) {
-      const HitRow hi = hits[i];
-      if (!(hi.score >= scut)) break;
-      if (i == a) continue;
-      if (!((double)hi.qs / st.L >= qpid_thresh)) continue;
-      if (d_is_parent_of(tax, st.unode_g, hi.node) || hi.node == st.unode_g) continue;
-      f(i, hi.rec, ha.rec);
-    }
-  }
-}
-
-__device__ __forceinline__ int pair_bin(const WorkDev& w, const Params& p, uint32_t sa, uint32_t sb) {
-  const uint32_t la = w.seg_len[sa], lb = w.seg_len[sb];
-  const uint32_t m = la < lb ? la : lb;
-  if (p.alphabet == 0) return dna_bin(m);
+__device__ __forceinline__ int pair_bin(const Params& p, uint32_t la, uint32_t lb) {
+  if (p.alphabet == 0) return dna_bin(la < lb ? la : lb);
   return 0;  // protein: one kernel, one bin
 }
 
-// Convergent tail of plan/decide: reserve list space and write the pairs.  `live` lanes have something to emit.
-__device__ __forceinline__ void emit_pairs(const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
-                                           SetState& st, uint32_t s, bool live, const Emit& em) {
-  uint32_t cnt[kNumBins];
-#pragma unroll
-  for (int k = 0; k < kNumBins; ++k) cnt[k] = 0;
-  uint32_t bad = 0, maxlen = 0;
-  if (live && em.mode) {
-    for_each_pair(b, w, tax, p, st, s, em, [&](uint32_t, uint32_t sa, uint32_t sb) {
-      const int bin = pair_bin(w, p, sa, sb);
-      maxlen = max(maxlen, w.seg_len[sa]);
-      if (bin >= kNumBins) { bad = 1; return; }
-#pragma unroll
-      for (int k = 0; k < kNumBins; ++k) cnt[k] += (k == bin) ? 1u : 0u;
-    });
+// ------------------------------------------------------------------------------------------------------------
+// Emit: one thread per hit row (+ one per record set for the anchor<->query alignment of pass 2).  Each thread
+// evaluates, for its own hit, the predicate "the loop the set is about to run can reach the alignment of this hit"
+// from the set's EmitInfo (written by plan/decide) and its row, and the active ones are stream-compacted per length
+// bin into the work lists of the alignment kernels: ballot + one atomic per wave and bin, consecutive lanes write
+// consecutive list entries.  Rows and lists are contiguous, so all of this is coalesced -- emission used to be
+// the slow half of the per-set kernel when each set's thread wrote its own pair records.
+// A list entry is a row position (< H) or H + s; the alignment kernels derive the two segments from it.
+//   pass 0 (:511-534): hit not perfect and score >= reeval threshold           -> (segment_i, query range)
+//   pass 1 (:604-638): i != anchor and querydistance[i] != 0                  -> (segment_i, segment_anchor)
+//   pass 2 (:757-778): i != anchor, score >= cut-off, qpid >= threshold and unode_global not cnode-or-above
+//                      -> (segment_i, segment_anchor);  anchor never aligned to the query (:792) -> (segment_anchor, query range)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kEmitBlock = 1024;  // one list reservation (atomic) per bin per 1024 rows: same-address atomics are ~11 ns each
+
+template <int P4>
+__global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Params p) {
+  __shared__ uint32_t s_cnt[kNumBins][kEmitBlock / 64];  // per bin, per wave: number of active lanes
+  __shared__ uint32_t s_base[kNumBins];
+  __shared__ uint32_t s_maxlen[kEmitBlock / 64];
+  const uint32_t pos = blockIdx.x * kEmitBlock + threadIdx.x;
+  const uint32_t H = b.n_records;
+  int bin = -1;
+  uint32_t maxlen = 0;
+  if (pos < H + b.n_sets) {
+    const bool is_query_pair = pos >= H;
+    const uint32_t s = is_query_pair ? pos - H : w.hit_set[pos];
+    const EmitInfo info = w.emit[s];
+    if (info.mode != 0) {
+      const uint32_t lo = b.set_offsets[s];
+      if (is_query_pair) {
+        if (info.mode == 3) {
+          const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor));
+          if (ha.qd == FLT_MAX) { bin = pair_bin(p, ha.seglen, info.qseglen); maxlen = ha.seglen; }
+        }
+      } else {
+        const uint32_t i = pos - lo;
+        if (i < info.n) {
+          const uint4* pi = hit_ptr<P4>(w, pos);
+          const HitCore h = load_core(pi);
+          uint32_t other_len = info.qseglen;
+          bool want = false;
+          if (info.mode == 1) want = !(h.meta & kMetaPerfect) && h.score >= info.fcut;
+          else if (i != info.anchor) {
+            if (info.mode == 2) want = h.qd != 0.f;
+            else if (h.score >= info.fcut && (double)h.qs / info.L >= info.qpid_thresh) {
+              uint32_t pb[4 * P4], pth[4 * P4];
+              const uint4* pbp = hit_ptr<P4>(w, lo + info.best);
+              load_path<P4>(pbp, pb);
+              load_path<P4>(pi, pth);
+              want = !(common<P4>(pb, meta_depth(load_core(pbp).meta), pth, meta_depth(h.meta)) >= info.d_unode_g);
+            }
+            if (want) other_len = load_core(hit_ptr<P4>(w, lo + info.anchor)).seglen;
+          }
+          if (want) {
+            bin = pair_bin(p, h.seglen, other_len);
+            maxlen = h.seglen;
+            if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = -1; }
+          }
+        }
+      }
+    }
   }
-  if (bad) raise_error(w, kErrUnsupported, s);
-  wave_max_to(&w.counters[kCtrMaxLen], maxlen);
-  uint32_t base[kNumBins];
+  // block-level compaction: wave ballots -> LDS -> one atomic per non-empty bin per block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long my_mask = 0ull;
 #pragma unroll
   for (int k = 0; k < kNumBins; ++k) {
-    // skip the wave-wide scan for bins nobody in the wave uses
-    const bool any = __any(cnt[k] != 0);
-    base[k] = any ? wave_reserve(&w.counters[k], cnt[k]) : 0u;
+    const unsigned long long mask = __ballot(bin == k);
+    if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(mask);
+    if (bin == k) my_mask = mask;
   }
-  if (live && em.mode && !bad) {
-    const uint32_t slot0 = b.set_offsets[s] + s;
-    uint32_t k_slot = 0;
-    for_each_pair(b, w, tax, p, st, s, em, [&](uint32_t i, uint32_t sa, uint32_t sb) {
-      const uint32_t slot = slot0 + k_slot++;
-      w.pair_a[slot] = sa;
-      w.pair_b[slot] = sb;
-      w.pair_i[slot] = i;
-      const int bin = pair_bin(w, p, sa, sb);
 #pragma unroll
-      for (int k = 0; k < kNumBins; ++k)
-        if (k == bin) w.bin_list[(size_t)k * w.T2 + base[k]++] = slot;
-    });
-    st.n_emitted = k_slot;
-  } else if (live) st.n_emitted = 0;
+  for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor(maxlen, d, 64));
+  if (lane == 0) s_maxlen[wave] = maxlen;
+  __syncthreads();
+  if (threadIdx.x < kNumBins) {  // thread k: exclusive prefix over the waves of bin k, then reserve
+    uint32_t run = 0;
+    for (int wv = 0; wv < kEmitBlock / 64; ++wv) { const uint32_t c = s_cnt[threadIdx.x][wv]; s_cnt[threadIdx.x][wv] = run; run += c; }
+    s_base[threadIdx.x] = run ? atomicAdd(&w.counters[threadIdx.x], run) : 0u;
+  } else if (threadIdx.x == 64) {
+    uint32_t m = 0;
+    for (int wv = 0; wv < kEmitBlock / 64; ++wv) m = max(m, s_maxlen[wv]);
+    if (m) atomicMax(&w.counters[kCtrMaxLen], m);
+  }
+  __syncthreads();
+  if (bin >= 0)
+    w.bin_list[(size_t)bin * w.T2 + s_base[bin] + s_cnt[bin][wave] + (uint32_t)__popcll(my_mask & ((1ull << lane) - 1ull))] = pos;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -253,22 +319,25 @@ __device__ __forceinline__ void emit_pairs(const BatchDev& b, const WorkDev& w, 
 // n == 1, perfect-best-hit shortcut; otherwise emits pass 0.  (Masking, query range, sorting and segment plans were
 // done per record by k_rank_records.)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
+template <int P4>
+__global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Params p, OutRow* __restrict__ rows,
                                                        OutStats* __restrict__ stats) {
   const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
   const bool live = s < b.n_sets;
   SetState st;
   st.phase = kDone;
-  Emit em{0, 0};
+  EmitInfo em{};
+  em.mode = 0;
   if (live) {
     const uint32_t lo = b.set_offsets[s], hi = b.set_offsets[s + 1];
     uint4 info = make_uint4(0u, 0u, 0u, 0u);
-    if (hi > lo) info = w.set_info[s];
+    uint2 qseg = make_uint2(0u, 0u);
+    if (hi > lo) { info = w.set_info[s]; qseg = w.set_qseg[s]; }
     const uint32_t n = info.x, qrstart = info.y, qrstop = info.z;
-    const HitRow* __restrict__ hits = w.hits + lo;
     st.n = n; st.qrstart = qrstart; st.qrstop = qrstop; st.L = qrstop - qrstart + 1;
-    st.support = 0; st.lca_all = kRoot; st.rtax = kRoot; st.lnode_g = st.unode_g = kRoot; st.ival_g = 0.f; st.bf_max = 1.f;
-    st.lrd_min = 255; st.anchor = 0; st.cnt0 = st.cnt1 = st.cnt2 = 0; st.n_emitted = 0;
+    st.qseglen = qseg.x; st.qsegerr = qseg.y;
+    st.support = 0; st.best = 0; st.d_lca_all = 0; st.d_rtax = 0; st.d_lnode_g = 0; st.d_unode_g = 0; st.ival_g = 0.f;
+    st.bf_max = 1.f; st.lrd_min = 255; st.anchor = 0; st.cnt0 = st.cnt1 = st.cnt2 = 0;
     OutRow row;
     row.begin = 1; row.end = b.query_len[s];  // initPredictionRecord, core/src/taxonpredictionmodel.hh:42-44
     row.lower = row.upper = row.rtax = kRoot; row.support = 0; row.ival = 0.f; row.flags = 0;
@@ -276,34 +345,50 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
     if (n == 0) {  // :359-368
       row.flags = kFlagIvalUntouched;
     } else if (n == 1) {  // :371-388
-      const HitRow h = hits[0];
+      const HitCore h = load_core(hit_ptr<P4>(w, lo));
       row.begin = __float_as_uint(h.qd); row.end = __float_as_uint(h.qs); row.ival = 1.f;
       row.lower = h.node; row.upper = kRoot; row.support = h.ident; row.rtax = h.node;
       row.flags = kFlagSingle;
     } else {
-      const HitRow h0 = hits[0];
-      const uint32_t L = st.L;
-      if (h0.alnlen == L && h0.ident == L) {  // :431-472
+      const uint4* p0 = hit_ptr<P4>(w, lo);
+      const HitCore h0 = load_core(p0);
+      if (h0.meta & kMetaPerfect) {  // :431-472: lnode / unode are points on hit 0's path
+        uint32_t path0[4 * P4];
+        load_path<P4>(p0, path0);
+        const uint32_t d0 = meta_depth(h0.meta);
         const float best = h0.score;
-        uint32_t lnode = h0.node, unode = kRoot;
+        uint32_t d_l = d0, d_u = 0;
         uint32_t i = 1;
         for (;;) {
-          if (i == n) { unode = kRoot; break; }
-          const float sc = hits[i].score;
-          if (sc == best) lnode = d_lca(tax, lnode, hits[i].node);
+          if (i == n) { d_u = 0; break; }  // unode = root
+          const uint4* pi = hit_ptr<P4>(w, lo + i);
+          HitCore hi2 = load_core(pi);
+          uint32_t pth[4 * P4];
+          load_path<P4>(pi, pth);
+          if (hi2.score == best) d_l = min(d_l, common<P4>(path0, d0, pth, meta_depth(hi2.meta)));
           else {
-            unode = lnode;
-            do { unode = d_lca(tax, unode, hits[i].node); } while (++i < n && hits[i].score == sc);
+            const float sc = hi2.score;
+            d_u = d_l;
+            for (;;) {
+              d_u = min(d_u, common<P4>(path0, d0, pth, meta_depth(hi2.meta)));
+              if (++i >= n) break;
+              pi = hit_ptr<P4>(w, lo + i);
+              hi2 = load_core(pi);
+              if (!(hi2.score == sc)) break;
+              load_path<P4>(pi, pth);
+            }
             break;
           }
           ++i;
         }
         row.begin = qrstart; row.end = qrstop; row.ival = 0.f;
-        row.lower = lnode; row.upper = unode; row.support = L; row.rtax = lnode; row.flags = kFlagShortcut;
+        row.lower = node_at<P4>(path0, d_l); row.upper = node_at<P4>(path0, d_u); row.support = st.L; row.rtax = row.lower;
+        row.flags = kFlagShortcut;
       } else {
         done = false;
         st.phase = kPass0Wait;
-        em.mode = 1;
+        em.mode = 1; em.n = n; em.L = st.L; em.qseglen = st.qseglen;
+        em.fcut = p.reeval_factor * h0.score;  // dbalignment_searchscore_threshold, :499
       }
     }
     if (done) {
@@ -312,17 +397,9 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
     } else {
       atomicAdd(&w.counters[kCtrActive], 1u);
     }
+    w.emit[s] = em;
+    w.state[s] = st;
   }
-  emit_pairs(b, w, tax, p, st, s, live, em);
-  if (live) w.state[s] = st;
-}
-
-hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
-                            void* out_rows, void* out_stats) {
-  if (b.n_sets == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_plan_sets, dim3((b.n_sets + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, w, tax, p,
-                     (OutRow*)out_rows, (OutStats*)out_stats);
-  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -371,31 +448,19 @@ struct BandAcc {
   }
 };
 
-// ------------------------------------------------------------------------------------------------------------
-// Decide: one thread per record set, one call per round.
-// ------------------------------------------------------------------------------------------------------------
-struct ResultCursor {  // walks this set's pair slots in emission order
-  const WorkDev& w;
-  uint32_t slot, end;
-  __device__ bool find(uint32_t i, float2& out, uint32_t& sa, uint32_t& sb) {
-    while (slot < end && w.pair_i[slot] != i) ++slot;
-    if (slot >= end) return false;
-    out = w.pair_res[slot]; sa = w.pair_a[slot]; sb = w.pair_b[slot];
-    ++slot;
-    return true;
-  }
-};
-
-// A consumed alignment must come from two readable segments, and (protein) must not have tripped the reference's
-// asserts selfscore >= mutual / distance >= 0 (:205,:240), which the kernel flags by a NaN distance.
-__device__ __forceinline__ bool seg_ok(const WorkDev& w, uint32_t s, uint32_t sa, uint32_t sb, float dist) {
-  const uint32_t e = (w.seg_info[sa] >> 4) | (w.seg_info[sb] >> 4);
-  if (e) { raise_error(w, (w.seg_info[sa] >> 4) ? (w.seg_info[sa] >> 4) : (w.seg_info[sb] >> 4), s); return false; }
+// A consumed alignment must come from readable segments, and (protein) must not have tripped the reference's asserts
+// selfscore >= mutual / distance >= 0 (:205,:240), which the kernel flags by a NaN distance.
+__device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t err_a, uint32_t err_b, float dist) {
+  if (err_a | err_b) { raise_error(w, err_a ? err_a : err_b, s); return false; }
   if (dist != dist) { raise_error(w, kErrAssert, s); return false; }
   return true;
 }
 
-__global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
+// ------------------------------------------------------------------------------------------------------------
+// Decide: one thread per record set, one call per round.
+// ------------------------------------------------------------------------------------------------------------
+template <int P4>
+__global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params p, OutRow* __restrict__ rows,
                                                     OutStats* __restrict__ stats, unsigned long long* prof_acc) {
   __shared__ float s_fmin[kMaxDepth + 1][kBlock];
   __shared__ float s_dmax[kMaxDepth + 1][kBlock];
@@ -405,81 +470,106 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
   st.phase = kDone;
   if (live) st = w.state[s];
   live = live && st.phase != kDone;
-  Emit em{0, 0};
   if (live) {
+    EmitInfo em{};
+    em.mode = 0; em.n = st.n; em.L = st.L; em.qseglen = st.qseglen;
     const uint32_t lo = b.set_offsets[s];
     const uint32_t n = st.n, L = st.L;
-    const uint32_t slot0 = lo + s;
-    HitRow* __restrict__ hits = w.hits + lo;  // this set's hits in SortFilter order, 32 B each, contiguous
+    constexpr int kStride4 = 2 + P4;
     const float X = p.exclude_factor;
-    ResultCursor cur{w, slot0, slot0 + st.n_emitted};
+    const float2* __restrict__ res = w.pair_res + lo;                  // res[i]: result of the alignment asked for hit i
+    const float2* __restrict__ qres_p = w.pair_res + b.n_records + s;  // result of the anchor <-> query alignment
     bool failed = false;
 
     if (st.phase == kPass0Wait) {  // ---- pass 0, :497-566 ----
-      const float thr = p.reeval_factor * hits[0].score;  // :499
+      uint32_t path0[4 * P4];
+      const uint4* p0 = hit_ptr<P4>(w, lo);
+      const HitCore h0 = load_core(p0);
+      load_path<P4>(p0, path0);
+      const uint32_t d0 = meta_depth(h0.meta);
+      const float thr = p.reeval_factor * h0.score;  // :499
       uint32_t index_best = 0;
       float best_d = 0.f, best_s = 0.f, best_sc = 0.f;
       uint32_t support = 0;
-      uint32_t lca_all = hits[0].node;
+      uint32_t d_all = d0;  // lca_allnodes as a point on hit 0's path (:495)
       for (uint32_t i = 0; i < n; ++i) {
-        const HitRow h = hits[i];
+        const uint4* pi = hit_ptr<P4>(w, lo + i);
+        const HitCore h = load_core(pi);
         float dist, sim;
         uint32_t flag = 0;
-        if (h.alnlen == L && h.ident == L) {  // :511-517
-          flag = kQGroup; dist = 0.f; sim = (float)h.ident;
+        if (h.meta & kMetaPerfect) {  // :511-517
+          flag = kMetaQGroup; dist = 0.f; sim = (float)h.ident;
         } else if (h.score >= thr) {  // :518-534
-          flag = kQGroup;
-          float2 res; uint32_t sa, sb;
-          if (!cur.find(i, res, sa, sb)) { raise_error(w, kErrInvalid, s); failed = true; break; }
-          if (!seg_ok(w, s, sa, sb, res.x)) { failed = true; break; }
-          dist = res.x;
+          flag = kMetaQGroup;
+          const float2 r2 = res[i];
+          if (!result_ok(w, s, meta_err(h.meta), st.qsegerr, r2.x)) { failed = true; break; }
+          dist = r2.x;
           ++st.cnt0;
           const float idf = (float)h.ident;
-          sim = res.y < idf ? idf : res.y;  // std::max(similarity, identities), :531
+          sim = r2.y < idf ? idf : r2.y;  // std::max(similarity, identities), :531
         } else {
           dist = FLT_MAX; sim = (float)h.ident;
         }
-        hits[i].qd = dist; hits[i].qs = sim; hits[i].flags = flag;
+        store_dyn(w, kStride4, lo + i, dist, sim, h.seglen, (h.meta & ~(kMetaQGroup | kMetaOutGroup)) | flag);
         if (i == 0) { best_d = dist; best_s = sim; best_sc = h.score; }  // index_best starts at 0 (:500)
         else if (dist < best_d) { index_best = i; best_d = dist; best_s = sim; best_sc = h.score; }  // :542-546
         else if (dist == best_d) {
           if (sim > best_s) { index_best = i; best_s = sim; best_sc = h.score; }
           else if (sim == best_s && h.score > best_sc) { index_best = i; best_sc = h.score; }
         }
-        support = max(support, (uint32_t)sim);     // :547
-        lca_all = d_lca(tax, lca_all, h.node);      // :548
+        support = max(support, (uint32_t)sim);  // :547
+        uint32_t pth[4 * P4];
+        load_path<P4>(pi, pth);
+        d_all = min(d_all, common<P4>(path0, d0, pth, meta_depth(h.meta)));  // :548
       }
       if (!failed) {
-        uint32_t rtax = hits[index_best].node;
+        uint32_t pb[4 * P4];
+        const uint4* pbp = hit_ptr<P4>(w, lo + index_best);
+        load_path<P4>(pbp, pb);
+        const uint32_t db = meta_depth(load_core(pbp).meta);
+        uint32_t d_rtax = db;  // rtax = node[index_best] (:553), then LCA with every member that stays in qgroup
         bool any = false;
         for (uint32_t i = 0; i < n; ++i) {  // :554-562
-          const HitRow h = hits[i];
-          if (!(h.flags & kQGroup)) continue;
-          if (h.qd != best_d || h.qs != best_s || h.score != best_sc) hits[i].flags = 0;
-          else { rtax = d_lca(tax, rtax, h.node); any = true; }
+          const uint4* pi = hit_ptr<P4>(w, lo + i);
+          const HitCore h = load_core(pi);
+          if (!(h.meta & kMetaQGroup)) continue;
+          if (h.qd != best_d || h.qs != best_s || h.score != best_sc) store_dyn(w, kStride4, lo + i, h.qd, h.qs, h.seglen, h.meta & ~kMetaQGroup);
+          else {
+            uint32_t pth[4 * P4];
+            load_path<P4>(pi, pth);
+            d_rtax = min(d_rtax, common<P4>(pb, db, pth, meta_depth(h.meta)));
+            any = true;
+          }
         }
         if (!any) { raise_error(w, kErrAssert, s); failed = true; }  // assert(!qgroup.empty()), :563
-        st.support = support; st.lca_all = lca_all; st.rtax = rtax;
-        st.ival_g = 0.f; st.lnode_g = st.unode_g = rtax; st.bf_max = 1.f; st.lrd_min = 255;  // :569-579
+        st.support = support; st.best = index_best; st.d_lca_all = d_all; st.d_rtax = d_rtax;
+        st.ival_g = 0.f; st.d_lnode_g = st.d_unode_g = d_rtax; st.bf_max = 1.f; st.lrd_min = 255;  // :569-579
         st.phase = kPass1Select;
       }
     } else if (st.phase == kPass1Wait) {  // ---- pass 1 for one anchor, :580-728 ----
       const uint32_t a = st.anchor;
-      const float qdist = hits[a].qd;
-      const uint32_t rnode = hits[a].node;
-      uint32_t* __restrict__ ogi = w.og_idx + slot0;
-      int32_t* __restrict__ ogd = w.og_dist + slot0;
+      uint32_t pa[4 * P4], pb[4 * P4];
+      const uint4* pap = hit_ptr<P4>(w, lo + a);
+      const HitCore ha = load_core(pap);
+      load_path<P4>(pap, pa);
+      const uint32_t da = meta_depth(ha.meta);
+      const uint4* pbp = hit_ptr<P4>(w, lo + st.best);
+      load_path<P4>(pbp, pb);
+      const uint32_t db = meta_depth(load_core(pbp).meta);
+      const float qdist = ha.qd;
+      uint32_t* __restrict__ ogi = w.og_idx + lo;
+      int32_t* __restrict__ ogd = w.og_dist + lo;
       uint32_t nog = 0;
       BandAcc band{&s_fmin[0][threadIdx.x], &s_dmax[0][threadIdx.x], 0};
-      band.reset(tax.depth[rnode]);  // BandFactor(...); addSequence(0, rnode) (:581,586): the anchor entry only sets the start rank
-      uint32_t lnode = st.rtax;
+      band.reset(da);  // BandFactor(...); addSequence(0, rnode) (:581,586): the anchor entry only sets the start rank
+      uint32_t d_lnode = st.d_rtax;  // lnode = rtax (:587), a point on the best hit's path
       float ldist = 0.f, udist = FLT_MAX;
       double qpid_upper = 0., cut_g = 0., cut_h = 0.;  // :599-601
       int scut = 0;                                     // :602 (int!)
-      for (uint32_t i = 0; lnode != kRoot && i < n; ++i) {  // :604
-        const HitRow h = hits[i];
+      for (uint32_t i = 0; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
+        const uint4* pi = hit_ptr<P4>(w, lo + i);
+        const HitCore h = load_core(pi);
         if (!(h.score >= (float)scut)) break;
-        const uint32_t cnode = h.node;
         const double qsearchpid = (double)h.ident / L;
         const double qpid = (double)h.qs / L;
         const double qpid_thresh = cut_g < cut_h ? cut_h : cut_g;
@@ -488,16 +578,18 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
         if (i == a) dist = 0.f;
         else if (h.qd == 0.f) dist = qdist;  // :620-621
         else {
-          float2 res; uint32_t sa, sb;
-          if (!cur.find(i, res, sa, sb)) { raise_error(w, kErrInvalid, s); failed = true; break; }
-          if (!seg_ok(w, s, sa, sb, res.x)) { failed = true; break; }
-          dist = res.x;
+          const float2 r2 = res[i];
+          if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
+          dist = r2.x;
           ++st.cnt1;
         }
-        band.add(dist, tax.depth[d_lca(tax, cnode, rnode)]);  // :641
-        if (dist == 0.f) hits[i].flags = h.flags & ~(uint32_t)kQGroup;  // :644
+        uint32_t pth[4 * P4];
+        load_path<P4>(pi, pth);
+        const uint32_t dh = meta_depth(h.meta);
+        band.add(dist, common<P4>(pa, da, pth, dh));  // :641
+        if (dist == 0.f) store_dyn(w, kStride4, lo + i, h.qd, h.qs, h.seglen, h.meta & ~kMetaQGroup);  // :644
         else if (dist <= qdist) {  // :646-650
-          lnode = d_lca(tax, lnode, cnode);
+          d_lnode = min(d_lnode, common<P4>(pb, db, pth, dh));
           if (dist > ldist) ldist = dist;
         } else {  // :651-662
           if (dist < udist) {
@@ -531,78 +623,86 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
           if (kept) { ogi[keep] = ogi[k]; ogd[keep] = ogd[k]; ++keep; }
         }
         nog = keep;
-        uint32_t unode = lnode;  // :690 -- (float)INT_MAX != FLT_MAX, so always taken
+        uint32_t d_unode = d_lnode;  // unode = lnode, :690 -- (float)INT_MAX != FLT_MAX, so always taken
         for (uint32_t k = 0; k < nog; ++k) {  // :691-711
           const uint32_t i = ogi[k];
           const float dist = (float)ogd[k];
-          const uint32_t cnode = hits[i].node;
           if (dist > min_upper_dist) continue;
-          unode = d_lca(tax, cnode, unode);
-          const uint32_t lca_root_dist = tax.depth[d_lca(tax, cnode, st.rtax)];
+          const uint4* pi = hit_ptr<P4>(w, lo + i);
+          const HitCore h = load_core(pi);
+          uint32_t pth[4 * P4];
+          load_path<P4>(pi, pth);
+          const uint32_t cb = common<P4>(pb, db, pth, meta_depth(h.meta));
+          d_unode = min(d_unode, cb);                          // unode = LCA(cnode, unode)
+          const uint32_t lca_root_dist = min(st.d_rtax, cb);   // depth(LCA(cnode, rtax))
           if (lca_root_dist > st.lrd_min) continue;
           if (lca_root_dist < st.lrd_min) {
             st.lrd_min = lca_root_dist;
-            for (uint32_t j = 0; j < n; ++j) hits[j].flags &= ~(uint32_t)kOutGroup;
+            for (uint32_t j = 0; j < n; ++j) {  // outgroup.clear()
+              const HitCore hj = load_core(hit_ptr<P4>(w, lo + j));
+              if (hj.meta & kMetaOutGroup) store_dyn(w, kStride4, lo + j, hj.qd, hj.qs, hj.seglen, hj.meta & ~kMetaOutGroup);
+            }
           }
-          hits[i].flags |= kOutGroup;
+          const HitCore hn = load_core(pi);  // re-read: the clear above may have touched this row
+          store_dyn(w, kStride4, lo + i, hn.qd, hn.qs, hn.seglen, hn.meta | kMetaOutGroup);
         }
         float ival = 0.f;  // :714-719
-        if (unode != lnode && ldist < qdist) ival = (qdist - ldist) / (udist - ldist);
-        st.ival_g = st.ival_g < ival ? ival : st.ival_g;          // :724
-        st.unode_g = d_lca(tax, st.unode_g, unode);               // :726
-        st.lnode_g = d_lca(tax, st.lnode_g, lnode);               // :727
+        if (d_unode != d_lnode && ldist < qdist) ival = (qdist - ldist) / (udist - ldist);
+        st.ival_g = st.ival_g < ival ? ival : st.ival_g;   // :724
+        st.d_unode_g = min(st.d_unode_g, d_unode);         // :726
+        st.d_lnode_g = min(st.d_lnode_g, d_lnode);         // :727
         bool more = false;
-        for (uint32_t j = 0; j < n; ++j) more |= (hits[j].flags & kQGroup) != 0;
-        st.phase = (more && st.lnode_g != kRoot) ? kPass1Select : kPass2Select;  // :729
+        for (uint32_t j = 0; j < n; ++j) more |= (load_core(hit_ptr<P4>(w, lo + j)).meta & kMetaQGroup) != 0;
+        st.phase = (more && st.d_lnode_g != 0) ? kPass1Select : kPass2Select;  // :729
       }
     } else if (st.phase == kPass2Wait) {  // ---- pass 2 for one anchor, :750-820 ----
       const uint32_t a = st.anchor;
-      const HitRow ha = hits[a];
+      const HitCore ha = load_core(hit_ptr<P4>(w, lo + a));
+      uint32_t pb[4 * P4];
+      const uint4* pbp = hit_ptr<P4>(w, lo + st.best);
+      load_path<P4>(pbp, pb);
+      const uint32_t db = meta_depth(load_core(pbp).meta);
       float qd_a = ha.qd, qs_a = ha.qs;
       const double qpid_anchor = (double)qs_a / L;
       const double g = qpid_anchor * 2. - 1., h2 = qpid_anchor * X;
       const double qpid_thresh = g < h2 ? h2 : g;
       const float scut = ha.score * X;  // :754 (float here)
-      // the (anchor, query) pair, if emitted, sits in the first slot
-      float2 qres = make_float2(0.f, 0.f);
-      bool have_q = false;
-      if (cur.slot < cur.end && w.pair_i[cur.slot] == kQueryTag) {
-        qres = w.pair_res[cur.slot];
-        have_q = true;
-        ++cur.slot;
-      }
-      const uint32_t qslot = slot0;
       for (uint32_t i = 0; i < n; ++i) {  // :757
-        const HitRow h = hits[i];
+        const uint4* pi = hit_ptr<P4>(w, lo + i);
+        const HitCore h = load_core(pi);
         if (!(h.score >= scut)) break;
         const double qpid = (double)(i == a ? qs_a : h.qs) / L;
         if (!(qpid >= qpid_thresh)) continue;
-        const uint32_t cnode = h.node;
+        uint32_t pth[4 * P4];
+        load_path<P4>(pi, pth);
+        const uint32_t cb = common<P4>(pb, db, pth, meta_depth(h.meta));
         float dist;
         if (i == a) dist = 0.f;
         else {
-          if (d_is_parent_of(tax, st.unode_g, cnode) || cnode == st.unode_g) continue;  // :771
-          float2 res; uint32_t sa, sb;
-          if (!cur.find(i, res, sa, sb)) { raise_error(w, kErrInvalid, s); failed = true; break; }
-          if (!seg_ok(w, s, sa, sb, res.x)) { failed = true; break; }
-          dist = res.x;
+          if (cb >= st.d_unode_g) continue;  // isParentOf(unode_global, cnode) || cnode == unode_global, :771
+          const float2 r2 = res[i];
+          if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
+          dist = r2.x;
           ++st.cnt2;
-          hits[i].qd = dist;  // :785
+          store_dyn(w, kStride4, lo + i, dist, h.qs, h.seglen, h.meta);  // querydistance[i] = dist, :785
         }
-        if (dist == 0.f) hits[i].flags = h.flags & ~(uint32_t)kOutGroup;  // :789
-        else {
+        if (dist == 0.f) {  // :789
+          const HitCore hn = load_core(pi);
+          store_dyn(w, kStride4, lo + i, hn.qd, hn.qs, hn.seglen, hn.meta & ~kMetaOutGroup);
+        } else {
           float qdist_ex;
           if (qd_a == FLT_MAX) {  // :792-808
-            if (!have_q) { raise_error(w, kErrInvalid, s); failed = true; break; }
-            if (!seg_ok(w, s, w.pair_a[qslot], w.pair_b[qslot], qres.x)) { failed = true; break; }
-            const float d2 = qres.x;
-            const float s2 = qres.y < qs_a ? qs_a : qres.y;
+            const float2 q2 = *qres_p;
+            if (!result_ok(w, s, meta_err(ha.meta), st.qsegerr, q2.x)) { failed = true; break; }
+            const float d2 = q2.x;
+            const float s2 = q2.y < qs_a ? qs_a : q2.y;
             qd_a = d2; qs_a = s2;
-            hits[a].qd = d2; hits[a].qs = s2;
+            const HitCore han = load_core(hit_ptr<P4>(w, lo + a));
+            store_dyn(w, kStride4, lo + a, d2, s2, han.seglen, han.meta);
             qdist_ex = d2 * st.bf_max;
             ++st.cnt2;
           } else qdist_ex = qd_a * st.bf_max;  // :809
-          if (dist <= qdist_ex) st.unode_g = d_lca(tax, st.unode_g, cnode);  // :811-813
+          if (dist <= qdist_ex) st.d_unode_g = min(st.d_unode_g, cb);  // unode_global = LCA(unode_global, cnode), :811-813
         }
       }
       if (!failed) st.phase = kPass2Select;
@@ -611,43 +711,86 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
     // ---- choose what to align next ----
     if (!failed && st.phase == kPass1Select) {  // :582-583
       uint32_t a = 0;
-      while (a < n && !(hits[a].flags & kQGroup)) ++a;
-      hits[a].flags &= ~(uint32_t)kQGroup;
+      HitCore h = load_core(hit_ptr<P4>(w, lo));
+      while (a + 1 < n && !(h.meta & kMetaQGroup)) { ++a; h = load_core(hit_ptr<P4>(w, lo + a)); }
+      store_dyn(w, kStride4, lo + a, h.qd, h.qs, h.seglen, h.meta & ~kMetaQGroup);
       st.anchor = a; st.phase = kPass1Wait; em.mode = 2; em.anchor = a;
     } else if (!failed && st.phase == kPass2Select) {  // :739-747
       bool found = false;
       for (uint32_t a = 0; a < n; ++a) {
-        const uint32_t f = hits[a].flags;
-        if (!(f & kOutGroup)) continue;
-        hits[a].flags = f & ~(uint32_t)kOutGroup;
-        if (st.unode_g == st.lca_all) continue;
-        st.anchor = a; st.phase = kPass2Wait; em.mode = 3; em.anchor = a; found = true;
+        const HitCore h = load_core(hit_ptr<P4>(w, lo + a));
+        if (!(h.meta & kMetaOutGroup)) continue;
+        store_dyn(w, kStride4, lo + a, h.qd, h.qs, h.seglen, h.meta & ~kMetaOutGroup);
+        if (st.d_unode_g == st.d_lca_all) continue;  // unode_global == lca_allnodes: both lie on the best hit's path
+        st.anchor = a; st.phase = kPass2Wait; found = true;
+        em.mode = 3; em.anchor = a; em.best = st.best; em.d_unode_g = st.d_unode_g;
+        em.fcut = h.score * X;                                   // qsearchscore_thresh_heuristic, :754
+        const double qpid_anchor = (double)h.qs / L;             // :750-753
+        const double g2 = qpid_anchor * 2. - 1., h3 = qpid_anchor * X;
+        em.qpid_thresh = g2 < h3 ? h3 : g2;
         break;
       }
       if (!found) {  // :824-833
-        if (st.unode_g == st.lnode_g) st.ival_g = 1.f;
+        if (st.d_unode_g == st.d_lnode_g) st.ival_g = 1.f;
+        uint32_t pb[4 * P4];
+        load_path<P4>(hit_ptr<P4>(w, lo + st.best), pb);
         OutRow row;
         row.begin = st.qrstart; row.end = st.qrstop; row.ival = st.ival_g;
-        row.lower = st.lnode_g; row.upper = st.unode_g; row.support = st.support; row.rtax = st.rtax; row.flags = 0;
+        row.lower = node_at<P4>(pb, st.d_lnode_g); row.upper = node_at<P4>(pb, st.d_unode_g); row.support = st.support;
+        row.rtax = node_at<P4>(pb, st.d_rtax); row.flags = 0;
         rows[s] = row;
         if (stats) stats[s] = OutStats{n, st.cnt0, st.cnt1, st.cnt2};
-        if (prof_acc) atomicAdd(&prof_acc[3], (unsigned long long)(st.cnt0 + st.cnt1 + st.cnt2));
-        if (!(row.lower == row.upper || d_is_parent_of(tax, row.upper, row.lower))) raise_error(w, kErrAssert, s);  // predictionrecord.hh:153
+        if (prof_acc) atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * 4 + 3], (unsigned long long)(st.cnt0 + st.cnt1 + st.cnt2));
+        if (st.d_unode_g > st.d_lnode_g) raise_error(w, kErrAssert, s);  // setNodeRange assert, predictionrecord.hh:153
         st.phase = kDone;
       }
     }
-    if (failed) st.phase = kDone;
+    if (failed) { st.phase = kDone; em.mode = 0; }
     if (st.phase != kDone) atomicAdd(&w.counters[kCtrActive], 1u);
+    w.emit[s] = em;
+    w.state[s] = st;
   }
-  emit_pairs(b, w, tax, p, st, s, live, em);
-  if (live) w.state[s] = st;
+}
+
+// ---- launchers: P4 = number of 16-byte quads of the taxon path = ceil(max depth / 4) ----
+#define RPA_DISPATCH_P4(P4V, CALL)                 \
+  switch (P4V) {                                   \
+    case 1: { constexpr int P4 = 1; CALL; } break; \
+    case 2: { constexpr int P4 = 2; CALL; } break; \
+    case 3: { constexpr int P4 = 3; CALL; } break; \
+    case 4: { constexpr int P4 = 4; CALL; } break; \
+    default: return hipErrorInvalidValue;          \
+  }
+
+hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
+                               const StoreDev& db, const Params& p) {
+  if (b.n_records == 0) return hipSuccess;
+  const dim3 grid((b.n_records + kBlock - 1) / kBlock);
+  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_rank_records<P4>, grid, dim3(kBlock), 0, st, b, w, tax, q, db, p));
+  return hipGetLastError();
+}
+
+hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
+                            void* out_rows, void* out_stats) {
+  if (b.n_sets == 0) return hipSuccess;
+  const dim3 grid((b.n_sets + kBlock - 1) / kBlock);
+  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_plan_sets<P4>, grid, dim3(kBlock), 0, st, b, w, p, (OutRow*)out_rows, (OutStats*)out_stats));
+  return hipGetLastError();
+}
+
+hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p) {
+  const uint32_t total = b.n_records + b.n_sets;
+  if (total == 0) return hipSuccess;
+  const dim3 grid((total + kEmitBlock - 1) / kEmitBlock);
+  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_emit<P4>, grid, dim3(kEmitBlock), 0, st, b, w, p));
+  return hipGetLastError();
 }
 
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc) {
   if (b.n_sets == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_decide, dim3((b.n_sets + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, w, tax, p, (OutRow*)out_rows,
-                     (OutStats*)out_stats, prof_acc);
+  const dim3 grid((b.n_sets + kBlock - 1) / kBlock);
+  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_decide<P4>, grid, dim3(kBlock), 0, st, b, w, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc));
   return hipGetLastError();
 }
 
@@ -681,8 +824,8 @@ __global__ __launch_bounds__(kBlock) void k_bin_pairs(WorkDev w, uint32_t n_pair
     const uint32_t sa = w.pair_a[t], sb = w.pair_b[t];
     if (sa >= w.T || sb >= w.T) raise_error(w, kErrSeqId, t);
     else {
-      bin = pair_bin(w, p, sa, sb);
       const uint32_t la = w.seg_len[sa], lb = w.seg_len[sb];
+      bin = pair_bin(p, la, lb);
       maxlen = la;
       if (bin >= kNumBins) { raise_error(w, kErrUnsupported, t); bin = -1; }
       else if (la == 0 || lb == 0) { raise_error(w, kErrRange, t); bin = -1; }

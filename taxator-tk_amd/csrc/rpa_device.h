@@ -8,11 +8,11 @@ namespace rpa {
 
 constexpr int kBlock = 256;          // 4 wave64 per workgroup everywhere
 constexpr uint32_t kRoot = 0;        // taxonomy node 0 is the root
-constexpr uint32_t kQueryTag = 0xFFFFFFFFu;  // pair_i value of an (anchor, query) pair
 constexpr int kShortWords = 8;       // per-lane Myers kernel: pattern <= 8*32 = 256 residues
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel: pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr int kNumBins = kShortWords + kLongMaxWPL;  // bins 0..7: short, words = bin+1 ; bins 8..15: long, words per lane = bin-7
 constexpr uint32_t kMaxPattern = 64u * kLongMaxWPL * 32u;
+constexpr int kProfParts = 64;        // profiling accumulators are split 64 ways (block index & 63) and summed on the host
 constexpr int kMaxDepth = 15;         // deepest taxonomy level the placement kernel's per-rank LDS tables hold (NCBI pruned: 8)
 
 // error codes mirror include/taxator_rpa.h
@@ -25,6 +25,10 @@ struct TaxDev {
   const uint32_t* right;
   const uint8_t* depth;
   uint32_t n_nodes;
+  // per-node ancestor table built at rpa_create: anc[node * 4*path_quads + (d-1)] = ancestor of node at depth d
+  // (d = 1 .. depth[node]; 0xFFFFFFFF beyond).  Copied into every hit row, so the placement kernels never walk `parent`.
+  const uint32_t* anc;
+  int path_quads;  // ceil(max depth / 4), 1..4
 };
 
 // Resident sequence store: residues packed little-endian into 32-bit words, 4 bit (DNA) or 8 bit (protein) each.
@@ -48,41 +52,63 @@ struct BatchDev {
 
 enum Phase : uint32_t { kDone = 0, kPass0Wait = 1, kPass1Wait = 2, kPass2Wait = 3, kPass1Select = 4, kPass2Select = 5 };
 
-// Per record-set state carried between rounds (one thread owns one set).
+// Per record-set state carried between rounds (one thread owns one set).  Taxon nodes are kept as DEPTHS on the
+// best hit's root path (see place_kernels.hip).
 struct SetState {
   uint32_t phase;
-  uint32_t n;        // active (unmasked) records
-  uint32_t L;        // qrlength
+  uint32_t n;          // active (unmasked) records
+  uint32_t L;          // qrlength
   uint32_t qrstart, qrstop;
-  uint32_t support;  // anchors_support
-  uint32_t lca_all;  // lca_allnodes
-  uint32_t rtax;
-  uint32_t lnode_g, unode_g;
+  uint32_t qseglen;    // length of the query range segment after clipping
+  uint32_t qsegerr;    // its fetch error code (0 = ok)
+  uint32_t support;    // anchors_support
+  uint32_t best;       // index_best of pass 0: the hit whose path the depths below refer to
+  uint32_t d_lca_all;  // lca_allnodes
+  uint32_t d_rtax;
+  uint32_t d_lnode_g, d_unode_g;
   float ival_g;
   float bf_max;
-  uint32_t lrd_min;  // lca_root_dist_min
+  uint32_t lrd_min;    // lca_root_dist_min
   uint32_t anchor;
   uint32_t cnt0, cnt1, cnt2;
-  uint32_t n_emitted;  // pairs emitted for the round in flight
 };
 
-// One hit of a record set at its SortFilter position: everything the per-set threads read per hit, contiguous (32 B).
-struct HitRow {
+// One hit of a record set at its SortFilter position: 32 bytes of fields + the taxon path (4*path_quads words),
+// i.e. 64 bytes per hit for taxonomies up to 8 levels deep.  Rows of a set are contiguous.
+struct HitCore {
   float score;       // getScore()
   uint32_t ident;    // getIdentities()
-  uint32_t alnlen;   // getAlignmentLength()
   uint32_t node;     // getReferenceNode()
   uint32_t rec;      // record index in the batch = segment id of the hit's reference segment
   float qd;          // querydistance[i]
   float qs;          // querysimilarity[i]
-  uint32_t flags;    // bit0 member of qgroup, bit1 member of outgroup
+  uint32_t seglen;   // length of the reference segment
+  uint32_t meta;     // kMeta* bits
+};
+constexpr uint32_t kMetaQGroup = 1u, kMetaOutGroup = 2u, kMetaPerfect = 4u;  // perfect: alnlen == L && identities == L
+constexpr int kMetaErrShift = 4, kMetaDepthShift = 8;                         // 4 bits segment error code, 8 bits node depth
+
+// What a record set wants aligned in the coming round (written by plan/decide, read by k_emit and the alignment kernels).
+struct EmitInfo {
+  uint32_t mode;        // 0 nothing, 1 pass 0 (vs query range), 2 pass 1 (vs anchor), 3 pass 2 (vs anchor)
+  uint32_t anchor;      // index_anchor
+  uint32_t n;           // active hits
+  uint32_t L;           // qrlength
+  float fcut;           // pass 0: re-evaluation score threshold (:499); pass 2: qsearchscore_thresh_heuristic (:754)
+  uint32_t d_unode_g;   // pass 2: depth of unode_global on the best hit's path
+  double qpid_thresh;   // pass 2 (:750-753)
+  uint32_t best;        // pass 2: index_best
+  uint32_t qseglen;     // length of the query range segment
 };
 
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
 struct WorkDev {
   SetState* state;      // S
-  HitRow* hits;         // H   hits of set s at [set_off[s], set_off[s]+n) in sorted order
+  uint32_t* hits;       // H rows of (8 + 4*path_quads) words; hits of set s at rows [set_off[s], set_off[s]+n), sorted
   uint4* set_info;      // S   (n active, qrstart, qrstop, -)
+  uint2* set_qseg;      // S   (query segment length, error code)
+  EmitInfo* emit;       // S
+  uint32_t* hit_set;    // H   row position -> record set
   // segments: id r in [0,H) = reference segment of record r, id H+s = query range of set s
   uint32_t* seg_len;    // T   residues (0 if never planned)
   uint32_t* seg_cap16;  // T   slot size in 16-byte units
@@ -90,17 +116,20 @@ struct WorkDev {
   uint64_t* seg_src;    // T   first source residue (global residue index in the store)
   uint8_t* seg_info;    // T   bit0 reverse-complement, bit1 from query store, bits 4-7 error code
   uint32_t* arena;      // packed segments
-  // pairs of the round in flight: slot region of set s = [set_off[s]+s, set_off[s+1]+s+1)
-  uint32_t* pair_a;     // T   segment id
-  uint32_t* pair_b;     // T
-  uint32_t* pair_i;     // T   hit index i the result belongs to (kQueryTag for anchor<->query)
-  float2* pair_res;     // T   (distance, similarity)
-  uint4* pair_ext;      // optional (rpa_align_pairs only): matches, mismatches, gaps, length
+  // explicit pairs (rpa_align_pairs only; null in rpa_predict_batch, where a work-list entry is a row position and
+  // the alignment kernels derive the segments from the row and the set's EmitInfo)
+  uint32_t* pair_a;     // T2  segment id
+  uint32_t* pair_b;     // T2
+  float2* pair_res;     // T   (distance, similarity); [set_off[s]+i] for hit i of set s, [H+s] for anchor<->query
+  uint4* pair_ext;      // optional (rpa_align_pairs only): matches, mismatches, gaps, length; indexed like pair_res
   uint32_t* bin_list;   // kNumBins * T2
   uint32_t* counters;   // kNumCounters words, layout below
   // pass-1 scratch (per set region like the pair slots)
   uint32_t* og_idx;     // T
   int32_t* og_dist;     // T
+  const uint32_t* set_offsets;  // S+1 (copy of the batch's, for the alignment kernels)
+  uint32_t H;    // n_records
+  int row_quads; // 2 + path_quads: 16-byte quads per hit row
   uint32_t T;    // number of segments
   uint32_t T2;   // number of pair slots = stride of each bin list
 };
@@ -124,11 +153,12 @@ hipError_t launch_exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_
                                      uint32_t* total_out);
 size_t scan_workspace_elems(uint32_t n);
 
-hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const StoreDev& q, const StoreDev& db,
-                               const Params& p);
+hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
+                               const StoreDev& db, const Params& p);
 hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                             void* out_rows, void* out_stats);
 hipError_t launch_materialize(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& q, const StoreDev& db);
+hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p);
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc);
 
@@ -145,6 +175,25 @@ hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint3
 hipError_t launch_align_protein(hipStream_t st, const uint32_t* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
+
+// Work-list entry -> (segment A, segment B, result index).  Order matters for protein (A is the horizontal sequence):
+// getAlignment(segments[i], qrseq) (:526), getAlignment(segments[i], segments[index_anchor]) (:630,778),
+// getAlignment(segments[index_anchor], qrseq) (:797).
+__device__ __forceinline__ void resolve_pair(const WorkDev& w, uint32_t entry, uint32_t& seg_a, uint32_t& seg_b, uint32_t& dst) {
+  dst = entry;
+  if (w.pair_a) { seg_a = w.pair_a[entry]; seg_b = w.pair_b[entry]; return; }
+  const uint4* rows = reinterpret_cast<const uint4*>(w.hits);
+  if (entry >= w.H) {  // anchor <-> query range
+    const uint32_t s = entry - w.H;
+    seg_a = rows[(size_t)(w.set_offsets[s] + w.emit[s].anchor) * w.row_quads].w;  // HitCore::rec
+    seg_b = entry;                                                                 // segment id of the query range = H + s
+    return;
+  }
+  const uint32_t s = w.hit_set[entry];
+  seg_a = rows[(size_t)entry * w.row_quads].w;
+  const uint32_t mode = w.emit[s].mode;
+  seg_b = mode == 1 ? w.H + s : rows[(size_t)(w.set_offsets[s] + w.emit[s].anchor) * w.row_quads].w;
+}
 
 // bin of a pair whose shorter sequence has m residues (DNA); kNumBins = too long
 __host__ __device__ __forceinline__ int dna_bin(uint32_t m) {

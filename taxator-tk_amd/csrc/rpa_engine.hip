@@ -54,13 +54,13 @@ struct rpa_engine {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   Params params{};
-  DevBuf tax_parent, tax_left, tax_right, tax_depth;
+  DevBuf tax_parent, tax_left, tax_right, tax_depth, tax_anc;
   TaxDev tax{};
   Store stores[2];
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8;
-  DevBuf state, hits, set_info, seg_len, seg_cap16, seg_off16, seg_src, seg_info, arena, pair_a, pair_b, pair_i,
+  DevBuf state, hits, set_info, set_qseg, emit, hit_set, seg_len, seg_cap16, seg_off16, seg_src, seg_info, arena, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, scan_ws, out_rows, out_stats, tmp_letters,
       tmp_words, tmp_offsets, protein_ws;
   uint32_t* h_counters = nullptr;  // pinned
@@ -163,8 +163,10 @@ int profile_end(rpa_engine* e) {
     HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_pool[pr.first], e->ev_pool[pr.second]));
     e->prof.align_ms += ms;
   }
-  unsigned long long acc[4];
-  HIP_TRY(e, hipMemcpy(acc, e->prof_acc.p, sizeof(acc), hipMemcpyDeviceToHost));
+  unsigned long long parts[kProfParts * 4], acc[4] = {0, 0, 0, 0};
+  HIP_TRY(e, hipMemcpy(parts, e->prof_acc.p, sizeof(parts), hipMemcpyDeviceToHost));
+  for (int k = 0; k < kProfParts; ++k)
+    for (int j = 0; j < 4; ++j) acc[j] += parts[k * 4 + j];
   e->prof.pairs = acc[0]; e->prof.residue_bytes = acc[1]; e->prof.cells = acc[2]; e->prof.demanded = acc[3];
   return RPA_OK;
 }
@@ -172,27 +174,34 @@ int profile_end(rpa_engine* e) {
 // Working-set allocation shared by predict and align_pairs.  T = segments, T2 = pair slots.
 int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, bool want_ext, WorkDev* w) {
   HIP_TRY(e, e->state.ensure((size_t)(S ? S : 1) * sizeof(SetState)));
-  HIP_TRY(e, e->hits.ensure((size_t)(H ? H : 1) * sizeof(HitRow)));
+  HIP_TRY(e, e->hits.ensure((size_t)(H ? H : 1) * (size_t)(2 + e->tax.path_quads) * 16));
   HIP_TRY(e, e->set_info.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
+  HIP_TRY(e, e->set_qseg.ensure((size_t)(S ? S : 1) * sizeof(uint2)));
+  HIP_TRY(e, e->emit.ensure((size_t)(S ? S : 1) * sizeof(EmitInfo)));
+  HIP_TRY(e, e->hit_set.ensure((size_t)(H ? H : 1) * 4));
   HIP_TRY(e, e->seg_len.ensure((size_t)(T ? T : 1) * 4));
   HIP_TRY(e, e->seg_cap16.ensure((size_t)(T ? T : 1) * 4));
   HIP_TRY(e, e->seg_off16.ensure((size_t)(T ? T : 1) * 4));
   HIP_TRY(e, e->seg_src.ensure((size_t)(T ? T : 1) * 8));
   HIP_TRY(e, e->seg_info.ensure((size_t)(T ? T : 1)));
-  HIP_TRY(e, e->pair_a.ensure((size_t)(T2 ? T2 : 1) * 4));
-  HIP_TRY(e, e->pair_b.ensure((size_t)(T2 ? T2 : 1) * 4));
-  HIP_TRY(e, e->pair_i.ensure((size_t)(T2 ? T2 : 1) * 4));
-  HIP_TRY(e, e->pair_res.ensure((size_t)(T2 ? T2 : 1) * 8));
-  if (want_ext) HIP_TRY(e, e->pair_ext.ensure((size_t)(T2 ? T2 : 1) * 16));
+  if (want_ext) {  // explicit pair arrays exist only for rpa_align_pairs
+    HIP_TRY(e, e->pair_a.ensure((size_t)(T2 ? T2 : 1) * 4));
+    HIP_TRY(e, e->pair_b.ensure((size_t)(T2 ? T2 : 1) * 4));
+  }
+  const size_t n_res = (size_t)(T > T2 ? T : T2) + 1;  // predict: one per hit + one per set; align_pairs: one per pair
+  HIP_TRY(e, e->pair_res.ensure(n_res * 8));
+  if (want_ext) HIP_TRY(e, e->pair_ext.ensure(n_res * 16));
   HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * 4 * kNumBins));
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->scan_ws.ensure(scan_workspace_elems(T) * 4));
-  w->state = e->state.as<SetState>(); w->hits = e->hits.as<HitRow>(); w->set_info = e->set_info.as<uint4>();
+  w->state = e->state.as<SetState>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
+  w->set_qseg = e->set_qseg.as<uint2>(); w->emit = e->emit.as<EmitInfo>(); w->hit_set = e->hit_set.as<uint32_t>();
   w->seg_len = e->seg_len.as<uint32_t>(); w->seg_cap16 = e->seg_cap16.as<uint32_t>(); w->seg_off16 = e->seg_off16.as<uint32_t>();
   w->seg_src = e->seg_src.as<uint64_t>(); w->seg_info = e->seg_info.as<uint8_t>(); w->arena = nullptr;
-  w->pair_a = e->pair_a.as<uint32_t>(); w->pair_b = e->pair_b.as<uint32_t>(); w->pair_i = e->pair_i.as<uint32_t>();
+  w->pair_a = want_ext ? e->pair_a.as<uint32_t>() : nullptr; w->pair_b = want_ext ? e->pair_b.as<uint32_t>() : nullptr;
+  w->set_offsets = nullptr; w->H = H; w->row_quads = 2 + e->tax.path_quads;
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
   w->bin_list = e->bin_list.as<uint32_t>(); w->counters = e->counters.as<uint32_t>();
   w->og_idx = e->og_idx.as<uint32_t>();
@@ -286,10 +295,29 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   CREATE_TRY(hipMemcpy(e->tax_left.p, tax->left, n * 4, hipMemcpyHostToDevice));
   CREATE_TRY(hipMemcpy(e->tax_right.p, tax->right, n * 4, hipMemcpyHostToDevice));
   CREATE_TRY(hipMemcpy(e->tax_depth.p, tax->depth, n, hipMemcpyHostToDevice));
+  // per-node ancestor table (taxon paths): walk the parent pointers once on the host
+  uint32_t max_depth = 1;
+  for (uint32_t i = 0; i < tax->n_nodes; ++i) max_depth = tax->depth[i] > max_depth ? tax->depth[i] : max_depth;
+  const int path_quads = (int)((max_depth + 3) / 4);
+  const size_t P = (size_t)path_quads * 4;
+  {
+    std::vector<uint32_t> anc(n * P, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < tax->n_nodes; ++i) {
+      uint32_t v = i;
+      for (uint32_t d = tax->depth[i]; d >= 1; --d) {
+        if (tax->depth[v] != d) { fail(e, RPA_ERR_INVALID, "rpa_create: depth of node %u is not depth(parent)+1", v); return bail(RPA_ERR_INVALID); }
+        anc[(size_t)i * P + (d - 1)] = v;
+        v = tax->parent[v];
+      }
+      if (v != 0) { fail(e, RPA_ERR_INVALID, "rpa_create: node %u does not descend from node 0", i); return bail(RPA_ERR_INVALID); }
+    }
+    CREATE_TRY(e->tax_anc.ensure(n * P * 4));
+    CREATE_TRY(hipMemcpy(e->tax_anc.p, anc.data(), n * P * 4, hipMemcpyHostToDevice));
+  }
   e->tax = TaxDev{e->tax_parent.as<const uint32_t>(), e->tax_left.as<const uint32_t>(), e->tax_right.as<const uint32_t>(),
-                  e->tax_depth.as<const uint8_t>(), tax->n_nodes};
-  CREATE_TRY(e->prof_acc.ensure(4 * sizeof(unsigned long long)));
-  CREATE_TRY(hipMemset(e->prof_acc.p, 0, 4 * sizeof(unsigned long long)));
+                  e->tax_depth.as<const uint8_t>(), tax->n_nodes, e->tax_anc.as<const uint32_t>(), path_quads};
+  CREATE_TRY(e->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long)));
+  CREATE_TRY(hipMemset(e->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
 #undef CREATE_TRY
   *out = e;
   return RPA_OK;
@@ -299,9 +327,9 @@ void rpa_destroy(rpa_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->in_f32, &e->in_u8, &e->state, &e->hits,
+  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->state, &e->hits,
                     &e->set_info, &e->seg_len, &e->seg_cap16, &e->seg_off16, &e->seg_src, &e->seg_info,
-                    &e->arena, &e->pair_a, &e->pair_b, &e->pair_i, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
+                    &e->arena, &e->pair_a, &e->pair_b, &e->emit, &e->hit_set, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->scan_ws, &e->out_rows, &e->out_stats, &e->tmp_letters,
                     &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc};
   for (DevBuf* b : bufs) b->release();
@@ -429,12 +457,15 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
   HIP_TRY(e, hipMemsetAsync(w.seg_cap16, 0, (size_t)T * 4, e->stream));
   HIP_TRY(e, hipMemsetAsync(w.seg_info, 0, (size_t)T, e->stream));
   const StoreDev q = e->stores[RPA_STORE_QUERY].view(), db = e->stores[RPA_STORE_DB].view();
-  HIP_TRY(e, launch_rank_records(e->stream, b, w, q, db, e->params));
+  w.set_offsets = b.set_offsets;
+  HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
   HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev));
   rc = build_arena(e, &w, q, db);
   if (rc) return rc;
   uint64_t rounds = 0;
   for (;;) {
+    // plan/decide left, per set, what it wants aligned next (EmitInfo); k_emit turns that into per-bin work lists
+    HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, e->params));
     HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     rc = check_device_error(e, e->h_counters);
@@ -514,7 +545,7 @@ int rpa_profile_reset(rpa_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(e, hipSetDevice(e->device));
   memset(&e->prof, 0, sizeof(e->prof));
-  HIP_TRY(e, hipMemset(e->prof_acc.p, 0, 4 * sizeof(unsigned long long)));
+  HIP_TRY(e, hipMemset(e->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
   return RPA_OK;
 }
 
