@@ -63,16 +63,13 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restri
   const uint32_t t = blockIdx.x * kBlock + tid;
   const bool active = t < n_list;
   uint32_t dst = 0, m = 0, n = 0;
-  const uint4* __restrict__ pat = nullptr;
-  const uint4* __restrict__ txt = nullptr;
+  SegView pat{}, txt{};
   if (active) {
     uint32_t a, b;
     resolve_pair(w, list[t], a, b, dst);
-    uint32_t la = w.seg_len[a], lb = w.seg_len[b];
-    if (la < lb) { uint32_t x = a; a = b; b = x; x = la; la = lb; lb = x; }  // a = long (text), b = short (pattern), :144-147
-    n = la; m = lb;
-    txt = reinterpret_cast<const uint4*>(w.arena + (size_t)w.seg_off16[a] * 4);
-    pat = reinterpret_cast<const uint4*>(w.arena + (size_t)w.seg_off16[b] * 4);
+    SegView va = seg_view(w, a), vb = seg_view(w, b);
+    if (va.len < vb.len) { txt = vb; pat = va; } else { txt = va; pat = vb; }  // pattern = shorter (:144-147)
+    n = txt.len; m = pat.len;
   }
   if (prof_acc) profile_add(prof_acc, active, n, m);
 
@@ -81,11 +78,11 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restri
   for (int wi = 0; wi < NW; ++wi) {
     uint32_t A = 0, C = 0, G = 0, T = 0, N = 0;
     if (active && (uint32_t)wi * 32u < m) {
-      const uint4 x = pat[wi];
+      const uint4 x = pat.fetch32(wi * 32u);
       uint32_t p0, p1, pn;
       planes32(x, p0, p1, pn);
       const uint32_t rem = m - wi * 32u;
-      const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);  // slot tail is zero = 'A': mask it out
+      const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);  // residues past the end must match nothing
       N = pn & vm;
       T = p1 & p0 & vm;
       G = p1 & ~p0 & vm;
@@ -132,30 +129,37 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restri
     dist += (int32_t)((HP >> lastbit) & 1u) - (int32_t)((HN >> lastbit) & 1u);
   };
 
-  // Whole dwords (8 columns) need no per-column bound check; only the last partial dword of a lane does.
-  const uint32_t full_dwords = n >> 3;
-  uint32_t dw = 0;
-  for (; dw + 4 <= full_dwords; dw += 4) {
-    const uint4 tx = txt[dw >> 2];
-    const uint32_t td[4] = {tx.x, tx.y, tx.z, tx.w};
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t d = td[q];
+  // Text streaming straight from the resident store, 8 nt (one dword) per step.  Forward segments walk the store
+  // upwards, reverse-strand segments downwards (then nibble-reverse + complement); either way consecutive dwords
+  // share a store word, so each step costs ONE new (L1-resident) dword load, issued one step ahead of its use,
+  // plus a funnel shift.  Both directions run the same instruction stream (selects, no divergence).
+  const int32_t dir = txt.rc ? -1 : 1;
+  // source nibble index of the first nucleotide of text dword 0: forward src; reverse src+len-8 (may be < 0 for tiny stores)
+  const int64_t g0 = txt.rc ? (int64_t)(txt.src + n) - 8 : (int64_t)txt.src;
+  const uint32_t sh = (uint32_t)(g0 & 7) * 4u;
+  int64_t idx = g0 >> 3;  // store word holding that nibble (floor)
+  auto load_word = [&](int64_t i) -> uint32_t { return i >= 0 ? txt.words[i] : 0u; };
+  // forward needs words (idx, idx+1), then (idx+1, idx+2)...; reverse needs (idx, idx+1), then (idx-1, idx)...
+  uint32_t keep = load_word(txt.rc ? idx + 1 : idx);  // the word shared with the next step
+  int64_t next_i = txt.rc ? idx : idx + 1;
+  uint32_t pending = load_word(next_i);
+  const uint32_t n_dwords = (n + 7u) >> 3;
+  for (uint32_t dw = 0; dw < n_dwords; ++dw) {
+    const uint32_t fresh = pending;
+    next_i += dir;
+    if (dw + 1 < n_dwords) pending = load_word(next_i);  // prefetch for the next step
+    const uint32_t hi = txt.rc ? keep : fresh, lo = txt.rc ? fresh : keep;
+    uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
+    keep = fresh;
+    const uint32_t r = revcomp8(d);
+    d = txt.rc ? r : d;
+    const uint32_t cols = n - dw * 8u;  // columns left, >= 1
+    if (cols >= 8u) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) column((d >> (4 * k)) & 7u);
-    }
-  }
-  {  // tail: up to 3 full dwords + one partial
-    const uint4 tx = txt[dw >> 2];
-    const uint32_t td[4] = {tx.x, tx.y, tx.z, tx.w};
+    } else {
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t d = td[q];
-      const uint32_t col0 = (dw + q) * 8u;
-      if (col0 >= n) break;
-#pragma unroll 1
-      for (int k = 0; k < 8; ++k)
-        if (col0 + k < n) column((d >> (4 * k)) & 7u);
+      for (uint32_t k = 0; k < cols; ++k) column((d >> (4 * k)) & 7u);
     }
   }
   // distance, similarity = matches = len_short - (d - lendiff) = len_long - d   (:154-164)
@@ -199,18 +203,16 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint32_t* __restrict__ 
   const int lane = threadIdx.x;
   uint32_t a, b, dst;
   resolve_pair(w, list[t], a, b, dst);
-  uint32_t la = w.seg_len[a], lb = w.seg_len[b];
-  if (la < lb) { uint32_t x = a; a = b; b = x; x = la; la = lb; lb = x; }
-  const uint32_t n = la, m = lb;
+  SegView txt = seg_view(w, a), pat = seg_view(w, b);
+  if (txt.len < pat.len) { const SegView x = txt; txt = pat; pat = x; }
+  const uint32_t n = txt.len, m = pat.len;
   if (prof_acc && lane == 0) {
     unsigned long long* acc = prof_acc + (blockIdx.x & (kProfParts - 1)) * 4;
     atomicAdd(&acc[0], 1ull);
-    atomicAdd(&acc[1], (unsigned long long)la + lb + 8ull);
-    atomicAdd(&acc[2], (unsigned long long)la * lb);
+    atomicAdd(&acc[1], (unsigned long long)n + m + 8ull);
+    atomicAdd(&acc[2], (unsigned long long)n * m);
   }
-  const uint32_t* __restrict__ txt = w.arena + (size_t)w.seg_off16[a] * 4;
-  const uint32_t txt_words = w.seg_cap16[a] * 4;
-  const uint4* __restrict__ pat = reinterpret_cast<const uint4*>(w.arena + (size_t)w.seg_off16[b] * 4);
+  const uint32_t txt_words = (n + 7u) / 8u;
   const uint32_t total_words = (m + 31u) / 32u;  // <= 64 * WPL by binning
   const uint32_t w0 = (uint32_t)lane * WPL;
   const uint32_t last_word = total_words - 1u;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint32_t* __restrict__ 
     const uint32_t wi = w0 + k;
     P0[k] = P1[k] = PN[k] = VM[k] = 0;
     if (wi < total_words) {
-      planes32(pat[wi], P0[k], P1[k], PN[k]);
+      planes32(pat.fetch32(wi * 32u), P0[k], P1[k], PN[k]);
       const uint32_t rem = m - wi * 32u;
       VM[k] = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
     }
@@ -233,13 +235,13 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint32_t* __restrict__ 
   }
   const uint32_t steps = n + lanes_used - 1u;
   uint32_t msg = 0;  // bits 0..2: carries out of my run for my column; bits 4..6: text symbol; bit 8: valid
-  uint32_t tx_cur = (uint32_t)lane < txt_words ? txt[lane] : 0u;  // text dwords [0,64)
-  uint32_t tx_nxt = 64u + lane < txt_words ? txt[64 + lane] : 0u;
+  uint32_t tx_cur = (uint32_t)lane < txt_words ? txt.fetch8((uint32_t)lane * 8u) : 0u;  // text dwords [0,64)
+  uint32_t tx_nxt = 64u + lane < txt_words ? txt.fetch8((64u + lane) * 8u) : 0u;
   for (uint32_t step = 0; step < steps; ++step) {
     if ((step & 511u) == 0u && step) {  // 512 columns = 64 dwords consumed: rotate the prefetch buffers
       tx_cur = tx_nxt;
       const uint32_t idx = ((step >> 9) + 1u) * 64u + lane;
-      tx_nxt = idx < txt_words ? txt[idx] : 0u;
+      tx_nxt = idx < txt_words ? txt.fetch8(idx * 8u) : 0u;
     }
     const uint32_t dword = __shfl(tx_cur, (int)((step >> 3) & 63u), 64);
     uint32_t in = __shfl_up(msg, 1, 64);

@@ -71,9 +71,10 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint32_t* __restric
   if (active) {
     uint32_t sa, sb;
     resolve_pair(w, list[t], sa, sb, dst);
-    la = w.seg_len[sa]; lb = w.seg_len[sb];
-    pa = reinterpret_cast<const uint8_t*>(w.arena + (size_t)w.seg_off16[sa] * 4);
-    pb = reinterpret_cast<const uint8_t*>(w.arena + (size_t)w.seg_off16[sb] * 4);
+    const SegView va = seg_view(w, sa), vb = seg_view(w, sb);  // protein segments are plain byte ranges of the store
+    la = va.len; lb = vb.len;
+    pa = reinterpret_cast<const uint8_t*>(va.words) + va.src;
+    pb = reinterpret_cast<const uint8_t*>(vb.words) + vb.src;
   }
   if (prof_acc) {
     // same accounting as the DNA kernels: pairs, len_a+len_b+8, cells
@@ -106,7 +107,10 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint32_t* __restric
     // residues of the strip's rows: B[k*R .. k*R+R)
     uint32_t brow[R / 4];
 #pragma unroll
-    for (int q = 0; q < R / 4; ++q) brow[q] = reinterpret_cast<const uint32_t*>(pb + (size_t)k * R)[q];
+    for (int q = 0; q < R / 4; ++q) {  // pb is byte aligned only: assemble the words from bytes (rows past lb are never used)
+      const uint8_t* bp = pb + (size_t)k * R + 4 * q;
+      brow[q] = (uint32_t)bp[0] | ((uint32_t)bp[1] << 8) | ((uint32_t)bp[2] << 16) | ((uint32_t)bp[3] << 24);
+    }
     int32_t Ls[R];
     uint32_t Lc[R];
 #pragma unroll

@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t node_at(const uint32_t (&path)[4 * P4], uint
 // Protein with reverse coordinates trips a live assert in the reference (:864).  Returns (length, error code).
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, const StoreDev& store, bool from_query,
-                                              uint32_t seq, uint32_t start, uint32_t stop, bool rc, int bits) {
+                                              uint32_t seq, uint32_t start, uint32_t stop, bool rc) {
   uint32_t err = 0, len = 0;
   uint64_t src = 0;
   if (seq >= store.n_seqs) err = kErrSeqId;
@@ -117,11 +117,7 @@ __device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, co
       else { len = stop - start + 1; src = off + (start - 1); }
     }
   }
-  const uint32_t per16 = 128u / (uint32_t)bits;  // residues per 16-byte unit
-  w.seg_len[seg] = len;
-  w.seg_cap16[seg] = (len + per16 - 1) / per16;
-  w.seg_src[seg] = src;
-  w.seg_info[seg] = (uint8_t)((rc ? 1u : 0u) | (from_query ? 2u : 0u) | (err << 4));
+  w.seg[seg] = SegDesc{(uint32_t)src, (uint32_t)(src >> 32), len, (rc ? 1u : 0u) | (from_query ? 2u : 0u) | (err << 4)};
   return make_uint2(len, err);
 }
 
@@ -159,10 +155,9 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     const bool before = (sj > sc) || (sj == sc && (ij > id || (ij == id && j < r)));
     rank += before ? 1u : 0u;
   }
-  const int bits = p.alphabet == 0 ? 4 : 8;
   if (r == beg) {
     uint2 qp = make_uint2(0u, 0u);
-    if (n >= 2) qp = plan_segment(w, b.n_records + s, qstore, true, b.query_seq[s], qrstart, qrstop, false, bits);  // :415
+    if (n >= 2) qp = plan_segment(w, b.n_records + s, qstore, true, b.query_seq[s], qrstart, qrstop, false);  // :415
     w.set_info[s] = make_uint4(n, qrstart, qrstop, 0u);
     w.set_qseg[s] = qp;
   }
@@ -172,12 +167,12 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     const uint32_t left_ext = b.qstart[r] - qrstart, right_ext = qrstop - b.qstop[r];  // :523
     const uint32_t start = b.rstart[r], stop = b.rstop[r];
     if (start <= stop) {
-      sp = plan_segment(w, r, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false, bits);
+      sp = plan_segment(w, r, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false);
     } else if (p.alphabet != 0) {
-      w.seg_len[r] = 0; w.seg_cap16[r] = 0; w.seg_src[r] = 0; w.seg_info[r] = (uint8_t)(kErrAssert << 4);
+      w.seg[r] = SegDesc{0u, 0u, 0u, (uint32_t)kErrAssert << 4};
       sp = make_uint2(0u, (uint32_t)kErrAssert);
     } else {
-      sp = plan_segment(w, r, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true, bits);
+      sp = plan_segment(w, r, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true);
     }
   }
   const uint32_t node = b.node[r];
@@ -797,21 +792,17 @@ hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, co
 // ------------------------------------------------------------------------------------------------------------
 // Pair-level entry (rpa_align_pairs): every sequence of an arena-shaped store is one segment; explicit pair list.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_plan_plain_segments(WorkDev w, StoreDev store, int bits) {
+__global__ __launch_bounds__(kBlock) void k_plan_plain_segments(WorkDev w, StoreDev store) {
   const uint32_t seg = blockIdx.x * kBlock + threadIdx.x;
   if (seg >= w.T) return;
   const uint64_t off = store.offsets[seg];
-  const uint32_t len = (uint32_t)(store.offsets[seg + 1] - off);
-  const uint32_t per16 = 128u / (uint32_t)bits;
-  w.seg_len[seg] = len;
-  w.seg_cap16[seg] = (len + per16 - 1) / per16;
-  w.seg_src[seg] = off;
-  w.seg_info[seg] = 0;
+  w.seg[seg] = SegDesc{(uint32_t)off, (uint32_t)(off >> 32), (uint32_t)(store.offsets[seg + 1] - off), 0u};
 }
 
 hipError_t launch_plan_plain_segments(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& store) {
   if (w.T == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_plan_plain_segments, dim3((w.T + kBlock - 1) / kBlock), dim3(kBlock), 0, st, w, store, alphabet == 0 ? 4 : 8);
+  (void)alphabet;
+  hipLaunchKernelGGL(k_plan_plain_segments, dim3((w.T + kBlock - 1) / kBlock), dim3(kBlock), 0, st, w, store);
   return hipGetLastError();
 }
 
@@ -824,7 +815,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_pairs(WorkDev w, uint32_t n_pair
     const uint32_t sa = w.pair_a[t], sb = w.pair_b[t];
     if (sa >= w.T || sb >= w.T) raise_error(w, kErrSeqId, t);
     else {
-      const uint32_t la = w.seg_len[sa], lb = w.seg_len[sb];
+      const uint32_t la = w.seg[sa].len, lb = w.seg[sb].len;
       bin = pair_bin(p, la, lb);
       maxlen = la;
       if (bin >= kNumBins) { raise_error(w, kErrUnsupported, t); bin = -1; }

@@ -88,6 +88,13 @@ struct HitCore {
 constexpr uint32_t kMetaQGroup = 1u, kMetaOutGroup = 2u, kMetaPerfect = 4u;  // perfect: alnlen == L && identities == L
 constexpr int kMetaErrShift = 4, kMetaDepthShift = 8;                         // 4 bits segment error code, 8 bits node depth
 
+// Segment descriptor (a7): `len` residues starting at residue `src` of a store; reverse strand = read backwards + complement.
+struct SegDesc {
+  uint32_t src_lo, src_hi;  // first residue (global residue index in the store), 64 bit
+  uint32_t len;             // 0 if never planned / unreadable
+  uint32_t info;            // bit0 reverse-complement, bit1 from the query store, bits 4-7 fetch error code
+};
+
 // What a record set wants aligned in the coming round (written by plan/decide, read by k_emit and the alignment kernels).
 struct EmitInfo {
   uint32_t mode;        // 0 nothing, 1 pass 0 (vs query range), 2 pass 1 (vs anchor), 3 pass 2 (vs anchor)
@@ -109,13 +116,12 @@ struct WorkDev {
   uint2* set_qseg;      // S   (query segment length, error code)
   EmitInfo* emit;       // S
   uint32_t* hit_set;    // H   row position -> record set
-  // segments: id r in [0,H) = reference segment of record r, id H+s = query range of set s
-  uint32_t* seg_len;    // T   residues (0 if never planned)
-  uint32_t* seg_cap16;  // T   slot size in 16-byte units
-  uint32_t* seg_off16;  // T   slot offset in 16-byte units (exclusive scan of seg_cap16)
-  uint64_t* seg_src;    // T   first source residue (global residue index in the store)
-  uint8_t* seg_info;    // T   bit0 reverse-complement, bit1 from query store, bits 4-7 error code
-  uint32_t* arena;      // packed segments
+  // segments: id r in [0,H) = reference segment of record r, id H+s = query range of set s.  A segment is only a
+  // descriptor: the alignment kernels read the residues straight out of the resident stores (funnel-shifted to the
+  // segment's start, reverse-complemented on the fly for reverse-strand hits) -- no per-batch copy of the sequences.
+  SegDesc* seg;               // T
+  const uint32_t* store_q;    // packed query store
+  const uint32_t* store_db;   // packed reference store
   // explicit pairs (rpa_align_pairs only; null in rpa_predict_batch, where a work-list entry is a row position and
   // the alignment kernels derive the segments from the row and the set's EmitInfo)
   uint32_t* pair_a;     // T2  segment id
@@ -149,15 +155,11 @@ struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells
 
 // ---- launchers (each enqueues on `st`, returns the hipError of the launch) ----
 hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* letters, uint64_t n_residues, uint32_t* words);
-hipError_t launch_exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums,
-                                     uint32_t* total_out);
-size_t scan_workspace_elems(uint32_t n);
 
 hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
                                const StoreDev& db, const Params& p);
 hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                             void* out_rows, void* out_stats);
-hipError_t launch_materialize(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& q, const StoreDev& db);
 hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p);
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc);
@@ -193,6 +195,48 @@ __device__ __forceinline__ void resolve_pair(const WorkDev& w, uint32_t entry, u
   seg_a = rows[(size_t)entry * w.row_quads].w;
   const uint32_t mode = w.emit[s].mode;
   seg_b = mode == 1 ? w.H + s : rows[(size_t)(w.set_offsets[s] + w.emit[s].anchor) * w.row_quads].w;
+}
+
+// ---- reading a segment out of the packed store --------------------------------------------------------------
+__device__ __forceinline__ uint32_t revcomp8(uint32_t x) {  // 8 packed nt: reverse the nibble order, A<->T, C<->G, N stays
+  x = __builtin_bswap32(x);
+  x = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);
+  const uint32_t lt4 = (~x >> 2) & 0x11111111u;  // 1 per nibble whose code is < 4
+  return x ^ (lt4 * 3u);
+}
+
+struct SegView {  // a segment as the kernels read it
+  const uint32_t* words;
+  uint64_t src;
+  uint32_t len;
+  bool rc;
+  // 8 nucleotides (one dword, 4 bit each) starting at residue p of the segment; nucleotides past the end are unspecified.
+  // Forward: two adjacent store words funnel-shifted (v_alignbit).  Reverse strand (seqan::reverseComplement,
+  // core/src/sequencestorage.hh:364-369): the 8 source nucleotides that END at src+len-1-p, nibble-reversed, complemented.
+  __device__ __forceinline__ uint32_t fetch8(uint32_t p) const {
+    if (!rc) {
+      const uint64_t g = src + p;
+      return __builtin_amdgcn_alignbit(words[g / 8 + 1], words[g / 8], (uint32_t)(g % 8) * 4u);  // stores end in slack words
+    }
+    const int64_t gs = (int64_t)(src + len - 1 - p) - 7;
+    uint32_t x;
+    if (gs >= 0) x = __builtin_amdgcn_alignbit(words[(uint64_t)gs / 8 + 1], words[(uint64_t)gs / 8], (uint32_t)((uint64_t)gs % 8) * 4u);
+    else x = gs > -8 ? words[0] << (uint32_t)(-gs * 4) : 0u;  // within 7 nt of the very start of the store
+    return revcomp8(x);
+  }
+  __device__ __forceinline__ uint4 fetch32(uint32_t p) const { return make_uint4(fetch8(p), fetch8(p + 8), fetch8(p + 16), fetch8(p + 24)); }
+  // protein (8 bit per residue, forward only)
+  __device__ __forceinline__ uint32_t byte_at(uint32_t p) const { return reinterpret_cast<const uint8_t*>(words)[src + p]; }
+};
+
+__device__ __forceinline__ SegView seg_view(const WorkDev& w, uint32_t seg) {
+  const uint4 d = reinterpret_cast<const uint4*>(w.seg)[seg];
+  SegView v;
+  v.words = (d.w & 2u) ? w.store_q : w.store_db;
+  v.src = ((uint64_t)d.y << 32) | d.x;
+  v.len = d.z;
+  v.rc = d.w & 1u;
+  return v;
 }
 
 // bin of a pair whose shorter sequence has m residues (DNA); kNumBins = too long

@@ -2,7 +2,7 @@
 //
 // One engine = one GPU = one RPAPredictionModel instance of the reference (core/src/taxonpredictionmodelsequence.hh:326-339)
 // plus its two sequence stores (core/taxator.cpp:230-249), resident in HBM.  rpa_predict_batch drives the rounds
-//   rank -> plan -> scan -> materialise -> { align bins -> decide }*      (kernels: place_/seq_/align_*_kernels.hip)
+//   rank -> plan -> { emit -> align bins -> decide }*      (kernels: place_/align_*_kernels.hip)
 // on one HIP stream.  The host reads one small counter block per round (pairs per bin, live sets, error word).
 // There is no CPU compute path: every entry point fails with RPA_ERR_DEVICE when no gfx950 device answers.
 #include <hip/hip_runtime.h>
@@ -60,8 +60,8 @@ struct rpa_engine {
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8;
-  DevBuf state, hits, set_info, set_qseg, emit, hit_set, seg_len, seg_cap16, seg_off16, seg_src, seg_info, arena, pair_a, pair_b,
-      pair_res, pair_ext, bin_list, counters, og_idx, og_dist, scan_ws, out_rows, out_stats, tmp_letters,
+  DevBuf state, hits, set_info, set_qseg, emit, hit_set, seg, pair_a, pair_b,
+      pair_res, pair_ext, bin_list, counters, og_idx, og_dist, out_rows, out_stats, tmp_letters,
       tmp_words, tmp_offsets, protein_ws;
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
@@ -179,11 +179,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->set_qseg.ensure((size_t)(S ? S : 1) * sizeof(uint2)));
   HIP_TRY(e, e->emit.ensure((size_t)(S ? S : 1) * sizeof(EmitInfo)));
   HIP_TRY(e, e->hit_set.ensure((size_t)(H ? H : 1) * 4));
-  HIP_TRY(e, e->seg_len.ensure((size_t)(T ? T : 1) * 4));
-  HIP_TRY(e, e->seg_cap16.ensure((size_t)(T ? T : 1) * 4));
-  HIP_TRY(e, e->seg_off16.ensure((size_t)(T ? T : 1) * 4));
-  HIP_TRY(e, e->seg_src.ensure((size_t)(T ? T : 1) * 8));
-  HIP_TRY(e, e->seg_info.ensure((size_t)(T ? T : 1)));
+  HIP_TRY(e, e->seg.ensure((size_t)(T ? T : 1) * sizeof(SegDesc)));
   if (want_ext) {  // explicit pair arrays exist only for rpa_align_pairs
     HIP_TRY(e, e->pair_a.ensure((size_t)(T2 ? T2 : 1) * 4));
     HIP_TRY(e, e->pair_b.ensure((size_t)(T2 ? T2 : 1) * 4));
@@ -195,11 +191,9 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
-  HIP_TRY(e, e->scan_ws.ensure(scan_workspace_elems(T) * 4));
   w->state = e->state.as<SetState>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
   w->set_qseg = e->set_qseg.as<uint2>(); w->emit = e->emit.as<EmitInfo>(); w->hit_set = e->hit_set.as<uint32_t>();
-  w->seg_len = e->seg_len.as<uint32_t>(); w->seg_cap16 = e->seg_cap16.as<uint32_t>(); w->seg_off16 = e->seg_off16.as<uint32_t>();
-  w->seg_src = e->seg_src.as<uint64_t>(); w->seg_info = e->seg_info.as<uint8_t>(); w->arena = nullptr;
+  w->seg = e->seg.as<SegDesc>(); w->store_q = nullptr; w->store_db = nullptr;
   w->pair_a = want_ext ? e->pair_a.as<uint32_t>() : nullptr; w->pair_b = want_ext ? e->pair_b.as<uint32_t>() : nullptr;
   w->set_offsets = nullptr; w->H = H; w->row_quads = 2 + e->tax.path_quads;
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
@@ -207,20 +201,6 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->og_idx = e->og_idx.as<uint32_t>();
   w->og_dist = e->og_dist.as<int32_t>();
   w->T = T; w->T2 = T2;
-  return RPA_OK;
-}
-
-// seg_cap16 -> seg_off16, allocate the arena, materialise the segments.
-int build_arena(rpa_engine* e, WorkDev* w, const StoreDev& q, const StoreDev& db) {
-  uint32_t* total_dev = w->counters + kNumCounters;
-  HIP_TRY(e, launch_exclusive_scan_u32(e->stream, w->seg_cap16, w->seg_off16, w->T, e->scan_ws.as<uint32_t>(), total_dev));
-  HIP_TRY(e, hipMemcpyAsync(e->h_counters, total_dev, 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  const uint64_t total16 = e->h_counters[0];
-  if (total16 >= 0xFFFFFFF0ull) return fail(e, RPA_ERR_UNSUPPORTED, "segment arena exceeds 64 GiB; split the batch");
-  HIP_TRY(e, e->arena.ensure((size_t)(total16 + 64) * 16));  // + slack: the long kernel prefetches up to 512 B past a slot
-  w->arena = e->arena.as<uint32_t>();
-  HIP_TRY(e, launch_materialize(e->stream, e->params.alphabet, *w, q, db));
   return RPA_OK;
 }
 
@@ -328,9 +308,9 @@ void rpa_destroy(rpa_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->state, &e->hits,
-                    &e->set_info, &e->seg_len, &e->seg_cap16, &e->seg_off16, &e->seg_src, &e->seg_info,
-                    &e->arena, &e->pair_a, &e->pair_b, &e->emit, &e->hit_set, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
-                    &e->og_idx, &e->og_dist, &e->scan_ws, &e->out_rows, &e->out_stats, &e->tmp_letters,
+                    &e->set_info, &e->seg,
+                    &e->pair_a, &e->pair_b, &e->emit, &e->hit_set, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
+                    &e->og_idx, &e->og_dist, &e->out_rows, &e->out_stats, &e->tmp_letters,
                     &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
@@ -368,7 +348,7 @@ static int pack_store(rpa_engine* e, Store* st, uint32_t n_seqs, const uint8_t* 
   }
   const int bits = e->params.alphabet == RPA_DNA ? 4 : 8;
   const uint64_t n_words = (total * bits + 31) / 32;
-  HIP_TRY(e, st->words.ensure((size_t)(n_words + 4) * 4));
+  HIP_TRY(e, st->words.ensure((size_t)(n_words + 64) * 4));  // slack: kernels may read a few words past the last residue
   const uint8_t* dev_letters = letters;
   if (mem_kind == RPA_MEM_HOST && total) {
     HIP_TRY(e, letters_buf->ensure((size_t)total + 8));
@@ -453,15 +433,12 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
   rc = profile_begin(e);
   if (rc) return rc;
   HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * (kNumCounters + 1), e->stream));
-  HIP_TRY(e, hipMemsetAsync(w.seg_len, 0, (size_t)T * 4, e->stream));
-  HIP_TRY(e, hipMemsetAsync(w.seg_cap16, 0, (size_t)T * 4, e->stream));
-  HIP_TRY(e, hipMemsetAsync(w.seg_info, 0, (size_t)T, e->stream));
+  HIP_TRY(e, hipMemsetAsync(w.seg, 0, (size_t)T * sizeof(SegDesc), e->stream));
   const StoreDev q = e->stores[RPA_STORE_QUERY].view(), db = e->stores[RPA_STORE_DB].view();
   w.set_offsets = b.set_offsets;
+  w.store_q = q.words; w.store_db = db.words;
   HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
   HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev));
-  rc = build_arena(e, &w, q, db);
-  if (rc) return rc;
   uint64_t rounds = 0;
   for (;;) {
     // plan/decide left, per set, what it wants aligned next (EmitInfo); k_emit turns that into per-bin work lists
@@ -513,9 +490,8 @@ int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, cons
   rc = profile_begin(e);
   if (rc) return rc;
   const StoreDev sv = tmp.view();
+  w.store_q = sv.words; w.store_db = sv.words;
   HIP_TRY(e, launch_plan_plain_segments(e->stream, e->params.alphabet, w, sv));
-  rc = build_arena(e, &w, sv, sv);
-  if (rc) return rc;
   HIP_TRY(e, launch_bin_pairs(e->stream, e->params.alphabet, w, n_pairs));
   HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));

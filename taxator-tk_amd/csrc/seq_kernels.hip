@@ -1,10 +1,11 @@
-// taxator-tk_amd/csrc/seq_kernels.hip -- residue packing, segment materialisation, exclusive scan (gfx950).
+// taxator-tk_amd/csrc/seq_kernels.hip -- residue packing of the resident sequence stores (gfx950).
 //
-// Replaces, on the device, the byte->ordinal conversion and sub-sequence fetch of the reference's sequence stores:
-//   core/src/sequencestorage.hh:341-369 (getSequence / getSequenceReverseComplement of the indexed store),
-//   core/src/faidx.h:315-350 (readRegion: chars -> alphabet ordinals through the SeqAn tables),
-//   core/src/taxonpredictionmodelsequence.hh:856-880 (segment = hit range extended to the query range; RC for rstart>rstop).
-// These kernels are HBM-streaming work (a few bytes in, a few bytes out per residue); no LDS reuse to exploit.
+// Replaces, on the device, the byte->ordinal conversion of the reference's sequence readers
+//   core/src/faidx.h:315-350 (readRegion: chars -> alphabet ordinals through the SeqAn tables,
+//   seqan/basic/alphabet_residue_tabs.h:107-140, 397-430).
+// The sub-sequence fetch itself (core/src/sequencestorage.hh:341-369, taxonpredictionmodelsequence.hh:856-880) needs no
+// kernel: a segment is a descriptor and the alignment kernels read it in place (SegView in rpa_device.h).
+// HBM-streaming work: 8 bytes in, 4 bytes out per thread; the 256-entry table sits in LDS.
 #include "rpa_device.h"
 #include "rpa_tables.inc"
 
@@ -71,161 +72,6 @@ hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* lett
     hipLaunchKernelGGL(k_pack_letters<4>, dim3((unsigned)blocks), dim3(kBlock), 0, st, letters, n_residues, words, n_words);
   else
     hipLaunchKernelGGL(k_pack_letters<8>, dim3((unsigned)blocks), dim3(kBlock), 0, st, letters, n_residues, words, n_words);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Exclusive scan of u32 (segment slot sizes -> slot offsets).  Three launches: per-block scan + block totals,
-// scan of the totals by one workgroup, add-back.  8 items per thread.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kBlock * kScanItems;
-
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
-  __shared__ uint32_t wave_sums[kBlock / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) wave_sums[wave] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < kBlock / 64; ++k) {
-    const uint32_t ws = wave_sums[k];
-    if (k < wave) base += ws;
-    tot += ws;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
-
-__global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
-                                                        uint32_t* __restrict__ block_sums) {
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  uint32_t v[kScanItems];
-  uint32_t sum = 0;
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    v[k] = (base + k < n) ? in[base + k] : 0u;
-    sum += v[k];
-  }
-  uint32_t total;
-  uint32_t run = block_exclusive_scan(sum, &total);
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    if (base + k < n) out[base + k] = run;
-    run += v[k];
-  }
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(kBlock) void k_scan_block_sums(uint32_t* __restrict__ block_sums, uint32_t n_blocks,
-                                                             uint32_t* __restrict__ total_out) {
-  uint32_t carry = 0;
-  for (uint32_t start = 0; start < n_blocks; start += kBlock) {
-    const uint32_t i = start + threadIdx.x;
-    const uint32_t v = i < n_blocks ? block_sums[i] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan(v, &total);
-    if (i < n_blocks) block_sums[i] = carry + ex;
-    carry += total;
-  }
-  if (threadIdx.x == 0) *total_out = carry;
-}
-
-__global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ block_sums) {
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  const uint32_t add = block_sums[blockIdx.x];
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k)
-    if (base + k < n) out[base + k] += add;
-}
-
-size_t scan_workspace_elems(uint32_t n) { return (size_t)(n + kScanTile - 1) / kScanTile + 1; }
-
-hipError_t launch_exclusive_scan_u32(hipStream_t st, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums,
-                                     uint32_t* total_out) {
-  if (n == 0) return hipMemsetAsync(total_out, 0, sizeof(uint32_t), st);
-  const uint32_t blocks = (n + kScanTile - 1) / kScanTile;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(blocks), dim3(kBlock), 0, st, in, out, n, block_sums);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(kBlock), 0, st, block_sums, blocks, total_out);
-  hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(kBlock), 0, st, out, n, block_sums);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Segment materialisation: copy [src, src+len) (or its reverse complement) out of the resident store into the
-// segment's 16-byte aligned slot, so that the alignment kernels can stream aligned 16-byte chunks.
-// 32 threads cooperate on one segment, one output word (8 nt / 4 aa) per thread per trip.
-// Reverse complement (seqan::reverseComplement, sequencestorage.hh:364-369): A<->T, C<->G, N stays.
-// ------------------------------------------------------------------------------------------------------------
-template <int BITS>
-__device__ __forceinline__ uint32_t load_residue(const uint32_t* __restrict__ words, uint64_t g) {
-  constexpr int PER = 32 / BITS;
-  constexpr uint32_t MASK = (1u << BITS) - 1u;
-  return (words[g / PER] >> ((uint32_t)(g % PER) * BITS)) & MASK;
-}
-
-template <int BITS>
-__global__ __launch_bounds__(kBlock) void k_materialize(WorkDev w, StoreDev q, StoreDev db) {
-  constexpr int PER = 32 / BITS;
-  const uint32_t seg = blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5);
-  if (seg >= w.T) return;
-  const uint32_t len = w.seg_len[seg];
-  if (len == 0) return;
-  const uint8_t info = w.seg_info[seg];
-  if (info >> 4) return;  // fetch error: never read
-  const uint32_t* __restrict__ src_words = (info & 2) ? q.words : db.words;
-  const uint64_t src = w.seg_src[seg];
-  const bool rc = info & 1;
-  uint32_t* __restrict__ dst = w.arena + (size_t)w.seg_off16[seg] * 4;
-  const uint32_t n_words = w.seg_cap16[seg] * 4;  // whole slot, so the tail is zero-filled
-  for (uint32_t wi = threadIdx.x & 31; wi < n_words; wi += 32) {
-    const uint32_t p0 = wi * PER;  // first residue of this output word
-    uint32_t out = 0;
-    if (p0 < len) {
-      const uint32_t rem = len - p0;
-      if (!rc) {
-        // PER residues starting at source residue src+p0: two adjacent store words, funnel-shifted (v_alignbit)
-        const uint64_t g = src + p0;
-        const uint64_t widx = g / PER;
-        const uint32_t sh = (uint32_t)(g % PER) * BITS;
-        out = __builtin_amdgcn_alignbit(src_words[widx + 1], src_words[widx], sh);  // the store has slack words at its end
-      } else if (BITS == 4) {
-        // output residue p <- complement of source residue src+len-1-p: fetch the 8 source nibbles [gs, gs+7] that end
-        // at src+len-1-p0, reverse the nibble order, complement (A<->T, C<->G, N stays)
-        const int64_t gs = (int64_t)(src + len - 1 - p0) - 7;
-        uint32_t x;
-        if (gs >= 0) {
-          const uint64_t widx = (uint64_t)gs / 8;
-          const uint32_t sh = (uint32_t)((uint64_t)gs % 8) * 4;
-          x = __builtin_amdgcn_alignbit(src_words[widx + 1], src_words[widx], sh);
-        } else {  // within 7 residues of the very start of the store: shift the first word up instead
-          x = src_words[0] << (uint32_t)(-gs * 4);
-        }
-        x = __builtin_bswap32(x);
-        x = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);
-        const uint32_t lt4 = (~x >> 2) & 0x11111111u;  // 1 per nibble whose code is < 4
-        out = x ^ (lt4 * 3u);
-      }
-      if (rem < (uint32_t)PER) out &= (1u << (rem * BITS)) - 1u;  // zero the slot tail
-    }
-    dst[wi] = out;
-  }
-}
-
-hipError_t launch_materialize(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& q, const StoreDev& db) {
-  if (w.T == 0) return hipSuccess;
-  const uint32_t blocks = (w.T + (kBlock / 32) - 1) / (kBlock / 32);
-  if (alphabet == 0)
-    hipLaunchKernelGGL(k_materialize<4>, dim3(blocks), dim3(kBlock), 0, st, w, q, db);
-  else
-    hipLaunchKernelGGL(k_materialize<8>, dim3(blocks), dim3(kBlock), 0, st, w, q, db);
   return hipGetLastError();
 }
 
