@@ -67,16 +67,33 @@ def cpu_baseline(synth, ds, seconds_target=12.0):
                       % (n_sample, n_hits, total, dt)}
 
 
+# BASELINE.json configs that fit one GPU per rank (per-GPU sizes; c5 is 100 k contigs over 8 GPUs = 12.5 k per GPU)
+CONFIGS = {
+    "c2": dict(sets=1_000_000, hits=20, seg_len=200, alphabet=0, genome_len=4000, level_rate=0.03, query_rate=0.05,
+               name="BASELINE config 2", kernel="k_myers_short (batched bit-parallel edit distance, one alignment per lane)"),
+    "c4": dict(sets=500_000, hits=20, seg_len=67, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08,
+               name="BASELINE config 4 (protein, 67 aa)", kernel="k_nw_protein (BLOSUM62 global DP with forward-carried path counters, one alignment per lane)"),
+    "c5": dict(sets=12_500, hits=50, seg_len=10_000, alphabet=0, genome_len=40_000, level_rate=0.03, query_rate=0.05,
+               name="BASELINE config 5 (10 kbp contigs, per-GPU share of 100 k)", kernel="k_myers_long (one alignment per wavefront, skewed carry schedule)"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sets", type=int, default=1_000_000, help="record sets per GPU (BASELINE config 2: 1 M)")
-    ap.add_argument("--hits", type=int, default=20)
-    ap.add_argument("--seg-len", type=int, default=200)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="c2 = the headline configuration (BASELINE config 2); c4 protein, c5 long contigs are extra measurements")
+    ap.add_argument("--sets", type=int, default=None, help="record sets per GPU (default: the configuration's)")
+    ap.add_argument("--hits", type=int, default=None)
+    ap.add_argument("--seg-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.sets = args.sets or cfg["sets"]
+    args.hits = args.hits or cfg["hits"]
+    args.seg_len = args.seg_len or cfg["seg_len"]
 
     import torch
     import torch.distributed as dist
@@ -96,25 +113,26 @@ def main():
     pkg = graft.load_package()
     synth = importlib.import_module("taxator_tk_amd.synth")
     t_gen = time.perf_counter()
-    ds = synth.make_dataset(n_sets=args.sets, n_hits=args.hits, seg_len=args.seg_len, branching=4, genome_len=4000,
-                            seed=2 + rank, device="cuda")
+    ds = synth.make_dataset(n_sets=args.sets, n_hits=args.hits, seg_len=args.seg_len, branching=4, genome_len=cfg["genome_len"],
+                            seed=2 + rank, device="cuda", alphabet=cfg["alphabet"], level_rate=cfg["level_rate"],
+                            query_rate=cfg["query_rate"])
     t_gen = time.perf_counter() - t_gen
 
-    model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA, device=local_rank)
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=cfg["alphabet"], device=local_rank)
     model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
     model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
     dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).cuda()
            for k, v in ds.batch.items()}
     rows = torch.zeros((ds.n_sets, 8), dtype=torch.int32, device="cuda")
     stats = torch.zeros((ds.n_sets, 4), dtype=torch.int32, device="cuda")
-    gathered = [torch.zeros_like(rows) for _ in range(world)] if (world > 1 and rank == 0) else None
+    sharding = importlib.import_module("taxator_tk_amd.sharding")
     stream = torch.cuda.current_stream()
     model.set_stream(stream.cuda_stream)
 
     def step():
         model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
         if world > 1:
-            dist.gather(rows, gathered, dst=0)  # X1: PredictionRecord rows to rank 0 over xGMI (RCCL)
+            sharding.gather_rows(rows, dst=0)  # X1: PredictionRecord rows of every rank to rank 0 over xGMI (RCCL)
 
     for _ in range(args.warmup):
         step()
@@ -151,16 +169,16 @@ def main():
             "metric": "query-segment realignments/sec",
             "value": value, "unit": "realignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %d record sets x %d hits x %d bp nucleotide RPA per GPU, mock NCBI taxonomy (b=4, 5462 nodes), batch resident in HBM"
-                                   % (args.sets, args.hits, args.seg_len),
+            "dtype": "u32" if cfg["alphabet"] == 0 else "i32", "data": "synthetic",
+            "config": {"workload": "%s: %d record sets x %d hits x %d %s RPA per GPU, mock NCBI taxonomy (b=4, 5462 nodes), batch resident in HBM"
+                                   % (cfg["name"], args.sets, args.hits, args.seg_len, "bp nucleotide" if cfg["alphabet"] == 0 else "aa protein"),
                        "record_sets_per_gpu": args.sets, "hits_per_set": args.hits, "segment_bp": args.seg_len,
                        "parallelism": "record sets sharded over %d GPU(s); RCCL gather of 32-byte rows" % world if world > 1 else "single GPU",
                        "unit_counted": "alignments demanded by the reference control flow (STATS gcounter), not speculative ones"},
             "record_sets_per_s": ds.n_sets * world * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None,
-                         "kernel": "k_myers_short (batched bit-parallel edit distance, one alignment per lane)",
+                         "kernel": cfg["kernel"],
                          "bytes_per_launch": prof["residue_bytes"] / n_launch,
                          "avg_launch_ms": prof["align_ms"] / n_launch, "launches": prof["launches"],
                          "computed_alignments_per_s_in_kernel": prof["pairs"] / max(align_s, 1e-12),

@@ -56,7 +56,7 @@ __device__ __forceinline__ void profile_add(unsigned long long* acc, bool active
 }
 
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restrict__ list, uint32_t n_list, WorkDev w,
+__global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
                                                          unsigned long long* prof_acc) {
   extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
   const int tid = threadIdx.x;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint32_t* __restri
   if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);  // match+mismatch = m, + gap = n
 }
 
-hipError_t launch_align_dna_short(hipStream_t st, int words, const uint32_t* list, uint32_t n, const WorkDev& w,
+hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const WorkDev& w,
                                   unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
   const uint32_t blocks = (n + kBlock - 1) / kBlock;
@@ -196,7 +196,7 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint32_t* lis
 // v_readlane).  Reference: the multi-block branch of the same SeqAn routine (global_alignment_myers_impl.h:129-191).
 // ------------------------------------------------------------------------------------------------------------
 template <int WPL>
-__global__ __launch_bounds__(64) void k_myers_long(const uint32_t* __restrict__ list, uint32_t n_list, WorkDev w,
+__global__ __launch_bounds__(64) void k_myers_long(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
                                                     unsigned long long* prof_acc) {
   const uint32_t t = blockIdx.x;
   if (t >= n_list) return;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint32_t* __restrict__ 
   }
 }
 
-hipError_t launch_align_dna_long(hipStream_t st, int wpl, const uint32_t* list, uint32_t n, const WorkDev& w,
+hipError_t launch_align_dna_long(hipStream_t st, int wpl, const uint2* list, uint32_t n, const WorkDev& w,
                                  unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
 #define RPA_LAUNCH_LONG(V) \

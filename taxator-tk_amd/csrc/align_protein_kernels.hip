@@ -44,7 +44,7 @@ static hipError_t upload_blosum() {
 }
 
 template <int R>
-__global__ __launch_bounds__(kBlock) void k_nw_protein(const uint32_t* __restrict__ list, uint32_t n_list, WorkDev w,
+__global__ __launch_bounds__(kBlock) void k_nw_protein(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
                                                         int2* __restrict__ scratch, uint32_t col_stride,
                                                         unsigned long long* prof_acc) {
   __shared__ uint32_t tab[kAA * kAAGroups * 32];  // [b][a/4][bank] -> 4 x int8 scores s(a, b)
@@ -181,7 +181,7 @@ size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len) {
   return threads * 2 * ((size_t)max_len + 2);
 }
 
-hipError_t launch_align_protein(hipStream_t st, const uint32_t* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
+hipError_t launch_align_protein(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
   hipError_t e = upload_blosum();

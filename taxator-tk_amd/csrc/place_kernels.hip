@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
   const uint32_t H = b.n_records;
   int bin = -1;
   uint32_t maxlen = 0;
+  uint2 entry = make_uint2(0u, 0u);
   if (pos < H + b.n_sets) {
     const bool is_query_pair = pos >= H;
     const uint32_t s = is_query_pair ? pos - H : w.hit_set[pos];
@@ -252,14 +253,14 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
       if (is_query_pair) {
         if (info.mode == 3) {
           const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor));
-          if (ha.qd == FLT_MAX) { bin = pair_bin(p, ha.seglen, info.qseglen); maxlen = ha.seglen; }
+          if (ha.qd == FLT_MAX) { bin = pair_bin(p, ha.seglen, info.qseglen); maxlen = ha.seglen; entry = make_uint2(ha.rec, pos | kDstIsB); }
         }
       } else {
         const uint32_t i = pos - lo;
         if (i < info.n) {
           const uint4* pi = hit_ptr<P4>(w, pos);
           const HitCore h = load_core(pi);
-          uint32_t other_len = info.qseglen;
+          uint32_t other_len = info.qseglen, other_seg = H + s;
           bool want = false;
           if (info.mode == 1) want = !(h.meta & kMetaPerfect) && h.score >= info.fcut;
           else if (i != info.anchor) {
@@ -271,11 +272,12 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
               load_path<P4>(pi, pth);
               want = !(common<P4>(pb, meta_depth(load_core(pbp).meta), pth, meta_depth(h.meta)) >= info.d_unode_g);
             }
-            if (want) other_len = load_core(hit_ptr<P4>(w, lo + info.anchor)).seglen;
+            if (want) { const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor)); other_len = ha.seglen; other_seg = ha.rec; }
           }
           if (want) {
             bin = pair_bin(p, h.seglen, other_len);
             maxlen = h.seglen;
+            entry = make_uint2(h.rec, other_seg);
             if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = -1; }
           }
         }
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
   }
   __syncthreads();
   if (bin >= 0)
-    w.bin_list[(size_t)bin * w.T2 + s_base[bin] + s_cnt[bin][wave] + (uint32_t)__popcll(my_mask & ((1ull << lane) - 1ull))] = pos;
+    w.bin_list[(size_t)bin * w.T2 + s_base[bin] + s_cnt[bin][wave] + (uint32_t)__popcll(my_mask & ((1ull << lane) - 1ull))] = entry;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     const uint32_t n = st.n, L = st.L;
     constexpr int kStride4 = 2 + P4;
     const float X = p.exclude_factor;
-    const float2* __restrict__ res = w.pair_res + lo;                  // res[i]: result of the alignment asked for hit i
+    const float2* __restrict__ res = w.pair_res;                       // res[rec]: result of the alignment asked for that hit
     const float2* __restrict__ qres_p = w.pair_res + b.n_records + s;  // result of the anchor <-> query alignment
     bool failed = false;
 
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           flag = kMetaQGroup; dist = 0.f; sim = (float)h.ident;
         } else if (h.score >= thr) {  // :518-534
           flag = kMetaQGroup;
-          const float2 r2 = res[i];
+          const float2 r2 = res[h.rec];
           if (!result_ok(w, s, meta_err(h.meta), st.qsegerr, r2.x)) { failed = true; break; }
           dist = r2.x;
           ++st.cnt0;
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         if (i == a) dist = 0.f;
         else if (h.qd == 0.f) dist = qdist;  // :620-621
         else {
-          const float2 r2 = res[i];
+          const float2 r2 = res[h.rec];
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
           ++st.cnt1;
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         if (i == a) dist = 0.f;
         else {
           if (cb >= st.d_unode_g) continue;  // isParentOf(unode_global, cnode) || cnode == unode_global, :771
-          const float2 r2 = res[i];
+          const float2 r2 = res[h.rec];
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
           ++st.cnt2;
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_pairs(WorkDev w, uint32_t n_pair
     const uint32_t c = (bin == k) ? 1u : 0u;
     if (!__any(c != 0)) continue;
     const uint32_t base = wave_reserve(&w.counters[k], c);
-    if (c) w.bin_list[(size_t)k * w.T2 + base] = t;
+    if (c) w.bin_list[(size_t)k * w.T2 + base] = make_uint2(t, 0u);
   }
 }
 

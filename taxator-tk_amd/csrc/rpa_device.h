@@ -126,9 +126,9 @@ struct WorkDev {
   // the alignment kernels derive the segments from the row and the set's EmitInfo)
   uint32_t* pair_a;     // T2  segment id
   uint32_t* pair_b;     // T2
-  float2* pair_res;     // T   (distance, similarity); [set_off[s]+i] for hit i of set s, [H+s] for anchor<->query
+  float2* pair_res;     // T   (distance, similarity); [rec] for the alignment asked for the hit of record rec, [H+s] for anchor<->query
   uint4* pair_ext;      // optional (rpa_align_pairs only): matches, mismatches, gaps, length; indexed like pair_res
-  uint32_t* bin_list;   // kNumBins * T2
+  uint2* bin_list;      // kNumBins * T2 entries (segment A, segment B | kDstIsB)
   uint32_t* counters;   // kNumCounters words, layout below
   // pass-1 scratch (per set region like the pair slots)
   uint32_t* og_idx;     // T
@@ -170,31 +170,26 @@ hipError_t launch_bin_pairs(hipStream_t st, int alphabet, const WorkDev& w, uint
 hipError_t launch_export_alignments(hipStream_t st, const WorkDev& w, uint32_t n_pairs, void* out);
 
 // alignment kernels over one bin list
-hipError_t launch_align_dna_short(hipStream_t st, int words, const uint32_t* list, uint32_t n, const WorkDev& w,
+hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const WorkDev& w,
                                   unsigned long long* prof_acc);
-hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint32_t* list, uint32_t n, const WorkDev& w,
+hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint2* list, uint32_t n, const WorkDev& w,
                                  unsigned long long* prof_acc);
-hipError_t launch_align_protein(hipStream_t st, const uint32_t* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
+hipError_t launch_align_protein(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
 
 // Work-list entry -> (segment A, segment B, result index).  Order matters for protein (A is the horizontal sequence):
 // getAlignment(segments[i], qrseq) (:526), getAlignment(segments[i], segments[index_anchor]) (:630,778),
-// getAlignment(segments[index_anchor], qrseq) (:797).
-__device__ __forceinline__ void resolve_pair(const WorkDev& w, uint32_t entry, uint32_t& seg_a, uint32_t& seg_b, uint32_t& dst) {
-  dst = entry;
-  if (w.pair_a) { seg_a = w.pair_a[entry]; seg_b = w.pair_b[entry]; return; }
-  const uint4* rows = reinterpret_cast<const uint4*>(w.hits);
-  if (entry >= w.H) {  // anchor <-> query range
-    const uint32_t s = entry - w.H;
-    seg_a = rows[(size_t)(w.set_offsets[s] + w.emit[s].anchor) * w.row_quads].w;  // HitCore::rec
-    seg_b = entry;                                                                 // segment id of the query range = H + s
-    return;
-  }
-  const uint32_t s = w.hit_set[entry];
-  seg_a = rows[(size_t)entry * w.row_quads].w;
-  const uint32_t mode = w.emit[s].mode;
-  seg_b = mode == 1 ? w.H + s : rows[(size_t)(w.set_offsets[s] + w.emit[s].anchor) * w.row_quads].w;
+// getAlignment(segments[index_anchor], qrseq) (:797).  k_emit writes the two segment ids into the entry, so an
+// alignment lane is two dependent loads away from its residues (entry -> descriptors -> store words).
+// Results of hit <-> x alignments are indexed by the hit's record index (= segment id A); the anchor <-> query
+// alignment of a set goes to slot H + s, flagged by the top bit of B.
+constexpr uint32_t kDstIsB = 0x80000000u;
+__device__ __forceinline__ void resolve_pair(const WorkDev& w, uint2 entry, uint32_t& seg_a, uint32_t& seg_b, uint32_t& dst) {
+  if (w.pair_a) { seg_a = w.pair_a[entry.x]; seg_b = w.pair_b[entry.x]; dst = entry.x; return; }  // rpa_align_pairs
+  seg_a = entry.x;
+  seg_b = entry.y & ~kDstIsB;
+  dst = (entry.y & kDstIsB) ? seg_b : seg_a;
 }
 
 // ---- reading a segment out of the packed store --------------------------------------------------------------

@@ -118,7 +118,7 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts) {
   for (int bin = 0; bin < kNumBins; ++bin) {
     const uint32_t n = counts[bin];
     if (!n) continue;
-    const uint32_t* list = w.bin_list + (size_t)bin * w.T2;
+    const uint2* list = w.bin_list + (size_t)bin * w.T2;
     size_t i0 = 0, i1 = 0;
     if (e->profiling) {
       hipEvent_t a = get_event(e), b = get_event(e);
@@ -187,7 +187,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   const size_t n_res = (size_t)(T > T2 ? T : T2) + 1;  // predict: one per hit + one per set; align_pairs: one per pair
   HIP_TRY(e, e->pair_res.ensure(n_res * 8));
   if (want_ext) HIP_TRY(e, e->pair_ext.ensure(n_res * 16));
-  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * 4 * kNumBins));
+  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kNumBins : 1)));
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
@@ -197,7 +197,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->pair_a = want_ext ? e->pair_a.as<uint32_t>() : nullptr; w->pair_b = want_ext ? e->pair_b.as<uint32_t>() : nullptr;
   w->set_offsets = nullptr; w->H = H; w->row_quads = 2 + e->tax.path_quads;
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
-  w->bin_list = e->bin_list.as<uint32_t>(); w->counters = e->counters.as<uint32_t>();
+  w->bin_list = e->bin_list.as<uint2>(); w->counters = e->counters.as<uint32_t>();
   w->og_idx = e->og_idx.as<uint32_t>();
   w->og_dist = e->og_dist.as<int32_t>();
   w->T = T; w->T2 = T2;

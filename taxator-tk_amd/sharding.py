@@ -1,0 +1,56 @@
+"""Multi-GPU plumbing of the RPA path: shard record sets over ranks, gather the 32-byte prediction rows to rank 0.
+
+Record sets are independent (core/taxator.cpp:69-74; README FAQ 10), so there is no data-path collective: each rank
+(one process per GPU) runs whole record sets of a contiguous shard and the only exchange is the gather of
+rpa_prediction rows (RCCL over xGMI on the GPU box, gloo in the CPU tests) -- the replacement of the reference's
+mutex-guarded stdout (core/src/concurrentoutstream.hh:56-75).  Backend-agnostic: uses whatever torch.distributed
+group is initialised.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_sets, world_size):
+    """Contiguous blocks of record sets per rank (keeps input order for the merge); returns world_size+1 bounds."""
+    return [(n_sets * r) // world_size for r in range(world_size + 1)]
+
+
+def slice_batch(batch, lo, hi):
+    """Record sets [lo, hi) of a host batch (dict of numpy arrays in rpa_batch layout), offsets rebased to 0."""
+    so = np.asarray(batch["set_offsets"])
+    r0, r1 = int(so[lo]), int(so[hi])
+    out = {}
+    for k, v in batch.items():
+        if v is None:
+            out[k] = None
+        elif k == "set_offsets":
+            out[k] = (so[lo:hi + 1] - so[lo]).astype(np.uint32)
+        elif k in ("query_seq", "query_len"):
+            out[k] = v[lo:hi]
+        else:
+            out[k] = v[r0:r1]
+    return out
+
+
+def gather_rows(rows, dst=0, group=None):
+    """rows: (n_local, 8) int32 tensor (any device).  Returns the rows of all ranks concatenated in rank order on `dst`
+    (None elsewhere).  Shards may differ in size: sizes are exchanged first, rows are padded to the largest shard."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return rows
+    n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    n_max = max(sizes)
+    padded = rows
+    if rows.shape[0] != n_max:
+        padded = torch.zeros((n_max,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        padded[: rows.shape[0]] = rows
+    bufs = [torch.zeros_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded.contiguous(), bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)

@@ -175,8 +175,9 @@ def make_dataset(n_sets, n_hits, seg_len=200, branching=4, genome_len=4000, seed
     gen.manual_seed(seed * 7919 + 13)
     t_anc = torch.from_numpy(ancs.astype(np.int64)).to(dev)
     q_letters_parts, q_lens, q_anc_parts = [], [], []
-    for c0 in range(0, n_sets, chunk):
-        c1 = min(n_sets, c0 + chunk)
+    qchunk = max(1, min(chunk, (1 << 27) // max(1, Wmax)))
+    for c0 in range(0, n_sets, qchunk):
+        c1 = min(n_sets, c0 + qchunk)
         m = c1 - c0
         base = torch.from_numpy(g_off[sp[c0:c1, 0]] + rs[c0:c1, 0]).to(dev)
         ln = torch.from_numpy(q_src_len[c0:c1]).to(dev)
@@ -235,7 +236,7 @@ def make_dataset(n_sets, n_hits, seg_len=200, branching=4, genome_len=4000, seed
     Lq = int(q_len.max())
     Lr = int((re - rs).max())
     big = torch.iinfo(torch.int64).max
-    step = max(1, chunk // 16)
+    step = max(1, min(chunk // 16, (1 << 26) // max(1, n_hits * max(Lq, Lr))))  # keep the (m, n_hits, L) temporaries bounded
     for c0 in range(0, n_sets, step):
         c1 = min(n_sets, c0 + step)
         qcol = torch.arange(Lq, device=dev)

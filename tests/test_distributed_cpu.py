@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: world_size 2, gloo.  Each rank runs its contiguous shard of record sets (the CPU checker stands
+in for the GPU engine here -- the thing under test is the sharding + gather plumbing that bench.py uses), rank 0
+gathers the 32-byte rows and must reproduce the single-process result in input order."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import __graft_entry__ as graft
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path, uneven):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    sharding = importlib.import_module("taxator_tk_amd.sharding")
+    from helpers import oracle as O
+    ds = synth.make_dataset(n_sets=301 if uneven else 300, n_hits=8, seg_len=120, branching=2, genome_len=1500, seed=3, variety=True)
+    bounds = sharding.shard_bounds(ds.n_sets, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    sub = sharding.slice_batch(ds.batch, lo, hi)
+    tax = O.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    q = O.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+    db = O.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+    rc, rows, st = O.predict_batch(tax, q, db, 0, sub["set_offsets"], sub["query_seq"], sub["query_len"],
+                                   synth.records_aos(sub, O.RECORD_DTYPE))
+    assert rc == 0
+    t = torch.from_numpy(rows.view(np.int32).reshape(-1, 8).copy())
+    allrows = sharding.gather_rows(t, dst=0)
+    dist.barrier()
+    if rank == 0:
+        rc, full, _ = O.predict_batch(tax, q, db, 0, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
+                                      synth.records_aos(ds.batch, O.RECORD_DTYPE))
+        ok = allrows.numpy().tobytes() == full.tobytes() and allrows.shape[0] == ds.n_sets
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    else:
+        assert allrows is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("uneven", [False, True])
+def test_shard_and_gather_world2(tmp_path, uneven):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), out, uneven), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_shard_bounds_and_slices():
+    graft.load_package()
+    sharding = importlib.import_module("taxator_tk_amd.sharding")
+    assert sharding.shard_bounds(10, 4) == [0, 2, 5, 7, 10]
+    b = dict(set_offsets=np.array([0, 2, 5, 6], np.uint32), query_seq=np.arange(3, dtype=np.uint32), query_len=np.array([9, 8, 7], np.uint32),
+             qstart=np.arange(6, dtype=np.uint32), filtered=None)
+    s = sharding.slice_batch(b, 1, 3)
+    assert list(s["set_offsets"]) == [0, 3, 4] and list(s["qstart"]) == [2, 3, 4, 5] and list(s["query_len"]) == [8, 7]
