@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librpa_hip.so")
+LIB_PATH = os.environ.get("RPA_LIB_PATH") or os.path.join(_HERE, "librpa_hip.so")  # RPA_LIB_PATH: A/B builds of the engine
 
 DNA, PROTEIN = 0, 1
 STORE_QUERY, STORE_DB = 0, 1
