@@ -56,8 +56,15 @@ typedef struct {
   float exclude_alignments_factor; /* -x, default 0.5   (taxator.cpp:286, ctor arg exclude_factor) */
   float reeval_bandwidth;          /* -t, default 0.05  (taxator.cpp:287, ctor arg reeval_bandwidth) */
   int device;                      /* HIP device ordinal */
-  uint32_t reserved[4];            /* must be zero */
+  /* Speculation chunks: how many hits of a record set get their alignment requested per round of the pass-1 / pass-2
+   * anchor loops (:604, :757).  The loops have data-dependent early exits; requesting everything at once (0) wastes
+   * alignments the reference would never compute, small chunks cost extra rounds.  Results and the demanded-alignment
+   * counters are identical for every setting.  RPA_SPECULATION_DEFAULT picks the engine's tuned values. */
+  uint32_t speculation_pass1;
+  uint32_t speculation_pass2;
+  uint32_t reserved[2];            /* must be zero */
 } rpa_params;
+#define RPA_SPECULATION_DEFAULT 0xFFFFFFFFu
 
 typedef struct rpa_engine rpa_engine;
 

@@ -48,7 +48,8 @@ class _Taxonomy(C.Structure):
 
 class _Params(C.Structure):
     _fields_ = [("alphabet", C.c_int), ("exclude_alignments_factor", C.c_float), ("reeval_bandwidth", C.c_float),
-                ("device", C.c_int), ("reserved", C.c_uint32 * 4)]
+                ("device", C.c_int), ("speculation_pass1", C.c_uint32), ("speculation_pass2", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
 
 
 class _Batch(C.Structure):
@@ -133,7 +134,7 @@ class RPAPredictionModel:
     tax: object with .parent/.left/.right (uint32) and .depth (uint8) arrays, node 0 = root (pruned taxonomy).
     """
 
-    def __init__(self, tax, alphabet=DNA, exclude_factor=0.5, reeval_bandwidth=0.05, device=0):
+    def __init__(self, tax, alphabet=DNA, exclude_factor=0.5, reeval_bandwidth=0.05, device=0, speculation=None):
         self._L = load_library()
         self._h = C.c_void_p()
         parent = np.ascontiguousarray(tax.parent, np.uint32)
@@ -144,6 +145,8 @@ class RPAPredictionModel:
         p = _Params()
         self._L.rpa_default_params(C.byref(p))
         p.alphabet, p.exclude_alignments_factor, p.reeval_bandwidth, p.device = alphabet, exclude_factor, reeval_bandwidth, device
+        if speculation is not None:  # (pass-1 chunk, pass-2 chunk); 0 = whole set at once; results do not depend on it
+            p.speculation_pass1, p.speculation_pass2 = speculation
         rc = self._L.rpa_create(C.byref(t), C.byref(p), C.byref(self._h))
         if rc:
             raise RpaError(rc, (self._L.rpa_last_error(None) or b"").decode())

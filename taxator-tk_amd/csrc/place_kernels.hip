@@ -253,11 +253,11 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
       if (is_query_pair) {
         if (info.mode == 3) {
           const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor));
-          if (ha.qd == FLT_MAX) { bin = pair_bin(p, ha.seglen, info.qseglen); maxlen = ha.seglen; entry = make_uint2(ha.rec, pos | kDstIsB); }
+          if (info.emit_query && ha.qd == FLT_MAX) { bin = pair_bin(p, ha.seglen, info.qseglen); maxlen = ha.seglen; entry = make_uint2(ha.rec, pos | kDstIsB); }
         }
       } else {
         const uint32_t i = pos - lo;
-        if (i < info.n) {
+        if (i < info.n && i >= info.i_lo && i < info.i_hi) {
           const uint4* pi = hit_ptr<P4>(w, pos);
           const HitCore h = load_core(pi);
           uint32_t other_len = info.qseglen, other_seg = H + s;
@@ -311,6 +311,72 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
     w.bin_list[(size_t)bin * w.T2 + s_base[bin] + s_cnt[bin][wave] + (uint32_t)__popcll(my_mask & ((1ull << lane) - 1ull))] = entry;
 }
 
+// Sparse rounds: when only a small fraction of the record sets is still running, scanning every row of the batch
+// would cost more than the work left.  One wavefront per live set; lane j looks at hits j, j+64, ...; lane 0 also
+// handles the anchor <-> query alignment.  Same predicate and same list format as k_emit.
+template <int P4>
+__global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, Params p) {
+  const uint32_t wave_id = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave_id >= w.counters[kCtrActive]) return;  // exact list length (the grid is sized by an upper bound); whole wave
+  const uint32_t s = w.live_in[wave_id];
+  const uint32_t H = b.n_records;
+  const EmitInfo info = w.emit[s];
+  if (info.mode == 0) return;
+  const uint32_t lo = b.set_offsets[s];
+  uint32_t anchor_len = 0, anchor_rec = 0;
+  float anchor_qd = 0.f;
+  if (info.mode != 1) { const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor)); anchor_len = ha.seglen; anchor_rec = ha.rec; anchor_qd = ha.qd; }
+  uint32_t pb[4 * P4];
+  uint32_t db = 0;
+  if (info.mode == 3) { const uint4* pbp = hit_ptr<P4>(w, lo + info.best); load_path<P4>(pbp, pb); db = meta_depth(load_core(pbp).meta); }
+  uint32_t maxlen = 0;
+  const uint32_t i_hi = min(info.i_hi, info.n);
+  // the query pair rides along as a virtual hit index i_hi handled by lane 0 in the first trip
+  for (uint32_t i0 = info.i_lo; i0 < i_hi || i0 == info.i_lo; i0 += 64) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    int bin = -1;
+    uint2 entry = make_uint2(0u, 0u);
+    if (i < i_hi) {
+      const uint4* pi = hit_ptr<P4>(w, lo + i);
+      const HitCore h = load_core(pi);
+      bool want = false;
+      uint32_t other_len = info.qseglen, other_seg = H + s;
+      if (info.mode == 1) want = !(h.meta & kMetaPerfect) && h.score >= info.fcut;
+      else if (i != info.anchor) {
+        if (info.mode == 2) want = h.qd != 0.f;
+        else if (h.score >= info.fcut && (double)h.qs / info.L >= info.qpid_thresh) {
+          uint32_t pth[4 * P4];
+          load_path<P4>(pi, pth);
+          want = !(common<P4>(pb, db, pth, meta_depth(h.meta)) >= info.d_unode_g);
+        }
+        other_len = anchor_len; other_seg = anchor_rec;
+      }
+      if (want) {
+        bin = pair_bin(p, h.seglen, other_len);
+        maxlen = max(maxlen, h.seglen);
+        entry = make_uint2(h.rec, other_seg);
+        if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = -1; }
+      }
+    }
+    if (i0 == info.i_lo && lane == 63 && info.mode == 3 && info.emit_query && anchor_qd == FLT_MAX && bin < 0) {
+      bin = pair_bin(p, anchor_len, info.qseglen); maxlen = max(maxlen, anchor_len);
+      entry = make_uint2(anchor_rec, (H + s) | kDstIsB);
+    }
+#pragma unroll
+    for (int k = 0; k < kNumBins; ++k) {
+      const unsigned long long mask = __ballot(bin == k);
+      if (mask == 0ull) continue;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&w.counters[k], (uint32_t)__popcll(mask));
+      base = __shfl(base, 0, 64);
+      if (bin == k) w.bin_list[(size_t)k * w.T2 + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
+    }
+    if (i0 + 64 >= i_hi) break;
+  }
+  wave_max_to(&w.counters[kCtrMaxLen], maxlen);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Plan: one thread per record set.  Handles everything predict() decides before any alignment (:341-472): n == 0,
 // n == 1, perfect-best-hit shortcut; otherwise emits pass 0.  (Masking, query range, sorting and segment plans were
@@ -334,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
     st.n = n; st.qrstart = qrstart; st.qrstop = qrstop; st.L = qrstop - qrstart + 1;
     st.qseglen = qseg.x; st.qsegerr = qseg.y;
     st.support = 0; st.best = 0; st.d_lca_all = 0; st.d_rtax = 0; st.d_lnode_g = 0; st.d_unode_g = 0; st.ival_g = 0.f;
-    st.bf_max = 1.f; st.lrd_min = 255; st.anchor = 0; st.cnt0 = st.cnt1 = st.cnt2 = 0;
+    st.bf_max = 1.f; st.lrd_min = 255; st.anchor = 0; st.cnt0 = st.cnt1 = st.cnt2 = 0; st.loop_live = 0; st.chunk_hi = 0; st.i_next = 0;
     OutRow row;
     row.begin = 1; row.end = b.query_len[s];  // initPredictionRecord, core/src/taxonpredictionmodel.hh:42-44
     row.lower = row.upper = row.rtax = kRoot; row.support = 0; row.ival = 0.f; row.flags = 0;
@@ -384,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
       } else {
         done = false;
         st.phase = kPass0Wait;
-        em.mode = 1; em.n = n; em.L = st.L; em.qseglen = st.qseglen;
+        em.mode = 1; em.n = n; em.L = st.L; em.qseglen = st.qseglen; em.i_lo = 0; em.i_hi = n;
         em.fcut = p.reeval_factor * h0.score;  // dbalignment_searchscore_threshold, :499
       }
     }
@@ -392,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
       rows[s] = row;
       if (stats) stats[s] = OutStats{n, 0, 0, 0};
     } else {
-      atomicAdd(&w.counters[kCtrActive], 1u);
+      w.live_out[atomicAdd(&w.counters[kCtrActive], 1u)] = s;
     }
     w.emit[s] = em;
     w.state[s] = st;
@@ -418,6 +484,13 @@ struct BandAcc {
   __device__ void reset(uint32_t ra) {
     anchor_rank = ra;
     for (uint32_t r = 0; r <= ra; ++r) { fmin[r * kBlock] = FLT_MAX; dmax[r * kBlock] = -1.f; }
+  }
+  __device__ void save(float* g) const {  // a paused loop parks its accumulators in HBM
+    for (uint32_t r = 0; r <= anchor_rank; ++r) { g[2 * r] = fmin[r * kBlock]; g[2 * r + 1] = dmax[r * kBlock]; }
+  }
+  __device__ void restore(uint32_t ra, const float* g) {
+    anchor_rank = ra;
+    for (uint32_t r = 0; r <= ra; ++r) { fmin[r * kBlock] = g[2 * r]; dmax[r * kBlock] = g[2 * r + 1]; }
   }
   __device__ void add(float dist, uint32_t rank) {  // BandFactor::addSequence (:267-269), rank = depth(LCA(node, anchor)) (:292-293)
     const float f = fmin[rank * kBlock], d = dmax[rank * kBlock];
@@ -461,8 +534,10 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
                                                     OutStats* __restrict__ stats, unsigned long long* prof_acc) {
   __shared__ float s_fmin[kMaxDepth + 1][kBlock];
   __shared__ float s_dmax[kMaxDepth + 1][kBlock];
-  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-  bool live = s < b.n_sets;
+  // dense rounds: one thread per record set; sparse rounds (few sets still running): one thread per entry of the live list
+  const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+  bool live = tid < (w.live_in ? w.n_live_in : b.n_sets);
+  const uint32_t s = live ? (w.live_in ? w.live_in[tid] : tid) : 0u;
   SetState st;
   st.phase = kDone;
   if (live) st = w.state[s];
@@ -556,14 +631,23 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       const float qdist = ha.qd;
       uint32_t* __restrict__ ogi = w.og_idx + lo;
       int32_t* __restrict__ ogd = w.og_dist + lo;
-      uint32_t nog = 0;
       BandAcc band{&s_fmin[0][threadIdx.x], &s_dmax[0][threadIdx.x], 0};
-      band.reset(da);  // BandFactor(...); addSequence(0, rnode) (:581,586): the anchor entry only sets the start rank
-      uint32_t d_lnode = st.d_rtax;  // lnode = rtax (:587), a point on the best hit's path
-      float ldist = 0.f, udist = FLT_MAX;
-      double qpid_upper = 0., cut_g = 0., cut_h = 0.;  // :599-601
-      int scut = 0;                                     // :602 (int!)
-      for (uint32_t i = 0; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
+      // loop state: fresh for a new anchor, restored when the previous round paused at the end of its chunk
+      uint32_t nog, d_lnode, i;
+      float ldist, udist;
+      double qpid_upper, cut_g, cut_h;  // :599-601
+      int scut;                         // :602 (int!)
+      if (!st.loop_live) {
+        band.reset(da);  // BandFactor(...); addSequence(0, rnode) (:581,586): the anchor entry only sets the start rank
+        nog = 0; d_lnode = st.d_rtax /* lnode = rtax, :587 */; ldist = 0.f; udist = FLT_MAX;
+        qpid_upper = cut_g = cut_h = 0.; scut = 0; i = 0;
+      } else {
+        band.restore(da, w.band_save + (size_t)s * 2 * (kMaxDepth + 1));
+        nog = st.nog; d_lnode = st.d_lnode; ldist = st.ldist; udist = st.udist;
+        qpid_upper = st.qpid_upper; cut_g = st.cut_g; cut_h = st.cut_h; scut = st.scut; i = st.i_next;
+      }
+      bool paused = false;
+      for (; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
         const uint4* pi = hit_ptr<P4>(w, lo + i);
         const HitCore h = load_core(pi);
         if (!(h.score >= (float)scut)) break;
@@ -575,6 +659,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         if (i == a) dist = 0.f;
         else if (h.qd == 0.f) dist = qdist;  // :620-621
         else {
+          if (i >= st.chunk_hi) { paused = true; break; }  // this alignment was not part of the chunk emitted last round
           const float2 r2 = res[h.rec];
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
@@ -601,6 +686,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           ogi[nog] = i; ogd[nog] = (int)dist; ++nog;
         }
       }
+      if (paused) {  // ask for the next chunk of this anchor's loop and come back
+        st.loop_live = 1; st.i_next = i; st.nog = nog; st.d_lnode = d_lnode; st.ldist = ldist; st.udist = udist;
+        st.qpid_upper = qpid_upper; st.cut_g = cut_g; st.cut_h = cut_h; st.scut = scut;
+        band.save(w.band_save + (size_t)s * 2 * (kMaxDepth + 1));
+        st.chunk_hi = p.spec1 ? min(n, i + p.spec1) : n;
+        em.mode = 2; em.anchor = a; em.i_lo = i; em.i_hi = st.chunk_hi;
+      } else
       if (!failed) {
         const float bandfactor = band.factor();  // :667
         st.bf_max = st.bf_max < bandfactor ? bandfactor : st.bf_max;
@@ -651,6 +743,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         bool more = false;
         for (uint32_t j = 0; j < n; ++j) more |= (load_core(hit_ptr<P4>(w, lo + j)).meta & kMetaQGroup) != 0;
         st.phase = (more && st.d_lnode_g != 0) ? kPass1Select : kPass2Select;  // :729
+        st.loop_live = 0;
       }
     } else if (st.phase == kPass2Wait) {  // ---- pass 2 for one anchor, :750-820 ----
       const uint32_t a = st.anchor;
@@ -660,11 +753,12 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       load_path<P4>(pbp, pb);
       const uint32_t db = meta_depth(load_core(pbp).meta);
       float qd_a = ha.qd, qs_a = ha.qs;
-      const double qpid_anchor = (double)qs_a / L;
-      const double g = qpid_anchor * 2. - 1., h2 = qpid_anchor * X;
-      const double qpid_thresh = g < h2 ? h2 : g;
-      const float scut = ha.score * X;  // :754 (float here)
-      for (uint32_t i = 0; i < n; ++i) {  // :757
+      const EmitInfo sel = w.emit[s];            // thresholds were fixed when the anchor was selected (:750-754)
+      const double qpid_thresh = sel.qpid_thresh;
+      const float scut = sel.fcut;
+      bool paused = false;
+      uint32_t i = st.loop_live ? st.i_next : 0u;
+      for (; i < n; ++i) {  // :757
         const uint4* pi = hit_ptr<P4>(w, lo + i);
         const HitCore h = load_core(pi);
         if (!(h.score >= scut)) break;
@@ -677,6 +771,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         if (i == a) dist = 0.f;
         else {
           if (cb >= st.d_unode_g) continue;  // isParentOf(unode_global, cnode) || cnode == unode_global, :771
+          if (i >= st.chunk_hi) { paused = true; break; }  // not part of the chunk emitted last round
           const float2 r2 = res[h.rec];
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
@@ -702,8 +797,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           if (dist <= qdist_ex) st.d_unode_g = min(st.d_unode_g, cb);  // unode_global = LCA(unode_global, cnode), :811-813
         }
       }
-      if (!failed) st.phase = kPass2Select;
+      if (paused) {
+        st.loop_live = 1; st.i_next = i;
+        st.chunk_hi = p.spec2 ? min(n, i + p.spec2) : n;
+        em = sel; em.mode = 3; em.i_lo = i; em.i_hi = st.chunk_hi; em.emit_query = 0; em.d_unode_g = st.d_unode_g;
+      } else if (!failed) { st.phase = kPass2Select; st.loop_live = 0; }
     }
+
 
     // ---- choose what to align next ----
     if (!failed && st.phase == kPass1Select) {  // :582-583
@@ -711,7 +811,9 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       HitCore h = load_core(hit_ptr<P4>(w, lo));
       while (a + 1 < n && !(h.meta & kMetaQGroup)) { ++a; h = load_core(hit_ptr<P4>(w, lo + a)); }
       store_dyn(w, kStride4, lo + a, h.qd, h.qs, h.seglen, h.meta & ~kMetaQGroup);
-      st.anchor = a; st.phase = kPass1Wait; em.mode = 2; em.anchor = a;
+      st.anchor = a; st.phase = kPass1Wait; st.loop_live = 0;
+      st.chunk_hi = p.spec1 ? min(n, p.spec1) : n;
+      em.mode = 2; em.anchor = a; em.i_lo = 0; em.i_hi = st.chunk_hi;
     } else if (!failed && st.phase == kPass2Select) {  // :739-747
       bool found = false;
       for (uint32_t a = 0; a < n; ++a) {
@@ -719,8 +821,10 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         if (!(h.meta & kMetaOutGroup)) continue;
         store_dyn(w, kStride4, lo + a, h.qd, h.qs, h.seglen, h.meta & ~kMetaOutGroup);
         if (st.d_unode_g == st.d_lca_all) continue;  // unode_global == lca_allnodes: both lie on the best hit's path
-        st.anchor = a; st.phase = kPass2Wait; found = true;
+        st.anchor = a; st.phase = kPass2Wait; found = true; st.loop_live = 0;
+        st.chunk_hi = p.spec2 ? min(n, p.spec2) : n;
         em.mode = 3; em.anchor = a; em.best = st.best; em.d_unode_g = st.d_unode_g;
+        em.i_lo = 0; em.i_hi = st.chunk_hi; em.emit_query = 1;
         em.fcut = h.score * X;                                   // qsearchscore_thresh_heuristic, :754
         const double qpid_anchor = (double)h.qs / L;             // :750-753
         const double g2 = qpid_anchor * 2. - 1., h3 = qpid_anchor * X;
@@ -743,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       }
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
-    if (st.phase != kDone) atomicAdd(&w.counters[kCtrActive], 1u);
+    if (st.phase != kDone) w.live_out[atomicAdd(&w.counters[kCtrActive], 1u)] = s;  // still running: next round's live list
     w.emit[s] = em;
     w.state[s] = st;
   }
@@ -776,6 +880,12 @@ hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w,
 }
 
 hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p) {
+  if (w.live_in) {  // sparse round: one wave per live set
+    if (w.n_live_in == 0) return hipSuccess;
+    const dim3 grid(((size_t)w.n_live_in * 64 + kBlock - 1) / kBlock);
+    RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_emit_sparse<P4>, grid, dim3(kBlock), 0, st, b, w, p));
+    return hipGetLastError();
+  }
   const uint32_t total = b.n_records + b.n_sets;
   if (total == 0) return hipSuccess;
   const dim3 grid((total + kEmitBlock - 1) / kEmitBlock);
@@ -785,8 +895,9 @@ hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, cons
 
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc) {
-  if (b.n_sets == 0) return hipSuccess;
-  const dim3 grid((b.n_sets + kBlock - 1) / kBlock);
+  const uint32_t n_threads = w.live_in ? w.n_live_in : b.n_sets;
+  if (n_threads == 0) return hipSuccess;
+  const dim3 grid((n_threads + kBlock - 1) / kBlock);
   RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_decide<P4>, grid, dim3(kBlock), 0, st, b, w, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc));
   return hipGetLastError();
 }
@@ -836,7 +947,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_pairs(WorkDev w, uint32_t n_pair
 
 hipError_t launch_bin_pairs(hipStream_t st, int alphabet, const WorkDev& w, uint32_t n_pairs) {
   if (n_pairs == 0) return hipSuccess;
-  Params p{alphabet, 0.f, 0.f};
+  Params p{alphabet, 0.f, 0.f, 0u, 0u};
   hipLaunchKernelGGL(k_bin_pairs, dim3((n_pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, st, w, n_pairs, p);
   return hipGetLastError();
 }

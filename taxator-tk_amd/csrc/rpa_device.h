@@ -71,6 +71,15 @@ struct SetState {
   uint32_t lrd_min;    // lca_root_dist_min
   uint32_t anchor;
   uint32_t cnt0, cnt1, cnt2;
+  // resumable loops: with a speculation chunk smaller than the set, a pass-1 / pass-2 loop runs over several rounds
+  uint32_t loop_live;  // 0: the loop of `anchor` has not started, 1: paused at i_next
+  uint32_t i_next;     // first hit the paused loop has not processed
+  uint32_t chunk_hi;   // hits below this index had their alignment emitted
+  uint32_t nog;        // pass 1: entries of outgroup_tmp so far
+  uint32_t d_lnode;    // pass 1: lnode (depth on the best hit's path)
+  float ldist, udist;
+  int32_t scut;        // qsearchscore_thresh_heuristic (:602)
+  double qpid_upper, cut_g, cut_h;
 };
 
 // One hit of a record set at its SortFilter position: 32 bytes of fields + the taxon path (4*path_quads words),
@@ -106,6 +115,9 @@ struct EmitInfo {
   double qpid_thresh;   // pass 2 (:750-753)
   uint32_t best;        // pass 2: index_best
   uint32_t qseglen;     // length of the query range segment
+  uint32_t i_lo, i_hi;  // only hits with i_lo <= i < i_hi are emitted this round (speculation chunk of the running loop)
+  uint32_t emit_query;  // pass 2: also emit the anchor <-> query alignment (first chunk of an anchor only)
+  uint32_t pad_;
 };
 
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
@@ -131,6 +143,12 @@ struct WorkDev {
   uint2* bin_list;      // kNumBins * T2 entries (segment A, segment B | kDstIsB)
   uint32_t* counters;   // kNumCounters words, layout below
   // pass-1 scratch (per set region like the pair slots)
+  float* band_save;     // S * 2*(kMaxDepth+1): BandFactor accumulators of paused pass-1 loops
+  // live lists: plan/decide append every set that is still running to live_out; a sparse round (few live sets) runs
+  // emit/decide over live_in instead of over the whole batch
+  const uint32_t* live_in;  // null in dense rounds
+  uint32_t n_live_in;
+  uint32_t* live_out;       // S
   uint32_t* og_idx;     // T
   int32_t* og_dist;     // T
   const uint32_t* set_offsets;  // S+1 (copy of the batch's, for the alignment kernels)
@@ -147,6 +165,7 @@ struct Params {
   int alphabet;
   float exclude_factor;   // exclude_alignments_factor_
   float reeval_factor;    // reeval_bandwidth_factor_ = (float)(1. - reeval_bandwidth)
+  uint32_t spec1, spec2;  // speculation chunk (hits per round) of the pass-1 / pass-2 loops; 0 = the whole set at once
 };
 
 struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells

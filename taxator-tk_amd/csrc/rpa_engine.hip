@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -61,11 +62,12 @@ struct rpa_engine {
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8;
   DevBuf state, hits, set_info, set_qseg, emit, hit_set, seg, pair_a, pair_b,
-      pair_res, pair_ext, bin_list, counters, og_idx, og_dist, out_rows, out_stats, tmp_letters,
+      pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
       tmp_words, tmp_offsets, protein_ws;
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
   bool profiling = false;
+  bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   DevBuf prof_acc;
   rpa_profile prof{};
   std::vector<hipEvent_t> ev_pool;
@@ -189,6 +191,9 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   if (want_ext) HIP_TRY(e, e->pair_ext.ensure(n_res * 16));
   HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kNumBins : 1)));
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
+  HIP_TRY(e, e->live_a.ensure((size_t)(S ? S : 1) * 4));
+  HIP_TRY(e, e->live_b.ensure((size_t)(S ? S : 1) * 4));
+  HIP_TRY(e, e->band_save.ensure((size_t)(S ? S : 1) * 2 * (kMaxDepth + 1) * 4));
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
   w->state = e->state.as<SetState>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
@@ -198,7 +203,8 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->set_offsets = nullptr; w->H = H; w->row_quads = 2 + e->tax.path_quads;
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
   w->bin_list = e->bin_list.as<uint2>(); w->counters = e->counters.as<uint32_t>();
-  w->og_idx = e->og_idx.as<uint32_t>();
+  w->og_idx = e->og_idx.as<uint32_t>(); w->band_save = e->band_save.as<float>();
+  w->live_in = nullptr; w->n_live_in = 0; w->live_out = e->live_a.as<uint32_t>();
   w->og_dist = e->og_dist.as<int32_t>();
   w->T = T; w->T2 = T2;
   return RPA_OK;
@@ -225,6 +231,8 @@ void rpa_default_params(rpa_params* p) {
   p->exclude_alignments_factor = 0.5f;  // taxator.cpp:286
   p->reeval_bandwidth = 0.05f;          // taxator.cpp:287
   p->device = 0;
+  p->speculation_pass1 = RPA_SPECULATION_DEFAULT;
+  p->speculation_pass2 = RPA_SPECULATION_DEFAULT;
 }
 
 const char* rpa_last_error(const rpa_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -252,6 +260,13 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.alphabet = params->alphabet;
   e->params.exclude_factor = params->exclude_alignments_factor;
   e->params.reeval_factor = (float)(1. - params->reeval_bandwidth);  // reeval_bandwidth_factor_(1. - reeval_bandwidth), :334
+  // speculation chunks (hits whose alignment is requested per round of a pass-1 / pass-2 loop): results never depend on
+  // them, only the number of alignments computed beyond what the reference demands and the number of rounds
+  e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 0u : 8u) : params->speculation_pass1;
+  e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 6u) : params->speculation_pass2;  // tools/spec_sweep.sh
+  e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
+  if (const char* v = getenv("RPA_SPEC1")) e->params.spec1 = (uint32_t)atoi(v);
+  if (const char* v = getenv("RPA_SPEC2")) e->params.spec2 = (uint32_t)atoi(v);
   auto bail = [&](int code) { g_create_error = e->err; rpa_destroy(e); return code; };
 #define CREATE_TRY(call)                                                                                  \
   do {                                                                                                    \
@@ -310,7 +325,7 @@ void rpa_destroy(rpa_engine* e) {
   DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->state, &e->hits,
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->hit_set, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
-                    &e->og_idx, &e->og_dist, &e->out_rows, &e->out_stats, &e->tmp_letters,
+                    &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
                     &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
@@ -440,21 +455,42 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
   HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
   HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev));
   uint64_t rounds = 0;
+  uint32_t prev_live = S;     // upper bound of the current live list's length (its exact length is counters[kCtrActive])
+  bool list_in_a = true;      // plan wrote the first live list into live_a
   for (;;) {
-    // plan/decide left, per set, what it wants aligned next (EmitInfo); k_emit turns that into per-bin work lists
+    // plan/decide left, per set, what it wants aligned next (EmitInfo) and appended the set to the live list.
+    // Dense round: scan every row / every set.  Sparse round (few sets left): walk the live list only.
+    uint32_t* cur_list = list_in_a ? e->live_a.as<uint32_t>() : e->live_b.as<uint32_t>();
+    uint32_t* next_list = list_in_a ? e->live_b.as<uint32_t>() : e->live_a.as<uint32_t>();
+    const bool sparse_emit = rounds > 0 && (uint64_t)prev_live * 24 <= S;
+    w.live_in = sparse_emit ? cur_list : nullptr;
+    w.n_live_in = prev_live;  // grid bound only: the kernel reads the exact length from counters[kCtrActive]
     HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, e->params));
     HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     rc = check_device_error(e, e->h_counters);
     if (rc) return rc;
-    if (e->h_counters[kCtrActive] == 0) break;
+    const uint32_t live_now = e->h_counters[kCtrActive];
+    if (live_now == 0) break;
     uint32_t counts[kNumRoundCounters];
     memcpy(counts, e->h_counters, sizeof(counts));
+    if (e->trace_rounds) {
+      uint64_t pairs = 0;
+      for (int k = 0; k < kNumBins; ++k) pairs += counts[k];
+      fprintf(stderr, "[rpa] round %llu (%s): live sets %u, alignments %llu\n", (unsigned long long)rounds, sparse_emit ? "sparse" : "dense",
+              live_now, (unsigned long long)pairs);
+    }
     rc = run_align_bins(e, w, counts);
     if (rc) return rc;
     HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kNumRoundCounters, e->stream));  // keep the error words
+    const bool sparse_decide = rounds > 0 && (uint64_t)live_now * 24 <= S;
+    w.live_in = sparse_decide ? cur_list : nullptr;
+    w.n_live_in = live_now;   // exact
+    w.live_out = next_list;
     HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev,
                              e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr));
+    prev_live = live_now;
+    list_in_a = !list_in_a;
     ++rounds;
     if (rounds > (uint64_t)H + S + 8) return fail(e, RPA_ERR_INVALID, "placement state machine did not terminate");
   }

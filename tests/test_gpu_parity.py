@@ -172,8 +172,8 @@ def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir):
         assert np.float32(got["similarity"]).tobytes() == np.float32(o["similarity"]).tobytes(), k
 
 
-def _engine_vs_oracle(pkg, oracle, synth, ds, alphabet):
-    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
+def _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, speculation=None):
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet, speculation=speculation)
     model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
     model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
     rows, stats = model.predict(ds.batch)
@@ -204,6 +204,17 @@ def test_predict_dna_variety(pkg, oracle, synth, seed):
     ds = synth.make_dataset(n_sets=3000, n_hits=20, seg_len=200, branching=4, genome_len=3000, seed=seed, variety=True)
     rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0)
     assert (rows["flags"] & 1).any() and (rows["flags"] & 2).any() and (rows["flags"] & 4).any()
+
+
+@pytest.mark.parametrize("speculation", [(0, 0), (1, 1), (3, 2), (7, 50)])
+def test_speculation_chunks_never_change_results(pkg, oracle, synth, speculation):
+    """The pass-1 / pass-2 anchor loops may be fed their alignments in chunks of any size (resumable loops): rows AND the
+    demanded-alignment counters must stay those of the reference control flow."""
+    ds = synth.make_dataset(n_sets=1500, n_hits=20, seg_len=150, branching=4, genome_len=3000, seed=21, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=speculation)
+    dp = synth.make_dataset(n_sets=300, n_hits=16, seg_len=60, branching=3, genome_len=1500, seed=22, alphabet=1,
+                            level_rate=0.06, query_rate=0.08, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, dp, 1, speculation=speculation)
 
 
 def test_predict_dna_ragged_sets_and_lengths(pkg, oracle, synth):
