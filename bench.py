@@ -4,7 +4,7 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path (rpa_predict_batch: rank -> plan -> materialise -> {align, decide}* ) over one
+A "step" is one pass of the hot path (rpa_predict_batch: rank -> plan -> {emit, align, decide}* ) over one
 synthetic batch that is already resident in HBM: BASELINE config 2, 1 M record sets x 20 hits x ~200 bp per GPU
 (weak scaling: every rank gets its own 1 M sets, seed 2 + rank).  The unit counted is the reference's own: one
 pairwise alignment demanded by RPAPredictionModel::predict's control flow (its gcounter, STATS column 7), NOT the
@@ -161,6 +161,15 @@ def main():
     demanded_all = int(d.item())
 
     if rank == 0:
+        # HBM traffic of the alignment kernels cannot be read from inside the process: it comes from the committed
+        # rocprofv3 PMC passes of this same command (profiles/*traffic.json, see profiles/README.md)
+        traffic, traffic_src = None, None
+        if args.config == "c2":
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+            if cands:
+                tj = json.load(open(cands[-1]))
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
         value = demanded_all * args.steps / elapsed
         n_launch = max(prof["launches"], 1)
         align_s = prof["align_ms"] / 1e3
@@ -177,7 +186,8 @@ def main():
                        "unit_counted": "alignments demanded by the reference control flow (STATS gcounter), not speculative ones"},
             "record_sets_per_s": ds.n_sets * world * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC)",
+                         "traffic_source": traffic_src,
                          "kernel": cfg["kernel"],
                          "bytes_per_launch": prof["residue_bytes"] / n_launch,
                          "avg_launch_ms": prof["align_ms"] / n_launch, "launches": prof["launches"],
