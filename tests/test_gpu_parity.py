@@ -339,3 +339,72 @@ def test_device_resident_batch_and_profile(pkg, oracle, synth):
     assert prof["demanded"] == demanded and prof["pairs"] >= demanded and prof["launches"] >= 3
     assert 0 < prof["align_ms"] <= prof["total_ms"]
     assert prof["residue_bytes"] > prof["pairs"] * 300 and prof["cells"] > prof["pairs"] * 150 * 150
+
+
+def test_reverse_strand_at_store_edges_and_tiny_segments(pkg, oracle):
+    """Segments that touch the first / last residues of the store, reverse strand included (the in-place reader's
+    funnel shift runs off the front of the store there), 1..40 nt long, against the oracle."""
+    rng = np.random.default_rng(17)
+    ref = rng.integers(0, 5, 300).astype(np.uint8)
+    qry = rng.integers(0, 4, 120).astype(np.uint8)
+
+    class T:  # root + 3 levels, 4 leaves
+        parent = np.array([0, 0, 1, 1, 2, 2, 3, 3], np.uint32)
+        depth = np.array([0, 1, 2, 2, 3, 3, 3, 3], np.uint8)
+        left = np.array([1, 2, 3, 9, 4, 6, 10, 12], np.uint32)
+        right = np.array([16, 15, 8, 14, 5, 7, 11, 13], np.uint32)
+
+    model = pkg.RPAPredictionModel(T(), alphabet=pkg.DNA, speculation=(2, 2))
+    model.load_store(pkg.STORE_QUERY, LETTERS_DNA[qry], np.array([0, 120], np.uint64))
+    model.load_store(pkg.STORE_DB, LETTERS_DNA[ref], np.array([0, 300], np.uint64))
+    tax = oracle.TaxArrays(T.parent, T.left, T.right, T.depth)
+    q = oracle.StoreArrays(qry, [0, 120])
+    db = oracle.StoreArrays(ref, [0, 300])
+    sets = []
+    for qs, qe in [(1, 1), (1, 3), (1, 8), (1, 9), (1, 40), (100, 120), (113, 120), (120, 120)]:
+        hits = []
+        span = qe - qs
+        for (a, b) in [(1, 1 + span), (1 + span, 1), (2, 2 + span), (2 + span, 2), (300 - span, 300), (300, 300 - span), (7, 7 + span), (9 + span, 9)]:
+            hits.append((qs, qe, a, b, float(rng.integers(10, 50)), int(rng.integers(0, span + 1)), span + 1, 0, int(rng.integers(4, 8)), 0))
+        sets.append(hits)
+    recs = np.array([h for s in sets for h in s], oracle.RECORD_DTYPE)
+    offs = np.cumsum([0] + [len(s) for s in sets]).astype(np.uint32)
+    batch = dict(set_offsets=offs, query_seq=np.zeros(len(sets), np.uint32), query_len=np.full(len(sets), 120, np.uint32),
+                 filtered=np.zeros(len(recs), np.uint8))
+    for f in ("qstart", "qstop", "rstart", "rstop", "score", "identities", "alnlen", "ref_seq", "node"):
+        batch[f] = recs[f].copy()
+    rows, stats = model.predict(batch)
+    rc, exp, est = oracle.predict_batch(tax, q, db, 0, offs, batch["query_seq"], batch["query_len"], recs)
+    assert rc == 0
+    assert rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes()
+    assert int(est["pass1"].sum()) > 0
+
+
+def test_large_record_sets(pkg, oracle, synth):
+    """Record sets far larger than a wavefront (300 hits) and a batch mixing set sizes 2..300."""
+    ds = synth.make_dataset(n_sets=40, n_hits=300, seg_len=120, branching=4, genome_len=1500, seed=31, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(16, 5))
+
+
+def test_empty_and_degenerate_batches(pkg):
+    class T:
+        parent = np.zeros(1, np.uint32)
+        left = np.array([1], np.uint32)
+        right = np.array([2], np.uint32)
+        depth = np.zeros(1, np.uint8)
+    model = pkg.RPAPredictionModel(T(), alphabet=pkg.DNA)
+    model.load_store(pkg.STORE_QUERY, LETTERS_DNA[np.zeros(10, np.uint8)], np.array([0, 10], np.uint64))
+    model.load_store(pkg.STORE_DB, LETTERS_DNA[np.zeros(10, np.uint8)], np.array([0, 10], np.uint64))
+    z32 = np.zeros(0, np.uint32)
+    empty = dict(set_offsets=np.zeros(1, np.uint32), query_seq=z32, query_len=z32, qstart=z32, qstop=z32, rstart=z32, rstop=z32,
+                 score=np.zeros(0, np.float32), identities=z32, alnlen=z32, ref_seq=z32, node=z32, filtered=np.zeros(0, np.uint8))
+    rows, stats = model.predict(empty)
+    assert len(rows) == 0
+    # record sets without any record (set_offsets repeats): every one comes back unclassified with the stale-ival flag
+    three = dict(empty)
+    three["set_offsets"] = np.zeros(4, np.uint32)
+    three["query_seq"] = np.zeros(3, np.uint32)
+    three["query_len"] = np.array([10, 10, 10], np.uint32)
+    rows, stats = model.predict(three)
+    assert list(rows["flags"]) == [1, 1, 1] and list(rows["end"]) == [10, 10, 10] and list(stats["n"]) == [0, 0, 0]
