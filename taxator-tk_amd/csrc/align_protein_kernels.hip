@@ -120,8 +120,10 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint2* __restrict__
     const bool first = k == 0, last = k + 1 == nstrips;
     int2 nxt = make_int2(0, 0);
     if (!first) nxt = sc[(size_t)1 * col_stride];
+    uint32_t a_next = pa[0];  // column residues are fetched one column ahead of their use
     for (uint32_t j = 1; j <= la; ++j) {
-      const uint32_t a = pa[j - 1];
+      const uint32_t a = a_next;
+      if (j < la) a_next = pa[j];
       const uint32_t colterm = (a >> 2) * 128u + bank4;
       const uint32_t shift = (a & 3u) * 8u;
       int32_t top_s;
@@ -181,7 +183,9 @@ size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len) {
   return threads * 2 * ((size_t)max_len + 2);
 }
 
-hipError_t launch_align_protein(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
+// Strip height per work list: pairs are binned by the R in {8,16,24,32} that wastes the fewest rows for their vertical
+// length (67 aa: 3 strips of 24 = 72 rows instead of 3 x 32 = 96).
+hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
   hipError_t e = upload_blosum();
@@ -195,8 +199,13 @@ hipError_t launch_align_protein(hipStream_t st, const uint2* list, uint32_t n, c
   for (uint32_t done = 0; done < n;) {
     const uint32_t chunk = (uint32_t)((size_t)(n - done) < threads ? (n - done) : threads);
     const uint32_t blocks = (chunk + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_nw_protein<32>, dim3(blocks), dim3(kBlock), 0, st, list + done, chunk, w,
-                       reinterpret_cast<int2*>(scratch), blocks * kBlock, prof_acc);
+#define RPA_LAUNCH_NW(RV) \
+  case RV: hipLaunchKernelGGL(k_nw_protein<RV>, dim3(blocks), dim3(kBlock), 0, st, list + done, chunk, w, reinterpret_cast<int2*>(scratch), blocks * kBlock, prof_acc); break;
+    switch (strip_rows) {
+      RPA_LAUNCH_NW(8) RPA_LAUNCH_NW(16) RPA_LAUNCH_NW(24) RPA_LAUNCH_NW(32)
+      default: return hipErrorInvalidValue;
+    }
+#undef RPA_LAUNCH_NW
     done += chunk;
   }
   return hipGetLastError();

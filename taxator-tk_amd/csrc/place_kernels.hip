@@ -216,7 +216,9 @@ __device__ __forceinline__ void wave_max_to(uint32_t* counter, uint32_t v) {
 
 __device__ __forceinline__ int pair_bin(const Params& p, uint32_t la, uint32_t lb) {
   if (p.alphabet == 0) return dna_bin(la < lb ? la : lb);
-  return 0;  // protein: one kernel, one bin
+  (void)la;
+  if (p.force_bin >= 0) return p.force_bin;
+  return protein_bin(lb);  // protein: B (second segment) is the vertical sequence cut into register strips
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_pairs(WorkDev w, uint32_t n_pair
 
 hipError_t launch_bin_pairs(hipStream_t st, int alphabet, const WorkDev& w, uint32_t n_pairs) {
   if (n_pairs == 0) return hipSuccess;
-  Params p{alphabet, 0.f, 0.f, 0u, 0u};
+  Params p{alphabet, 0.f, 0.f, 0u, 0u, -1};
   hipLaunchKernelGGL(k_bin_pairs, dim3((n_pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, st, w, n_pairs, p);
   return hipGetLastError();
 }

@@ -166,6 +166,7 @@ struct Params {
   float exclude_factor;   // exclude_alignments_factor_
   float reeval_factor;    // reeval_bandwidth_factor_ = (float)(1. - reeval_bandwidth)
   uint32_t spec1, spec2;  // speculation chunk (hits per round) of the pass-1 / pass-2 loops; 0 = the whole set at once
+  int force_bin;          // >= 0: put every pair into this bin (experiments: RPA_FORCE_BIN); -1 normally
 };
 
 struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells
@@ -193,7 +194,7 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
                                   unsigned long long* prof_acc);
 hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint2* list, uint32_t n, const WorkDev& w,
                                  unsigned long long* prof_acc);
-hipError_t launch_align_protein(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
+hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
 
@@ -209,6 +210,15 @@ __device__ __forceinline__ void resolve_pair(const WorkDev& w, uint2 entry, uint
   seg_a = entry.x;
   seg_b = entry.y & ~kDstIsB;
   dst = (entry.y & kDstIsB) ? seg_b : seg_a;
+}
+
+// protein: bin = strip height index (R = 8 * (bin + 1)).  One height for every pair: R = 24.  Measured on MI355X at
+// 67 aa (tools/ab_protein.sh, same device): R = 16 and 24 tie, R = 32 is 17 % slower (172 VGPRs -> 2 waves per SIMD),
+// R = 8 is 50 % slower (per-column overhead); choosing 16 or 24 per pair costs 7 % more than either alone (two
+// half-filled launches per round).  RPA_FORCE_BIN selects another height for experiments.
+__host__ __device__ __forceinline__ int protein_bin(uint32_t lb) {
+  (void)lb;
+  return 2;
 }
 
 // ---- reading a segment out of the packed store --------------------------------------------------------------

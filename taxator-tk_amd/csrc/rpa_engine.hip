@@ -134,7 +134,7 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts) {
     } else {
       const uint32_t max_len = counts[kCtrMaxLen];
       HIP_TRY(e, e->protein_ws.ensure(protein_scratch_words(n, max_len) * 4));
-      HIP_TRY(e, launch_align_protein(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
+      HIP_TRY(e, launch_align_protein(e->stream, 8 * (bin + 1), list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
     }
     if (e->profiling) {
       HIP_TRY(e, hipEventRecord(e->ev_pool[i1], e->stream));
@@ -189,7 +189,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   const size_t n_res = (size_t)(T > T2 ? T : T2) + 1;  // predict: one per hit + one per set; align_pairs: one per pair
   HIP_TRY(e, e->pair_res.ensure(n_res * 8));
   if (want_ext) HIP_TRY(e, e->pair_ext.ensure(n_res * 16));
-  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kNumBins : 1)));
+  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kNumBins : 4)));
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
   HIP_TRY(e, e->live_a.ensure((size_t)(S ? S : 1) * 4));
   HIP_TRY(e, e->live_b.ensure((size_t)(S ? S : 1) * 4));
@@ -265,6 +265,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 0u : 8u) : params->speculation_pass1;
   e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 6u) : params->speculation_pass2;  // tools/spec_sweep.sh
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
+  e->params.force_bin = -1;
+  if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
   if (const char* v = getenv("RPA_SPEC1")) e->params.spec1 = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SPEC2")) e->params.spec2 = (uint32_t)atoi(v);
   auto bail = [&](int code) { g_create_error = e->err; rpa_destroy(e); return code; };
@@ -477,8 +479,10 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
     if (e->trace_rounds) {
       uint64_t pairs = 0;
       for (int k = 0; k < kNumBins; ++k) pairs += counts[k];
-      fprintf(stderr, "[rpa] round %llu (%s): live sets %u, alignments %llu\n", (unsigned long long)rounds, sparse_emit ? "sparse" : "dense",
+      fprintf(stderr, "[rpa] round %llu (%s): live sets %u, alignments %llu, per bin:", (unsigned long long)rounds, sparse_emit ? "sparse" : "dense",
               live_now, (unsigned long long)pairs);
+      for (int k = 0; k < kNumBins; ++k) if (counts[k]) fprintf(stderr, " %d:%u", k, counts[k]);
+      fprintf(stderr, "\n");
     }
     rc = run_align_bins(e, w, counts);
     if (rc) return rc;
