@@ -534,8 +534,11 @@ __device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t
 template <int P4>
 __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params p, OutRow* __restrict__ rows,
                                                     OutStats* __restrict__ stats, unsigned long long* prof_acc) {
-  __shared__ float s_fmin[kMaxDepth + 1][kBlock];
-  __shared__ float s_dmax[kMaxDepth + 1][kBlock];
+  // BandFactor accumulators: (deepest taxonomy level + 1) ranks x 256 threads x {fmin, dmax}; sized at launch so that a
+  // pruned NCBI tree (8 levels) needs 18 KB and the kernel can share a CU with the alignment kernel of another stream
+  extern __shared__ float s_band[];
+  float* s_fmin = s_band;
+  float* s_dmax = s_band + (size_t)w.band_ranks * kBlock;
   // dense rounds: one thread per record set; sparse rounds (few sets still running): one thread per entry of the live list
   const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
   bool live = tid < (w.live_in ? w.n_live_in : b.n_sets);
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       const float qdist = ha.qd;
       uint32_t* __restrict__ ogi = w.og_idx + lo;
       int32_t* __restrict__ ogd = w.og_dist + lo;
-      BandAcc band{&s_fmin[0][threadIdx.x], &s_dmax[0][threadIdx.x], 0};
+      BandAcc band{s_fmin + threadIdx.x, s_dmax + threadIdx.x, 0};
       // loop state: fresh for a new anchor, restored when the previous round paused at the end of its chunk
       uint32_t nog, d_lnode, i;
       float ldist, udist;
@@ -900,7 +903,7 @@ hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, co
   const uint32_t n_threads = w.live_in ? w.n_live_in : b.n_sets;
   if (n_threads == 0) return hipSuccess;
   const dim3 grid((n_threads + kBlock - 1) / kBlock);
-  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_decide<P4>, grid, dim3(kBlock), 0, st, b, w, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc));
+  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_decide<P4>, grid, dim3(kBlock), (size_t)w.band_ranks * kBlock * 2 * sizeof(float), st, b, w, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc));
   return hipGetLastError();
 }
 

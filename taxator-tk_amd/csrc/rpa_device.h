@@ -29,6 +29,7 @@ struct TaxDev {
   // (d = 1 .. depth[node]; 0xFFFFFFFF beyond).  Copied into every hit row, so the placement kernels never walk `parent`.
   const uint32_t* anc;
   int path_quads;  // ceil(max depth / 4), 1..4
+  uint32_t max_depth;
 };
 
 // Resident sequence store: residues packed little-endian into 32-bit words, 4 bit (DNA) or 8 bit (protein) each.
@@ -144,6 +145,7 @@ struct WorkDev {
   uint32_t* counters;   // kNumCounters words, layout below
   // pass-1 scratch (per set region like the pair slots)
   float* band_save;     // S * 2*(kMaxDepth+1): BandFactor accumulators of paused pass-1 loops
+  uint32_t band_ranks;  // deepest taxonomy level + 1: rows of the LDS accumulators of k_decide
   // live lists: plan/decide append every set that is still running to live_out; a sparse round (few live sets) runs
   // emit/decide over live_in instead of over the whole batch
   const uint32_t* live_in;  // null in dense rounds

@@ -205,6 +205,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->bin_list = e->bin_list.as<uint2>(); w->counters = e->counters.as<uint32_t>();
   w->og_idx = e->og_idx.as<uint32_t>(); w->band_save = e->band_save.as<float>();
   w->live_in = nullptr; w->n_live_in = 0; w->live_out = e->live_a.as<uint32_t>();
+  w->band_ranks = e->tax.max_depth + 1;
   w->og_dist = e->og_dist.as<int32_t>();
   w->T = T; w->T2 = T2;
   return RPA_OK;
@@ -312,7 +313,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
     CREATE_TRY(hipMemcpy(e->tax_anc.p, anc.data(), n * P * 4, hipMemcpyHostToDevice));
   }
   e->tax = TaxDev{e->tax_parent.as<const uint32_t>(), e->tax_left.as<const uint32_t>(), e->tax_right.as<const uint32_t>(),
-                  e->tax_depth.as<const uint8_t>(), tax->n_nodes, e->tax_anc.as<const uint32_t>(), path_quads};
+                  e->tax_depth.as<const uint8_t>(), tax->n_nodes, e->tax_anc.as<const uint32_t>(), path_quads, max_depth};
   CREATE_TRY(e->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long)));
   CREATE_TRY(hipMemset(e->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
 #undef CREATE_TRY
