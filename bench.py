@@ -74,7 +74,7 @@ CONFIGS = {
     "c4": dict(sets=500_000, hits=20, seg_len=67, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08,
                name="BASELINE config 4 (protein, 67 aa)", kernel="k_nw_protein (BLOSUM62 global DP with forward-carried path counters, one alignment per lane)"),
     "c5": dict(sets=12_500, hits=50, seg_len=10_000, alphabet=0, genome_len=40_000, level_rate=0.03, query_rate=0.05,
-               name="BASELINE config 5 (10 kbp contigs, per-GPU share of 100 k)", kernel="k_myers_long (one alignment per wavefront, skewed carry schedule)"),
+               name="BASELINE config 5 (10 kbp contigs, per-GPU share of 100 k)", kernel="k_myers_strips (bit-parallel edit distance, one alignment per lane, pattern in register strips of 5-8 words)"),
 }
 
 

@@ -184,7 +184,191 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K2: pattern longer than 256 nt (up to 16384 nt) -- ONE ALIGNMENT PER WAVEFRONT.
+// K1s: pattern longer than 256 nt, many pairs -- still ONE ALIGNMENT PER LANE, the pattern cut into register strips.
+// The delta vectors of a strip of NW words (NW in 5..8, chosen per pair to waste the fewest rows) live in VGPRs and
+// the strip's match masks in LDS exactly as in K1; the lane sweeps the whole text once per strip.  What a strip hands
+// to the one below is, per text column, the add carry and the two shift carries out of its last word -- 3 bits, the
+// same message K2 passes between lanes -- kept as one byte per column in an HBM scratch laid out
+// [4 columns][thread] (a wave reads/writes 256 contiguous bytes per 4 columns; one dword load + store per 4 columns
+// against ~600 VALU issue slots).  Rows past the end of the pattern (the last strip is rarely full) match nothing,
+// which leaves rows <= m untouched; the score is tracked at the static bottom bit of the last strip and corrected at
+// the end by the vertical deltas of those phantom rows: D[m][n] = D[bottom][n] - (popc(VP & tail) - popc(VN & tail)).
+// Same bound as K1 (integer VALU issue); per-column strip overhead ~12 %.  Any pattern length fits.
+// ------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
+                                                          uint32_t* __restrict__ scratch, uint32_t stride,
+                                                          unsigned long long* prof_acc) {
+  extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
+  const int tid = threadIdx.x;
+  const uint32_t t = blockIdx.x * kBlock + tid;
+  const bool active = t < n_list;
+  uint32_t dst = 0, m = 0, n = 0;
+  SegView pat{}, txt{};
+  if (active) {
+    uint32_t a, b;
+    resolve_pair(w, list[t], a, b, dst);
+    SegView va = seg_view(w, a), vb = seg_view(w, b);
+    if (va.len < vb.len) { txt = vb; pat = va; } else { txt = va; pat = vb; }
+    n = txt.len; m = pat.len;
+  }
+  if (prof_acc) profile_add(prof_acc, active, n, m);
+  if (!active) return;  // no barrier below: a lane only ever touches its own LDS column
+
+  const uint32_t words = (m + 31u) / 32u;
+  const uint32_t nstrips = (words + NW - 1u) / NW;
+  uint32_t* __restrict__ sc = scratch + t;  // message dword g (columns 4g .. 4g+3) at sc[g * stride]
+  const uint32_t n_dwords = (n + 7u) >> 3;
+  const int32_t dir = txt.rc ? -1 : 1;
+  const int64_t g0 = txt.rc ? (int64_t)(txt.src + n) - 8 : (int64_t)txt.src;
+  const uint32_t sh = (uint32_t)(g0 & 7) * 4u;
+  const int64_t idx0 = g0 >> 3;
+  auto load_word = [&](int64_t i) -> uint32_t { return i >= 0 ? txt.words[i] : 0u; };
+
+  uint32_t VP[NW], VN[NW];
+  int32_t bottom = 0;
+  for (uint32_t s = 0; s < nstrips; ++s) {
+    const bool first = s == 0, last = s + 1u == nstrips;
+    const uint32_t wbase = s * NW;
+#pragma unroll
+    for (int wi = 0; wi < NW; ++wi) {
+      uint32_t A = 0, C = 0, G = 0, T = 0, N = 0;
+      const uint32_t pos = (wbase + wi) * 32u;
+      if (pos < m) {
+        const uint4 x = pat.fetch32(pos);
+        uint32_t p0, p1, pn;
+        planes32(x, p0, p1, pn);
+        const uint32_t rem = m - pos;
+        const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+        N = pn & vm;
+        T = p1 & p0 & vm;
+        G = p1 & ~p0 & vm;
+        C = p0 & ~p1 & ~pn & vm;
+        A = ~(p0 | p1 | pn) & vm;
+      }
+      peq[(0 * NW + wi) * kBlock + tid] = A;
+      peq[(1 * NW + wi) * kBlock + tid] = C;
+      peq[(2 * NW + wi) * kBlock + tid] = G;
+      peq[(3 * NW + wi) * kBlock + tid] = T;
+      peq[(4 * NW + wi) * kBlock + tid] = N;
+      VP[wi] = 0xFFFFFFFFu;
+      VN[wi] = 0u;
+    }
+    bottom = (int32_t)((wbase + NW) * 32u);  // D[bottom row of this strip][0]
+
+    // One column.  `in`: bit 0 add carry, bit 1 HP, bit 2 HN entering word 0 (higher bits are ignored); returns the same for the strip below.
+    auto column = [&](uint32_t c, uint32_t in) -> uint32_t {
+      const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
+      uint32_t carry = in & 1u, hp_prev = in << 30, hn_prev = in << 29, HP = 0, HN = 0;
+#pragma unroll
+      for (int wi = 0; wi < NW; ++wi) {
+        const uint32_t vp = VP[wi], vn = VN[wi];
+        const uint32_t X = e[wi * kBlock] | vn;
+        uint32_t cout;
+        const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
+        carry = cout;
+        const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);   // (sum ^ vp) | X
+        HN = vp & D0;
+        HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);                  // vn | ~(vp | D0)
+        const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
+        const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+        hp_prev = HP;
+        hn_prev = HN;
+        VN[wi] = Xs & D0;
+        VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);              // Hs | ~(Xs | D0)
+      }
+      const uint32_t hp = HP >> 31, hn = HN >> 31;
+      bottom += (int32_t)hp - (int32_t)hn;
+      return carry | (hp << 1) | (hn << 2);
+    };
+
+    int64_t next_i = txt.rc ? idx0 : idx0 + 1;
+    uint32_t keep = load_word(txt.rc ? idx0 + 1 : idx0);
+    uint32_t pending = load_word(next_i);
+    // row 0 of the matrix: +1 enters every column (HP carry 1), no add carry, no HN
+    uint32_t min0 = 0x02020202u, min1 = 0x02020202u;
+    if (!first) { min0 = sc[0]; if (n > 4u) min1 = sc[stride]; }
+    for (uint32_t dw = 0; dw < n_dwords; ++dw) {
+      const uint32_t fresh = pending;
+      next_i += dir;
+      const uint32_t in0 = min0, in1 = min1;
+      if (dw + 1 < n_dwords) {
+        pending = load_word(next_i);
+        if (!first) {  // boundary messages of the next 8 columns
+          min0 = sc[(size_t)(2u * dw + 2u) * stride];
+          if (n > (dw + 1u) * 8u + 4u) min1 = sc[(size_t)(2u * dw + 3u) * stride];
+        }
+      }
+      const uint32_t hi = txt.rc ? keep : fresh, lo = txt.rc ? fresh : keep;
+      uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
+      keep = fresh;
+      const uint32_t r = revcomp8(d);
+      d = txt.rc ? r : d;
+      const uint32_t cols = n - dw * 8u;
+      uint32_t out0 = 0, out1 = 0;
+      if (cols >= 8u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out0 |= column((d >> (4 * k)) & 7u, in0 >> (8 * k)) << (8 * k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out1 |= column((d >> (4 * k + 16)) & 7u, in1 >> (8 * k)) << (8 * k);
+      } else {
+#pragma unroll 1
+        for (uint32_t k = 0; k < cols; ++k) {
+          const uint32_t o = column((d >> (4 * k)) & 7u, (k < 4u ? in0 : in1) >> (8 * (k & 3u)));
+          if (k < 4u) out0 |= o << (8 * k); else out1 |= o << (8 * (k - 4u));
+        }
+      }
+      if (!last) {
+        sc[(size_t)(2u * dw) * stride] = out0;
+        if (cols > 4u) sc[(size_t)(2u * dw + 1u) * stride] = out1;
+      }
+    }
+  }
+  // phantom rows below the pattern in the last strip: take their vertical deltas off the bottom score
+  int32_t dist = bottom;
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) {
+    const uint32_t pos = ((nstrips - 1u) * NW + wi) * 32u;
+    const uint32_t tail = pos >= m ? 0xFFFFFFFFu : (m - pos >= 32u ? 0u : ~((1u << (m - pos)) - 1u));
+    dist -= (int32_t)__popc(VP[wi] & tail) - (int32_t)__popc(VN[wi] & tail);
+  }
+  w.pair_res[dst] = make_float2((float)dist, (float)((int32_t)n - dist));
+  if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
+}
+
+static size_t strip_words_per_thread(uint32_t max_len) { return 2 * (((size_t)max_len + 7) / 8) + 2; }
+
+size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len) {
+  size_t threads = ((size_t)n_pairs + kBlock - 1) / kBlock * kBlock;
+  // at most 4 GiB of boundary bytes in flight, and never fewer than one workgroup
+  const size_t cap = (((size_t)1 << 30) / strip_words_per_thread(max_len)) / kBlock * kBlock;
+  if (threads > cap) threads = cap ? cap : kBlock;
+  return threads * strip_words_per_thread(max_len);
+}
+
+hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2* list, uint32_t n, const WorkDev& w,
+                                   uint32_t* scratch, size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc) {
+  if (n == 0) return hipSuccess;
+  size_t threads = scratch_words / strip_words_per_thread(max_len) / kBlock * kBlock;
+  if (threads == 0) return hipErrorOutOfMemory;
+  const size_t lds = (size_t)5 * strip_words * kBlock * sizeof(uint32_t);
+  for (uint32_t done = 0; done < n;) {
+    const uint32_t chunk = (uint32_t)((size_t)(n - done) < threads ? (n - done) : threads);
+    const uint32_t blocks = (chunk + kBlock - 1) / kBlock;
+#define RPA_LAUNCH_STRIPS(NWV) \
+  case NWV: hipLaunchKernelGGL(k_myers_strips<NWV>, dim3(blocks), dim3(kBlock), lds, st, list + done, chunk, w, scratch, blocks * kBlock, prof_acc); break;
+    switch (strip_words) {
+      RPA_LAUNCH_STRIPS(5) RPA_LAUNCH_STRIPS(6) RPA_LAUNCH_STRIPS(7) RPA_LAUNCH_STRIPS(8)
+      default: return hipErrorInvalidValue;
+    }
+#undef RPA_LAUNCH_STRIPS
+    done += chunk;
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2: pattern longer than 256 nt (up to 16384 nt), FEW pairs (too few lanes' worth for K1s) -- ONE ALIGNMENT PER WAVEFRONT.
 // The pattern's 32-bit words are dealt to lanes in contiguous runs of WPL words (lane l owns words
 // [l*WPL, (l+1)*WPL), WPL = ceil(words/64) is a template parameter, pairs are binned by it); at step t lane l
 // processes text column t - l for its run, so the words of one column are computed on an anti-diagonal across

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
       if (is_query_pair) {
         if (info.mode == 3) {
           const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor));
-          if (info.emit_query && ha.qd == FLT_MAX) { bin = pair_bin(p, ha.seglen, info.qseglen); maxlen = ha.seglen; entry = make_uint2(ha.rec, pos | kDstIsB); }
+          if (info.emit_query && ha.qd == FLT_MAX) { bin = pair_bin(p, ha.seglen, info.qseglen); maxlen = p.alphabet == 0 ? max(ha.seglen, info.qseglen) : ha.seglen; entry = make_uint2(ha.rec, pos | kDstIsB); }
         }
       } else {
         const uint32_t i = pos - lo;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
           }
           if (want) {
             bin = pair_bin(p, h.seglen, other_len);
-            maxlen = h.seglen;
+            maxlen = p.alphabet == 0 ? max(h.seglen, other_len) : h.seglen;  // DNA: text = the longer one; protein: A
             entry = make_uint2(h.rec, other_seg);
             if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = -1; }
           }
@@ -356,13 +356,13 @@ __global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, P
       }
       if (want) {
         bin = pair_bin(p, h.seglen, other_len);
-        maxlen = max(maxlen, h.seglen);
+        maxlen = max(maxlen, p.alphabet == 0 ? max(h.seglen, other_len) : h.seglen);
         entry = make_uint2(h.rec, other_seg);
         if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = -1; }
       }
     }
     if (i0 == info.i_lo && lane == 63 && info.mode == 3 && info.emit_query && anchor_qd == FLT_MAX && bin < 0) {
-      bin = pair_bin(p, anchor_len, info.qseglen); maxlen = max(maxlen, anchor_len);
+      bin = pair_bin(p, anchor_len, info.qseglen); maxlen = max(maxlen, p.alphabet == 0 ? max(anchor_len, info.qseglen) : anchor_len);
       entry = make_uint2(anchor_rec, (H + s) | kDstIsB);
     }
 #pragma unroll
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_pairs(WorkDev w, uint32_t n_pair
     else {
       const uint32_t la = w.seg[sa].len, lb = w.seg[sb].len;
       bin = pair_bin(p, la, lb);
-      maxlen = la;
+      maxlen = p.alphabet == 0 ? max(la, lb) : la;
       if (bin >= kNumBins) { raise_error(w, kErrUnsupported, t); bin = -1; }
       else if (la == 0 || lb == 0) { raise_error(w, kErrRange, t); bin = -1; }
     }

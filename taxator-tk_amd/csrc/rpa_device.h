@@ -8,10 +8,12 @@ namespace rpa {
 
 constexpr int kBlock = 256;          // 4 wave64 per workgroup everywhere
 constexpr uint32_t kRoot = 0;        // taxonomy node 0 is the root
-constexpr int kShortWords = 8;       // per-lane Myers kernel: pattern <= 8*32 = 256 residues
-constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel: pattern <= 64 lanes * 8 words * 32 = 16384 residues
-constexpr int kNumBins = kShortWords + kLongMaxWPL;  // bins 0..7: short, words = bin+1 ; bins 8..15: long, words per lane = bin-7
-constexpr uint32_t kMaxPattern = 64u * kLongMaxWPL * 32u;
+constexpr int kShortWords = 8;       // per-lane Myers kernel: pattern <= 8*32 = 256 residues in one register strip
+constexpr int kStripMinWords = 5;    // longer patterns: register strips of 5..8 words, whichever wastes the fewest rows
+constexpr int kStripBins = kShortWords - kStripMinWords + 1;
+constexpr int kNumBins = kShortWords + kStripBins;  // bins 0..7: one strip of bin+1 words ; bins 8..11: strips of bin-3 words
+constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
+constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
 constexpr int kProfParts = 64;        // profiling accumulators are split 64 ways (block index & 63) and summed on the host
 constexpr int kMaxDepth = 15;         // deepest taxonomy level the placement kernel's per-rank LDS tables hold (NCBI pruned: 8)
 
@@ -194,6 +196,10 @@ hipError_t launch_export_alignments(hipStream_t st, const WorkDev& w, uint32_t n
 // alignment kernels over one bin list
 hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const WorkDev& w,
                                   unsigned long long* prof_acc);
+// multi-strip per-lane kernel; scratch holds one boundary byte per text column per thread in flight
+size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len);
+hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2* list, uint32_t n, const WorkDev& w,
+                                   uint32_t* scratch, size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint2* list, uint32_t n, const WorkDev& w,
                                  unsigned long long* prof_acc);
 hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
@@ -265,12 +271,20 @@ __device__ __forceinline__ SegView seg_view(const WorkDev& w, uint32_t seg) {
   return v;
 }
 
-// bin of a pair whose shorter sequence has m residues (DNA); kNumBins = too long
+// bin of a pair whose shorter sequence has m residues (DNA).  Up to 8 words: one strip of exactly that many words.
+// Beyond: the strip height in 5..8 words with the smallest strips x (height x 16 + 20) issue-slot estimate, i.e. the
+// fewest wasted rows (9 words -> 2 x 5, 17 -> 3 x 6, 25 -> 4 x 7 ...); any length fits.
 __host__ __device__ __forceinline__ int dna_bin(uint32_t m) {
   const uint32_t words = (m + 31u) / 32u;
   if (words <= (uint32_t)kShortWords) return words ? (int)words - 1 : 0;
-  const uint32_t wpl = (words + 63u) / 64u;
-  return wpl <= (uint32_t)kLongMaxWPL ? kShortWords + (int)wpl - 1 : kNumBins;
+  uint32_t best = 0xFFFFFFFFu;
+  int best_nw = kShortWords;
+  for (int nw = kShortWords; nw >= kStripMinWords; --nw) {  // ties -> taller strips (fewer sweeps of the text)
+    const uint32_t strips = (words + (uint32_t)nw - 1u) / (uint32_t)nw;
+    const uint32_t cost = strips > 0x00FFFFFFu ? 0xFFFFFFFEu : strips * ((uint32_t)nw * 16u + 20u);
+    if (cost < best) { best = cost; best_nw = nw; }
+  }
+  return kShortWords + best_nw - kStripMinWords;
 }
 
 // ---- small device helpers shared by the placement kernels ----

@@ -7,6 +7,8 @@
 // There is no CPU compute path: every entry point fails with RPA_ERR_DEVICE when no gfx950 device answers.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +69,7 @@ struct rpa_engine {
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
   bool profiling = false;
+  int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   DevBuf prof_acc;
   rpa_profile prof{};
@@ -109,7 +112,7 @@ const char* kernel_error_text(uint32_t code) {
     case kErrRange: return "sequence range error: segment start lies beyond the end of the sequence (SequenceRangeError)";
     case kErrSeqId: return "sequence index outside the store (SequenceNotFound)";
     case kErrAssert: return "a reference assert would abort here (reverse reference coordinates in protein mode, empty best-reference group or inconsistent node range)";
-    case kErrUnsupported: return "sequence pair longer than this build supports (pattern > 16384 residues)";
+    case kErrUnsupported: return "sequence pair not supported by this build";
     default: return "inconsistent batch";
   }
 }
@@ -130,7 +133,25 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts) {
     }
     if (e->params.alphabet == RPA_DNA) {
       if (bin < kShortWords) HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, w, acc));
-      else HIP_TRY(e, launch_align_dna_long(e->stream, bin - kShortWords + 1, list, n, w, acc));
+      else {
+        // Patterns of more than 256 nt.  Many pairs: one per lane, register strips (K1s).  Few pairs (not enough to give
+        // every SIMD a few waves of lanes): one per wavefront (K2), as long as the pattern fits its 64 x 8 words.
+        const uint32_t max_len = counts[kCtrMaxLen];  // longest sequence of any emitted pair: bounds text and pattern
+        // Measured on MI355X (tools/pairs_bench.py): K1s reaches ~66 T cell updates/s once ~160 k lanes are busy and
+        // ~0.4 G/s per lane below that; K2 ~50 T/s x (pattern words / (64 x words per lane)) from ~8 k waves on.
+        const double words = (max_len + 31u) / 32u, wpl = (uint32_t)((words + 63) / 64);
+        const double tp_lane = std::min(66e12, n * 0.4e9);
+        const double tp_wave = std::min(1.0, n / 8192.0) * 50e12 * words / (64.0 * wpl);
+        bool wave = max_len <= kWaveMaxPattern && tp_wave > tp_lane;
+        if (e->long_kernel == 1 && max_len <= kWaveMaxPattern) wave = true;
+        if (e->long_kernel == 2) wave = false;
+        if (wave) HIP_TRY(e, launch_align_dna_long(e->stream, (int)wpl, list, n, w, acc));
+        else {
+          HIP_TRY(e, e->protein_ws.ensure(dna_strip_scratch_words(n, max_len) * 4));
+          HIP_TRY(e, launch_align_dna_strips(e->stream, bin - kShortWords + kStripMinWords, list, n, w, e->protein_ws.as<uint32_t>(),
+                                             e->protein_ws.cap / 4, max_len, acc));
+        }
+      }
     } else {
       const uint32_t max_len = counts[kCtrMaxLen];
       HIP_TRY(e, e->protein_ws.ensure(protein_scratch_words(n, max_len) * 4));
@@ -268,6 +289,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
+  if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
   if (const char* v = getenv("RPA_SPEC1")) e->params.spec1 = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SPEC2")) e->params.spec2 = (uint32_t)atoi(v);
   auto bail = [&](int code) { g_create_error = e->err; rpa_destroy(e); return code; };

@@ -68,12 +68,20 @@ def test_dna_pairs_golden(pkg, oracle, golden_dir):
             v["dist"], v["match"], v["mismatch"], v["gap"], v["length"]), (len(v["a"]), len(v["b"]))
 
 
-def test_dna_pairs_random_all_bins(pkg, oracle):
+@pytest.mark.parametrize("long_kernel", ["wave", "lane", None])
+def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
+    """Every length bin of the nucleotide kernels against the oracle.  Patterns above 256 nt have two kernels (one pair
+    per wavefront for few pairs, register strips per lane for many, chosen by a cost model): both are forced in turn;
+    above 16384 nt only the strip kernel applies."""
+    if long_kernel: monkeypatch.setenv("RPA_LONG_KERNEL", long_kernel)
+    else: monkeypatch.delenv("RPA_LONG_KERNEL", raising=False)
     rng = np.random.default_rng(42)
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
     a_codes, b_codes = [], []
     lens = list(range(1, 70)) + [95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 223, 224, 225, 255, 256] * 3
     lens += [257, 300, 511, 512, 513, 1000, 2047, 2048, 2049, 3000, 4097, 6000, 8192, 10000, 12289, 16384]
+    lens += [288, 289, 320, 321, 384, 385, 448, 449, 544, 545, 576, 640, 641, 672, 768, 769, 800, 896, 1024, 1025, 1056, 1281]
+    lens += [16385, 20000, 33001]
     for la in lens:
         for mode in range(3):
             a = rng.integers(0, 5 if mode else 4, la).astype(np.uint8)
