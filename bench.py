@@ -14,7 +14,8 @@ path has: an RCCL gather of the 32-byte PredictionRecord rows to rank 0.
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (batched Myers edit distance): algorithmic
 bytes (len_a + len_b + 8 per computed alignment) over that kernel's device time measured with HIP events
 on the engine's stream inside the timed region.  `cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded
-sample of the same workload on this box's host cores.
+sample of the same workload on this box's host cores; `cpu_reference` (extra) times the reference's own vendored SeqAn
+pair call (oracle/_ref, kind "reference") on the first hits of the same batch.
 """
 import argparse
 import importlib
@@ -65,6 +66,66 @@ def cpu_baseline(synth, ds, seconds_target=12.0):
     return {"value": total / dt, "unit": "realignments/s", "cores": cores, "kind": "port",
             "sample": "first %d record sets x %d hits of the same batch (%d realignments, %.1f s wall, oracle C restatement, one thread per core)"
                       % (n_sample, n_hits, total, dt)}
+
+
+def cpu_reference_pairs(synth, ds, seconds_target=4.0, n_pairs=20000):
+    """The reference's own pair-level call (vendored SeqAn compiled in place, oracle/_ref/libseqan_ref.so) on all host
+    cores: getAlignmentDNA / getAlignmentProtein of (query range, hit's reference range) for the first hits of the same
+    batch -- the call that takes ~all of the reference's time (SURVEY 8a).  Extra information next to cpu_baseline;
+    None when the prebuilt checker is absent."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    path = os.path.join(ROOT, "oracle", "_ref", "libseqan_ref.so")
+    if not os.path.exists(path):
+        return None
+    R = C.CDLL(path)
+    b = ds.batch
+    n_pairs = int(min(n_pairs, len(b["qstart"])))
+    set_of = np.searchsorted(b["set_offsets"], np.arange(n_pairs), side="right") - 1
+    q = synth.encode(ds.query_letters, ds.alphabet)
+    db = synth.encode(ds.ref_letters, ds.alphabet)
+    comp = np.array([3, 2, 1, 0, 4], np.uint8)
+    seqs = []
+    for r in range(n_pairs):
+        qo = int(ds.query_offsets[b["query_seq"][set_of[r]]])
+        seqs.append(q[qo + int(b["qstart"][r]) - 1: qo + int(b["qstop"][r])])
+        ro = int(ds.ref_offsets[b["ref_seq"][r]])
+        lo, hi = int(b["rstart"][r]), int(b["rstop"][r])
+        seg = db[ro + min(lo, hi) - 1: ro + max(lo, hi)]
+        seqs.append(comp[seg[::-1]] if (lo > hi and ds.alphabet == 0) else seg)
+    letters = np.ascontiguousarray(np.concatenate(seqs))
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.uint64)
+    cores = os.cpu_count() or 1
+    bounds = np.linspace(0, n_pairs, cores + 1).astype(int)
+
+    def run(k, reps):
+        lo, hi = int(bounds[k]), int(bounds[k + 1])
+        pa = np.arange(lo, hi, dtype=np.uint32) * 2
+        pb = pa + 1
+        out = np.zeros((hi - lo, 6), np.int32)
+        fo = np.zeros((hi - lo, 2), np.float32)
+        for _ in range(reps):
+            if ds.alphabet == 0:
+                R.ref_align_dna_batch(C.c_void_p(letters.ctypes.data), C.c_void_p(offsets.ctypes.data), C.c_void_p(pa.ctypes.data),
+                                      C.c_void_p(pb.ctypes.data), C.c_int(hi - lo), C.c_void_p(out.ctypes.data))
+            else:
+                R.ref_align_protein_batch(C.c_void_p(letters.ctypes.data), C.c_void_p(offsets.ctypes.data), C.c_void_p(pa.ctypes.data),
+                                          C.c_void_p(pb.ctypes.data), C.c_int(hi - lo), C.c_void_p(out.ctypes.data), C.c_void_p(fo.ctypes.data))
+        return (hi - lo) * reps
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(lambda k: run(k, 1), range(cores)))
+    dt = max(time.perf_counter() - t0, 1e-3)
+    reps = max(1, int(seconds_target / dt))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(lambda k: run(k, reps), range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "pair alignments/s", "cores": cores, "kind": "reference",
+            "sample": "(query range, reference range) of the first %d hits of the same batch, %d passes (%d alignments, %.1f s wall), "
+                      "the reference's vendored SeqAn 2.4.0 through getAlignment%s's calls, one thread per core"
+                      % (n_pairs, reps, done, dt, "DNA" if ds.alphabet == 0 else "Protein")}
 
 
 # BASELINE.json configs that fit one GPU per rank (per-GPU sizes; c5 is 100 k contigs over 8 GPUs = 12.5 k per GPU)
@@ -200,6 +261,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, ds)
+            ref = cpu_reference_pairs(synth, ds)
+            if ref is not None:
+                out["cpu_reference"] = ref
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -76,4 +76,19 @@ void ref_align_protein(const uint8_t* a, int la, const uint8_t* b, int lb, int32
   fout[1] = (2 * mutualscore) * normfactor;
 }
 
+// Timing helpers for bench.py's cpu_reference leg: the same two calls over many pairs without a Python round trip
+// per pair.  Sequences are ordinals laid out back to back; sequence i = [offsets[i], offsets[i+1]).
+void ref_align_dna_batch(const uint8_t* letters, const uint64_t* offsets, const uint32_t* pa, const uint32_t* pb, int n,
+                         int32_t* out5) {
+  for (int k = 0; k < n; ++k)
+    ref_align_dna(letters + offsets[pa[k]], (int)(offsets[pa[k] + 1] - offsets[pa[k]]), letters + offsets[pb[k]],
+                  (int)(offsets[pb[k] + 1] - offsets[pb[k]]), out5 + 5 * (size_t)k);
+}
+void ref_align_protein_batch(const uint8_t* letters, const uint64_t* offsets, const uint32_t* pa, const uint32_t* pb,
+                             int n, int32_t* out6, float* fout2) {
+  for (int k = 0; k < n; ++k)
+    ref_align_protein(letters + offsets[pa[k]], (int)(offsets[pa[k] + 1] - offsets[pa[k]]), letters + offsets[pb[k]],
+                      (int)(offsets[pb[k] + 1] - offsets[pb[k]]), out6 + 6 * (size_t)k, fout2 + 2 * (size_t)k);
+}
+
 }  // extern "C"
