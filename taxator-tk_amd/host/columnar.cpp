@@ -1,0 +1,466 @@
+// taxator-tk_amd/host/columnar.cpp -- see columnar.hh.
+#include "columnar.hh"
+
+#include <algorithm>
+#include <chrono>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace taxator {
+
+void RecordColumns::resize(size_t n) {
+  qstart.resize(n); qstop.resize(n); qlen.resize(n); rstart.resize(n); rstop.resize(n); identities.resize(n); alnlen.resize(n);
+  ref_seq.resize(n); node.resize(n); score.resize(n); filtered.resize(n);
+}
+
+void RecordColumns::move_range(size_t dst, size_t src, size_t n) {
+  if (!n || dst == src) return;
+  auto mv = [&](auto& v) { memmove(v.data() + dst, v.data() + src, n * sizeof(v[0])); };
+  mv(qstart); mv(qstop); mv(qlen); mv(rstart); mv(rstop); mv(identities); mv(alnlen); mv(ref_seq); mv(node); mv(score); mv(filtered);
+}
+
+void ColumnarBatch::clear() {
+  set_offsets.assign(1, 0);
+  query_seq.clear(); query_len.clear(); qid_off.clear(); qid_len.clear(); qid_arena.clear();
+  rec.resize(0);
+}
+
+// ---- field conversions: accept exactly what the strict conversions of alignmentrecord.cpp accept, produce the same values ----
+
+// boost::lexical_cast<large_unsigned_int> as mirrored by to_u32: decimal digits only, whole field, value < 2^32
+static inline bool field_u32(const char* p, const char* e, uint32_t& out) {
+  if (p == e) return false;
+  if (*p == 0) { out = 0; return true; }  // (strtoull of "" with *end == 0)
+  uint64_t v = 0;
+  for (; p != e; ++p) {
+    if (*p == 0) break;  // the strict parser converts c_str(): an embedded NUL ends the field
+    const unsigned d = (unsigned char)*p - '0';
+    if (d > 9) return false;
+    v = v * 10 + d;
+    if (v > 0xFFFFFFFFull) v = 0x100000000ull;  // stays out of range, cannot wrap
+  }
+  if (v > 0xFFFFFFFFull) return false;
+  out = (uint32_t)v;
+  return true;
+}
+
+static const double kPow10[9] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8};
+
+// strtof over the whole field.  Fast path: [sign] digits [. digits] [e [sign] digits] with at most 7 significant digits
+// and a decimal exponent within +-8 -- then mantissa and power of ten are exact doubles, the product is exact and the
+// quotient is within 2^-53 of the true value, which cannot straddle a float rounding boundary for such short decimals,
+// so one rounding to float gives the correctly rounded result strtof returns.  Anything else goes through strtof.
+static bool field_f32(const char* p, const char* e, float& out) {
+  if (p == e) return false;
+  const char* s = p;
+  bool neg = false;
+  if (*s == '-' || *s == '+') { neg = *s == '-'; ++s; }
+  uint64_t mant = 0;
+  int sig = 0, frac = 0, ndig = 0;
+  bool fast = true;
+  for (; s != e && (unsigned)(*s - '0') <= 9u; ++s, ++ndig) {
+    if (mant || *s != '0') { mant = mant * 10 + (unsigned)(*s - '0'); if (++sig > 7) { fast = false; break; } }
+  }
+  if (fast && s != e && *s == '.') {
+    ++s;
+    for (; s != e && (unsigned)(*s - '0') <= 9u; ++s, ++ndig) {
+      ++frac;
+      if (mant || *s != '0') { mant = mant * 10 + (unsigned)(*s - '0'); if (++sig > 7) { fast = false; break; } }
+    }
+  }
+  if (fast && ndig == 0) fast = false;
+  int ex = 0;
+  if (fast && s != e && (*s == 'e' || *s == 'E')) {
+    ++s;
+    bool eneg = false;
+    if (s != e && (*s == '-' || *s == '+')) { eneg = *s == '-'; ++s; }
+    int ed = 0;
+    for (; s != e && (unsigned)(*s - '0') <= 9u; ++s, ++ed) { ex = ex * 10 + (*s - '0'); if (ex > 10000) ex = 10000; }
+    if (ed == 0) fast = false;
+    if (eneg) ex = -ex;
+  }
+  if (fast && s == e) {
+    const int e10 = ex - frac;
+    if (mant == 0) { out = neg ? -0.0f : 0.0f; return true; }
+    if (e10 >= -8 && e10 <= 8) {
+      const double d = e10 < 0 ? (double)mant / kPow10[-e10] : (double)mant * kPow10[e10];
+      out = (float)(neg ? -d : d);
+      return true;
+    }
+  }
+  // general case: what to_f32 does
+  if (isspace((unsigned char)*p)) return false;
+  char tmp[64];
+  const size_t n = (size_t)(e - p);
+  std::string big;
+  const char* z;
+  if (n < sizeof(tmp)) { memcpy(tmp, p, n); tmp[n] = 0; z = tmp; }
+  else { big.assign(p, n); z = big.c_str(); }
+  char* end = nullptr;
+  out = strtof(z, &end);
+  return *end == 0;  // as to_f32: an embedded NUL ends the conversion like the end of the field
+}
+
+// the E-value is only validated (strtod over the whole field); the RPA path never reads it
+static bool field_f64_valid(const char* p, const char* e) {
+  if (p == e) return false;
+  const char* s = p;
+  if (*s == '-' || *s == '+') ++s;
+  int nd = 0;
+  for (; s != e && (unsigned)(*s - '0') <= 9u; ++s) ++nd;
+  if (s != e && *s == '.') { ++s; for (; s != e && (unsigned)(*s - '0') <= 9u; ++s) ++nd; }
+  if (nd > 0) {
+    if (s == e) return true;
+    if (*s == 'e' || *s == 'E') {
+      ++s;
+      if (s != e && (*s == '-' || *s == '+')) ++s;
+      int ed = 0;
+      for (; s != e && (unsigned)(*s - '0') <= 9u; ++s) ++ed;
+      if (ed > 0 && s == e) return true;
+    }
+  }
+  if (isspace((unsigned char)*p)) return false;
+  std::string z(p, (size_t)(e - p));
+  char* end = nullptr;
+  (void)strtod(z.c_str(), &end);
+  return *end == 0;
+}
+
+// ---- reader ----
+
+ColumnarReader::ColumnarReader(FILE* in, const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db,
+                               const SequenceStore* query, bool split_alignments, unsigned threads, size_t block_bytes)
+    : in_(in), legacy_(acc2taxid, tax, db), query_(query), split_(split_alignments), threads_(threads), block_bytes_(block_bytes) {
+  if (threads_ == 0) threads_ = std::max(1u, std::thread::hardware_concurrency());
+  if (block_bytes_ < 4096) block_bytes_ = 4096;
+  // reference identifier -> (taxonomy node, index in the reference store); identifiers with a broken link are left out
+  // of the table, so that their lines fall through to the strict parser, which raises the matching exception
+  const std::vector<std::string>& ids = db->ids();
+  ref_map_.reserve(ids.size());
+  for (size_t i = 0; i < ids.size(); ++i) {
+    if (ref_map_.find(ids[i].data(), ids[i].size()) != FlatStringMap::npos) continue;  // first occurrence wins (getIndex)
+    uint32_t node;
+    try { node = tax->getNode(acc2taxid[ids[i]]); } catch (Exception&) { continue; }
+    ref_map_.insert(ids[i], (uint32_t)ref_node_.size());
+    ref_node_.push_back(node);
+    ref_seqidx_.push_back((uint32_t)i);
+  }
+  const std::vector<std::string>& qids = query->ids();
+  query_map_.reserve(qids.size());
+  for (size_t i = 0; i < qids.size(); ++i) query_map_.insert(qids[i], (uint32_t)i);
+}
+
+struct ColumnarReader::Chunk {
+  const char* begin;
+  const char* end;
+  size_t lines = 0, data_lines = 0;  // counted in pass 1
+  size_t first_record = 0;
+  uint64_t first_line = 0;
+  bool bad = false;
+  uint64_t bad_line = 0;             // 1-based global line number of the first rejected line
+  const char* bad_begin = nullptr;
+  const char* bad_end = nullptr;
+  size_t bad_record = 0;             // records before that line
+};
+
+static inline const char* line_end(const char* p, const char* end) {
+  const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+  return nl ? nl : end;
+}
+
+void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, ColumnarBatch& out) {
+  typedef std::chrono::steady_clock Clock;
+  static const bool trace = getenv("TAXATOR_READER_TRACE") != nullptr;
+  const Clock::time_point t0 = Clock::now();
+  // ---- cut the block into per-thread chunks at line boundaries ----
+  const size_t total = (size_t)(end - begin);
+  const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, total / 65536 + 1));
+  std::vector<Chunk> chunks(T);
+  const char* p = begin;
+  for (unsigned t = 0; t < T; ++t) {
+    chunks[t].begin = p;
+    const char* q = t + 1 == T ? end : begin + total * (t + 1) / T;
+    if (q < p) q = p;
+    if (q < end) { q = line_end(q, end); if (q < end) ++q; }
+    chunks[t].end = q;
+    p = q;
+  }
+  auto for_chunks = [&](auto&& fn) {
+    if (T == 1) { fn(chunks[0]); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([&, t] { fn(chunks[t]); });
+    fn(chunks[0]);
+    for (auto& x : th) x.join();
+  };
+  // ---- pass 1: count lines and data lines ----
+  for_chunks([](Chunk& c) {
+    for (const char* s = c.begin; s < c.end;) {
+      const char* e = line_end(s, c.end);
+      ++c.lines;
+      if (*s != '#' || s == e) ++c.data_lines;  // an empty line is a (bad) data line, fileparser.hh:61-67
+      s = e + 1;
+    }
+  });
+  const Clock::time_point t1 = Clock::now();
+  size_t nrec = carry_;
+  uint64_t line_no = line_base_;
+  for (Chunk& c : chunks) { c.first_record = nrec; c.first_line = line_no; nrec += c.data_lines; line_no += c.lines; }
+  cols_.resize(nrec);
+  qid_ptr_.resize(nrec);
+  qid_len_.resize(nrec);
+  const Clock::time_point t2 = Clock::now();
+  // ---- pass 2: parse in place ----
+  for_chunks([this](Chunk& c) {
+    size_t r = c.first_record;
+    uint64_t ln = c.first_line;
+    for (const char* s = c.begin; s < c.end;) {
+      const char* e = line_end(s, c.end);
+      ++ln;
+      const char* next = e + 1;
+      if (*s == '#' && s != e) { s = next; continue; }
+      bool ok = (e - s) > 1;
+      const char* f = s;
+      uint8_t filt = 0;
+      if (ok && *f == '*') { filt = 1; ++f; }
+      const char* fb[11];
+      const char* fe[11];
+      if (ok) {
+        int k = 0;
+        const char* q = f;
+        for (; k < 10; ++k) {
+          const char* tab = (const char*)memchr(q, '\t', (size_t)(e - q));
+          if (!tab) break;
+          fb[k] = q; fe[k] = tab; q = tab + 1;
+        }
+        if (k < 10) ok = false;
+        else {
+          const char* tab = (const char*)memchr(q, '\t', (size_t)(e - q));
+          fb[10] = q; fe[10] = tab ? tab : e;
+        }
+      }
+      uint32_t refv = FlatStringMap::npos;
+      ok = ok && field_u32(fb[1], fe[1], cols_.qstart[r]) && field_u32(fb[2], fe[2], cols_.qstop[r]) && cols_.qstart[r] <= cols_.qstop[r] &&
+           field_u32(fb[3], fe[3], cols_.qlen[r]) && field_u32(fb[5], fe[5], cols_.rstart[r]) && field_u32(fb[6], fe[6], cols_.rstop[r]) &&
+           field_f32(fb[7], fe[7], cols_.score[r]) && field_f64_valid(fb[8], fe[8]) && field_u32(fb[9], fe[9], cols_.identities[r]) &&
+           field_u32(fb[10], fe[10], cols_.alnlen[r]) &&
+           (refv = ref_map_.find(fb[4], (size_t)(fe[4] - fb[4]))) != FlatStringMap::npos;
+      if (!ok) {
+        c.bad = true; c.bad_line = ln; c.bad_begin = s; c.bad_end = e; c.bad_record = r;
+        return;
+      }
+      cols_.filtered[r] = filt;
+      cols_.node[r] = ref_node_[refv];
+      cols_.ref_seq[r] = ref_seqidx_[refv];
+      qid_ptr_[r] = fb[0];
+      qid_len_[r] = (uint32_t)(fe[0] - fb[0]);
+      ++r;
+      s = next;
+    }
+  });
+  const Clock::time_point t3 = Clock::now();
+  // ---- the first rejected line ends the usable part of the stream ----
+  size_t usable = nrec;
+  for (const Chunk& c : chunks) {
+    if (!c.bad) continue;
+    usable = c.bad_record;
+    failed_ = true;
+    fail_line_.assign(c.bad_begin, c.bad_end);
+    fail_line_no_ = c.bad_line;
+    break;
+  }
+  for (size_t r = 0; r < carry_; ++r) { qid_ptr_[r] = carry_qid_.data(); qid_len_[r] = (uint32_t)carry_qid_.size(); }
+  // ---- groups of one query identifier; the last one stays open unless the stream ended ----
+  out.clear();
+  gstart_.clear();
+  size_t i = 0;
+  const bool closed = eof && !failed_;
+  while (i < usable) {
+    size_t j = i + 1;
+    const char* q = qid_ptr_[i];
+    const uint32_t ql = qid_len_[i];
+    while (j < usable && qid_len_[j] == ql && (qid_ptr_[j] == q || !memcmp(qid_ptr_[j], q, ql))) ++j;
+    if (j == usable && !closed) break;  // open group: more of it may follow (or, after a bad line, it is lost as in the
+                                        // reference, whose generator throws while still reading this group)
+    gstart_.push_back(i);
+    i = j;
+  }
+  gstart_.push_back(i);  // records [0, i) belong to complete groups
+  const Clock::time_point t4 = Clock::now();
+  emit_groups(out);
+  if (!fail_query_.empty()) { carry_ = 0; return; }  // unknown query identifier: everything after it is dropped
+  if (failed_) { carry_ = 0; return; }
+  // carry the open group to the front of the columns
+  const size_t n_open = usable - i;
+  if (n_open) {
+    std::string keep(qid_ptr_[i], qid_len_[i]);
+    carry_qid_.swap(keep);
+    cols_.move_range(0, i, n_open);
+  }
+  carry_ = n_open;
+  line_base_ = line_no;
+  if (trace) {
+    auto ms = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "reader block: %zu bytes, %zu records, %u threads: count %.1f ms, allocate %.1f ms, parse %.1f ms, group %.1f ms, emit %.1f ms\n",
+            total, nrec, T, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, Clock::now()));
+  }
+}
+
+// Sort every complete group, cut it into record sets and write its records to their final place in `out`.  Groups are
+// independent and a group's records land at the positions they came from (only their order inside the group changes),
+// so ranges of groups go to different threads; the per-set columns are stitched together afterwards.
+void ColumnarReader::emit_groups(ColumnarBatch& out) {
+  const size_t G = gstart_.size() - 1;
+  RecordColumns& o = out.rec;
+  o.resize(gstart_[G]);
+  struct Part {
+    std::vector<uint32_t> set_len, set_qlen, group_sets, group_qseq;
+    size_t unknown = (size_t)-1;  // first group of the range whose query identifier is not in the store
+  };
+  const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, G / 2048 + 1));
+  std::vector<Part> parts(T);
+  auto work = [&](unsigned t) {
+    Part& part = parts[t];
+    std::vector<uint32_t> order;
+    auto before = [&](uint32_t a, uint32_t b) {
+      if (cols_.qstart[a] != cols_.qstart[b]) return cols_.qstart[a] < cols_.qstart[b];
+      return cols_.qstop[a] < cols_.qstop[b];
+    };
+    for (size_t g = G * t / T; g < G * (t + 1) / T; ++g) {
+      const size_t lo = gstart_[g], n = gstart_[g + 1] - lo;
+      const uint32_t qseq = query_map_.find(qid_ptr_[lo], qid_len_[lo]);
+      if (qseq == FlatStringMap::npos) { part.unknown = g; return; }  // SequenceStore::getIndex in RPAPredictionModel::predict's staging
+      order.resize(n);
+      for (size_t k = 0; k < n; ++k) order[k] = (uint32_t)(lo + k);
+      if (split_) {  // stable by (qstart, qstop), ties keep input order (alignmentrecord.hh:476-481)
+        if (n <= 64) {  // groups are short and mostly sorted already
+          for (size_t k = 1; k < n; ++k) {
+            const uint32_t x = order[k];
+            size_t m = k;
+            while (m > 0 && before(x, order[m - 1])) { order[m] = order[m - 1]; --m; }
+            order[m] = x;
+          }
+        } else std::stable_sort(order.begin(), order.end(), before);
+      }
+      for (size_t m = 0; m < n; ++m) {
+        const uint32_t s = order[m];
+        const size_t d = lo + m;
+        o.qstart[d] = cols_.qstart[s]; o.qstop[d] = cols_.qstop[s]; o.qlen[d] = cols_.qlen[s]; o.rstart[d] = cols_.rstart[s];
+        o.rstop[d] = cols_.rstop[s]; o.identities[d] = cols_.identities[s]; o.alnlen[d] = cols_.alnlen[s]; o.ref_seq[d] = cols_.ref_seq[s];
+        o.node[d] = cols_.node[s]; o.score[d] = cols_.score[s]; o.filtered[d] = cols_.filtered[s];
+      }
+      uint32_t n_sets = 0;
+      for (size_t k = 0; k < n;) {  // one record set: [k, e)
+        size_t e = k + 1;
+        if (split_) {
+          uint32_t rstop = o.qstop[lo + k];
+          while (e < n && o.qstart[lo + e] <= rstop) { rstop = std::max(rstop, o.qstop[lo + e]); ++e; }  // :485-504
+        } else e = n;  // :543-566
+        part.set_len.push_back((uint32_t)(e - k));
+        part.set_qlen.push_back(o.qlen[lo + k]);  // getQueryLength() of the set's first record
+        ++n_sets;
+        k = e;
+      }
+      part.group_sets.push_back(n_sets);
+      part.group_qseq.push_back(qseq);
+    }
+  };
+  if (T == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+  }
+  for (unsigned t = 0; t < T; ++t) {
+    const Part& part = parts[t];
+    size_t g = G * t / T, si = 0;
+    for (size_t k = 0; k < part.group_sets.size(); ++k, ++g) {
+      const size_t lo = gstart_[g];
+      for (uint32_t c = 0; c < part.group_sets[k]; ++c, ++si) {
+        out.query_seq.push_back(part.group_qseq[k]);
+        out.query_len.push_back(part.set_qlen[si]);
+        out.qid_off.push_back((uint32_t)out.qid_arena.size());
+        out.qid_len.push_back(qid_len_[lo]);
+        out.qid_arena.insert(out.qid_arena.end(), qid_ptr_[lo], qid_ptr_[lo] + qid_len_[lo]);
+        out.set_offsets.push_back(out.set_offsets.back() + part.set_len[si]);
+      }
+    }
+    if (part.unknown != (size_t)-1) {
+      failed_ = true;
+      fail_query_.assign(qid_ptr_[gstart_[part.unknown]], qid_len_[gstart_[part.unknown]]);
+      o.resize(gstart_[part.unknown]);
+      return;
+    }
+  }
+}
+
+ColumnarReader::~ColumnarReader() {
+  if (!io_thread_.joinable()) return;
+  if (eof_) { io_thread_.join(); return; }
+  // abandoned mid-stream (a failure upstream of the end): the thread may sit in a blocking read; let it go
+  io_->stop = true;
+  io_->free_q.push(nullptr);
+  io_thread_.detach();
+}
+
+bool ColumnarReader::next(ColumnarBatch& out) {
+  out.clear();
+  if (!io_) {  // first call: start reading ahead
+    io_ = std::make_shared<Io>();
+    io_->in = in_;
+    io_->block = block_bytes_;
+    for (IoBuf& b : io_->bufs) io_->free_q.push(&b);
+    std::shared_ptr<Io> io = io_;
+    io_thread_ = std::thread([io] {
+      for (;;) {
+        IoBuf* b = io->free_q.pop();
+        if (!b || io->stop) return;
+        if (b->cap < kHeadroom + io->block) { b->cap = kHeadroom + io->block; b->mem.reset(new char[b->cap]); }
+        b->n = fread(b->mem.get() + kHeadroom, 1, io->block, io->in);
+        b->eof = b->n < io->block;
+        const bool last = b->eof;
+        io->full_q.push(b);
+        if (last) return;
+      }
+    });
+  }
+  for (;;) {
+    if (failed_) {
+      if (!fail_query_.empty()) throw SequenceNotFound("seqid " + fail_query_);
+      AlignmentRecordTaxonomy rec;
+      try { legacy_.parse(fail_line_, rec); }
+      catch (Exception& e) { throw ParsingError(std::string(e.what()) + " [line " + std::to_string(fail_line_no_) + "]"); }
+      throw GeneralError("alignment line rejected by the columnar reader but accepted by the record parser [line " +
+                         std::to_string(fail_line_no_) + "]");
+    }
+    if (eof_) return false;
+    IoBuf* b = io_->full_q.pop();
+    eof_ = b->eof;
+    // the block with the previous tail in front of it
+    char* begin;
+    char* end;
+    if (tail_.size() <= kHeadroom) {
+      begin = b->mem.get() + kHeadroom - tail_.size();
+      memcpy(begin, tail_.data(), tail_.size());
+      end = b->mem.get() + kHeadroom + b->n;
+    } else {
+      joined_.resize(tail_.size() + b->n);
+      memcpy(joined_.data(), tail_.data(), tail_.size());
+      memcpy(joined_.data() + tail_.size(), b->mem.get() + kHeadroom, b->n);
+      begin = joined_.data();
+      end = begin + joined_.size();
+    }
+    // parse everything up to the last line break (everything, at the end of the stream)
+    char* usable = end;
+    if (!eof_) while (usable > begin && usable[-1] != '\n') --usable;
+    if (usable > begin || eof_) parse_block(begin, usable, eof_, out);
+    tail_.assign(usable, (size_t)(end - usable));  // (qid pointers of the open group were copied out by parse_block)
+    if (!eof_) io_->free_q.push(b);
+    if (out.n_sets() > 0) return true;
+    // nothing complete yet (one group or one line spanning blocks), a failure to raise, or the end of the stream
+  }
+}
+
+}  // namespace taxator

@@ -1,0 +1,108 @@
+// taxator-tk_amd/host/columnar.hh -- alignment TSV -> structure-of-arrays batches at memory speed (boundary, input side).
+//
+// Same input contract as AlignmentRecordFactory / RecordSetGenerator (alignmentrecord.hh in this directory, which mirror
+// core/src/alignmentrecord.hh:95-158,207-238,457-566 and core/src/fileparser.hh:29-76): '#' lines skipped, leading '*'
+// masks a record, 11 tab-separated fields (+ optional rest), strict numeric fields, consecutive lines of one query
+// identifier form a group, and with split=true the group is stably sorted by (query start, query stop) and cut wherever
+// a start exceeds the running maximum stop.  What differs is the shape: the reference allocates one heap object with
+// two std::strings per line and hands std::list<AlignmentRecord*> to predict(); this reader parses large blocks of the
+// stream with all host threads straight into the columns of rpa_batch (include/taxator_rpa.h), resolves reference
+// identifiers through one flat hash probe, and never materialises a per-record object.  A line the fast path rejects
+// is re-parsed by AlignmentRecordFactory::parse so that the error text (and its "[line N]" suffix) is the reference's.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "accessconv.hh"
+#include "alignmentrecord.hh"
+#include "channel.hh"
+#include "flatmap.hh"
+#include "sequencestorage.hh"
+#include "taxonomy.hh"
+
+namespace taxator {
+
+struct RecordColumns {
+  std::vector<uint32_t> qstart, qstop, qlen, rstart, rstop, identities, alnlen, ref_seq, node;
+  std::vector<float> score;
+  std::vector<uint8_t> filtered;
+  void resize(size_t n);
+  void move_range(size_t dst, size_t src, size_t n);  // overlapping-safe copy inside the columns
+  size_t size() const { return qstart.size(); }
+};
+
+// One batch of record sets in the layout rpa_predict_batch takes, plus what the GFF3 writer needs per set.
+struct ColumnarBatch {
+  std::vector<uint32_t> set_offsets;           // n_sets + 1
+  std::vector<uint32_t> query_seq, query_len;  // per set
+  std::vector<uint32_t> qid_off, qid_len;      // per set: query identifier inside qid_arena
+  std::vector<char> qid_arena;
+  RecordColumns rec;                           // per record, set by set (rec.qlen is not part of rpa_batch)
+  size_t n_sets() const { return query_seq.size(); }
+  size_t n_records() const { return rec.size(); }
+  void clear();
+};
+
+class ColumnarReader {
+ public:
+  // threads = 0: all hardware threads.  block_bytes: how much of the stream is parsed (and becomes one batch) at a time.
+  ColumnarReader(FILE* in, const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db, const SequenceStore* query,
+                 bool split_alignments, unsigned threads, size_t block_bytes);
+  // Fills `out` with the record sets of the next block; false when the stream is exhausted (out is then empty).
+  // Throws what RecordSetGenerator would throw (ParsingError ... [line N]) or what RPAPredictionModel::predict's staging
+  // would throw (SequenceNotFound for an unknown query identifier), but only after every record set that precedes the
+  // failure has been returned by earlier calls.
+  bool next(ColumnarBatch& out);
+  uint64_t lines_read() const { return line_base_; }
+  ~ColumnarReader();
+
+ private:
+  struct Chunk;
+  void parse_block(const char* begin, const char* end, bool eof, ColumnarBatch& out);
+  void emit_groups(ColumnarBatch& out);
+
+  FILE* in_;
+  AlignmentRecordFactory legacy_;  // error texts
+  const SequenceStore* query_;
+  bool split_;
+  unsigned threads_;
+  size_t block_bytes_;
+  FlatStringMap ref_map_, query_map_;
+  std::vector<uint32_t> ref_node_, ref_seqidx_;  // per ref_map_ value
+
+  // A background thread reads the stream one block ahead of the parser.  Each block lands behind `kHeadroom` spare bytes
+  // so that the unparsed tail of the previous block (normally a fraction of one line) can be put in front of it.
+  static constexpr size_t kHeadroom = 1 << 20;
+  struct IoBuf { std::unique_ptr<char[]> mem; size_t cap = 0, n = 0; bool eof = false; };
+  struct Io {
+    FILE* in = nullptr;
+    size_t block = 0;
+    IoBuf bufs[3];
+    Channel<IoBuf*> free_q, full_q;
+    bool stop = false;  // guarded by the channels' hand-over: written before a wake-up push, read after a pop
+  };
+  std::shared_ptr<Io> io_;      // shared with the (possibly detached) I/O thread
+  std::thread io_thread_;
+  std::string tail_;            // bytes after the last line break of the previous block
+  std::vector<char> joined_;    // only when tail_ does not fit the headroom (a line longer than 1 MiB)
+  bool eof_ = false;
+  uint64_t line_base_ = 0;      // lines consumed before buf_[0]
+
+  RecordColumns cols_;          // records of the block being assembled; the open group of the previous block sits in front
+  std::vector<const char*> qid_ptr_;
+  std::vector<uint32_t> qid_len_;
+  size_t carry_ = 0;            // records carried over (all of one query identifier = carry_qid_)
+  std::string carry_qid_;
+  std::vector<size_t> gstart_;  // first record of every complete group of the block, + end
+
+  bool failed_ = false;         // a deferred error: thrown by the next call of next()
+  std::string fail_line_;
+  uint64_t fail_line_no_ = 0;
+  std::string fail_query_;      // non-empty: SequenceNotFound for this query identifier
+};
+
+}  // namespace taxator

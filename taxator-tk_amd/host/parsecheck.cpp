@@ -1,0 +1,75 @@
+// taxator-tk_amd/host/parsecheck.cpp -- TEST UTILITY: dumps the record sets the two input paths build from one TSV stream.
+//   parsecheck <mapping.tax> <query.fasta> <ref.fasta> objects|columnar <split 0|1> [threads] [block_bytes]
+// "objects" = AlignmentRecordFactory + RecordSetGenerator (the mirror of the reference's object model), "columnar" =
+// ColumnarReader.  Both print one line per record set and per record and, on failure, "ERROR <text>" (exit code 1), so
+// that tests can require identical bytes from the two (no GPU involved).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+
+#include "columnar.hh"
+
+using namespace taxator;
+
+static void print_set(const char* qid, size_t qid_len, uint32_t qlen, uint32_t qseq, size_t n) {
+  fwrite("SET\t", 1, 4, stdout);
+  fwrite(qid, 1, qid_len, stdout);
+  printf("\t%u\t%u\t%zu\n", qlen, qseq, n);
+}
+static void print_rec(bool filt, uint32_t qs, uint32_t qe, uint32_t rs, uint32_t re, float score, uint32_t ident, uint32_t alnlen,
+                      uint32_t ref_seq, uint32_t node) {
+  uint32_t bits;
+  memcpy(&bits, &score, 4);
+  printf("%d\t%u\t%u\t%u\t%u\t%08x\t%u\t%u\t%u\t%u\n", filt ? 1 : 0, qs, qe, rs, re, bits, ident, alnlen, ref_seq, node);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) { fprintf(stderr, "usage: parsecheck mapping query.fasta ref.fasta objects|columnar split [threads] [block_bytes]\n"); return 2; }
+  const std::string mode = argv[4];
+  const bool split = atoi(argv[5]) != 0;
+  const unsigned threads = argc > 6 ? (unsigned)atoi(argv[6]) : 0;
+  const size_t block = argc > 7 ? (size_t)atoll(argv[7]) : (size_t)64 << 20;
+  std::unique_ptr<Taxonomy> tax(loadTaxonomyFromEnvironment(&default_ranks, true));
+  if (!tax) return 2;
+  try {
+    StrIDConverter acc(argv[1]);
+    SequenceStore query(argv[2]), db(argv[3]);
+    if (mode == "objects") {
+      AlignmentRecordFactory fac(acc, tax.get(), &db);
+      RecordSetGenerator gen(std::cin, fac, split);
+      RecordSetType rset;
+      while (gen.notEmpty()) {
+        rset.clear();
+        gen.getNext(rset);
+        const AlignmentRecordTaxonomy& f = rset.front();
+        print_set(f.query_identifier.data(), f.query_identifier.size(), f.query_length, query.getIndex(f.query_identifier), rset.size());
+        for (const AlignmentRecordTaxonomy& r : rset)
+          print_rec(r.blacklist_this, r.query_start, r.query_stop, r.reference_start, r.reference_stop, r.score, r.identities,
+                    r.alignment_length, r.reference_seq, r.reference_node);
+      }
+    } else {
+      ColumnarReader reader(stdin, acc, tax.get(), &db, &query, split, threads, block);
+      ColumnarBatch b;
+      const bool quiet = getenv("PARSECHECK_QUIET") != nullptr;  // timing runs: parse only
+      size_t sets = 0, recs = 0;
+      while (reader.next(b)) {
+        sets += b.n_sets(); recs += b.n_records();
+        if (quiet) continue;
+        for (size_t s = 0; s < b.n_sets(); ++s) {
+          print_set(b.qid_arena.data() + b.qid_off[s], b.qid_len[s], b.query_len[s], b.query_seq[s], b.set_offsets[s + 1] - b.set_offsets[s]);
+          for (uint32_t r = b.set_offsets[s]; r < b.set_offsets[s + 1]; ++r)
+            print_rec(b.rec.filtered[r], b.rec.qstart[r], b.rec.qstop[r], b.rec.rstart[r], b.rec.rstop[r], b.rec.score[r],
+                      b.rec.identities[r], b.rec.alnlen[r], b.rec.ref_seq[r], b.rec.node[r]);
+        }
+      }
+      if (quiet) fprintf(stderr, "columnar: %zu record sets, %zu records\n", sets, recs);
+    }
+  } catch (Exception& e) {
+    fflush(stdout);
+    printf("ERROR %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -2,19 +2,35 @@
 // Mirrors core/taxator.cpp: same option names/defaults (:267-294), taxonomy from $TAXATORTK_TAXONOMY_NCBI pruned to the
 // given ranks (:337-340), seqid->taxid mapping (:342), alignments streamed from stdin, GFF3 to stdout in input order
 // (doPredictionsSerial, :50-77), errors to stderr + EXIT_FAILURE (:381-386).  Only `-a rpa` exists here (the LCA-only
-// models are out of scope); -p is accepted and ignored (parallelism = the GPU); -i/-v index files are
-// accepted and ignored (the stores are resident in HBM, no on-disk index is needed); new: --device, --batch.
+// models are out of scope); -p sets the number of HOST threads that parse the input and format the output
+// (0 or absent = all); -i/-v index files are accepted and ignored (the stores are resident in HBM, no on-disk index is
+// needed); new: --device, --batch, --block-mb, --timing, --record-objects.
+//
+// Default data path (no per-record objects): a reader thread turns blocks of the TSV stream into columnar batches
+// (columnar.hh) while the main thread runs the previous batch on the GPU and a writer thread formats the one before
+// that into GFF3 (gff3writer.hh).  --record-objects selects the loop that mirrors the reference's object model
+// (RecordSetGenerator -> std::vector<AlignmentRecordTaxonomy> -> PredictionRecord); both produce the same bytes.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "accessconv.hh"
 #include "alignmentrecord.hh"
+#include "channel.hh"
+#include "columnar.hh"
+#include "gff3writer.hh"
 #include "exception.hh"
 #include "predictionrecord.hh"
 #include "sequencestorage.hh"
@@ -30,9 +46,12 @@ struct Options {
   std::vector<std::string> ranks;
   bool split_alignments = true, alignments_sorted = false, delete_unmarked = true;
   float filterout = 0.5f, toppercent = 0.05f;
-  unsigned processors = 1;
+  unsigned processors = 0;
+  bool record_objects = false;
+  double block_mb = 128;
   int device = 0;
-  size_t batch = 1u << 16;
+  bool timing = false;
+  size_t batch = 0;  // 0: one GPU call per parsed block (columnar path) / 65536 record sets (record-object path)
 };
 
 static void usage(std::ostream& o) {
@@ -45,12 +64,127 @@ static void usage(std::ostream& o) {
        "  -v [ --query-sequences-index ] arg accepted, unused (store is resident in HBM)\n"
        "  -f [ --ref-sequences ] arg         reference sequences FASTA\n"
        "  -i [ --ref-sequences-index ] arg   accepted, unused (store is resident in HBM)\n"
-       "  -p [ --processors ] arg (=1)       accepted, unused (parallelism is the GPU)\n"
+       "  -p [ --processors ] arg (=0)       host threads for parsing and output formatting, 0 = all\n"
        "  -l [ --logfile ] arg (=/dev/null)  per record set STATS lines are appended here\n"
        "  -b [ --dataformat ] arg (=nucleotide)  nucleotide | protein\n"
        "  advanced: -r ranks..., -s split-alignments (=1), -o alignments-sorted (=0), -d delete-notranks (=1),\n"
-       "            -x heuristic-cutoff (=0.5), -t toppercent (=0.05), --device N (=0), --batch N (=65536 record sets)\n";
+       "            -x heuristic-cutoff (=0.5), -t toppercent (=0.05), --device N (=0), --batch N (record sets per GPU call),\n"
+       "            --block-mb N (=128, input block parsed at a time), --timing, --record-objects (per-record object loop)\n";
 }
+
+namespace {
+
+struct Work {
+  ColumnarBatch batch;
+  std::vector<rpa_prediction> rows;
+  std::vector<rpa_stats> stats;
+  bool last = false;            // end of stream (or failure): no batch inside
+  std::exception_ptr err;
+};
+
+struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, records = 0; };
+
+typedef std::chrono::steady_clock Clock;
+double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+// reader thread -> main thread (GPU) -> writer thread, three Work objects in circulation
+void run_columnar(ColumnarReader& reader, RPAPredictionModel& rpa, const Taxonomy& tax, std::ostream* logsink, size_t max_sets,
+                  unsigned threads, Timing& tm) {
+  Work works[3];
+  Channel<Work*> free_q, parsed_q, predicted_q;
+  for (Work& w : works) free_q.push(&w);
+  std::atomic<bool> stop(false);
+  std::thread reader_thread([&] {
+    for (;;) {
+      Work* w = free_q.pop();
+      if (stop.load()) return;
+      w->last = false; w->err = nullptr;
+      const Clock::time_point t0 = Clock::now();
+      try { if (!reader.next(w->batch)) w->last = true; }
+      catch (...) { w->err = std::current_exception(); w->last = true; }
+      tm.parse += secs(t0, Clock::now());
+      parsed_q.push(w);
+      if (w->last) return;
+    }
+  });
+  float stale_ival = -1.f;  // predictionrecord.hh:40; the reference reuses one PredictionRecord (taxator.cpp:66)
+  std::thread writer_thread([&] {
+    std::vector<float> ival;
+    std::vector<std::string> parts, log_parts;
+    for (;;) {
+      Work* w = predicted_q.pop();
+      if (w->last) return;
+      const Clock::time_point t0 = Clock::now();
+      const ColumnarBatch& b = w->batch;
+      const size_t S = b.n_sets();
+      ival.resize(S);
+      for (size_t s = 0; s < S; ++s) {
+        if (!(w->rows[s].flags & RPA_FLAG_IVAL_UNTOUCHED)) stale_ival = w->rows[s].ival;
+        ival[s] = stale_ival;
+      }
+      const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, S / 4096 + 1));
+      parts.assign(T, std::string());
+      log_parts.assign(T, std::string());
+      auto format = [&](unsigned t) {
+        const size_t lo = S * t / T, hi = S * (t + 1) / T;
+        std::string& out = parts[t];
+        out.reserve((hi - lo) * 112);
+        for (size_t s = lo; s < hi; ++s)
+          append_gff3(out, tax, b.qid_arena.data() + b.qid_off[s], b.qid_len[s], b.query_len[s], w->rows[s], ival[s]);
+        if (logsink) {  // the STATS line of the reference log (:837), timing columns left out
+          std::string& lg = log_parts[t];
+          for (size_t s = lo; s < hi; ++s) {
+            const rpa_stats& st = w->stats[s];
+            lg.append("STATS\t"); lg.append(b.qid_arena.data() + b.qid_off[s], b.qid_len[s]);
+            const uint32_t v[5] = {st.n, st.pass0, st.pass1, st.pass2, st.pass0 + st.pass1 + st.pass2};
+            for (uint32_t x : v) { lg.push_back('\t'); append_u32(lg, x); }
+            lg.push_back('\n');
+          }
+        }
+      };
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < T; ++t) th.emplace_back(format, t);
+      format(0);
+      for (auto& x : th) x.join();
+      for (const std::string& p : parts) fwrite(p.data(), 1, p.size(), stdout);
+      if (logsink) for (const std::string& p : log_parts) logsink->write(p.data(), (std::streamsize)p.size());
+      tm.write += secs(t0, Clock::now());
+      free_q.push(w);
+    }
+  });
+  std::exception_ptr failure;
+  for (;;) {
+    Work* w = parsed_q.pop();
+    if (w->last) { failure = w->err; predicted_q.push(w); break; }
+    const Clock::time_point t0 = Clock::now();
+    const size_t S = w->batch.n_sets();
+    w->rows.resize(S);
+    w->stats.resize(S);
+    try {
+      const size_t step = max_sets ? max_sets : S;
+      for (size_t lo = 0; lo < S; lo += step) {
+        const size_t hi = std::min(S, lo + step);
+        rpa.predictColumns(w->batch, lo, hi, w->rows.data() + lo, w->stats.data() + lo);
+      }
+    } catch (...) {
+      failure = std::current_exception();
+      w->last = true;
+      predicted_q.push(w);
+      break;
+    }
+    tm.predict += secs(t0, Clock::now());
+    tm.sets += S; tm.records += w->batch.n_records();
+    predicted_q.push(w);
+  }
+  writer_thread.join();
+  stop.store(true);
+  for (int k = 0; k < 3; ++k) free_q.push(nullptr);  // wake the reader if it waits for a Work object
+  reader_thread.join();
+  fflush(stdout);
+  if (failure) std::rethrow_exception(failure);
+}
+
+}  // namespace
 
 static bool parse_bool(const std::string& v) { return !(v == "0" || v == "false" || v == "no" || v == "off"); }
 
@@ -79,6 +213,9 @@ int main(int argc, char** argv) {
     else if (a == "-x" || a == "--heuristic-cutoff") o.filterout = (float)atof(val("--heuristic-cutoff").c_str());
     else if (a == "-t" || a == "--toppercent") o.toppercent = (float)atof(val("--toppercent").c_str());
     else if (a == "--device") o.device = atoi(val("--device").c_str());
+    else if (a == "--timing") o.timing = true;
+    else if (a == "--record-objects") o.record_objects = true;
+    else if (a == "--block-mb") o.block_mb = atof(val("--block-mb").c_str());
     else if (a == "--batch") o.batch = (size_t)atoll(val("--batch").c_str());
     else if (a == "-r" || a == "--ranks") { while (i + 1 < argc && argv[i + 1][0] != '-') o.ranks.push_back(argv[++i]); }
     else { std::cerr << "unrecognised option '" << a << "'" << std::endl; return EXIT_FAILURE; }
@@ -97,6 +234,9 @@ int main(int argc, char** argv) {
     std::cout << "data format can either be nucleotide or protein" << std::endl;
     return EXIT_FAILURE;
   }
+  const Clock::time_point t_start = Clock::now();
+  double t_parse = 0, t_predict = 0, t_write = 0;
+  size_t n_sets = 0, n_records = 0;
   std::unique_ptr<Taxonomy> tax(loadTaxonomyFromEnvironment(&o.ranks, o.delete_unmarked));
   if (!tax) return EXIT_FAILURE;
   try {
@@ -105,19 +245,43 @@ int main(int argc, char** argv) {
     SequenceStore query_storage(o.query);
     SequenceStore db_storage(o.db);
     RPAPredictionModel rpa(tax.get(), query_storage, db_storage, o.filterout, o.toppercent, o.dataformat == "protein", o.device);
+    const Clock::time_point t_loaded = Clock::now();
+    if (!o.record_objects) {
+      std::cout << GFF3Header() << std::flush;
+      ColumnarReader reader(stdin, *seqid2taxid, tax.get(), &db_storage, &query_storage, o.split_alignments, o.processors,
+                            (size_t)std::max(4096.0, o.block_mb * 1048576.0));
+      Timing tm;
+      const bool logging = o.logfile != "/dev/null";
+      try { run_columnar(reader, rpa, *tax, logging ? &logsink : nullptr, o.batch, o.processors ? o.processors : std::thread::hardware_concurrency(), tm); }
+      catch (...) {
+        if (o.timing) std::cerr << "TIMING\tincomplete" << std::endl;
+        throw;
+      }
+      if (o.timing)
+        std::cerr << "TIMING\tload_s=" << secs(t_start, t_loaded) << "\tparse_s=" << tm.parse << "\tpredict_s=" << tm.predict << "\twrite_s="
+                  << tm.write << "\twall_s=" << secs(t_loaded, Clock::now()) << "\trecord_sets=" << tm.sets << "\trecords=" << tm.records
+                  << "\t(columnar pipeline: the three stages overlap)" << std::endl;
+      return EXIT_SUCCESS;
+    }
     AlignmentRecordFactory fac(*seqid2taxid, tax.get(), &db_storage);
     RecordSetGenerator recgen(std::cin, fac, o.split_alignments);
     std::vector<RecordSetType> sets;
     std::vector<PredictionRecord> precs;
     std::cout << GFF3Header();
     std::ostringstream outbuf;
+    const size_t batch_sets = o.batch ? o.batch : (size_t)1 << 16;
     while (recgen.notEmpty()) {
+      const Clock::time_point t0 = Clock::now();
       sets.clear();
-      while (recgen.notEmpty() && sets.size() < o.batch) {
+      while (recgen.notEmpty() && sets.size() < batch_sets) {
         sets.emplace_back();
         recgen.getNext(sets.back());
+        n_records += sets.back().size();
       }
+      n_sets += sets.size();
+      const Clock::time_point t1 = Clock::now();
       rpa.predict(sets, precs, logsink);
+      const Clock::time_point t2 = Clock::now();
       outbuf.str("");
       for (size_t s = 0; s < sets.size(); ++s) outbuf << precs[s];
       std::cout << outbuf.str();
@@ -125,7 +289,12 @@ int main(int argc, char** argv) {
       for (size_t s = 0; s < sets.size(); ++s)  // the STATS line of the reference log (:837), timing columns as 0
         logsink << "STATS\t" << precs[s].getQueryIdentifier() << '\t' << st[s].n << '\t' << st[s].pass0 << '\t' << st[s].pass1 << '\t'
                 << st[s].pass2 << '\t' << (st[s].pass0 + st[s].pass1 + st[s].pass2) << "\n";
+      const Clock::time_point t3 = Clock::now();
+      t_parse += secs(t0, t1); t_predict += secs(t1, t2); t_write += secs(t2, t3);
     }
+    if (o.timing)
+      std::cerr << "TIMING\tload_s=" << secs(t_start, t_loaded) << "\tparse_s=" << t_parse << "\tpredict_s=" << t_predict << "\twrite_s="
+                << t_write << "\trecord_sets=" << n_sets << "\trecords=" << n_records << std::endl;
     return EXIT_SUCCESS;
   } catch (Exception& e) {
     std::cerr << "An unrecoverable error occurred: " << e.what() << std::endl;  // taxator.cpp:381-386

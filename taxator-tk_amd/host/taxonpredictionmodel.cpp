@@ -1,6 +1,7 @@
 // taxator-tk_amd/host/taxonpredictionmodel.cpp -- see taxonpredictionmodel.hh.
 #include "taxonpredictionmodel.hh"
 
+#include "columnar.hh"
 #include "exception.hh"
 
 namespace taxator {
@@ -75,6 +76,21 @@ void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, s
     prec.setNodeRange(r.lower, r.upper, r.support);
     prec.setBestReferenceTaxon(r.rtax);
   }
+}
+
+void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats) {
+  if (hi <= lo) return;
+  const uint32_t base = cb.set_offsets[lo];
+  set_offsets_.resize(hi - lo + 1);
+  for (size_t s = lo; s <= hi; ++s) set_offsets_[s - lo] = cb.set_offsets[s] - base;
+  rpa_batch b;
+  b.n_sets = (uint32_t)(hi - lo); b.n_records = cb.set_offsets[hi] - base;
+  b.set_offsets = set_offsets_.data(); b.query_seq = cb.query_seq.data() + lo; b.query_len = cb.query_len.data() + lo;
+  b.qstart = cb.rec.qstart.data() + base; b.qstop = cb.rec.qstop.data() + base; b.rstart = cb.rec.rstart.data() + base;
+  b.rstop = cb.rec.rstop.data() + base; b.score = cb.rec.score.data() + base; b.identities = cb.rec.identities.data() + base;
+  b.alnlen = cb.rec.alnlen.data() + base; b.ref_seq = cb.rec.ref_seq.data() + base; b.node = cb.rec.node.data() + base;
+  b.filtered = cb.rec.filtered.data() + base; b.mem_kind = RPA_MEM_HOST;
+  check(engine_, rpa_predict_batch(engine_, &b, rows, stats, RPA_MEM_HOST));
 }
 
 }  // namespace taxator

@@ -34,6 +34,9 @@ class RPAPredictionModel : public TaxonPredictionModel {
   ~RPAPredictionModel() override;
   void predict(const std::vector<RecordSetType>& recordsets, std::vector<PredictionRecord>& precs, std::ostream& logsink) override;
   const std::vector<rpa_stats>& lastStats() const { return stats_; }
+  // The same call for record sets that are already in columns (columnar.hh): sets [lo, hi) of `batch`, rows and STATS
+  // counters written to rows[0 .. hi-lo) / stats[0 .. hi-lo).  No per-record objects on this path.
+  void predictColumns(const struct ColumnarBatch& batch, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats);
  private:
   const SequenceStore& query_sequences_;
   rpa_engine* engine_ = nullptr;

@@ -34,9 +34,12 @@ def _unpack(golden_dir, name, ext, tmp_path):
 
 
 @pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])
-def test_cli_reproduces_reference_gff3(golden_dir, tmp_path, name, ext, extra):
+@pytest.mark.parametrize("path", [[], ["--record-objects"], ["--block-mb", "0.004", "-p", "3"]])
+def test_cli_reproduces_reference_gff3(golden_dir, tmp_path, name, ext, extra, path):
+    """Default = columnar pipeline (reader / GPU / writer threads); --record-objects = the per-record object loop; tiny
+    blocks = many batches with groups straddling block boundaries.  Same bytes as the reference printed."""
     folder = _unpack(golden_dir, name, ext, tmp_path)
-    r = _run(folder, ext, extra + ["--batch", "97"])  # several batches: the stale-ival state must carry across them
+    r = _run(folder, ext, extra + path + ["--batch", "97"])  # several GPU calls: the stale-ival state must carry across them
     assert r.returncode == 0, r.stderr
     assert r.stdout == open(os.path.join(folder, "out.gff3")).read()
 
@@ -51,6 +54,9 @@ def test_cli_config1_plumbing(oracle, tmp_path):
     log = str(tmp_path / "log.txt")
     r = _run(folder, ".fna", log=log)
     assert r.returncode == 0, r.stderr
+    log2 = str(tmp_path / "log2.txt")
+    r2 = _run(folder, ".fna", extra=["--record-objects"], log=log2)
+    assert r2.returncode == 0 and r2.stdout == r.stdout and open(log2).read() == open(log).read()
     fds = R.Dataset(folder, 0)
     b = fds.batch()
     tax = oracle.TaxArrays(fds.tax.parent, fds.tax.left, fds.tax.right, fds.tax.depth)
@@ -63,18 +69,19 @@ def test_cli_config1_plumbing(oracle, tmp_path):
     assert [int(l[3]) + int(l[4]) + int(l[5]) for l in stats_lines] == [int(x) for x in st["pass0"] + st["pass1"] + st["pass2"]]
 
 
-def test_cli_errors_like_the_reference(golden_dir, tmp_path):
+@pytest.mark.parametrize("path", [[], ["--record-objects"]])
+def test_cli_errors_like_the_reference(golden_dir, tmp_path, path):
     folder = os.path.join(golden_dir, "survey_edge")
     bad = tmp_path / "bad.tsv"
     bad.write_text("e0\t1\t200\t200\tnope\t101\t300\t400\t0\t200\t200\n")
     work = tmp_path / "w"
     shutil.copytree(folder, work)
     shutil.copy(bad, work / "aln_bad.tsv")
-    r = _run(str(work), ".fna", aln="aln_bad.tsv", query="query_edge.fna")
+    r = _run(str(work), ".fna", extra=path, aln="aln_bad.tsv", query="query_edge.fna")
     assert r.returncode == 1 and "bad taxon mapping for alignment reference sequence" in r.stderr  # alignmentrecord.hh:214-219
     (work / "aln_bad.tsv").write_text("e0\t200\t1\t200\tref3\t101\t300\t400\t0\t200\t200\n")
-    r = _run(str(work), ".fna", aln="aln_bad.tsv", query="query_edge.fna")
+    r = _run(str(work), ".fna", extra=path, aln="aln_bad.tsv", query="query_edge.fna")
     assert r.returncode == 1 and "reverse query positions not allowed" in r.stderr               # alignmentrecord.hh:114
     (work / "aln_bad.tsv").write_text("e0\t1\t200\t200\tref3\t99999101\t99999300\t400\t0\t150\t200\ne0\t1\t200\t200\tref2\t101\t300\t300\t0\t180\t200\n")
-    r = _run(str(work), ".fna", aln="aln_bad.tsv", query="query_edge.fna")
+    r = _run(str(work), ".fna", extra=path, aln="aln_bad.tsv", query="query_edge.fna")
     assert r.returncode == 1 and "SequenceRangeError" in r.stderr
