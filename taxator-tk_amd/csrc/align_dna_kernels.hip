@@ -100,9 +100,6 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
   uint32_t VP[NW], VN[NW];
 #pragma unroll
   for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
-  int32_t dist = (int32_t)m;  // D[m][0]
-  const uint32_t lastbit = (m - 1u) & 31u;  // m >= 1 (zero-length segments are range errors upstream)
-
   // One text column: NW chained word updates (add carry in VCC via v_addc_co, shift carries via v_alignbit).
   auto column = [&](uint32_t c) {
     const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
@@ -126,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
       VN[wi] = Xs & D0;
       VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);              // Hs | ~(Xs | D0)
     }
-    dist += (int32_t)((HP >> lastbit) & 1u) - (int32_t)((HN >> lastbit) & 1u);
+    (void)HP; (void)HN;
   };
 
   // Text streaming straight from the resident store, 8 nt (one dword) per step.  Forward segments walk the store
@@ -161,6 +158,17 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
 #pragma unroll 1
       for (uint32_t k = 0; k < cols; ++k) column((d >> (4 * k)) & 7u);
     }
+  }
+  // The score is not tracked per column (the reference adds the horizontal delta of the pattern's last row after every
+  // text character, global_alignment_myers_impl.h:120-123): row 0 of a global alignment holds D[0][j] = j, so
+  // D[m][n] = n + sum of the vertical deltas of the last column = n + popc(VP & rows<m) - popc(VN & rows<m).
+  // This also makes the kernel exact for ANY m <= 32*NW (rows past the pattern match nothing and sit below row m).
+  int32_t dist = (int32_t)n;
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) {
+    const uint32_t pos = (uint32_t)wi * 32u;
+    const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
+    dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
   }
   // distance, similarity = matches = len_short - (d - lendiff) = len_long - d   (:154-164)
   w.pair_res[dst] = make_float2((float)dist, (float)((int32_t)n - dist));

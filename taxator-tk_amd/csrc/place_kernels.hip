@@ -68,10 +68,42 @@ __device__ __forceinline__ void load_path(const uint4* p, uint32_t (&path)[4 * P
     path[4 * k] = v.x; path[4 * k + 1] = v.y; path[4 * k + 2] = v.z; path[4 * k + 3] = v.w;
   }
 }
-// mutable fields of a row (qd, qs, meta) live in its second 16-byte half
-__device__ __forceinline__ void store_dyn(const WorkDev& w, int stride4, uint32_t pos, float qd, float qs, uint32_t seglen, uint32_t meta) {
-  reinterpret_cast<uint4*>(w.hits)[(size_t)pos * stride4 + 1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), seglen, meta);
+// A whole row in registers.  The decision loops fetch row i+1 (and its alignment result) before they work on row i,
+// so the HBM latency of a row is hidden behind the previous row's arithmetic instead of being paid n times in sequence.
+template <int P4>
+struct Row { uint4 q[2 + P4]; };
+template <int P4>
+__device__ __forceinline__ Row<P4> load_row(const WorkDev& w, uint32_t pos) {
+  const uint4* p = hit_ptr<P4>(w, pos);
+  Row<P4> r;
+#pragma unroll
+  for (int k = 0; k < 2 + P4; ++k) r.q[k] = p[k];
+  return r;
 }
+template <int P4>
+__device__ __forceinline__ HitCore row_core(const Row<P4>& r) {
+  HitCore c;
+  c.score = __uint_as_float(r.q[0].x); c.ident = r.q[0].y; c.node = r.q[0].z; c.rec = r.q[0].w;
+  c.qd = __uint_as_float(r.q[1].x); c.qs = __uint_as_float(r.q[1].y); c.seglen = r.q[1].z; c.meta = r.q[1].w;
+  return c;
+}
+template <int P4>
+__device__ __forceinline__ void row_path(const Row<P4>& r, uint32_t (&path)[4 * P4]) {
+#pragma unroll
+  for (int k = 0; k < P4; ++k) {
+    path[4 * k] = r.q[2 + k].x; path[4 * k + 1] = r.q[2 + k].y; path[4 * k + 2] = r.q[2 + k].z; path[4 * k + 3] = r.q[2 + k].w;
+  }
+}
+// the only mutable fields of a row: querydistance / querysimilarity (first 8 bytes of its second quad)
+__device__ __forceinline__ void store_qdqs(const WorkDev& w, int stride4, uint32_t pos, float qd, float qs) {
+  reinterpret_cast<float2*>(reinterpret_cast<uint4*>(w.hits) + (size_t)pos * stride4 + 1)[0] = make_float2(qd, qs);
+}
+__device__ __forceinline__ void store_qd(const WorkDev& w, int stride4, uint32_t pos, float qd) {
+  reinterpret_cast<float*>(reinterpret_cast<uint4*>(w.hits) + (size_t)pos * stride4 + 1)[0] = qd;
+}
+// qgroup / outgroup bit sets of one record set (WorkDev::flags)
+__device__ __forceinline__ void bit_clear(uint32_t* words, uint32_t i) { words[i >> 5] &= ~(1u << (i & 31u)); }
+__device__ __forceinline__ void bit_set(uint32_t* words, uint32_t i) { words[i >> 5] |= 1u << (i & 31u); }
 __device__ __forceinline__ uint32_t meta_depth(uint32_t meta) { return (meta >> kMetaDepthShift) & 0xFFu; }
 __device__ __forceinline__ uint32_t meta_err(uint32_t meta) { return (meta >> kMetaErrShift) & 0xFu; }
 
@@ -131,14 +163,52 @@ __device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, co
 // ------------------------------------------------------------------------------------------------------------
 template <int P4>
 __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, TaxDev tax, StoreDev qstore, StoreDev dbstore, Params p) {
-  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  // Record -> record set.  The records of a workgroup are consecutive, so their sets are consecutive too: the first
+  // wave finds the set of the block's first record with a 64-ary search over set_offsets (4 dependent probes for 1 M
+  // sets instead of 20 per thread), the block stages the next kBlock+1 offsets in LDS and every thread finishes with a
+  // search in LDS.  Only a block whose range holds more than kBlock set boundaries (runs of empty sets) falls back to
+  // the global search.  "Set of r" = largest s with set_offsets[s] <= r (empty sets share an offset: take the last).
+  __shared__ uint32_t s_off[kBlock + 1];
+  __shared__ uint32_t s_first;
+  const uint32_t r0 = blockIdx.x * kBlock;  // < n_records by the grid size
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    uint32_t lo = 0, hi = b.n_sets;  // set_offsets[lo] <= r0 < set_offsets[hi]
+    while (hi - lo > 1) {
+      const uint32_t step = (hi - lo + 63u) / 64u;
+      const uint64_t probe = (uint64_t)lo + (uint64_t)(lane + 1) * step;
+      const bool ok = probe < hi && b.set_offsets[probe] <= r0;  // monotone over the lanes
+      const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));
+      const uint64_t nhi = (uint64_t)lo + (uint64_t)(cnt + 1u) * step;
+      lo += cnt * step;
+      hi = nhi < hi ? (uint32_t)nhi : hi;
+    }
+    if (lane == 0) s_first = lo;
+  }
+  __syncthreads();
+  const uint32_t first = s_first;
+  for (uint32_t k = threadIdx.x; k <= (uint32_t)kBlock; k += kBlock) {
+    const uint64_t idx = (uint64_t)first + k;
+    s_off[k] = b.set_offsets[idx < b.n_sets ? idx : b.n_sets];
+  }
+  __syncthreads();
+  const uint32_t r = r0 + threadIdx.x;
   if (r >= b.n_records) return;
-  uint32_t lo = 0, hi = b.n_sets;  // largest s with set_offsets[s] <= r  (empty sets share an offset: take the last one)
+  uint32_t lo = 0, hi = kBlock + 1;  // largest j in [0, kBlock] with s_off[j] <= r  (s_off[0] <= r0 <= r)
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (b.set_offsets[mid] <= r) lo = mid; else hi = mid;
+    if (s_off[mid] <= r) lo = mid; else hi = mid;
   }
-  const uint32_t s = lo;
+  uint32_t s = first + lo;
+  if (lo == (uint32_t)kBlock && s < b.n_sets) {  // window exhausted: more than kBlock boundaries in this block's range
+    uint32_t glo = s, ghi = b.n_sets;
+    while (ghi - glo > 1) {
+      const uint32_t mid = glo + ((ghi - glo) >> 1);
+      if (b.set_offsets[mid] <= r) glo = mid; else ghi = mid;
+    }
+    s = glo;
+  }
+  if (s >= b.n_sets) s = b.n_sets - 1;  // clamped window entries (cannot be selected: set_offsets[n_sets] > r)
   w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
   const uint32_t beg = b.set_offsets[s], end = b.set_offsets[s + 1];
   const bool me_filtered = rec_filtered(b, r);
@@ -162,17 +232,18 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     w.set_qseg[s] = qp;
   }
   if (me_filtered) return;
+  const uint32_t pos = beg + rank;  // row position = segment id = result slot of this hit
   uint2 sp = make_uint2(0u, 0u);
   if (n >= 2) {
     const uint32_t left_ext = b.qstart[r] - qrstart, right_ext = qrstop - b.qstop[r];  // :523
     const uint32_t start = b.rstart[r], stop = b.rstop[r];
     if (start <= stop) {
-      sp = plan_segment(w, r, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false);
+      sp = plan_segment(w, pos, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false);
     } else if (p.alphabet != 0) {
-      w.seg[r] = SegDesc{0u, 0u, 0u, (uint32_t)kErrAssert << 4};
+      w.seg[pos] = SegDesc{0u, 0u, 0u, (uint32_t)kErrAssert << 4};
       sp = make_uint2(0u, (uint32_t)kErrAssert);
     } else {
-      sp = plan_segment(w, r, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true);
+      sp = plan_segment(w, pos, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true);
     }
   }
   const uint32_t node = b.node[r];
@@ -181,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   const uint32_t meta = (perfect ? kMetaPerfect : 0u) | (sp.y << kMetaErrShift) | ((uint32_t)tax.depth[node] << kMetaDepthShift);
   float qd = FLT_MAX, qs = 0.f;  // :475-476
   if (n == 1) { qd = __uint_as_float(b.qstart[r]); qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
-  uint4* row = reinterpret_cast<uint4*>(w.hits) + (size_t)(beg + rank) * (2 + P4);
+  uint4* row = reinterpret_cast<uint4*>(w.hits) + (size_t)pos * (2 + P4);
   row[0] = make_uint4(__float_as_uint(sc), id, node, r);
   row[1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta);
   const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
@@ -234,88 +305,145 @@ __device__ __forceinline__ int pair_bin(const Params& p, uint32_t la, uint32_t l
 //   pass 2 (:757-778): i != anchor, score >= cut-off, qpid >= threshold and unode_global not cnode-or-above
 //                      -> (segment_i, segment_anchor);  anchor never aligned to the query (:792) -> (segment_anchor, query range)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kEmitBlock = 1024;  // one list reservation (atomic) per bin per 1024 rows: same-address atomics are ~11 ns each
+constexpr int kEmitBlock = 1024;  // one list reservation (atomic) per bin per workgroup: same-address atomics are ~11 ns each
+constexpr int kEmitRows = 4;      // row positions per thread: the three dependent loads (set -> EmitInfo -> row) of four
+                                  // rows are in flight together; the kernel is bound by that latency chain, not by bytes
+constexpr int kEmitSpan = kEmitBlock * kEmitRows;
+
+// "can the loop the set is about to run reach the alignment of the hit at row `pos`?" -- everything but the row loads.
+// Returns the bin (or -1) and fills entry / maxlen.  q0/q1 are the first two quads of the row.
+template <int P4>
+__device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& w, const Params& p, const EmitInfo& info, uint32_t s,
+                                              uint32_t lo, uint32_t pos, const uint4 q0, const uint4 q1, uint2& entry, uint32_t& maxlen) {
+  const uint32_t H = b.n_records;
+  const float score = __uint_as_float(q0.x), qd = __uint_as_float(q1.x), qs = __uint_as_float(q1.y);
+  const uint32_t seglen = q1.z, meta = q1.w;
+  bool want = false;
+  if (info.mode == 1) want = !(meta & kMetaPerfect) && score >= info.fcut;
+  else if (info.mode == 2) want = qd != 0.f;
+  else if (score >= info.fcut && (double)qs / info.L >= info.qpid_thresh) {
+    uint32_t pb[4 * P4], pth[4 * P4];
+    const uint4* pbp = hit_ptr<P4>(w, lo + info.best);
+    load_path<P4>(pbp, pb);
+    load_path<P4>(hit_ptr<P4>(w, pos), pth);
+    want = !(common<P4>(pb, meta_depth(load_core(pbp).meta), pth, meta_depth(meta)) >= info.d_unode_g);
+  }
+  if (!want) return -1;
+  const uint32_t other_len = info.mode == 1 ? info.qseglen : info.anchor_len;
+  const uint32_t other_seg = info.mode == 1 ? H + s : lo + info.anchor;
+  int bin = pair_bin(p, seglen, other_len);
+  maxlen = p.alphabet == 0 ? max(seglen, other_len) : seglen;  // DNA: text = the longer one; protein: A
+  entry = make_uint2(pos, other_seg);
+  if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = -1; }
+  return bin;
+}
 
 template <int P4>
 __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Params p) {
-  __shared__ uint32_t s_cnt[kNumBins][kEmitBlock / 64];  // per bin, per wave: number of active lanes
-  __shared__ uint32_t s_base[kNumBins];
-  __shared__ uint32_t s_maxlen[kEmitBlock / 64];
-  const uint32_t pos = blockIdx.x * kEmitBlock + threadIdx.x;
-  const uint32_t H = b.n_records;
-  int bin = -1;
+  constexpr int kVW = kEmitSpan / 64;  // "virtual waves": runs of 64 consecutive row positions
+  static_assert(kVW == 64, "the prefix over virtual waves is done by one wavefront");
+  __shared__ uint32_t s_cnt[kNumBins][kVW];  // per bin, per virtual wave: number of active lanes, then its list offset
+  __shared__ uint32_t s_maxlen[kVW];
+  const uint32_t H = b.n_records, total = H + b.n_sets;
+  const uint32_t pos0 = blockIdx.x * kEmitSpan + threadIdx.x;
+  uint32_t set_of[kEmitRows], lo[kEmitRows];
+  EmitInfo info[kEmitRows];
+  uint4 q0[kEmitRows], q1[kEmitRows];
+  bool cand[kEmitRows];
+#pragma unroll
+  for (int k = 0; k < kEmitRows; ++k) {  // level 1: row position -> record set
+    const uint32_t pos = pos0 + k * kEmitBlock;
+    set_of[k] = pos < H ? w.hit_set[pos] : (pos < total ? pos - H : 0xFFFFFFFFu);
+  }
+#pragma unroll
+  for (int k = 0; k < kEmitRows; ++k) {  // level 2: what the set wants
+    info[k].mode = 0; lo[k] = 0;
+    if (set_of[k] != 0xFFFFFFFFu) { info[k] = w.emit[set_of[k]]; lo[k] = b.set_offsets[set_of[k]]; }
+  }
+#pragma unroll
+  for (int k = 0; k < kEmitRows; ++k) {  // level 3: the row, only where the set's running loop covers it
+    const uint32_t pos = pos0 + k * kEmitBlock;
+    const uint32_t i = pos - lo[k];
+    cand[k] = pos < H && info[k].mode != 0 && i < info[k].n && i >= info[k].i_lo && i < info[k].i_hi &&
+              (info[k].mode == 1 || i != info[k].anchor);
+    q0[k] = q1[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (cand[k]) { const uint4* pr = hit_ptr<P4>(w, pos); q0[k] = pr[0]; q1[k] = pr[1]; }
+  }
+  int bin[kEmitRows];
+  uint2 entry[kEmitRows];
   uint32_t maxlen = 0;
-  uint2 entry = make_uint2(0u, 0u);
-  if (pos < H + b.n_sets) {
-    const bool is_query_pair = pos >= H;
-    const uint32_t s = is_query_pair ? pos - H : w.hit_set[pos];
-    const EmitInfo info = w.emit[s];
-    if (info.mode != 0) {
-      const uint32_t lo = b.set_offsets[s];
-      if (is_query_pair) {
-        if (info.mode == 3) {
-          const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor));
-          if (info.emit_query && ha.qd == FLT_MAX) { bin = pair_bin(p, ha.seglen, info.qseglen); maxlen = p.alphabet == 0 ? max(ha.seglen, info.qseglen) : ha.seglen; entry = make_uint2(ha.rec, pos | kDstIsB); }
-        }
-      } else {
-        const uint32_t i = pos - lo;
-        if (i < info.n && i >= info.i_lo && i < info.i_hi) {
-          const uint4* pi = hit_ptr<P4>(w, pos);
-          const HitCore h = load_core(pi);
-          uint32_t other_len = info.qseglen, other_seg = H + s;
-          bool want = false;
-          if (info.mode == 1) want = !(h.meta & kMetaPerfect) && h.score >= info.fcut;
-          else if (i != info.anchor) {
-            if (info.mode == 2) want = h.qd != 0.f;
-            else if (h.score >= info.fcut && (double)h.qs / info.L >= info.qpid_thresh) {
-              uint32_t pb[4 * P4], pth[4 * P4];
-              const uint4* pbp = hit_ptr<P4>(w, lo + info.best);
-              load_path<P4>(pbp, pb);
-              load_path<P4>(pi, pth);
-              want = !(common<P4>(pb, meta_depth(load_core(pbp).meta), pth, meta_depth(h.meta)) >= info.d_unode_g);
-            }
-            if (want) { const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor)); other_len = ha.seglen; other_seg = ha.rec; }
-          }
-          if (want) {
-            bin = pair_bin(p, h.seglen, other_len);
-            maxlen = p.alphabet == 0 ? max(h.seglen, other_len) : h.seglen;  // DNA: text = the longer one; protein: A
-            entry = make_uint2(h.rec, other_seg);
-            if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = -1; }
-          }
-        }
-      }
+#pragma unroll
+  for (int k = 0; k < kEmitRows; ++k) {
+    const uint32_t pos = pos0 + k * kEmitBlock;
+    bin[k] = -1;
+    entry[k] = make_uint2(0u, 0u);
+    uint32_t ml = 0;
+    if (cand[k]) bin[k] = emit_predicate<P4>(b, w, p, info[k], set_of[k], lo[k], pos, q0[k], q1[k], entry[k], ml);
+    else if (pos >= H && pos < total && info[k].mode == 3 && info[k].emit_query) {  // anchor <-> query range (:792-797)
+      bin[k] = pair_bin(p, info[k].anchor_len, info[k].qseglen);
+      ml = p.alphabet == 0 ? max(info[k].anchor_len, info[k].qseglen) : info[k].anchor_len;
+      entry[k] = make_uint2(lo[k] + info[k].anchor, pos | kDstIsB);
+      if (bin[k] >= kNumBins) { raise_error(w, kErrUnsupported, set_of[k]); bin[k] = -1; }
     }
+    maxlen = max(maxlen, ml);
   }
   // block-level compaction: wave ballots -> LDS -> one atomic per non-empty bin per block
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long my_mask = 0ull;
+  unsigned long long my_mask[kEmitRows];
 #pragma unroll
-  for (int k = 0; k < kNumBins; ++k) {
-    const unsigned long long mask = __ballot(bin == k);
-    if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(mask);
-    if (bin == k) my_mask = mask;
+  for (int k = 0; k < kEmitRows; ++k) {
+    my_mask[k] = 0ull;
+    const int vw = k * (kEmitBlock / 64) + wave;
+#pragma unroll
+    for (int kk = 0; kk < kNumBins; ++kk) {
+      const unsigned long long mask = __ballot(bin[k] == kk);
+      if (lane == 0) s_cnt[kk][vw] = (uint32_t)__popcll(mask);
+      if (bin[k] == kk) my_mask[k] = mask;
+    }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor(maxlen, d, 64));
   if (lane == 0) s_maxlen[wave] = maxlen;
   __syncthreads();
-  if (threadIdx.x < kNumBins) {  // thread k: exclusive prefix over the waves of bin k, then reserve
-    uint32_t run = 0;
-    for (int wv = 0; wv < kEmitBlock / 64; ++wv) { const uint32_t c = s_cnt[threadIdx.x][wv]; s_cnt[threadIdx.x][wv] = run; run += c; }
-    s_base[threadIdx.x] = run ? atomicAdd(&w.counters[threadIdx.x], run) : 0u;
-  } else if (threadIdx.x == 64) {
-    uint32_t m = 0;
-    for (int wv = 0; wv < kEmitBlock / 64; ++wv) m = max(m, s_maxlen[wv]);
-    if (m) atomicMax(&w.counters[kCtrMaxLen], m);
+  if (wave == 0) {  // lane l = virtual wave l: exclusive prefix per bin, one reservation per non-empty bin
+#pragma unroll
+    for (int kk = 0; kk < kNumBins; ++kk) {
+      const uint32_t c = s_cnt[kk][lane];
+      if (!__any(c != 0u)) continue;
+      uint32_t inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      uint32_t base = 0;
+      if (lane == 63) base = atomicAdd(&w.counters[kk], inc);
+      base = __shfl(base, 63, 64);
+      s_cnt[kk][lane] = base + inc - c;
+    }
+  } else if (wave == 1) {
+    uint32_t m = lane < kEmitBlock / 64 ? s_maxlen[lane] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, 64));
+    if (lane == 0 && m) atomicMax(&w.counters[kCtrMaxLen], m);
   }
   __syncthreads();
-  if (bin >= 0)
-    w.bin_list[(size_t)bin * w.T2 + s_base[bin] + s_cnt[bin][wave] + (uint32_t)__popcll(my_mask & ((1ull << lane) - 1ull))] = entry;
+#pragma unroll
+  for (int k = 0; k < kEmitRows; ++k)
+    if (bin[k] >= 0)
+      w.bin_list[(size_t)bin[k] * w.T2 + s_cnt[bin[k]][k * (kEmitBlock / 64) + wave] + (uint32_t)__popcll(my_mask[k] & ((1ull << lane) - 1ull))] = entry[k];
+}
+
+// In a sparse round every launch is latency-bound (a few thousand lanes at most), so all patterns of up to 256 nt go
+// into ONE list, run by the widest one-strip kernel (exact for any pattern that fits its strip), instead of one
+// serialised ~60 us launch per pattern-length class.
+__device__ __forceinline__ int sparse_bin(const Params& p, int bin) {
+  return (p.alphabet == 0 && bin >= 0 && bin < kShortWords && p.force_bin < 0) ? kShortWords - 1 : bin;
 }
 
 // Sparse rounds: when only a small fraction of the record sets is still running, scanning every row of the batch
 // would cost more than the work left.  One wavefront per live set; lane j looks at hits j, j+64, ...; lane 0 also
-// handles the anchor <-> query alignment.  Same predicate and same list format as k_emit.
+// emits the anchor <-> query alignment.  Same predicate and same list format as k_emit.
 template <int P4>
 __global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, Params p) {
   const uint32_t wave_id = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -326,44 +454,17 @@ __global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, P
   const EmitInfo info = w.emit[s];
   if (info.mode == 0) return;
   const uint32_t lo = b.set_offsets[s];
-  uint32_t anchor_len = 0, anchor_rec = 0;
-  float anchor_qd = 0.f;
-  if (info.mode != 1) { const HitCore ha = load_core(hit_ptr<P4>(w, lo + info.anchor)); anchor_len = ha.seglen; anchor_rec = ha.rec; anchor_qd = ha.qd; }
-  uint32_t pb[4 * P4];
-  uint32_t db = 0;
-  if (info.mode == 3) { const uint4* pbp = hit_ptr<P4>(w, lo + info.best); load_path<P4>(pbp, pb); db = meta_depth(load_core(pbp).meta); }
   uint32_t maxlen = 0;
   const uint32_t i_hi = min(info.i_hi, info.n);
-  // the query pair rides along as a virtual hit index i_hi handled by lane 0 in the first trip
-  for (uint32_t i0 = info.i_lo; i0 < i_hi || i0 == info.i_lo; i0 += 64) {
+  for (uint32_t i0 = info.i_lo; i0 < i_hi; i0 += 64) {
     const uint32_t i = i0 + (uint32_t)lane;
     int bin = -1;
     uint2 entry = make_uint2(0u, 0u);
-    if (i < i_hi) {
-      const uint4* pi = hit_ptr<P4>(w, lo + i);
-      const HitCore h = load_core(pi);
-      bool want = false;
-      uint32_t other_len = info.qseglen, other_seg = H + s;
-      if (info.mode == 1) want = !(h.meta & kMetaPerfect) && h.score >= info.fcut;
-      else if (i != info.anchor) {
-        if (info.mode == 2) want = h.qd != 0.f;
-        else if (h.score >= info.fcut && (double)h.qs / info.L >= info.qpid_thresh) {
-          uint32_t pth[4 * P4];
-          load_path<P4>(pi, pth);
-          want = !(common<P4>(pb, db, pth, meta_depth(h.meta)) >= info.d_unode_g);
-        }
-        other_len = anchor_len; other_seg = anchor_rec;
-      }
-      if (want) {
-        bin = pair_bin(p, h.seglen, other_len);
-        maxlen = max(maxlen, p.alphabet == 0 ? max(h.seglen, other_len) : h.seglen);
-        entry = make_uint2(h.rec, other_seg);
-        if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = -1; }
-      }
-    }
-    if (i0 == info.i_lo && lane == 63 && info.mode == 3 && info.emit_query && anchor_qd == FLT_MAX && bin < 0) {
-      bin = pair_bin(p, anchor_len, info.qseglen); maxlen = max(maxlen, p.alphabet == 0 ? max(anchor_len, info.qseglen) : anchor_len);
-      entry = make_uint2(anchor_rec, (H + s) | kDstIsB);
+    if (i < i_hi && (info.mode == 1 || i != info.anchor)) {
+      const uint4* pr = hit_ptr<P4>(w, lo + i);
+      uint32_t ml = 0;
+      bin = sparse_bin(p, emit_predicate<P4>(b, w, p, info, s, lo, lo + i, pr[0], pr[1], entry, ml));
+      maxlen = max(maxlen, ml);
     }
 #pragma unroll
     for (int k = 0; k < kNumBins; ++k) {
@@ -374,7 +475,15 @@ __global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, P
       base = __shfl(base, 0, 64);
       if (bin == k) w.bin_list[(size_t)k * w.T2 + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
     }
-    if (i0 + 64 >= i_hi) break;
+  }
+  if (info.mode == 3 && info.emit_query && lane == 0) {  // anchor <-> query range (:792-797)
+    int bin = pair_bin(p, info.anchor_len, info.qseglen);
+    if (bin >= kNumBins) raise_error(w, kErrUnsupported, s);
+    else {
+      bin = sparse_bin(p, bin);
+      maxlen = max(maxlen, p.alphabet == 0 ? max(info.anchor_len, info.qseglen) : info.anchor_len);
+      w.bin_list[(size_t)bin * w.T2 + atomicAdd(&w.counters[bin], 1u)] = make_uint2(lo + info.anchor, (H + s) | kDstIsB);
+    }
   }
   wave_max_to(&w.counters[kCtrMaxLen], maxlen);
 }
@@ -529,7 +638,9 @@ __device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Decide: one thread per record set, one call per round.
+// Decide: one thread per record set, one call per round.  Every loop over the hits keeps the NEXT row (64 bytes) and
+// its alignment result in flight while it works on the current one; qgroup / outgroup are bit sets in WorkDev::flags,
+// so "first member", "any member left" and "clear" never touch the rows.
 // ------------------------------------------------------------------------------------------------------------
 template <int P4>
 __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params p, OutRow* __restrict__ rows,
@@ -554,31 +665,43 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     const uint32_t n = st.n, L = st.L;
     constexpr int kStride4 = 2 + P4;
     const float X = p.exclude_factor;
-    const float2* __restrict__ res = w.pair_res;                       // res[rec]: result of the alignment asked for that hit
+    const float2* __restrict__ res = w.pair_res + lo;                  // res[i]: result of the alignment asked for hit i
     const float2* __restrict__ qres_p = w.pair_res + b.n_records + s;  // result of the anchor <-> query alignment
+    const uint32_t nw = (n + 31u) >> 5;
+    uint32_t* fq = w.flags + lo;   // qgroup bits
+    uint32_t* fo = fq + nw;        // outgroup bits
     bool failed = false;
 
     if (st.phase == kPass0Wait) {  // ---- pass 0, :497-566 ----
       uint32_t path0[4 * P4];
-      const uint4* p0 = hit_ptr<P4>(w, lo);
-      const HitCore h0 = load_core(p0);
-      load_path<P4>(p0, path0);
-      const uint32_t d0 = meta_depth(h0.meta);
-      const float thr = p.reeval_factor * h0.score;  // :499
+      uint32_t d0 = 0;
+      float thr = 0.f;
       uint32_t index_best = 0;
       float best_d = 0.f, best_s = 0.f, best_sc = 0.f;
       uint32_t support = 0;
-      uint32_t d_all = d0;  // lca_allnodes as a point on hit 0's path (:495)
+      uint32_t d_all = 0;  // lca_allnodes as a point on hit 0's path (:495)
+      uint32_t qword = 0;
+      Row<P4> nxt = load_row<P4>(w, lo);
+      float2 rn = res[0];
       for (uint32_t i = 0; i < n; ++i) {
-        const uint4* pi = hit_ptr<P4>(w, lo + i);
-        const HitCore h = load_core(pi);
+        const Row<P4> cur = nxt;
+        const float2 r2 = rn;
+        if (i + 1 < n) { nxt = load_row<P4>(w, lo + i + 1); rn = res[i + 1]; }
+        const HitCore h = row_core<P4>(cur);
+        uint32_t pth[4 * P4];
+        row_path<P4>(cur, pth);
+        if (i == 0) {
+#pragma unroll
+          for (int d = 0; d < 4 * P4; ++d) path0[d] = pth[d];
+          d0 = meta_depth(h.meta); d_all = d0;
+          thr = p.reeval_factor * h.score;  // :499
+        }
         float dist, sim;
-        uint32_t flag = 0;
+        bool member = false;
         if (h.meta & kMetaPerfect) {  // :511-517
-          flag = kMetaQGroup; dist = 0.f; sim = (float)h.ident;
+          member = true; dist = 0.f; sim = (float)h.ident;
         } else if (h.score >= thr) {  // :518-534
-          flag = kMetaQGroup;
-          const float2 r2 = res[h.rec];
+          member = true;
           if (!result_ok(w, s, meta_err(h.meta), st.qsegerr, r2.x)) { failed = true; break; }
           dist = r2.x;
           ++st.cnt0;
@@ -587,7 +710,9 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         } else {
           dist = FLT_MAX; sim = (float)h.ident;
         }
-        store_dyn(w, kStride4, lo + i, dist, sim, h.seglen, (h.meta & ~(kMetaQGroup | kMetaOutGroup)) | flag);
+        store_qdqs(w, kStride4, lo + i, dist, sim);
+        if (member) qword |= 1u << (i & 31u);
+        if ((i & 31u) == 31u || i + 1 == n) { fq[i >> 5] = qword; qword = 0; }
         if (i == 0) { best_d = dist; best_s = sim; best_sc = h.score; }  // index_best starts at 0 (:500)
         else if (dist < best_d) { index_best = i; best_d = dist; best_s = sim; best_sc = h.score; }  // :542-546
         else if (dist == best_d) {
@@ -595,28 +720,32 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           else if (sim == best_s && h.score > best_sc) { index_best = i; best_sc = h.score; }
         }
         support = max(support, (uint32_t)sim);  // :547
-        uint32_t pth[4 * P4];
-        load_path<P4>(pi, pth);
         d_all = min(d_all, common<P4>(path0, d0, pth, meta_depth(h.meta)));  // :548
       }
       if (!failed) {
+        for (uint32_t k = 0; k < nw; ++k) fo[k] = 0u;  // outgroup starts empty (:578)
+        const Row<P4> rb = load_row<P4>(w, lo + index_best);
         uint32_t pb[4 * P4];
-        const uint4* pbp = hit_ptr<P4>(w, lo + index_best);
-        load_path<P4>(pbp, pb);
-        const uint32_t db = meta_depth(load_core(pbp).meta);
+        row_path<P4>(rb, pb);
+        const uint32_t db = meta_depth(row_core<P4>(rb).meta);
         uint32_t d_rtax = db;  // rtax = node[index_best] (:553), then LCA with every member that stays in qgroup
         bool any = false;
-        for (uint32_t i = 0; i < n; ++i) {  // :554-562
-          const uint4* pi = hit_ptr<P4>(w, lo + i);
-          const HitCore h = load_core(pi);
-          if (!(h.meta & kMetaQGroup)) continue;
-          if (h.qd != best_d || h.qs != best_s || h.score != best_sc) store_dyn(w, kStride4, lo + i, h.qd, h.qs, h.seglen, h.meta & ~kMetaQGroup);
-          else {
-            uint32_t pth[4 * P4];
-            load_path<P4>(pi, pth);
-            d_rtax = min(d_rtax, common<P4>(pb, db, pth, meta_depth(h.meta)));
-            any = true;
+        for (uint32_t k = 0; k < nw; ++k) {  // :554-562, members only
+          uint32_t word = fq[k], keep = word;
+          while (word) {
+            const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+            word &= word - 1u;
+            const Row<P4> ri = load_row<P4>(w, lo + k * 32u + bit);
+            const HitCore h = row_core<P4>(ri);
+            if (h.qd != best_d || h.qs != best_s || h.score != best_sc) keep &= ~(1u << bit);
+            else {
+              uint32_t pth[4 * P4];
+              row_path<P4>(ri, pth);
+              d_rtax = min(d_rtax, common<P4>(pb, db, pth, meta_depth(h.meta)));
+              any = true;
+            }
           }
+          fq[k] = keep;
         }
         if (!any) { raise_error(w, kErrAssert, s); failed = true; }  // assert(!qgroup.empty()), :563
         st.support = support; st.best = index_best; st.d_lca_all = d_all; st.d_rtax = d_rtax;
@@ -626,13 +755,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     } else if (st.phase == kPass1Wait) {  // ---- pass 1 for one anchor, :580-728 ----
       const uint32_t a = st.anchor;
       uint32_t pa[4 * P4], pb[4 * P4];
-      const uint4* pap = hit_ptr<P4>(w, lo + a);
-      const HitCore ha = load_core(pap);
-      load_path<P4>(pap, pa);
+      const Row<P4> ra = load_row<P4>(w, lo + a);
+      const Row<P4> rb = load_row<P4>(w, lo + st.best);
+      const HitCore ha = row_core<P4>(ra);
+      row_path<P4>(ra, pa);
       const uint32_t da = meta_depth(ha.meta);
-      const uint4* pbp = hit_ptr<P4>(w, lo + st.best);
-      load_path<P4>(pbp, pb);
-      const uint32_t db = meta_depth(load_core(pbp).meta);
+      row_path<P4>(rb, pb);
+      const uint32_t db = meta_depth(row_core<P4>(rb).meta);
       const float qdist = ha.qd;
       uint32_t* __restrict__ ogi = w.og_idx + lo;
       int32_t* __restrict__ ogd = w.og_dist + lo;
@@ -652,9 +781,14 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         qpid_upper = st.qpid_upper; cut_g = st.cut_g; cut_h = st.cut_h; scut = st.scut; i = st.i_next;
       }
       bool paused = false;
+      Row<P4> nxt = ra;
+      float2 rn = make_float2(0.f, 0.f);
+      if (i < n) { nxt = load_row<P4>(w, lo + i); rn = res[i]; }
       for (; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
-        const uint4* pi = hit_ptr<P4>(w, lo + i);
-        const HitCore h = load_core(pi);
+        const Row<P4> cur = nxt;
+        const float2 r2 = rn;
+        if (i + 1 < n) { nxt = load_row<P4>(w, lo + i + 1); rn = res[i + 1]; }
+        const HitCore h = row_core<P4>(cur);
         if (!(h.score >= (float)scut)) break;
         const double qsearchpid = (double)h.ident / L;
         const double qpid = (double)h.qs / L;
@@ -665,16 +799,15 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         else if (h.qd == 0.f) dist = qdist;  // :620-621
         else {
           if (i >= st.chunk_hi) { paused = true; break; }  // this alignment was not part of the chunk emitted last round
-          const float2 r2 = res[h.rec];
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
           ++st.cnt1;
         }
         uint32_t pth[4 * P4];
-        load_path<P4>(pi, pth);
+        row_path<P4>(cur, pth);
         const uint32_t dh = meta_depth(h.meta);
         band.add(dist, common<P4>(pa, da, pth, dh));  // :641
-        if (dist == 0.f) store_dyn(w, kStride4, lo + i, h.qd, h.qs, h.seglen, h.meta & ~kMetaQGroup);  // :644
+        if (dist == 0.f) bit_clear(fq, i);  // :644
         else if (dist <= qdist) {  // :646-650
           d_lnode = min(d_lnode, common<P4>(pb, db, pth, dh));
           if (dist > ldist) ldist = dist;
@@ -696,97 +829,93 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         st.qpid_upper = qpid_upper; st.cut_g = cut_g; st.cut_h = cut_h; st.scut = scut;
         band.save(w.band_save + (size_t)s * 2 * (kMaxDepth + 1));
         st.chunk_hi = p.spec1 ? min(n, i + p.spec1) : n;
-        em.mode = 2; em.anchor = a; em.i_lo = i; em.i_hi = st.chunk_hi;
+        em.mode = 2; em.anchor = a; em.anchor_len = ha.seglen; em.i_lo = i; em.i_hi = st.chunk_hi;
       } else
       if (!failed) {
         const float bandfactor = band.factor();  // :667
         st.bf_max = st.bf_max < bandfactor ? bandfactor : st.bf_max;
         const float qdist_ex = qdist * bandfactor;  // :669
         float min_upper_dist = (float)INT_MAX;       // :670
-        uint32_t keep = 0;
-        for (uint32_t k = 0; k < nog; ++k) {  // :673-687
+        // :673-687.  The reference also erases entries here (distance beyond both the band and the current minimum);
+        // an erased entry stays above the final min_upper_dist (that value only rises while it is <= qdist_ex), so the
+        // walk below skips it by its own test and the erase needs no copy.
+        for (uint32_t k = 0; k < nog; ++k) {
           const float dist = (float)ogd[k];
-          bool kept = true;
           if (dist > qdist_ex) {
-            if (dist > min_upper_dist) kept = false;
-            else if (dist < min_upper_dist) min_upper_dist = dist;
+            if (dist < min_upper_dist) min_upper_dist = dist;
           } else {
             if (min_upper_dist > qdist_ex) min_upper_dist = dist;
             else min_upper_dist = min_upper_dist < dist ? dist : min_upper_dist;
           }
-          if (kept) { ogi[keep] = ogi[k]; ogd[keep] = ogd[k]; ++keep; }
         }
-        nog = keep;
         uint32_t d_unode = d_lnode;  // unode = lnode, :690 -- (float)INT_MAX != FLT_MAX, so always taken
         for (uint32_t k = 0; k < nog; ++k) {  // :691-711
-          const uint32_t i = ogi[k];
           const float dist = (float)ogd[k];
           if (dist > min_upper_dist) continue;
-          const uint4* pi = hit_ptr<P4>(w, lo + i);
-          const HitCore h = load_core(pi);
+          const uint32_t io = ogi[k];
+          const Row<P4> ri = load_row<P4>(w, lo + io);
           uint32_t pth[4 * P4];
-          load_path<P4>(pi, pth);
-          const uint32_t cb = common<P4>(pb, db, pth, meta_depth(h.meta));
+          row_path<P4>(ri, pth);
+          const uint32_t cb = common<P4>(pb, db, pth, meta_depth(row_core<P4>(ri).meta));
           d_unode = min(d_unode, cb);                          // unode = LCA(cnode, unode)
           const uint32_t lca_root_dist = min(st.d_rtax, cb);   // depth(LCA(cnode, rtax))
           if (lca_root_dist > st.lrd_min) continue;
           if (lca_root_dist < st.lrd_min) {
             st.lrd_min = lca_root_dist;
-            for (uint32_t j = 0; j < n; ++j) {  // outgroup.clear()
-              const HitCore hj = load_core(hit_ptr<P4>(w, lo + j));
-              if (hj.meta & kMetaOutGroup) store_dyn(w, kStride4, lo + j, hj.qd, hj.qs, hj.seglen, hj.meta & ~kMetaOutGroup);
-            }
+            for (uint32_t kk = 0; kk < nw; ++kk) fo[kk] = 0u;  // outgroup.clear()
           }
-          const HitCore hn = load_core(pi);  // re-read: the clear above may have touched this row
-          store_dyn(w, kStride4, lo + i, hn.qd, hn.qs, hn.seglen, hn.meta | kMetaOutGroup);
+          bit_set(fo, io);
         }
         float ival = 0.f;  // :714-719
         if (d_unode != d_lnode && ldist < qdist) ival = (qdist - ldist) / (udist - ldist);
         st.ival_g = st.ival_g < ival ? ival : st.ival_g;   // :724
         st.d_unode_g = min(st.d_unode_g, d_unode);         // :726
         st.d_lnode_g = min(st.d_lnode_g, d_lnode);         // :727
-        bool more = false;
-        for (uint32_t j = 0; j < n; ++j) more |= (load_core(hit_ptr<P4>(w, lo + j)).meta & kMetaQGroup) != 0;
+        uint32_t more = 0;
+        for (uint32_t k = 0; k < nw; ++k) more |= fq[k];
         st.phase = (more && st.d_lnode_g != 0) ? kPass1Select : kPass2Select;  // :729
         st.loop_live = 0;
       }
     } else if (st.phase == kPass2Wait) {  // ---- pass 2 for one anchor, :750-820 ----
       const uint32_t a = st.anchor;
-      const HitCore ha = load_core(hit_ptr<P4>(w, lo + a));
+      const Row<P4> ra = load_row<P4>(w, lo + a);
+      const Row<P4> rb = load_row<P4>(w, lo + st.best);
+      const HitCore ha = row_core<P4>(ra);
       uint32_t pb[4 * P4];
-      const uint4* pbp = hit_ptr<P4>(w, lo + st.best);
-      load_path<P4>(pbp, pb);
-      const uint32_t db = meta_depth(load_core(pbp).meta);
+      row_path<P4>(rb, pb);
+      const uint32_t db = meta_depth(row_core<P4>(rb).meta);
       float qd_a = ha.qd, qs_a = ha.qs;
       const EmitInfo sel = w.emit[s];            // thresholds were fixed when the anchor was selected (:750-754)
       const double qpid_thresh = sel.qpid_thresh;
       const float scut = sel.fcut;
       bool paused = false;
       uint32_t i = st.loop_live ? st.i_next : 0u;
+      Row<P4> nxt = ra;
+      float2 rn = make_float2(0.f, 0.f);
+      if (i < n) { nxt = load_row<P4>(w, lo + i); rn = res[i]; }
       for (; i < n; ++i) {  // :757
-        const uint4* pi = hit_ptr<P4>(w, lo + i);
-        const HitCore h = load_core(pi);
+        const Row<P4> cur = nxt;
+        const float2 r2 = rn;
+        if (i + 1 < n) { nxt = load_row<P4>(w, lo + i + 1); rn = res[i + 1]; }
+        const HitCore h = row_core<P4>(cur);
         if (!(h.score >= scut)) break;
-        const double qpid = (double)(i == a ? qs_a : h.qs) / L;
+        const double qpid = (double)(i == a ? qs_a : h.qs) / L;  // the anchor's row may have been updated below
         if (!(qpid >= qpid_thresh)) continue;
         uint32_t pth[4 * P4];
-        load_path<P4>(pi, pth);
+        row_path<P4>(cur, pth);
         const uint32_t cb = common<P4>(pb, db, pth, meta_depth(h.meta));
         float dist;
         if (i == a) dist = 0.f;
         else {
           if (cb >= st.d_unode_g) continue;  // isParentOf(unode_global, cnode) || cnode == unode_global, :771
           if (i >= st.chunk_hi) { paused = true; break; }  // not part of the chunk emitted last round
-          const float2 r2 = res[h.rec];
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
           ++st.cnt2;
-          store_dyn(w, kStride4, lo + i, dist, h.qs, h.seglen, h.meta);  // querydistance[i] = dist, :785
+          store_qd(w, kStride4, lo + i, dist);  // querydistance[i] = dist, :785
         }
-        if (dist == 0.f) {  // :789
-          const HitCore hn = load_core(pi);
-          store_dyn(w, kStride4, lo + i, hn.qd, hn.qs, hn.seglen, hn.meta & ~kMetaOutGroup);
-        } else {
+        if (dist == 0.f) bit_clear(fo, i);  // :789
+        else {
           float qdist_ex;
           if (qd_a == FLT_MAX) {  // :792-808
             const float2 q2 = *qres_p;
@@ -794,8 +923,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
             const float d2 = q2.x;
             const float s2 = q2.y < qs_a ? qs_a : q2.y;
             qd_a = d2; qs_a = s2;
-            const HitCore han = load_core(hit_ptr<P4>(w, lo + a));
-            store_dyn(w, kStride4, lo + a, d2, s2, han.seglen, han.meta);
+            store_qdqs(w, kStride4, lo + a, d2, s2);
             qdist_ex = d2 * st.bf_max;
             ++st.cnt2;
           } else qdist_ex = qd_a * st.bf_max;  // :809
@@ -809,32 +937,39 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       } else if (!failed) { st.phase = kPass2Select; st.loop_live = 0; }
     }
 
-
     // ---- choose what to align next ----
-    if (!failed && st.phase == kPass1Select) {  // :582-583
-      uint32_t a = 0;
-      HitCore h = load_core(hit_ptr<P4>(w, lo));
-      while (a + 1 < n && !(h.meta & kMetaQGroup)) { ++a; h = load_core(hit_ptr<P4>(w, lo + a)); }
-      store_dyn(w, kStride4, lo + a, h.qd, h.qs, h.seglen, h.meta & ~kMetaQGroup);
+    if (!failed && st.phase == kPass1Select) {  // :582-583: anchor = first member of qgroup
+      uint32_t a = n - 1;  // (the reference's scan would stop at the last hit if the group were empty; it never is)
+      for (uint32_t k = 0; k < nw; ++k) {
+        const uint32_t word = fq[k];
+        if (word) { const uint32_t bit = (uint32_t)__ffs((int)word) - 1u; a = k * 32u + bit; fq[k] = word & (word - 1u); break; }
+      }
+      const HitCore h = load_core(hit_ptr<P4>(w, lo + a));
       st.anchor = a; st.phase = kPass1Wait; st.loop_live = 0;
       st.chunk_hi = p.spec1 ? min(n, p.spec1) : n;
-      em.mode = 2; em.anchor = a; em.i_lo = 0; em.i_hi = st.chunk_hi;
+      em.mode = 2; em.anchor = a; em.anchor_len = h.seglen; em.i_lo = 0; em.i_hi = st.chunk_hi;
     } else if (!failed && st.phase == kPass2Select) {  // :739-747
       bool found = false;
-      for (uint32_t a = 0; a < n; ++a) {
-        const HitCore h = load_core(hit_ptr<P4>(w, lo + a));
-        if (!(h.meta & kMetaOutGroup)) continue;
-        store_dyn(w, kStride4, lo + a, h.qd, h.qs, h.seglen, h.meta & ~kMetaOutGroup);
-        if (st.d_unode_g == st.d_lca_all) continue;  // unode_global == lca_allnodes: both lie on the best hit's path
-        st.anchor = a; st.phase = kPass2Wait; found = true; st.loop_live = 0;
-        st.chunk_hi = p.spec2 ? min(n, p.spec2) : n;
-        em.mode = 3; em.anchor = a; em.best = st.best; em.d_unode_g = st.d_unode_g;
-        em.i_lo = 0; em.i_hi = st.chunk_hi; em.emit_query = 1;
-        em.fcut = h.score * X;                                   // qsearchscore_thresh_heuristic, :754
-        const double qpid_anchor = (double)h.qs / L;             // :750-753
-        const double g2 = qpid_anchor * 2. - 1., h3 = qpid_anchor * X;
-        em.qpid_thresh = g2 < h3 ? h3 : g2;
-        break;
+      if (st.d_unode_g == st.d_lca_all) {  // unode_global == lca_allnodes (both on the best hit's path): every anchor is skipped
+        for (uint32_t k = 0; k < nw; ++k) fo[k] = 0u;
+      } else {
+        for (uint32_t k = 0; k < nw && !found; ++k) {
+          const uint32_t word = fo[k];
+          if (!word) continue;
+          const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+          fo[k] = word & (word - 1u);
+          const uint32_t a = k * 32u + bit;
+          const HitCore h = load_core(hit_ptr<P4>(w, lo + a));
+          st.anchor = a; st.phase = kPass2Wait; found = true; st.loop_live = 0;
+          st.chunk_hi = p.spec2 ? min(n, p.spec2) : n;
+          em.mode = 3; em.anchor = a; em.anchor_len = h.seglen; em.best = st.best; em.d_unode_g = st.d_unode_g;
+          em.i_lo = 0; em.i_hi = st.chunk_hi;
+          em.emit_query = h.qd == FLT_MAX ? 1u : 0u;             // anchor never aligned to the query yet (:792)
+          em.fcut = h.score * X;                                   // qsearchscore_thresh_heuristic, :754
+          const double qpid_anchor = (double)h.qs / L;             // :750-753
+          const double g2 = qpid_anchor * 2. - 1., h3 = qpid_anchor * X;
+          em.qpid_thresh = g2 < h3 ? h3 : g2;
+        }
       }
       if (!found) {  // :824-833
         if (st.d_unode_g == st.d_lnode_g) st.ival_g = 1.f;
@@ -893,7 +1028,7 @@ hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, cons
   }
   const uint32_t total = b.n_records + b.n_sets;
   if (total == 0) return hipSuccess;
-  const dim3 grid((total + kEmitBlock - 1) / kEmitBlock);
+  const dim3 grid((total + kEmitSpan - 1) / kEmitSpan);
   RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_emit<P4>, grid, dim3(kEmitBlock), 0, st, b, w, p));
   return hipGetLastError();
 }

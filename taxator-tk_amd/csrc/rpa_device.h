@@ -91,13 +91,13 @@ struct HitCore {
   float score;       // getScore()
   uint32_t ident;    // getIdentities()
   uint32_t node;     // getReferenceNode()
-  uint32_t rec;      // record index in the batch = segment id of the hit's reference segment
+  uint32_t rec;      // record index in the batch (informational: segments and results are indexed by ROW position)
   float qd;          // querydistance[i]
   float qs;          // querysimilarity[i]
   uint32_t seglen;   // length of the reference segment
-  uint32_t meta;     // kMeta* bits
+  uint32_t meta;     // kMeta* bits (static after k_rank_records)
 };
-constexpr uint32_t kMetaQGroup = 1u, kMetaOutGroup = 2u, kMetaPerfect = 4u;  // perfect: alnlen == L && identities == L
+constexpr uint32_t kMetaPerfect = 4u;  // perfect: alnlen == L && identities == L
 constexpr int kMetaErrShift = 4, kMetaDepthShift = 8;                         // 4 bits segment error code, 8 bits node depth
 
 // Segment descriptor (a7): `len` residues starting at residue `src` of a store; reverse strand = read backwards + complement.
@@ -119,8 +119,8 @@ struct EmitInfo {
   uint32_t best;        // pass 2: index_best
   uint32_t qseglen;     // length of the query range segment
   uint32_t i_lo, i_hi;  // only hits with i_lo <= i < i_hi are emitted this round (speculation chunk of the running loop)
-  uint32_t emit_query;  // pass 2: also emit the anchor <-> query alignment (first chunk of an anchor only)
-  uint32_t pad_;
+  uint32_t emit_query;  // pass 2: also emit the anchor <-> query alignment (first chunk of an anchor whose querydistance is unset)
+  uint32_t anchor_len;  // pass 1/2: length of the anchor's reference segment
 };
 
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
@@ -131,7 +131,10 @@ struct WorkDev {
   uint2* set_qseg;      // S   (query segment length, error code)
   EmitInfo* emit;       // S
   uint32_t* hit_set;    // H   row position -> record set
-  // segments: id r in [0,H) = reference segment of record r, id H+s = query range of set s.  A segment is only a
+  // qgroup / outgroup membership (:480-481,:578) as bit sets: for a set with n >= 2 active hits at rows [lo, lo+n),
+  // words flags[lo .. lo+nw) hold the qgroup bits and flags[lo+nw .. lo+2nw) the outgroup bits, nw = ceil(n/32) (2nw <= n)
+  uint32_t* flags;      // H
+  // segments: id pos in [0,H) = reference segment of the hit at row pos, id H+s = query range of set s.  A segment is only a
   // descriptor: the alignment kernels read the residues straight out of the resident stores (funnel-shifted to the
   // segment's start, reverse-complemented on the fly for reverse-strand hits) -- no per-batch copy of the sequences.
   SegDesc* seg;               // T
@@ -141,7 +144,7 @@ struct WorkDev {
   // the alignment kernels derive the segments from the row and the set's EmitInfo)
   uint32_t* pair_a;     // T2  segment id
   uint32_t* pair_b;     // T2
-  float2* pair_res;     // T   (distance, similarity); [rec] for the alignment asked for the hit of record rec, [H+s] for anchor<->query
+  float2* pair_res;     // T   (distance, similarity); [pos] for the alignment asked for the hit at row pos, [H+s] for anchor<->query
   uint4* pair_ext;      // optional (rpa_align_pairs only): matches, mismatches, gaps, length; indexed like pair_res
   uint2* bin_list;      // kNumBins * T2 entries (segment A, segment B | kDstIsB)
   uint32_t* counters;   // kNumCounters words, layout below
@@ -210,7 +213,7 @@ size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
 // getAlignment(segments[i], qrseq) (:526), getAlignment(segments[i], segments[index_anchor]) (:630,778),
 // getAlignment(segments[index_anchor], qrseq) (:797).  k_emit writes the two segment ids into the entry, so an
 // alignment lane is two dependent loads away from its residues (entry -> descriptors -> store words).
-// Results of hit <-> x alignments are indexed by the hit's record index (= segment id A); the anchor <-> query
+// Results of hit <-> x alignments are indexed by the hit's row position (= segment id A); the anchor <-> query
 // alignment of a set goes to slot H + s, flagged by the top bit of B.
 constexpr uint32_t kDstIsB = 0x80000000u;
 __device__ __forceinline__ void resolve_pair(const WorkDev& w, uint2 entry, uint32_t& seg_a, uint32_t& seg_b, uint32_t& dst) {
