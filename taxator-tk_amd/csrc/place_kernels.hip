@@ -170,7 +170,18 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   // the global search.  "Set of r" = largest s with set_offsets[s] <= r (empty sets share an offset: take the last).
   __shared__ uint32_t s_off[kBlock + 1];
   __shared__ uint32_t s_first;
+  // the fields the per-set scan below compares, for the block's own records: the scan of a 20-hit set is 20 x 4 loads
+  // per thread, nearly all of them to records of this block -> LDS (broadcast reads) instead of the vector memory path
+  __shared__ uint4 s_rec[kBlock];      // score bits, identities, qstart, qstop
+  __shared__ uint8_t s_filt[kBlock];
   const uint32_t r0 = blockIdx.x * kBlock;  // < n_records by the grid size
+  {
+    const uint32_t rr = r0 + threadIdx.x;
+    if (rr < b.n_records) {
+      s_rec[threadIdx.x] = make_uint4(__float_as_uint(b.score[rr]), b.identities[rr], b.qstart[rr], b.qstop[rr]);
+      s_filt[threadIdx.x] = rec_filtered(b, rr) ? 1 : 0;
+    }
+  }
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     uint32_t lo = 0, hi = b.n_sets;  // set_offsets[lo] <= r0 < set_offsets[hi]
@@ -211,17 +222,24 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   if (s >= b.n_sets) s = b.n_sets - 1;  // clamped window entries (cannot be selected: set_offsets[n_sets] > r)
   w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
   const uint32_t beg = b.set_offsets[s], end = b.set_offsets[s + 1];
-  const bool me_filtered = rec_filtered(b, r);
-  const float sc = b.score[r];
-  const uint32_t id = b.identities[r];
+  const bool me_filtered = s_filt[threadIdx.x] != 0;
+  const float sc = __uint_as_float(s_rec[threadIdx.x].x);
+  const uint32_t id = s_rec[threadIdx.x].y;
   uint32_t rank = 0, n = 0, qrstart = 0xFFFFFFFFu, qrstop = 0;
+  float smax = 0.f;  // score of the set's best record (its first one in SortFilter order)
   for (uint32_t j = beg; j < end; ++j) {
-    if (rec_filtered(b, j)) continue;
+    uint4 v;
+    bool filt;
+    const uint32_t jl = j - r0;  // wraps for j < r0
+    if (jl < (uint32_t)kBlock) { v = s_rec[jl]; filt = s_filt[jl] != 0; }
+    else { v = make_uint4(__float_as_uint(b.score[j]), b.identities[j], b.qstart[j], b.qstop[j]); filt = rec_filtered(b, j); }
+    if (filt) continue;
+    const float sj = __uint_as_float(v.x);
+    const uint32_t ij = v.y;
+    smax = n == 0 ? sj : (sj > smax ? sj : smax);
     ++n;
-    qrstart = min(qrstart, b.qstart[j]);
-    qrstop = max(qrstop, b.qstop[j]);
-    const float sj = b.score[j];
-    const uint32_t ij = b.identities[j];
+    qrstart = min(qrstart, v.z);
+    qrstop = max(qrstop, v.w);
     const bool before = (sj > sc) || (sj == sc && (ij > id || (ij == id && j < r)));
     rank += before ? 1u : 0u;
   }
@@ -253,6 +271,9 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   float qd = FLT_MAX, qs = 0.f;  // :475-476
   if (n == 1) { qd = __uint_as_float(b.qstart[r]); qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
   uint4* row = reinterpret_cast<uint4*>(w.hits) + (size_t)pos * (2 + P4);
+  if (sp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); sp.x = 0; }
+  // compact per-row word for k_emit: segment length + "pass 0 re-aligns this hit" (:511-518, threshold :499)
+  w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u);
   row[0] = make_uint4(__float_as_uint(sc), id, node, r);
   row[1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta);
   const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
@@ -310,23 +331,27 @@ constexpr int kEmitRows = 4;      // row positions per thread: the three depende
                                   // rows are in flight together; the kernel is bound by that latency chain, not by bytes
 constexpr int kEmitSpan = kEmitBlock * kEmitRows;
 
-// "can the loop the set is about to run reach the alignment of the hit at row `pos`?" -- everything but the row loads.
-// Returns the bin (or -1) and fills entry / maxlen.  q0/q1 are the first two quads of the row.
+// "can the loop the set is about to run reach the alignment of the hit at row `pos`?"  Passes 0 and 1 decide from the
+// row's 4-byte lite word alone; pass 2 (few sets, late rounds) reads the row.  Returns the bin (or -1), fills entry / maxlen.
 template <int P4>
 __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& w, const Params& p, const EmitInfo& info, uint32_t s,
-                                              uint32_t lo, uint32_t pos, const uint4 q0, const uint4 q1, uint2& entry, uint32_t& maxlen) {
+                                              uint32_t lo, uint32_t pos, const uint32_t lite, uint2& entry, uint32_t& maxlen) {
   const uint32_t H = b.n_records;
-  const float score = __uint_as_float(q0.x), qd = __uint_as_float(q1.x), qs = __uint_as_float(q1.y);
-  const uint32_t seglen = q1.z, meta = q1.w;
+  const uint32_t seglen = lite & kLiteLenMask;
   bool want = false;
-  if (info.mode == 1) want = !(meta & kMetaPerfect) && score >= info.fcut;
-  else if (info.mode == 2) want = qd != 0.f;
-  else if (score >= info.fcut && (double)qs / info.L >= info.qpid_thresh) {
-    uint32_t pb[4 * P4], pth[4 * P4];
-    const uint4* pbp = hit_ptr<P4>(w, lo + info.best);
-    load_path<P4>(pbp, pb);
-    load_path<P4>(hit_ptr<P4>(w, pos), pth);
-    want = !(common<P4>(pb, meta_depth(load_core(pbp).meta), pth, meta_depth(meta)) >= info.d_unode_g);
+  if (info.mode == 1) want = (lite & kLiteWant0) != 0u;
+  else if (info.mode == 2) want = !(lite & kLiteZeroQd);
+  else {
+    const uint4* pr = hit_ptr<P4>(w, pos);
+    const uint4 q0 = pr[0], q1 = pr[1];
+    const float score = __uint_as_float(q0.x), qs = __uint_as_float(q1.y);
+    if (score >= info.fcut && (double)qs / info.L >= info.qpid_thresh) {
+      uint32_t pb[4 * P4], pth[4 * P4];
+      const uint4* pbp = hit_ptr<P4>(w, lo + info.best);
+      load_path<P4>(pbp, pb);
+      load_path<P4>(pr, pth);
+      want = !(common<P4>(pb, meta_depth(load_core(pbp).meta), pth, meta_depth(q1.w)) >= info.d_unode_g);
+    }
   }
   if (!want) return -1;
   const uint32_t other_len = info.mode == 1 ? info.qseglen : info.anchor_len;
@@ -339,35 +364,25 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
 }
 
 template <int P4>
-__global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Params p) {
+__global__ __launch_bounds__(kEmitBlock, 8) void k_emit(BatchDev b, WorkDev w, Params p) {  // two resident blocks per CU: one computes while the other waits on its loads
   constexpr int kVW = kEmitSpan / 64;  // "virtual waves": runs of 64 consecutive row positions
   static_assert(kVW == 64, "the prefix over virtual waves is done by one wavefront");
   __shared__ uint32_t s_cnt[kNumBins][kVW];  // per bin, per virtual wave: number of active lanes, then its list offset
   __shared__ uint32_t s_maxlen[kVW];
   const uint32_t H = b.n_records, total = H + b.n_sets;
   const uint32_t pos0 = blockIdx.x * kEmitSpan + threadIdx.x;
-  uint32_t set_of[kEmitRows], lo[kEmitRows];
-  EmitInfo info[kEmitRows];
-  uint4 q0[kEmitRows], q1[kEmitRows];
-  bool cand[kEmitRows];
+  uint32_t set_of[kEmitRows], lo[kEmitRows], lite[kEmitRows];
+  uint4 desc[kEmitRows];
 #pragma unroll
-  for (int k = 0; k < kEmitRows; ++k) {  // level 1: row position -> record set
+  for (int k = 0; k < kEmitRows; ++k) {  // level 1: row position -> record set; the row's lite word rides along
     const uint32_t pos = pos0 + k * kEmitBlock;
     set_of[k] = pos < H ? w.hit_set[pos] : (pos < total ? pos - H : 0xFFFFFFFFu);
+    lite[k] = pos < H ? w.lite[pos] : 0u;
   }
 #pragma unroll
-  for (int k = 0; k < kEmitRows; ++k) {  // level 2: what the set wants
-    info[k].mode = 0; lo[k] = 0;
-    if (set_of[k] != 0xFFFFFFFFu) { info[k] = w.emit[set_of[k]]; lo[k] = b.set_offsets[set_of[k]]; }
-  }
-#pragma unroll
-  for (int k = 0; k < kEmitRows; ++k) {  // level 3: the row, only where the set's running loop covers it
-    const uint32_t pos = pos0 + k * kEmitBlock;
-    const uint32_t i = pos - lo[k];
-    cand[k] = pos < H && info[k].mode != 0 && i < info[k].n && i >= info[k].i_lo && i < info[k].i_hi &&
-              (info[k].mode == 1 || i != info[k].anchor);
-    q0[k] = q1[k] = make_uint4(0u, 0u, 0u, 0u);
-    if (cand[k]) { const uint4* pr = hit_ptr<P4>(w, pos); q0[k] = pr[0]; q1[k] = pr[1]; }
+  for (int k = 0; k < kEmitRows; ++k) {  // level 2: what the set wants (16-byte descriptor)
+    desc[k] = make_uint4(0u, 0u, 0u, 0u); lo[k] = 0;
+    if (set_of[k] != 0xFFFFFFFFu) { desc[k] = w.emit_lite[set_of[k]]; lo[k] = b.set_offsets[set_of[k]]; }
   }
   int bin[kEmitRows];
   uint2 entry[kEmitRows];
@@ -375,15 +390,35 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(BatchDev b, WorkDev w, Para
 #pragma unroll
   for (int k = 0; k < kEmitRows; ++k) {
     const uint32_t pos = pos0 + k * kEmitBlock;
+    const uint32_t mode = desc[k].x & 3u, anchor = desc[k].x >> 2;
+    const uint32_t i = pos - lo[k];
     bin[k] = -1;
     entry[k] = make_uint2(0u, 0u);
     uint32_t ml = 0;
-    if (cand[k]) bin[k] = emit_predicate<P4>(b, w, p, info[k], set_of[k], lo[k], pos, q0[k], q1[k], entry[k], ml);
-    else if (pos >= H && pos < total && info[k].mode == 3 && info[k].emit_query) {  // anchor <-> query range (:792-797)
-      bin[k] = pair_bin(p, info[k].anchor_len, info[k].qseglen);
-      ml = p.alphabet == 0 ? max(info[k].anchor_len, info[k].qseglen) : info[k].anchor_len;
-      entry[k] = make_uint2(lo[k] + info[k].anchor, pos | kDstIsB);
-      if (bin[k] >= kNumBins) { raise_error(w, kErrUnsupported, set_of[k]); bin[k] = -1; }
+    if (pos < H) {
+      if (mode != 0u && i >= desc[k].y && i < desc[k].z && (mode == 1u || i != anchor)) {
+        if (mode != 3u) {  // passes 0 and 1: the lite word decides
+          const bool want = mode == 1u ? (lite[k] & kLiteWant0) != 0u : !(lite[k] & kLiteZeroQd);
+          if (want) {
+            const uint32_t seglen = lite[k] & kLiteLenMask, other_len = desc[k].w;
+            bin[k] = pair_bin(p, seglen, other_len);
+            ml = p.alphabet == 0 ? max(seglen, other_len) : seglen;  // DNA: text = the longer one; protein: A
+            entry[k] = make_uint2(pos, mode == 1u ? H + set_of[k] : lo[k] + anchor);
+            if (bin[k] >= kNumBins) { raise_error(w, kErrUnsupported, set_of[k]); bin[k] = -1; }
+          }
+        } else {
+          const EmitInfo info = w.emit[set_of[k]];
+          bin[k] = emit_predicate<P4>(b, w, p, info, set_of[k], lo[k], pos, lite[k], entry[k], ml);
+        }
+      }
+    } else if (pos < total && mode == 3u) {  // anchor <-> query range (:792-797)
+      const EmitInfo info = w.emit[set_of[k]];
+      if (info.emit_query) {
+        bin[k] = pair_bin(p, info.anchor_len, info.qseglen);
+        ml = p.alphabet == 0 ? max(info.anchor_len, info.qseglen) : info.anchor_len;
+        entry[k] = make_uint2(lo[k] + info.anchor, pos | kDstIsB);
+        if (bin[k] >= kNumBins) { raise_error(w, kErrUnsupported, set_of[k]); bin[k] = -1; }
+      }
     }
     maxlen = max(maxlen, ml);
   }
@@ -461,9 +496,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, P
     int bin = -1;
     uint2 entry = make_uint2(0u, 0u);
     if (i < i_hi && (info.mode == 1 || i != info.anchor)) {
-      const uint4* pr = hit_ptr<P4>(w, lo + i);
       uint32_t ml = 0;
-      bin = sparse_bin(p, emit_predicate<P4>(b, w, p, info, s, lo, lo + i, pr[0], pr[1], entry, ml));
+      bin = sparse_bin(p, emit_predicate<P4>(b, w, p, info, s, lo, lo + i, w.lite[lo + i], entry, ml));
       maxlen = max(maxlen, ml);
     }
 #pragma unroll
@@ -486,6 +520,26 @@ __global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, P
     }
   }
   wave_max_to(&w.counters[kCtrMaxLen], maxlen);
+}
+
+// Append the record sets that are still running to the next round's live list: one reservation per workgroup
+// (same-address atomics serialise at ~11 ns each; a dense round appends up to n_sets entries).  All threads call.
+__device__ __forceinline__ void append_live(const WorkDev& w, bool running, uint32_t s) {
+  __shared__ uint32_t s_live[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(running);
+  if (lane == 0) s_live[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; ++k) { const uint32_t c = s_live[k]; s_live[k] = total; total += c; }
+    const uint32_t base = total ? atomicAdd(&w.counters[kCtrActive], total) : 0u;
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; ++k) s_live[k] += base;
+  }
+  __syncthreads();
+  if (running) w.live_out[s_live[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -568,12 +622,12 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
     if (done) {
       rows[s] = row;
       if (stats) stats[s] = OutStats{n, 0, 0, 0};
-    } else {
-      w.live_out[atomicAdd(&w.counters[kCtrActive], 1u)] = s;
     }
     w.emit[s] = em;
+    w.emit_lite[s] = emit_desc(em);
     w.state[s] = st;
   }
+  append_live(w, live && st.phase != kDone, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -681,12 +735,14 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       uint32_t support = 0;
       uint32_t d_all = 0;  // lca_allnodes as a point on hit 0's path (:495)
       uint32_t qword = 0;
-      Row<P4> nxt = load_row<P4>(w, lo);
-      float2 rn = res[0];
+      Row<P4> nxt = load_row<P4>(w, lo), nx2 = nxt;  // rows i+1 and i+2 are in flight while row i is worked on
+      float2 rn = res[0], rn2 = rn;
+      if (n > 1) { nx2 = load_row<P4>(w, lo + 1); rn2 = res[1]; }
       for (uint32_t i = 0; i < n; ++i) {
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
-        if (i + 1 < n) { nxt = load_row<P4>(w, lo + i + 1); rn = res[i + 1]; }
+        nxt = nx2; rn = rn2;
+        if (i + 2 < n) { nx2 = load_row<P4>(w, lo + i + 2); rn2 = res[i + 2]; }
         const HitCore h = row_core<P4>(cur);
         uint32_t pth[4 * P4];
         row_path<P4>(cur, pth);
@@ -711,6 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           dist = FLT_MAX; sim = (float)h.ident;
         }
         store_qdqs(w, kStride4, lo + i, dist, sim);
+        if (dist == 0.f) w.lite[lo + i] = h.seglen | kLiteZeroQd;  // pass 1 will not align this hit (:620-621)
         if (member) qword |= 1u << (i & 31u);
         if ((i & 31u) == 31u || i + 1 == n) { fq[i >> 5] = qword; qword = 0; }
         if (i == 0) { best_d = dist; best_s = sim; best_sc = h.score; }  // index_best starts at 0 (:500)
@@ -781,13 +838,15 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         qpid_upper = st.qpid_upper; cut_g = st.cut_g; cut_h = st.cut_h; scut = st.scut; i = st.i_next;
       }
       bool paused = false;
-      Row<P4> nxt = ra;
-      float2 rn = make_float2(0.f, 0.f);
+      Row<P4> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
+      float2 rn = make_float2(0.f, 0.f), rn2 = rn;
       if (i < n) { nxt = load_row<P4>(w, lo + i); rn = res[i]; }
+      if (i + 1 < n) { nx2 = load_row<P4>(w, lo + i + 1); rn2 = res[i + 1]; }
       for (; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
-        if (i + 1 < n) { nxt = load_row<P4>(w, lo + i + 1); rn = res[i + 1]; }
+        nxt = nx2; rn = rn2;
+        if (i + 2 < n) { nx2 = load_row<P4>(w, lo + i + 2); rn2 = res[i + 2]; }
         const HitCore h = row_core<P4>(cur);
         if (!(h.score >= (float)scut)) break;
         const double qsearchpid = (double)h.ident / L;
@@ -890,13 +949,15 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       const float scut = sel.fcut;
       bool paused = false;
       uint32_t i = st.loop_live ? st.i_next : 0u;
-      Row<P4> nxt = ra;
-      float2 rn = make_float2(0.f, 0.f);
+      Row<P4> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
+      float2 rn = make_float2(0.f, 0.f), rn2 = rn;
       if (i < n) { nxt = load_row<P4>(w, lo + i); rn = res[i]; }
+      if (i + 1 < n) { nx2 = load_row<P4>(w, lo + i + 1); rn2 = res[i + 1]; }
       for (; i < n; ++i) {  // :757
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
-        if (i + 1 < n) { nxt = load_row<P4>(w, lo + i + 1); rn = res[i + 1]; }
+        nxt = nx2; rn = rn2;
+        if (i + 2 < n) { nx2 = load_row<P4>(w, lo + i + 2); rn2 = res[i + 2]; }
         const HitCore h = row_core<P4>(cur);
         if (!(h.score >= scut)) break;
         const double qpid = (double)(i == a ? qs_a : h.qs) / L;  // the anchor's row may have been updated below
@@ -987,10 +1048,11 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       }
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
-    if (st.phase != kDone) w.live_out[atomicAdd(&w.counters[kCtrActive], 1u)] = s;  // still running: next round's live list
     w.emit[s] = em;
+    w.emit_lite[s] = emit_desc(em);
     w.state[s] = st;
   }
+  append_live(w, live && st.phase != kDone, s);  // still running: next round's live list
 }
 
 // ---- launchers: P4 = number of 16-byte quads of the taxon path = ceil(max depth / 4) ----

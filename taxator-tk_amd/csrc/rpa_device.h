@@ -97,6 +97,9 @@ struct HitCore {
   uint32_t seglen;   // length of the reference segment
   uint32_t meta;     // kMeta* bits (static after k_rank_records)
 };
+constexpr uint32_t kLiteLenMask = 0x3FFFFFFFu;  // reference segments of 2^30 residues and more are refused
+constexpr uint32_t kLiteWant0 = 0x80000000u;    // pass 0 aligns this hit to the query range (not perfect, score >= threshold)
+constexpr uint32_t kLiteZeroQd = 0x40000000u;   // querydistance[i] == 0 after pass 0: pass 1 never aligns it (:620)
 constexpr uint32_t kMetaPerfect = 4u;  // perfect: alnlen == L && identities == L
 constexpr int kMetaErrShift = 4, kMetaDepthShift = 8;                         // 4 bits segment error code, 8 bits node depth
 
@@ -123,6 +126,12 @@ struct EmitInfo {
   uint32_t anchor_len;  // pass 1/2: length of the anchor's reference segment
 };
 
+// The 16 bytes of EmitInfo that k_emit needs in passes 0 and 1 (one load instead of the 56-byte struct):
+// x = mode | anchor << 2, y = i_lo, z = i_hi (<= n), w = length of the other segment (query range in pass 0, anchor in pass 1/2)
+__host__ __device__ __forceinline__ uint4 emit_desc(const EmitInfo& e) {
+  return uint4{e.mode | (e.anchor << 2), e.i_lo, e.i_hi < e.n ? e.i_hi : e.n, e.mode == 1u ? e.qseglen : e.anchor_len};
+}
+
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
 struct WorkDev {
   SetState* state;      // S
@@ -130,10 +139,13 @@ struct WorkDev {
   uint4* set_info;      // S   (n active, qrstart, qrstop, -)
   uint2* set_qseg;      // S   (query segment length, error code)
   EmitInfo* emit;       // S
+  uint4* emit_lite;     // S   emit_desc(emit[s])
   uint32_t* hit_set;    // H   row position -> record set
   // qgroup / outgroup membership (:480-481,:578) as bit sets: for a set with n >= 2 active hits at rows [lo, lo+n),
   // words flags[lo .. lo+nw) hold the qgroup bits and flags[lo+nw .. lo+2nw) the outgroup bits, nw = ceil(n/32) (2nw <= n)
   uint32_t* flags;      // H
+  // what k_emit needs of a row in passes 0 and 1, 4 bytes instead of the 64-byte row: segment length | kLite* bits
+  uint32_t* lite;       // H
   // segments: id pos in [0,H) = reference segment of the hit at row pos, id H+s = query range of set s.  A segment is only a
   // descriptor: the alignment kernels read the residues straight out of the resident stores (funnel-shifted to the
   // segment's start, reverse-complemented on the fly for reverse-strand hits) -- no per-batch copy of the sequences.
