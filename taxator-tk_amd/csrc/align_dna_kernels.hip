@@ -55,18 +55,21 @@ __device__ __forceinline__ void profile_add(unsigned long long* acc, bool active
   }
 }
 
+// The kernel walks up to two work lists back to back (list, then list2): a pattern-length class with too few pairs
+// to fill the chip rides along with the next wider class instead of paying a serialised launch of its own.
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
+__global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict__ list, uint32_t n_list,
+                                                         const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
                                                          unsigned long long* prof_acc) {
   extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
   const int tid = threadIdx.x;
   const uint32_t t = blockIdx.x * kBlock + tid;
-  const bool active = t < n_list;
+  const bool active = t < n_list + n_list2;
   uint32_t dst = 0, m = 0, n = 0;
   SegView pat{}, txt{};
   if (active) {
     uint32_t a, b;
-    resolve_pair(w, list[t], a, b, dst);
+    resolve_pair(w, t < n_list ? list[t] : list2[t - n_list], a, b, dst);
     SegView va = seg_view(w, a), vb = seg_view(w, b);
     if (va.len < vb.len) { txt = vb; pat = va; } else { txt = va; pat = vb; }  // pattern = shorter (:144-147)
     n = txt.len; m = pat.len;
@@ -126,37 +129,40 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
     (void)HP; (void)HN;
   };
 
-  // Text streaming straight from the resident store, 8 nt (one dword) per step.  Forward segments walk the store
-  // upwards, reverse-strand segments downwards (then nibble-reverse + complement); either way consecutive dwords
-  // share a store word, so each step costs ONE new (L1-resident) dword load, issued one step ahead of its use,
-  // plus a funnel shift.  Both directions run the same instruction stream (selects, no divergence).
-  const int32_t dir = txt.rc ? -1 : 1;
-  // source nibble index of the first nucleotide of text dword 0: forward src; reverse src+len-8 (may be < 0 for tiny stores)
-  const int64_t g0 = txt.rc ? (int64_t)(txt.src + n) - 8 : (int64_t)txt.src;
-  const uint32_t sh = (uint32_t)(g0 & 7) * 4u;
-  int64_t idx = g0 >> 3;  // store word holding that nibble (floor)
-  auto load_word = [&](int64_t i) -> uint32_t { return i >= 0 ? txt.words[i] : 0u; };
-  // forward needs words (idx, idx+1), then (idx+1, idx+2)...; reverse needs (idx, idx+1), then (idx-1, idx)...
-  uint32_t keep = load_word(txt.rc ? idx + 1 : idx);  // the word shared with the next step
-  int64_t next_i = txt.rc ? idx : idx + 1;
-  uint32_t pending = load_word(next_i);
-  const uint32_t n_dwords = (n + 7u) >> 3;
-  for (uint32_t dw = 0; dw < n_dwords; ++dw) {
-    const uint32_t fresh = pending;
-    next_i += dir;
-    if (dw + 1 < n_dwords) pending = load_word(next_i);  // prefetch for the next step
-    const uint32_t hi = txt.rc ? keep : fresh, lo = txt.rc ? fresh : keep;
-    uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
-    keep = fresh;
-    const uint32_t r = revcomp8(d);
-    d = txt.rc ? r : d;
-    const uint32_t cols = n - dw * 8u;  // columns left, >= 1
-    if (cols >= 8u) {
+  // Text streaming straight from the resident store.  The n mod 8 leading columns go first (one dword, a short loop
+  // that every lane of the wave runs at the same time), so that the main loop only ever sees full dwords: 8 unrolled
+  // columns per step with no partial-dword branch, and no tail in which a wave executes both the fast and the slow path.
+  // Forward segments walk the store upwards, reverse-strand segments downwards (then nibble-reverse + complement);
+  // either way consecutive dwords share a store word, so each step costs ONE new (L1-resident) dword load, issued one
+  // step ahead of its use, plus a funnel shift.  Both directions run the same instruction stream (selects).
+  const uint32_t head = n & 7u, full = n >> 3;
+  if (head) {
+    const uint32_t d = txt.fetch8(0u);
+#pragma unroll 1
+    for (uint32_t k = 0; k < head; ++k) column((d >> (4 * k)) & 7u);
+  }
+  if (full) {
+    const int32_t dir = txt.rc ? -1 : 1;
+    // source nibble index of the first nucleotide of main dword 0: forward src+head; reverse src+8*(full-1) (text
+    // position p is source nibble src+n-1-p, and n-head = 8*full)
+    const uint64_t g0 = txt.rc ? txt.src + 8ull * (full - 1u) : txt.src + head;
+    const uint32_t sh = (uint32_t)(g0 & 7u) * 4u;
+    const uint64_t idx = g0 >> 3;  // store word holding that nibble
+    // forward needs words (idx, idx+1), then (idx+1, idx+2)...; reverse needs (idx, idx+1), then (idx-1, idx)...
+    uint32_t keep = txt.words[txt.rc ? idx + 1 : idx];  // the word shared with the next step (stores end in slack words)
+    int64_t next_i = (int64_t)(txt.rc ? idx : idx + 1);
+    uint32_t pending = txt.words[next_i];
+    for (uint32_t dw = 0; dw < full; ++dw) {
+      const uint32_t fresh = pending;
+      next_i += dir;
+      if (dw + 1 < full) pending = txt.words[next_i];  // prefetch for the next step
+      const uint32_t hi = txt.rc ? keep : fresh, lo = txt.rc ? fresh : keep;
+      uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
+      keep = fresh;
+      const uint32_t r = revcomp8(d);
+      d = txt.rc ? r : d;
 #pragma unroll
       for (int k = 0; k < 8; ++k) column((d >> (4 * k)) & 7u);
-    } else {
-#pragma unroll 1
-      for (uint32_t k = 0; k < cols; ++k) column((d >> (4 * k)) & 7u);
     }
   }
   // The score is not tracked per column (the reference adds the horizontal delta of the pattern's last row after every
@@ -175,13 +181,14 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
   if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);  // match+mismatch = m, + gap = n
 }
 
-hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const WorkDev& w,
-                                  unsigned long long* prof_acc) {
-  if (n == 0) return hipSuccess;
-  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
+                                  const WorkDev& w, unsigned long long* prof_acc) {
+  if ((uint64_t)n + n2 == 0) return hipSuccess;
+  if ((uint64_t)n + n2 > 0xFFFFFF00ull) return hipErrorInvalidValue;
+  const uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
   const size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
 #define RPA_LAUNCH_MYERS(NWV) \
-  case NWV: hipLaunchKernelGGL(k_myers_short<NWV>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, prof_acc); break;
+  case NWV: hipLaunchKernelGGL(k_myers_short<NWV>, dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, prof_acc); break;
   switch (words) {
     RPA_LAUNCH_MYERS(1) RPA_LAUNCH_MYERS(2) RPA_LAUNCH_MYERS(3) RPA_LAUNCH_MYERS(4)
     RPA_LAUNCH_MYERS(5) RPA_LAUNCH_MYERS(6) RPA_LAUNCH_MYERS(7) RPA_LAUNCH_MYERS(8)

@@ -209,8 +209,9 @@ hipError_t launch_bin_pairs(hipStream_t st, int alphabet, const WorkDev& w, uint
 hipError_t launch_export_alignments(hipStream_t st, const WorkDev& w, uint32_t n_pairs, void* out);
 
 // alignment kernels over one bin list
-hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const WorkDev& w,
-                                  unsigned long long* prof_acc);
+// walks `list` then `list2` (n2 may be 0): pairs of a narrower class may ride along, the kernel is exact for any pattern <= 32*words
+hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
+                                  const WorkDev& w, unsigned long long* prof_acc);
 // multi-strip per-lane kernel; scratch holds one boundary byte per text column per thread in flight
 size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len);
 hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2* list, uint32_t n, const WorkDev& w,

@@ -118,12 +118,27 @@ const char* kernel_error_text(uint32_t code) {
 }
 
 // Launch the alignment kernels for every non-empty bin list (counts come from the host copy of the counters).
-int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts) {
+// A one-strip class (pattern <= 256 nt) with fewer pairs than this does not get a launch of its own when a wider
+// one-strip class also has work: its list is appended to that launch (a sparse launch costs ~60 us whatever its size,
+// and the wider kernel is exact for the narrower patterns at the price of the extra rows).
+constexpr uint32_t kRideAlongPairs = 262144;
+
+int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
   unsigned long long* acc = e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr;
+  const uint32_t* counts = counts_in;
+  int rider = -1;  // a narrower one-strip class waiting for the next launch
   for (int bin = 0; bin < kNumBins; ++bin) {
     const uint32_t n = counts[bin];
     if (!n) continue;
     const uint2* list = w.bin_list + (size_t)bin * w.T2;
+    const uint2* list2 = nullptr;
+    uint32_t n2 = 0;
+    if (e->params.alphabet == RPA_DNA && bin < kShortWords) {
+      bool wider = false;
+      for (int k = bin + 1; k < kShortWords; ++k) wider = wider || counts[k] != 0;
+      if (rider < 0 && n < kRideAlongPairs && wider) { rider = bin; continue; }  // picked up by the next one-strip launch
+      if (rider >= 0) { list2 = w.bin_list + (size_t)rider * w.T2; n2 = counts[rider]; rider = -1; }
+    }
     size_t i0 = 0, i1 = 0;
     if (e->profiling) {
       hipEvent_t a = get_event(e), b = get_event(e);
@@ -132,7 +147,7 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts) {
       HIP_TRY(e, hipEventRecord(a, e->stream));
     }
     if (e->params.alphabet == RPA_DNA) {
-      if (bin < kShortWords) HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, w, acc));
+      if (bin < kShortWords) HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, list2, n2, w, acc));
       else {
         // Patterns of more than 256 nt.  Many pairs: one per lane, register strips (K1s).  Few pairs (not enough to give
         // every SIMD a few waves of lanes): one per wavefront (K2), as long as the pattern fits its 64 x 8 words.
