@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
     dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
   }
   // distance, similarity = matches = len_short - (d - lendiff) = len_long - d   (:154-164)
-  w.pair_res[dst] = make_float2((float)dist, (float)((int32_t)n - dist));
+  w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)n - dist));
   if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);  // match+mismatch = m, + gap = n
 }
 
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
     const uint32_t tail = pos >= m ? 0xFFFFFFFFu : (m - pos >= 32u ? 0u : ~((1u << (m - pos)) - 1u));
     dist -= (int32_t)__popc(VP[wi] & tail) - (int32_t)__popc(VN[wi] & tail);
   }
-  w.pair_res[dst] = make_float2((float)dist, (float)((int32_t)n - dist));
+  w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)n - dist));
   if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
 }
 
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint2* __restrict__ lis
   }
   dist = __shfl(dist, (int)(last_word / WPL), 64);  // the lane that owns the last word holds the distance
   if (lane == 0) {
-    w.pair_res[dst] = make_float2((float)dist, (float)((int32_t)n - dist));
+    w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)n - dist));
     if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
   }
 }

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint2* __restrict__
   float distance = (float)(selfscore - 2 * mutual) * normfactor;      // :232
   const float similarity = (float)(2 * mutual) * normfactor;          // :233
   if (!(selfscore >= mutual) || !(distance >= 0.f)) distance = __builtin_nanf("");  // live asserts :205,:240 -> flagged, raised if consumed
-  w.pair_res[dst] = make_float2(distance, similarity);
+  w.pair_res[res_index(w, dst)] = make_float2(distance, similarity);
   if (w.pair_ext) w.pair_ext[dst] = make_uint4(nmatch, mismatch, gap, len);
 }
 

@@ -49,35 +49,64 @@ __device__ __forceinline__ void raise_error(const WorkDev& w, uint32_t code, uin
 }
 
 // ---- hit rows -------------------------------------------------------------------------------------------------
+// Where the rows of one record set live.  Tiled layout (WorkDev::tile_base set): 64 consecutive record sets form a
+// tile; row i, quad q of the tile's set number l sits at quad index (tile_base + 64 i) Q + 64 q + l, so when the 64
+// lanes of a wave (= 64 consecutive sets) read "quad q of my row i" they read 1 KB of contiguous memory, and the
+// alignment result of row i at slot tile_base + 64 i + l likewise.  Linear layout (fallback for batches whose sets
+// differ wildly in size, where padding every tile to its largest set would waste memory): rows of a set contiguous.
 template <int P4>
-__device__ __forceinline__ const uint4* hit_ptr(const WorkDev& w, uint32_t pos) {
-  return reinterpret_cast<const uint4*>(w.hits) + (size_t)pos * (2 + P4);
-}
-__device__ __forceinline__ HitCore load_core(const uint4* p) {
-  const uint4 a = p[0], b = p[1];
-  HitCore c;
-  c.score = __uint_as_float(a.x); c.ident = a.y; c.node = a.z; c.rec = a.w;
-  c.qd = __uint_as_float(b.x); c.qs = __uint_as_float(b.y); c.seglen = b.z; c.meta = b.w;
-  return c;
-}
+struct Row { uint4 q[2 + P4]; };  // a whole row in registers
+
 template <int P4>
-__device__ __forceinline__ void load_path(const uint4* p, uint32_t (&path)[4 * P4]) {
+struct SetRows {
+  uint4* p;         // quad 0 of row 0
+  size_t si, sq;    // quads from a row to the next / from a quad of a row to the next
+  float2* res;      // result slot of row 0
+  size_t sr;        // slots from a row to the next
+  __device__ __forceinline__ Row<P4> load(uint32_t i) const {
+    const uint4* r = p + (size_t)i * si;
+    Row<P4> o;
 #pragma unroll
-  for (int k = 0; k < P4; ++k) {
-    const uint4 v = p[2 + k];
-    path[4 * k] = v.x; path[4 * k + 1] = v.y; path[4 * k + 2] = v.z; path[4 * k + 3] = v.w;
+    for (int k = 0; k < 2 + P4; ++k) o.q[k] = r[(size_t)k * sq];
+    return o;
   }
-}
-// A whole row in registers.  The decision loops fetch row i+1 (and its alignment result) before they work on row i,
-// so the HBM latency of a row is hidden behind the previous row's arithmetic instead of being paid n times in sequence.
-template <int P4>
-struct Row { uint4 q[2 + P4]; };
-template <int P4>
-__device__ __forceinline__ Row<P4> load_row(const WorkDev& w, uint32_t pos) {
-  const uint4* p = hit_ptr<P4>(w, pos);
-  Row<P4> r;
+  __device__ __forceinline__ HitCore core(uint32_t i) const {
+    const uint4* r = p + (size_t)i * si;
+    const uint4 a = r[0], b = r[sq];
+    HitCore c;
+    c.score = __uint_as_float(a.x); c.ident = a.y; c.node = a.z; c.rec = a.w;
+    c.qd = __uint_as_float(b.x); c.qs = __uint_as_float(b.y); c.seglen = b.z; c.meta = b.w;
+    return c;
+  }
+  __device__ __forceinline__ void path(uint32_t i, uint32_t (&path)[4 * P4]) const {
+    const uint4* r = p + (size_t)i * si;
 #pragma unroll
-  for (int k = 0; k < 2 + P4; ++k) r.q[k] = p[k];
+    for (int k = 0; k < P4; ++k) {
+      const uint4 v = r[(size_t)(2 + k) * sq];
+      path[4 * k] = v.x; path[4 * k + 1] = v.y; path[4 * k + 2] = v.z; path[4 * k + 3] = v.w;
+    }
+  }
+  __device__ __forceinline__ void store_quad(uint32_t i, int k, uint4 v) const { p[(size_t)i * si + (size_t)k * sq] = v; }
+  // the only mutable fields of a row: querydistance / querysimilarity (first 8 bytes of its second quad)
+  __device__ __forceinline__ void store_qdqs(uint32_t i, float qd, float qs) const {
+    reinterpret_cast<float2*>(p + (size_t)i * si + sq)[0] = make_float2(qd, qs);
+  }
+  __device__ __forceinline__ void store_qd(uint32_t i, float qd) const { reinterpret_cast<float*>(p + (size_t)i * si + sq)[0] = qd; }
+  __device__ __forceinline__ float2 result(uint32_t i) const { return res[(size_t)i * sr]; }
+};
+template <int P4>
+__device__ __forceinline__ SetRows<P4> set_rows(const WorkDev& w, uint32_t s, uint32_t lo) {
+  constexpr size_t Q = 2 + P4;
+  SetRows<P4> r;
+  uint4* base = reinterpret_cast<uint4*>(w.hits);
+  if (w.tile_base) {
+    const size_t t0 = w.tile_base[s >> 6], l = s & 63u;
+    r.p = base + t0 * Q + l; r.si = 64 * Q; r.sq = 64;
+    r.res = w.pair_res + t0 + l; r.sr = 64;
+  } else {
+    r.p = base + (size_t)lo * Q; r.si = Q; r.sq = 1;
+    r.res = w.pair_res + lo; r.sr = 1;
+  }
   return r;
 }
 template <int P4>
@@ -94,18 +123,11 @@ __device__ __forceinline__ void row_path(const Row<P4>& r, uint32_t (&path)[4 * 
     path[4 * k] = r.q[2 + k].x; path[4 * k + 1] = r.q[2 + k].y; path[4 * k + 2] = r.q[2 + k].z; path[4 * k + 3] = r.q[2 + k].w;
   }
 }
-// the only mutable fields of a row: querydistance / querysimilarity (first 8 bytes of its second quad)
-__device__ __forceinline__ void store_qdqs(const WorkDev& w, int stride4, uint32_t pos, float qd, float qs) {
-  reinterpret_cast<float2*>(reinterpret_cast<uint4*>(w.hits) + (size_t)pos * stride4 + 1)[0] = make_float2(qd, qs);
-}
-__device__ __forceinline__ void store_qd(const WorkDev& w, int stride4, uint32_t pos, float qd) {
-  reinterpret_cast<float*>(reinterpret_cast<uint4*>(w.hits) + (size_t)pos * stride4 + 1)[0] = qd;
-}
+__device__ __forceinline__ uint32_t meta_depth(uint32_t meta) { return (meta >> kMetaDepthShift) & 0xFFu; }
+__device__ __forceinline__ uint32_t meta_err(uint32_t meta) { return (meta >> kMetaErrShift) & 0xFu; }
 // qgroup / outgroup bit sets of one record set (WorkDev::flags)
 __device__ __forceinline__ void bit_clear(uint32_t* words, uint32_t i) { words[i >> 5] &= ~(1u << (i & 31u)); }
 __device__ __forceinline__ void bit_set(uint32_t* words, uint32_t i) { words[i >> 5] |= 1u << (i & 31u); }
-__device__ __forceinline__ uint32_t meta_depth(uint32_t meta) { return (meta >> kMetaDepthShift) & 0xFFu; }
-__device__ __forceinline__ uint32_t meta_err(uint32_t meta) { return (meta >> kMetaErrShift) & 0xFu; }
 
 // length of the common prefix of two root paths = depth of the LCA of the two nodes
 template <int P4>
@@ -174,7 +196,14 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   // per thread, nearly all of them to records of this block -> LDS (broadcast reads) instead of the vector memory path
   __shared__ uint4 s_rec[kBlock];      // score bits, identities, qstart, qstop
   __shared__ uint8_t s_filt[kBlock];
-  const uint32_t r0 = blockIdx.x * kBlock;  // < n_records by the grid size
+  // Rows are written in the tiled layout: the 64-byte row of a record lands 16 bytes at a time in lines it shares with
+  // the same row of the 63 neighbouring record sets, i.e. with records handled by this and the next few workgroups.
+  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so consecutive LOGICAL blocks are mapped
+  // to hardware blocks b, b+8, b+16, ...: the workgroups that complete each other's lines share an L2.
+  const uint32_t per_xcd = gridDim.x / 8u;  // the grid is a multiple of 8
+  const uint32_t lblock = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+  const uint32_t r0 = lblock * kBlock;
+  if (r0 >= b.n_records) return;  // padding blocks of the grid (whole workgroup)
   {
     const uint32_t rr = r0 + threadIdx.x;
     if (rr < b.n_records) {
@@ -270,15 +299,16 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   const uint32_t meta = (perfect ? kMetaPerfect : 0u) | (sp.y << kMetaErrShift) | ((uint32_t)tax.depth[node] << kMetaDepthShift);
   float qd = FLT_MAX, qs = 0.f;  // :475-476
   if (n == 1) { qd = __uint_as_float(b.qstart[r]); qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
-  uint4* row = reinterpret_cast<uint4*>(w.hits) + (size_t)pos * (2 + P4);
+  const SetRows<P4> R = set_rows<P4>(w, s, beg);
+  w.res_slot[pos] = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);  // where the alignment kernels put this hit's result
   if (sp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); sp.x = 0; }
   // compact per-row word for k_emit: segment length + "pass 0 re-aligns this hit" (:511-518, threshold :499)
   w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u);
-  row[0] = make_uint4(__float_as_uint(sc), id, node, r);
-  row[1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta);
+  R.store_quad(rank, 0, make_uint4(__float_as_uint(sc), id, node, r));
+  R.store_quad(rank, 1, make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta));
   const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
 #pragma unroll
-  for (int k = 0; k < P4; ++k) row[2 + k] = anc[k];
+  for (int k = 0; k < P4; ++k) R.store_quad(rank, 2 + k, anc[k]);
 }
 
 // Pair emission bookkeeping: a thread first counts what it will emit per bin, reserves list space with one atomic
@@ -342,15 +372,14 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
   if (info.mode == 1) want = (lite & kLiteWant0) != 0u;
   else if (info.mode == 2) want = !(lite & kLiteZeroQd);
   else {
-    const uint4* pr = hit_ptr<P4>(w, pos);
-    const uint4 q0 = pr[0], q1 = pr[1];
-    const float score = __uint_as_float(q0.x), qs = __uint_as_float(q1.y);
-    if (score >= info.fcut && (double)qs / info.L >= info.qpid_thresh) {
+    const SetRows<P4> R = set_rows<P4>(w, s, lo);
+    const uint32_t i = pos - lo;
+    const HitCore h = R.core(i);
+    if (h.score >= info.fcut && (double)h.qs / info.L >= info.qpid_thresh) {
       uint32_t pb[4 * P4], pth[4 * P4];
-      const uint4* pbp = hit_ptr<P4>(w, lo + info.best);
-      load_path<P4>(pbp, pb);
-      load_path<P4>(pr, pth);
-      want = !(common<P4>(pb, meta_depth(load_core(pbp).meta), pth, meta_depth(q1.w)) >= info.d_unode_g);
+      R.path(info.best, pb);
+      R.path(i, pth);
+      want = !(common<P4>(pb, meta_depth(R.core(info.best).meta), pth, meta_depth(h.meta)) >= info.d_unode_g);
     }
   }
   if (!want) return -1;
@@ -573,26 +602,25 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
     if (n == 0) {  // :359-368
       row.flags = kFlagIvalUntouched;
     } else if (n == 1) {  // :371-388
-      const HitCore h = load_core(hit_ptr<P4>(w, lo));
+      const HitCore h = set_rows<P4>(w, s, lo).core(0u);
       row.begin = __float_as_uint(h.qd); row.end = __float_as_uint(h.qs); row.ival = 1.f;
       row.lower = h.node; row.upper = kRoot; row.support = h.ident; row.rtax = h.node;
       row.flags = kFlagSingle;
     } else {
-      const uint4* p0 = hit_ptr<P4>(w, lo);
-      const HitCore h0 = load_core(p0);
+      const SetRows<P4> R = set_rows<P4>(w, s, lo);
+      const HitCore h0 = R.core(0u);
       if (h0.meta & kMetaPerfect) {  // :431-472: lnode / unode are points on hit 0's path
         uint32_t path0[4 * P4];
-        load_path<P4>(p0, path0);
+        R.path(0u, path0);
         const uint32_t d0 = meta_depth(h0.meta);
         const float best = h0.score;
         uint32_t d_l = d0, d_u = 0;
         uint32_t i = 1;
         for (;;) {
           if (i == n) { d_u = 0; break; }  // unode = root
-          const uint4* pi = hit_ptr<P4>(w, lo + i);
-          HitCore hi2 = load_core(pi);
+          HitCore hi2 = R.core(i);
           uint32_t pth[4 * P4];
-          load_path<P4>(pi, pth);
+          R.path(i, pth);
           if (hi2.score == best) d_l = min(d_l, common<P4>(path0, d0, pth, meta_depth(hi2.meta)));
           else {
             const float sc = hi2.score;
@@ -600,10 +628,9 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
             for (;;) {
               d_u = min(d_u, common<P4>(path0, d0, pth, meta_depth(hi2.meta)));
               if (++i >= n) break;
-              pi = hit_ptr<P4>(w, lo + i);
-              hi2 = load_core(pi);
+              hi2 = R.core(i);
               if (!(hi2.score == sc)) break;
-              load_path<P4>(pi, pth);
+              R.path(i, pth);
             }
             break;
           }
@@ -717,10 +744,9 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     em.mode = 0; em.n = st.n; em.L = st.L; em.qseglen = st.qseglen;
     const uint32_t lo = b.set_offsets[s];
     const uint32_t n = st.n, L = st.L;
-    constexpr int kStride4 = 2 + P4;
     const float X = p.exclude_factor;
-    const float2* __restrict__ res = w.pair_res + lo;                  // res[i]: result of the alignment asked for hit i
-    const float2* __restrict__ qres_p = w.pair_res + b.n_records + s;  // result of the anchor <-> query alignment
+    const SetRows<P4> R = set_rows<P4>(w, s, lo);              // rows and alignment results of this set
+    const float2* __restrict__ qres_p = w.pair_res + w.P + s;  // result of the anchor <-> query alignment
     const uint32_t nw = (n + 31u) >> 5;
     uint32_t* fq = w.flags + lo;   // qgroup bits
     uint32_t* fo = fq + nw;        // outgroup bits
@@ -735,14 +761,14 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       uint32_t support = 0;
       uint32_t d_all = 0;  // lca_allnodes as a point on hit 0's path (:495)
       uint32_t qword = 0;
-      Row<P4> nxt = load_row<P4>(w, lo), nx2 = nxt;  // rows i+1 and i+2 are in flight while row i is worked on
-      float2 rn = res[0], rn2 = rn;
-      if (n > 1) { nx2 = load_row<P4>(w, lo + 1); rn2 = res[1]; }
+      Row<P4> nxt = R.load(0u), nx2 = nxt;  // rows i+1 and i+2 are in flight while row i is worked on
+      float2 rn = R.result(0), rn2 = rn;
+      if (n > 1) { nx2 = R.load(1); rn2 = R.result(1); }
       for (uint32_t i = 0; i < n; ++i) {
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
         nxt = nx2; rn = rn2;
-        if (i + 2 < n) { nx2 = load_row<P4>(w, lo + i + 2); rn2 = res[i + 2]; }
+        if (i + 2 < n) { nx2 = R.load(i + 2); rn2 = R.result(i + 2); }
         const HitCore h = row_core<P4>(cur);
         uint32_t pth[4 * P4];
         row_path<P4>(cur, pth);
@@ -766,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         } else {
           dist = FLT_MAX; sim = (float)h.ident;
         }
-        store_qdqs(w, kStride4, lo + i, dist, sim);
+        R.store_qdqs(i, dist, sim);
         if (dist == 0.f) w.lite[lo + i] = h.seglen | kLiteZeroQd;  // pass 1 will not align this hit (:620-621)
         if (member) qword |= 1u << (i & 31u);
         if ((i & 31u) == 31u || i + 1 == n) { fq[i >> 5] = qword; qword = 0; }
@@ -781,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       }
       if (!failed) {
         for (uint32_t k = 0; k < nw; ++k) fo[k] = 0u;  // outgroup starts empty (:578)
-        const Row<P4> rb = load_row<P4>(w, lo + index_best);
+        const Row<P4> rb = R.load(index_best);
         uint32_t pb[4 * P4];
         row_path<P4>(rb, pb);
         const uint32_t db = meta_depth(row_core<P4>(rb).meta);
@@ -792,7 +818,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           while (word) {
             const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
             word &= word - 1u;
-            const Row<P4> ri = load_row<P4>(w, lo + k * 32u + bit);
+            const Row<P4> ri = R.load(k * 32u + bit);
             const HitCore h = row_core<P4>(ri);
             if (h.qd != best_d || h.qs != best_s || h.score != best_sc) keep &= ~(1u << bit);
             else {
@@ -812,8 +838,8 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     } else if (st.phase == kPass1Wait) {  // ---- pass 1 for one anchor, :580-728 ----
       const uint32_t a = st.anchor;
       uint32_t pa[4 * P4], pb[4 * P4];
-      const Row<P4> ra = load_row<P4>(w, lo + a);
-      const Row<P4> rb = load_row<P4>(w, lo + st.best);
+      const Row<P4> ra = R.load(a);
+      const Row<P4> rb = R.load(st.best);
       const HitCore ha = row_core<P4>(ra);
       row_path<P4>(ra, pa);
       const uint32_t da = meta_depth(ha.meta);
@@ -840,13 +866,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       bool paused = false;
       Row<P4> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
       float2 rn = make_float2(0.f, 0.f), rn2 = rn;
-      if (i < n) { nxt = load_row<P4>(w, lo + i); rn = res[i]; }
-      if (i + 1 < n) { nx2 = load_row<P4>(w, lo + i + 1); rn2 = res[i + 1]; }
+      if (i < n) { nxt = R.load(i); rn = R.result(i); }
+      if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
       for (; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
         nxt = nx2; rn = rn2;
-        if (i + 2 < n) { nx2 = load_row<P4>(w, lo + i + 2); rn2 = res[i + 2]; }
+        if (i + 2 < n) { nx2 = R.load(i + 2); rn2 = R.result(i + 2); }
         const HitCore h = row_core<P4>(cur);
         if (!(h.score >= (float)scut)) break;
         const double qsearchpid = (double)h.ident / L;
@@ -912,7 +938,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           const float dist = (float)ogd[k];
           if (dist > min_upper_dist) continue;
           const uint32_t io = ogi[k];
-          const Row<P4> ri = load_row<P4>(w, lo + io);
+          const Row<P4> ri = R.load(io);
           uint32_t pth[4 * P4];
           row_path<P4>(ri, pth);
           const uint32_t cb = common<P4>(pb, db, pth, meta_depth(row_core<P4>(ri).meta));
@@ -937,8 +963,8 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       }
     } else if (st.phase == kPass2Wait) {  // ---- pass 2 for one anchor, :750-820 ----
       const uint32_t a = st.anchor;
-      const Row<P4> ra = load_row<P4>(w, lo + a);
-      const Row<P4> rb = load_row<P4>(w, lo + st.best);
+      const Row<P4> ra = R.load(a);
+      const Row<P4> rb = R.load(st.best);
       const HitCore ha = row_core<P4>(ra);
       uint32_t pb[4 * P4];
       row_path<P4>(rb, pb);
@@ -951,13 +977,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       uint32_t i = st.loop_live ? st.i_next : 0u;
       Row<P4> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
       float2 rn = make_float2(0.f, 0.f), rn2 = rn;
-      if (i < n) { nxt = load_row<P4>(w, lo + i); rn = res[i]; }
-      if (i + 1 < n) { nx2 = load_row<P4>(w, lo + i + 1); rn2 = res[i + 1]; }
+      if (i < n) { nxt = R.load(i); rn = R.result(i); }
+      if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
       for (; i < n; ++i) {  // :757
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
         nxt = nx2; rn = rn2;
-        if (i + 2 < n) { nx2 = load_row<P4>(w, lo + i + 2); rn2 = res[i + 2]; }
+        if (i + 2 < n) { nx2 = R.load(i + 2); rn2 = R.result(i + 2); }
         const HitCore h = row_core<P4>(cur);
         if (!(h.score >= scut)) break;
         const double qpid = (double)(i == a ? qs_a : h.qs) / L;  // the anchor's row may have been updated below
@@ -973,7 +999,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
           ++st.cnt2;
-          store_qd(w, kStride4, lo + i, dist);  // querydistance[i] = dist, :785
+          R.store_qd(i, dist);  // querydistance[i] = dist, :785
         }
         if (dist == 0.f) bit_clear(fo, i);  // :789
         else {
@@ -984,7 +1010,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
             const float d2 = q2.x;
             const float s2 = q2.y < qs_a ? qs_a : q2.y;
             qd_a = d2; qs_a = s2;
-            store_qdqs(w, kStride4, lo + a, d2, s2);
+            R.store_qdqs(a, d2, s2);
             qdist_ex = d2 * st.bf_max;
             ++st.cnt2;
           } else qdist_ex = qd_a * st.bf_max;  // :809
@@ -1005,7 +1031,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         const uint32_t word = fq[k];
         if (word) { const uint32_t bit = (uint32_t)__ffs((int)word) - 1u; a = k * 32u + bit; fq[k] = word & (word - 1u); break; }
       }
-      const HitCore h = load_core(hit_ptr<P4>(w, lo + a));
+      const HitCore h = R.core(a);
       st.anchor = a; st.phase = kPass1Wait; st.loop_live = 0;
       st.chunk_hi = p.spec1 ? min(n, p.spec1) : n;
       em.mode = 2; em.anchor = a; em.anchor_len = h.seglen; em.i_lo = 0; em.i_hi = st.chunk_hi;
@@ -1020,7 +1046,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
           fo[k] = word & (word - 1u);
           const uint32_t a = k * 32u + bit;
-          const HitCore h = load_core(hit_ptr<P4>(w, lo + a));
+          const HitCore h = R.core(a);
           st.anchor = a; st.phase = kPass2Wait; found = true; st.loop_live = 0;
           st.chunk_hi = p.spec2 ? min(n, p.spec2) : n;
           em.mode = 3; em.anchor = a; em.anchor_len = h.seglen; em.best = st.best; em.d_unode_g = st.d_unode_g;
@@ -1035,7 +1061,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       if (!found) {  // :824-833
         if (st.d_unode_g == st.d_lnode_g) st.ival_g = 1.f;
         uint32_t pb[4 * P4];
-        load_path<P4>(hit_ptr<P4>(w, lo + st.best), pb);
+        R.path(st.best, pb);
         OutRow row;
         row.begin = st.qrstart; row.end = st.qrstop; row.ival = st.ival_g;
         row.lower = node_at<P4>(pb, st.d_lnode_g); row.upper = node_at<P4>(pb, st.d_unode_g); row.support = st.support;
@@ -1055,6 +1081,47 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
   append_live(w, live && st.phase != kDone, s);  // still running: next round's live list
 }
 
+// ---- tiled row layout: per tile of 64 record sets, 64 x (largest record count of the tile) row slots ----
+__global__ __launch_bounds__(kBlock) void k_tile_caps(const uint32_t* __restrict__ set_offsets, uint32_t n_sets, uint32_t n_tiles,
+                                                       uint32_t* __restrict__ tile_base) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_tiles) return;
+  const uint32_t s0 = t * 64u, s1 = min(n_sets, s0 + 64u);
+  uint32_t cap = 0, prev = set_offsets[s0];
+  for (uint32_t s = s0; s < s1; ++s) { const uint32_t nx = set_offsets[s + 1]; cap = max(cap, nx - prev); prev = nx; }
+  tile_base[t] = cap;  // scanned in place by k_tile_scan
+}
+// exclusive prefix sum of 64 * cap over the tiles, one workgroup; saturates at 0xFFFFFFFF (the caller then uses the linear layout)
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t n_tiles, uint32_t* __restrict__ tile_base) {
+  __shared__ unsigned long long s_sum[1024];
+  const uint32_t per = (n_tiles + 1023u) / 1024u;
+  const uint32_t lo = min(n_tiles, threadIdx.x * per), hi = min(n_tiles, lo + per);
+  unsigned long long sum = 0;
+  for (uint32_t t = lo; t < hi; ++t) sum += 64ull * tile_base[t];
+  s_sum[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int k = 0; k < 1024; ++k) { const unsigned long long c = s_sum[k]; s_sum[k] = run; run += c; }
+    tile_base[n_tiles] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+  }
+  __syncthreads();
+  unsigned long long run = s_sum[threadIdx.x];
+  for (uint32_t t = lo; t < hi; ++t) {
+    const unsigned long long c = 64ull * tile_base[t];
+    tile_base[t] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+    run += c;
+  }
+}
+
+hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t* tile_base) {
+  const uint32_t n_tiles = (n_sets + 63u) / 64u;
+  if (n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tile_caps, dim3((n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, st, set_offsets, n_sets, n_tiles, tile_base);
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, n_tiles, tile_base);
+  return hipGetLastError();
+}
+
 // ---- launchers: P4 = number of 16-byte quads of the taxon path = ceil(max depth / 4) ----
 #define RPA_DISPATCH_P4(P4V, CALL)                 \
   switch (P4V) {                                   \
@@ -1068,7 +1135,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
 hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
                                const StoreDev& db, const Params& p) {
   if (b.n_records == 0) return hipSuccess;
-  const dim3 grid((b.n_records + kBlock - 1) / kBlock);
+  const dim3 grid(((b.n_records + kBlock - 1) / kBlock + 7u) / 8u * 8u);  // multiple of 8: see the XCD mapping in the kernel
   RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_rank_records<P4>, grid, dim3(kBlock), 0, st, b, w, tax, q, db, p));
   return hipGetLastError();
 }

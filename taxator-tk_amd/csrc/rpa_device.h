@@ -135,7 +135,10 @@ __host__ __device__ __forceinline__ uint4 emit_desc(const EmitInfo& e) {
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
 struct WorkDev {
   SetState* state;      // S
-  uint32_t* hits;       // H rows of (8 + 4*path_quads) words; hits of set s at rows [set_off[s], set_off[s]+n), sorted
+  uint32_t* hits;       // P row slots of (8 + 4*path_quads) words in SortFilter order per set; tiled or linear (SetRows, place_kernels.hip)
+  const uint32_t* tile_base;  // ceil(S/64) first row slot of every tile of 64 record sets; null = linear layout (slot = row position)
+  uint32_t* res_slot;   // H   row position -> slot of pair_res that holds the hit's alignment result (null in rpa_align_pairs)
+  uint32_t P;           // row slots (= H in the linear layout); the anchor<->query result of set s is at pair_res[P + s]
   uint4* set_info;      // S   (n active, qrstart, qrstop, -)
   uint2* set_qseg;      // S   (query segment length, error code)
   EmitInfo* emit;       // S
@@ -156,7 +159,7 @@ struct WorkDev {
   // the alignment kernels derive the segments from the row and the set's EmitInfo)
   uint32_t* pair_a;     // T2  segment id
   uint32_t* pair_b;     // T2
-  float2* pair_res;     // T   (distance, similarity); [pos] for the alignment asked for the hit at row pos, [H+s] for anchor<->query
+  float2* pair_res;     // P+S (distance, similarity); [res_slot[pos]] for the alignment asked for the hit at row pos, [P+s] for anchor<->query
   uint4* pair_ext;      // optional (rpa_align_pairs only): matches, mismatches, gaps, length; indexed like pair_res
   uint2* bin_list;      // kNumBins * T2 entries (segment A, segment B | kDstIsB)
   uint32_t* counters;   // kNumCounters words, layout below
@@ -194,6 +197,10 @@ struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells
 
 // ---- launchers (each enqueues on `st`, returns the hipError of the launch) ----
 hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* letters, uint64_t n_residues, uint32_t* words);
+
+// tiled row layout: tile_base[t] = first row slot of tile t (64 record sets, each padded to the tile's largest record
+// count), tile_base[n_tiles] = total slots.  Two small launches; the caller reads the total back to size the buffers.
+hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t* tile_base);
 
 hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
                                const StoreDev& db, const Params& p);
@@ -234,6 +241,12 @@ __device__ __forceinline__ void resolve_pair(const WorkDev& w, uint2 entry, uint
   seg_a = entry.x;
   seg_b = entry.y & ~kDstIsB;
   dst = (entry.y & kDstIsB) ? seg_b : seg_a;
+}
+
+// where an alignment kernel stores the result of destination id `dst` (a row position, or H + s for anchor <-> query)
+__device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
+  if (!w.res_slot) return dst;  // rpa_align_pairs: one slot per pair
+  return dst < w.H ? w.res_slot[dst] : w.P + (dst - w.H);
 }
 
 // protein: bin = strip height index (R = 8 * (bin + 1)).  One height for every pair: R = 24.  Measured on MI355X at

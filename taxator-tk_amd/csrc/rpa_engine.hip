@@ -63,7 +63,7 @@ struct rpa_engine {
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8;
-  DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, flags, lite, seg, pair_a, pair_b,
+  DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
       tmp_words, tmp_offsets, protein_ws;
   uint32_t* h_counters = nullptr;  // pinned
@@ -71,6 +71,7 @@ struct rpa_engine {
   bool profiling = false;
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
+  bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
   DevBuf prof_acc;
   rpa_profile prof{};
   std::vector<hipEvent_t> ev_pool;
@@ -210,9 +211,11 @@ int profile_end(rpa_engine* e) {
 }
 
 // Working-set allocation shared by predict and align_pairs.  T = segments, T2 = pair slots.
-int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, bool want_ext, WorkDev* w) {
+// P = row slots (tiled layout: padded; linear: H); tiled selects the layout of the rows / results (predict only).
+int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, bool want_ext, WorkDev* w, uint32_t P, bool tiled) {
   HIP_TRY(e, e->state.ensure((size_t)(S ? S : 1) * sizeof(SetState)));
-  HIP_TRY(e, e->hits.ensure((size_t)(H ? H : 1) * (size_t)(2 + e->tax.path_quads) * 16));
+  HIP_TRY(e, e->hits.ensure((size_t)(P ? P : 1) * (size_t)(2 + e->tax.path_quads) * 16));
+  if (!want_ext) HIP_TRY(e, e->res_slot.ensure((size_t)(H ? H : 1) * 4));
   HIP_TRY(e, e->set_info.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
   HIP_TRY(e, e->set_qseg.ensure((size_t)(S ? S : 1) * sizeof(uint2)));
   HIP_TRY(e, e->emit.ensure((size_t)(S ? S : 1) * sizeof(EmitInfo)));
@@ -225,7 +228,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
     HIP_TRY(e, e->pair_a.ensure((size_t)(T2 ? T2 : 1) * 4));
     HIP_TRY(e, e->pair_b.ensure((size_t)(T2 ? T2 : 1) * 4));
   }
-  const size_t n_res = (size_t)(T > T2 ? T : T2) + 1;  // predict: one per hit + one per set; align_pairs: one per pair
+  const size_t n_res = (size_t)(want_ext ? (T > T2 ? T : T2) : (size_t)P + S) + 1;  // predict: one per row slot + one per set; align_pairs: one per pair
   HIP_TRY(e, e->pair_res.ensure(n_res * 8));
   if (want_ext) HIP_TRY(e, e->pair_ext.ensure(n_res * 16));
   HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kNumBins : 4)));
@@ -242,6 +245,8 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->seg = e->seg.as<SegDesc>(); w->store_q = nullptr; w->store_db = nullptr;
   w->pair_a = want_ext ? e->pair_a.as<uint32_t>() : nullptr; w->pair_b = want_ext ? e->pair_b.as<uint32_t>() : nullptr;
   w->set_offsets = nullptr; w->H = H; w->row_quads = 2 + e->tax.path_quads;
+  w->P = P; w->tile_base = (!want_ext && tiled) ? e->tile_base.as<const uint32_t>() : nullptr;
+  w->res_slot = want_ext ? nullptr : e->res_slot.as<uint32_t>();
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
   w->bin_list = e->bin_list.as<uint2>(); w->counters = e->counters.as<uint32_t>();
   w->og_idx = e->og_idx.as<uint32_t>(); w->band_save = e->band_save.as<float>();
@@ -307,6 +312,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 0u : 8u) : params->speculation_pass1;
   e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 6u) : params->speculation_pass2;  // tools/spec_sweep.sh
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
+  if (const char* v = getenv("RPA_ROW_LAYOUT")) e->linear_rows = !strcmp(v, "linear");
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
@@ -369,7 +375,7 @@ void rpa_destroy(rpa_engine* e) {
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->state, &e->hits,
                     &e->set_info, &e->seg,
-                    &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->flags, &e->lite, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
+                    &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
                     &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc};
   for (DevBuf* b : bufs) b->release();
@@ -479,8 +485,22 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
     b.filtered = batch->filtered;
   } else return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: bad mem_kind");
 
+  // Row layout.  Tiled (64 record sets side by side, see SetRows in place_kernels.hip) makes the placement kernels'
+  // row accesses coalesced; it pads every tile to its largest set, so batches whose padding would exceed ~50 % of the
+  // rows (wildly different set sizes) keep the linear layout.  The slot count comes back from the device.
+  const uint32_t n_tiles = (S + 63u) / 64u;
+  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 1) * 4));
+  uint32_t P = H;
+  bool tiled = false;
+  if (!e->linear_rows) {
+    HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>()));
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->tile_base.as<uint32_t>() + n_tiles, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const uint64_t slots = e->h_counters[0];
+    if (slots != 0xFFFFFFFFull && slots <= (uint64_t)H + H / 2 + 65536u && slots + S < 0xFFFFFFF0ull) { P = (uint32_t)slots; tiled = true; }
+  }
   WorkDev w{};
-  int rc = alloc_work(e, S, H, T, T, false, &w);
+  int rc = alloc_work(e, S, H, T, T, false, &w, P, tiled);
   if (rc) return rc;
   void* rows_dev = out;
   void* stats_dev = stats;
@@ -564,7 +584,7 @@ int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, cons
   e->tmp_words = tmp.words; e->tmp_offsets = tmp.offsets;
   if (rc) return rc;
   WorkDev w{};
-  rc = alloc_work(e, 1, 1, n_seqs, n_pairs, true, &w);
+  rc = alloc_work(e, 1, 1, n_seqs, n_pairs, true, &w, 1, false);
   if (rc) return rc;
   const hipMemcpyKind kind = mem_kind == RPA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   HIP_TRY(e, hipMemcpyAsync(w.pair_a, pair_a, (size_t)n_pairs * 4, kind, e->stream));
