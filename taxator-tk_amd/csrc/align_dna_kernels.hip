@@ -149,20 +149,49 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
     const uint32_t sh = (uint32_t)(g0 & 7u) * 4u;
     const uint64_t idx = g0 >> 3;  // store word holding that nibble
     // forward needs words (idx, idx+1), then (idx+1, idx+2)...; reverse needs (idx, idx+1), then (idx-1, idx)...
-    uint32_t keep = txt.words[txt.rc ? idx + 1 : idx];  // the word shared with the next step (stores end in slack words)
+    uint32_t keep = txt.words[txt.rc ? idx + 1 : idx];  // the word shared with the next step (stores begin and end in slack words)
     int64_t next_i = (int64_t)(txt.rc ? idx : idx + 1);
-    uint32_t pending = txt.words[next_i];
-    for (uint32_t dw = 0; dw < full; ++dw) {
-      const uint32_t fresh = pending;
-      next_i += dir;
-      if (dw + 1 < full) pending = txt.words[next_i];  // prefetch for the next step
+    auto dword_of = [&](uint32_t fresh) -> uint32_t {  // the next 8 text nucleotides, given the next store word
       const uint32_t hi = txt.rc ? keep : fresh, lo = txt.rc ? fresh : keep;
-      uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
+      const uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
       keep = fresh;
       const uint32_t r = revcomp8(d);
-      d = txt.rc ? r : d;
+      return txt.rc ? r : d;
+    };
+    // full mod 4 single dwords first, then 32 nucleotides (one 16-byte load) per step.  Every lane streams its own text,
+    // 64 different cache lines per wave-level load, and the 16 resident waves of a CU cycle through four times the L1:
+    // a lane's line is gone again by its next load, so each load is an L2 access that moves a whole sector for the few
+    // bytes used.  Fetching 16 bytes at a time quarters those accesses (4-byte loads made the kernel L2-bound for
+    // patterns of <= 5 words and cost ~15 % at 7).
+    const uint32_t singles = full & 3u, chunks = full >> 2;
+#pragma unroll 1
+    for (uint32_t k = 0; k < singles; ++k) {
+      const uint32_t d = dword_of(txt.words[next_i]);
+      next_i += dir;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) column((d >> (4 * k)) & 7u);
+      for (int c = 0; c < 8; ++c) column((d >> (4 * c)) & 7u);
+    }
+    if (chunks) {
+      auto load4 = [&](int64_t i) -> uint4 {  // the four store words the next step consumes, in store order
+        const uint32_t* p4 = txt.words + (txt.rc ? i - 3 : i);
+        return make_uint4(p4[0], p4[1], p4[2], p4[3]);
+      };
+      uint4 pending = load4(next_i);
+      for (uint32_t ch = 0; ch < chunks; ++ch) {
+        const uint4 v = pending;
+        next_i += 4 * dir;
+        if (ch + 1 < chunks) pending = load4(next_i);  // prefetch for the next step
+        const uint32_t w0 = txt.rc ? v.w : v.x, w1 = txt.rc ? v.z : v.y, w2 = txt.rc ? v.y : v.z, w3 = txt.rc ? v.x : v.w;
+        const uint32_t d0 = dword_of(w0), d1 = dword_of(w1), d2 = dword_of(w2), d3 = dword_of(w3);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) column((d0 >> (4 * c)) & 7u);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) column((d1 >> (4 * c)) & 7u);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) column((d2 >> (4 * c)) & 7u);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) column((d3 >> (4 * c)) & 7u);
+      }
     }
   }
   // The score is not tracked per column (the reference adds the horizontal delta of the pattern's last row after every

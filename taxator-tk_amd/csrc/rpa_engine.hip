@@ -43,12 +43,15 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+constexpr size_t kLeadWords = 16, kTailWords = 64;  // slack around the packed residues (16-byte text loads, funnel shifts)
+
 struct Store {
   DevBuf words, offsets;
   uint32_t n_seqs = 0;
   uint64_t n_residues = 0;
   bool loaded = false;
-  StoreDev view() const { return StoreDev{words.as<const uint32_t>(), offsets.as<const uint64_t>(), n_seqs}; }
+  // the packed words sit behind kLeadWords zero words: a reverse-strand reader may fetch a few words below its segment
+  StoreDev view() const { return StoreDev{words.as<const uint32_t>() + kLeadWords, offsets.as<const uint64_t>(), n_seqs}; }
 };
 
 }  // namespace
@@ -414,7 +417,9 @@ static int pack_store(rpa_engine* e, Store* st, uint32_t n_seqs, const uint8_t* 
   }
   const int bits = e->params.alphabet == RPA_DNA ? 4 : 8;
   const uint64_t n_words = (total * bits + 31) / 32;
-  HIP_TRY(e, st->words.ensure((size_t)(n_words + 64) * 4));  // slack: kernels may read a few words past the last residue
+  HIP_TRY(e, st->words.ensure((size_t)(n_words + kLeadWords + kTailWords) * 4));  // slack: kernels may read a few words around a segment
+  HIP_TRY(e, hipMemsetAsync(st->words.p, 0, kLeadWords * 4, e->stream));
+  HIP_TRY(e, hipMemsetAsync(st->words.as<uint32_t>() + kLeadWords + n_words, 0, kTailWords * 4, e->stream));
   const uint8_t* dev_letters = letters;
   if (mem_kind == RPA_MEM_HOST && total) {
     HIP_TRY(e, letters_buf->ensure((size_t)total + 8));
@@ -423,7 +428,7 @@ static int pack_store(rpa_engine* e, Store* st, uint32_t n_seqs, const uint8_t* 
   } else if (total && ((uintptr_t)letters & 7u)) {
     return fail(e, RPA_ERR_INVALID, "device letter buffer must be 8-byte aligned");
   }
-  HIP_TRY(e, launch_pack_letters(e->stream, e->params.alphabet, dev_letters, total, st->words.as<uint32_t>()));
+  HIP_TRY(e, launch_pack_letters(e->stream, e->params.alphabet, dev_letters, total, st->words.as<uint32_t>() + kLeadWords));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   st->n_seqs = n_seqs; st->n_residues = total; st->loaded = true;
   return RPA_OK;
