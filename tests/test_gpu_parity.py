@@ -416,3 +416,39 @@ def test_empty_and_degenerate_batches(pkg):
     three["query_len"] = np.array([10, 10, 10], np.uint32)
     rows, stats = model.predict(three)
     assert list(rows["flags"]) == [1, 1, 1] and list(rows["end"]) == [10, 10, 10] and list(stats["n"]) == [0, 0, 0]
+
+
+def _subset_batch(ds, keep_counts):
+    """The batch of `ds` with only the first keep_counts[s] records of record set s (records are independent)."""
+    b = ds.batch
+    so = b["set_offsets"].astype(np.int64)
+    idx = np.concatenate([np.arange(so[s], so[s] + min(int(k), int(so[s + 1] - so[s]))) for s, k in enumerate(keep_counts)])
+    out = {}
+    for k, v in b.items():
+        if k == "set_offsets":
+            out[k] = np.concatenate([[0], np.cumsum([min(int(c), int(so[s + 1] - so[s])) for s, c in enumerate(keep_counts)])]).astype(np.uint32)
+        elif k in ("query_seq", "query_len"):
+            out[k] = v.copy()
+        else:
+            out[k] = v[idx].copy()
+    return out
+
+
+@pytest.mark.parametrize("layout", [None, "linear"])
+def test_row_layouts_tiled_and_linear(pkg, oracle, synth, layout, monkeypatch):
+    """The hit rows live either tiled (64 record sets side by side, every tile padded to its largest set) or linear.  A
+    batch of evenly sized sets takes the tiled layout; one whose padding would dwarf the rows (a 300-hit set in every
+    tile of 2..5-hit sets) falls back to linear by itself; RPA_ROW_LAYOUT=linear forces it.  Same rows either way."""
+    if layout:
+        monkeypatch.setenv("RPA_ROW_LAYOUT", layout)
+    import copy
+    ds = synth.make_dataset(n_sets=4096, n_hits=300, seg_len=48, branching=3, genome_len=1200, seed=41, variety=True)
+    rng = np.random.default_rng(5)
+    keep = rng.integers(2, 6, ds.n_sets)
+    keep[::64] = 300                      # one big set per tile: 64 x 300 slots per tile against ~500 rows
+    skew = copy.copy(ds)
+    skew.batch = _subset_batch(ds, keep)
+    _engine_vs_oracle(pkg, oracle, synth, skew, 0)
+    even = copy.copy(ds)
+    even.batch = _subset_batch(ds, np.full(ds.n_sets, 7))
+    _engine_vs_oracle(pkg, oracle, synth, even, 0, speculation=(3, 2))
