@@ -16,6 +16,8 @@
 //
 // K2 (pattern 257..16384 nt): ONE ALIGNMENT PER WAVE, words striped over lanes, anti-diagonal (skewed) schedule with
 // the three inter-word carries handed lane to lane by DPP shifts.  See below.
+#include <stdlib.h>
+
 #include "rpa_device.h"
 
 namespace rpa {
@@ -76,12 +78,14 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
   }
   if (prof_acc) profile_add(prof_acc, active, n, m);
 
-  // ---- Peq build (bit planes -> five match masks per 32-residue word) ----
+  // ---- Peq build (bit planes -> five match masks per 32-residue word); the pattern is read 16 bytes per word ----
+  NtStream ps;
+  if (active) ps.init(pat, 0u);
 #pragma unroll
   for (int wi = 0; wi < NW; ++wi) {
     uint32_t A = 0, C = 0, G = 0, T = 0, N = 0;
     if (active && (uint32_t)wi * 32u < m) {
-      const uint4 x = pat.fetch32(wi * 32u);
+      const uint4 x = ps.next32();
       uint32_t p0, p1, pn;
       planes32(x, p0, p1, pn);
       const uint32_t rem = m - wi * 32u;
@@ -129,68 +133,41 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
     (void)HP; (void)HN;
   };
 
-  // Text streaming straight from the resident store.  The n mod 8 leading columns go first (one dword, a short loop
-  // that every lane of the wave runs at the same time), so that the main loop only ever sees full dwords: 8 unrolled
-  // columns per step with no partial-dword branch, and no tail in which a wave executes both the fast and the slow path.
-  // Forward segments walk the store upwards, reverse-strand segments downwards (then nibble-reverse + complement);
-  // either way consecutive dwords share a store word, so each step costs ONE new (L1-resident) dword load, issued one
-  // step ahead of its use, plus a funnel shift.  Both directions run the same instruction stream (selects).
+  // Text streaming straight from the resident store (NtStream, rpa_device.h).  The n mod 8 leading columns go first (a
+  // short loop that every lane of the wave runs at the same time), so that the main loop only ever sees full dwords:
+  // 8 unrolled columns per dword with no partial-dword branch, and no tail in which a wave executes both the fast and
+  // the slow path.  Forward and reverse-strand segments run the same instruction stream (selects, no divergence).
   const uint32_t head = n & 7u, full = n >> 3;
+  NtStream ts;
+  ts.init(txt, 0u);
   if (head) {
-    const uint32_t d = txt.fetch8(0u);
+    const uint32_t d = ts.next8();  // positions 0..7; only the first n mod 8 are consumed here
 #pragma unroll 1
     for (uint32_t k = 0; k < head; ++k) column((d >> (4 * k)) & 7u);
+    if (full) ts.init(txt, head);   // the main loop starts at position n mod 8
   }
   if (full) {
-    const int32_t dir = txt.rc ? -1 : 1;
-    // source nibble index of the first nucleotide of main dword 0: forward src+head; reverse src+8*(full-1) (text
-    // position p is source nibble src+n-1-p, and n-head = 8*full)
-    const uint64_t g0 = txt.rc ? txt.src + 8ull * (full - 1u) : txt.src + head;
-    const uint32_t sh = (uint32_t)(g0 & 7u) * 4u;
-    const uint64_t idx = g0 >> 3;  // store word holding that nibble
-    // forward needs words (idx, idx+1), then (idx+1, idx+2)...; reverse needs (idx, idx+1), then (idx-1, idx)...
-    uint32_t keep = txt.words[txt.rc ? idx + 1 : idx];  // the word shared with the next step (stores begin and end in slack words)
-    int64_t next_i = (int64_t)(txt.rc ? idx : idx + 1);
-    auto dword_of = [&](uint32_t fresh) -> uint32_t {  // the next 8 text nucleotides, given the next store word
-      const uint32_t hi = txt.rc ? keep : fresh, lo = txt.rc ? fresh : keep;
-      const uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
-      keep = fresh;
-      const uint32_t r = revcomp8(d);
-      return txt.rc ? r : d;
-    };
-    // full mod 4 single dwords first, then 32 nucleotides (one 16-byte load) per step.  Every lane streams its own text,
-    // 64 different cache lines per wave-level load, and the 16 resident waves of a CU cycle through four times the L1:
-    // a lane's line is gone again by its next load, so each load is an L2 access that moves a whole sector for the few
-    // bytes used.  Fetching 16 bytes at a time quarters those accesses (4-byte loads made the kernel L2-bound for
-    // patterns of <= 5 words and cost ~15 % at 7).
+    // full mod 4 single dwords first, then 32 nucleotides (one 16-byte load, issued a step ahead) per step
     const uint32_t singles = full & 3u, chunks = full >> 2;
 #pragma unroll 1
     for (uint32_t k = 0; k < singles; ++k) {
-      const uint32_t d = dword_of(txt.words[next_i]);
-      next_i += dir;
+      const uint32_t d = ts.next8();
 #pragma unroll
       for (int c = 0; c < 8; ++c) column((d >> (4 * c)) & 7u);
     }
     if (chunks) {
-      auto load4 = [&](int64_t i) -> uint4 {  // the four store words the next step consumes, in store order
-        const uint32_t* p4 = txt.words + (txt.rc ? i - 3 : i);
-        return make_uint4(p4[0], p4[1], p4[2], p4[3]);
-      };
-      uint4 pending = load4(next_i);
+      uint4 pending = ts.load4();
       for (uint32_t ch = 0; ch < chunks; ++ch) {
-        const uint4 v = pending;
-        next_i += 4 * dir;
-        if (ch + 1 < chunks) pending = load4(next_i);  // prefetch for the next step
-        const uint32_t w0 = txt.rc ? v.w : v.x, w1 = txt.rc ? v.z : v.y, w2 = txt.rc ? v.y : v.z, w3 = txt.rc ? v.x : v.w;
-        const uint32_t d0 = dword_of(w0), d1 = dword_of(w1), d2 = dword_of(w2), d3 = dword_of(w3);
+        const uint4 d = ts.take32(pending);
+        if (ch + 1 < chunks) pending = ts.load4();  // prefetch for the next step
 #pragma unroll
-        for (int c = 0; c < 8; ++c) column((d0 >> (4 * c)) & 7u);
+        for (int c = 0; c < 8; ++c) column((d.x >> (4 * c)) & 7u);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) column((d1 >> (4 * c)) & 7u);
+        for (int c = 0; c < 8; ++c) column((d.y >> (4 * c)) & 7u);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) column((d2 >> (4 * c)) & 7u);
+        for (int c = 0; c < 8; ++c) column((d.z >> (4 * c)) & 7u);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) column((d3 >> (4 * c)) & 7u);
+        for (int c = 0; c < 8; ++c) column((d.w >> (4 * c)) & 7u);
       }
     }
   }
@@ -215,7 +192,9 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
   if ((uint64_t)n + n2 == 0) return hipSuccess;
   if ((uint64_t)n + n2 > 0xFFFFFF00ull) return hipErrorInvalidValue;
   const uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
-  const size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
+  size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
+  static const size_t lds_pad = getenv("RPA_LDS_PAD") ? (size_t)atoi(getenv("RPA_LDS_PAD")) : 0;  // occupancy experiments only
+  lds += lds_pad;
 #define RPA_LAUNCH_MYERS(NWV) \
   case NWV: hipLaunchKernelGGL(k_myers_short<NWV>, dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, prof_acc); break;
   switch (words) {

@@ -290,6 +290,54 @@ struct SegView {  // a segment as the kernels read it
   __device__ __forceinline__ uint32_t byte_at(uint32_t p) const { return reinterpret_cast<const uint8_t*>(words)[src + p]; }
 };
 
+// A segment read front to back, 8 or 32 nucleotides per step, in SEGMENT order (reverse-strand segments come out
+// reversed and complemented).  Consecutive steps share a store word, so a step costs one new 4-byte or one 16-byte load
+// plus funnel shifts.  Why 16 bytes where possible: every lane streams its own sequence, i.e. 64 different cache lines
+// per wave-level load; with 16 resident waves per CU a lane's line has left the 32 KB L1 again before the lane's next
+// load, so each load is an L2 access that moves a whole sector for the few bytes used.  Reads run up to 4 store words
+// past either end of the segment: stores carry zeroed slack words in front and behind.
+struct NtStream {
+  const uint32_t* words;
+  int64_t next_i;   // store word the next step consumes first
+  uint32_t keep;    // the word shared with the previous step
+  uint32_t sh;      // funnel shift in bits
+  int32_t dir;      // +1 forward, -1 reverse strand
+  bool rc;
+  // start at segment position `first` (text position p of a reverse segment is store nibble src+len-1-p)
+  __device__ __forceinline__ void init(const SegView& v, uint32_t first) {
+    words = v.words; rc = v.rc; dir = v.rc ? -1 : 1;
+    const int64_t g0 = v.rc ? (int64_t)(v.src + v.len) - 8 - (int64_t)first : (int64_t)(v.src + first);
+    sh = (uint32_t)(g0 & 7) * 4u;
+    const int64_t idx = g0 >> 3;  // floor: may be -1 at the very start of the store
+    keep = words[v.rc ? idx + 1 : idx];
+    next_i = v.rc ? idx : idx + 1;
+  }
+  __device__ __forceinline__ uint32_t dword_of(uint32_t fresh) {
+    const uint32_t hi = rc ? keep : fresh, lo = rc ? fresh : keep;
+    const uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
+    keep = fresh;
+    const uint32_t r = revcomp8(d);
+    return rc ? r : d;
+  }
+  __device__ __forceinline__ uint32_t next8() {  // one 4-byte load
+    const uint32_t fresh = words[next_i];
+    next_i += dir;
+    return dword_of(fresh);
+  }
+  __device__ __forceinline__ uint4 load4() const {  // the four store words the next next32 consumes, in store order
+    const uint32_t* p4 = words + (rc ? next_i - 3 : next_i);
+    return make_uint4(p4[0], p4[1], p4[2], p4[3]);
+  }
+  __device__ __forceinline__ uint4 take32(const uint4 v) {  // v = load4() of this position (possibly issued a step ahead)
+    next_i += 4 * dir;
+    const uint32_t w0 = rc ? v.w : v.x, w1 = rc ? v.z : v.y, w2 = rc ? v.y : v.z, w3 = rc ? v.x : v.w;
+    uint4 o;
+    o.x = dword_of(w0); o.y = dword_of(w1); o.z = dword_of(w2); o.w = dword_of(w3);
+    return o;
+  }
+  __device__ __forceinline__ uint4 next32() { return take32(load4()); }
+};
+
 __device__ __forceinline__ SegView seg_view(const WorkDev& w, uint32_t seg) {
   const uint4 d = reinterpret_cast<const uint4*>(w.seg)[seg];
   SegView v;
