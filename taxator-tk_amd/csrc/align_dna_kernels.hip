@@ -242,23 +242,20 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
   const uint32_t nstrips = (words + NW - 1u) / NW;
   uint32_t* __restrict__ sc = scratch + t;  // message dword g (columns 4g .. 4g+3) at sc[g * stride]
   const uint32_t n_dwords = (n + 7u) >> 3;
-  const int32_t dir = txt.rc ? -1 : 1;
-  const int64_t g0 = txt.rc ? (int64_t)(txt.src + n) - 8 : (int64_t)txt.src;
-  const uint32_t sh = (uint32_t)(g0 & 7) * 4u;
-  const int64_t idx0 = g0 >> 3;
-  auto load_word = [&](int64_t i) -> uint32_t { return i >= 0 ? txt.words[i] : 0u; };
 
   uint32_t VP[NW], VN[NW];
   int32_t bottom = 0;
   for (uint32_t s = 0; s < nstrips; ++s) {
     const bool first = s == 0, last = s + 1u == nstrips;
     const uint32_t wbase = s * NW;
+    NtStream ps;  // the strip's part of the pattern, 16 bytes per word (NtStream, rpa_device.h)
+    ps.init(pat, wbase * 32u);
 #pragma unroll
     for (int wi = 0; wi < NW; ++wi) {
       uint32_t A = 0, C = 0, G = 0, T = 0, N = 0;
       const uint32_t pos = (wbase + wi) * 32u;
       if (pos < m) {
-        const uint4 x = pat.fetch32(pos);
+        const uint4 x = ps.next32();
         uint32_t p0, p1, pn;
         planes32(x, p0, p1, pn);
         const uint32_t rem = m - pos;
@@ -305,28 +302,28 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
       return carry | (hp << 1) | (hn << 2);
     };
 
-    int64_t next_i = txt.rc ? idx0 : idx0 + 1;
-    uint32_t keep = load_word(txt.rc ? idx0 + 1 : idx0);
-    uint32_t pending = load_word(next_i);
+    // the text: 32 nucleotides (one 16-byte load, issued four dwords ahead) per four steps
+    NtStream ts;
+    ts.init(txt, 0u);
+    uint4 pending = ts.load4();
+    uint4 buf = make_uint4(0u, 0u, 0u, 0u);
     // row 0 of the matrix: +1 enters every column (HP carry 1), no add carry, no HN
     uint32_t min0 = 0x02020202u, min1 = 0x02020202u;
     if (!first) { min0 = sc[0]; if (n > 4u) min1 = sc[stride]; }
     for (uint32_t dw = 0; dw < n_dwords; ++dw) {
-      const uint32_t fresh = pending;
-      next_i += dir;
+      if ((dw & 3u) == 0u) {
+        buf = ts.take32(pending);
+        if (dw + 4 < n_dwords) pending = ts.load4();
+      }
       const uint32_t in0 = min0, in1 = min1;
       if (dw + 1 < n_dwords) {
-        pending = load_word(next_i);
         if (!first) {  // boundary messages of the next 8 columns
           min0 = sc[(size_t)(2u * dw + 2u) * stride];
           if (n > (dw + 1u) * 8u + 4u) min1 = sc[(size_t)(2u * dw + 3u) * stride];
         }
       }
-      const uint32_t hi = txt.rc ? keep : fresh, lo = txt.rc ? fresh : keep;
-      uint32_t d = __builtin_amdgcn_alignbit(hi, lo, sh);
-      keep = fresh;
-      const uint32_t r = revcomp8(d);
-      d = txt.rc ? r : d;
+      const uint32_t q4 = dw & 3u;
+      const uint32_t d = q4 == 0u ? buf.x : q4 == 1u ? buf.y : q4 == 2u ? buf.z : buf.w;
       const uint32_t cols = n - dw * 8u;
       uint32_t out0 = 0, out1 = 0;
       if (cols >= 8u) {
