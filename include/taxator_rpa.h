@@ -140,6 +140,29 @@ typedef struct {
  * says.  Results are in input order.  Synchronous: returns when the rows are written. */
 int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind);
 
+/* The reference's alignment-free models behind the same seam (taxator -a dummy | simple-lca | megan-lca | n-best-lca,
+ * core/taxator.cpp:346-361): DummyPredictionModel, LCASimplePredictionModel, MeganLCAPredictionModel,
+ * NBestLCAPredictionModel (core/src/taxonpredictionmodel.hh:57-253) with the filters they run
+ * (core/src/alignmentsfilter.hh:349-386,493-532,612-626).  The batch is the same rpa_batch (rstart/rstop/identities/
+ * alnlen/ref_seq/query_seq are not read and may be NULL); `evalue` (n_records, getEValue(), may be NULL = 0) and
+ * `node_unclassified` (n_nodes, Taxon::is_unclassified, core/src/ncbidata.cpp:119-126; may be NULL) live where
+ * batch->mem_kind says.  No sequence store is needed.  Rows: lower == upper == the predicted node, support = width of
+ * the query range, ival = -1 with RPA_FLAG_IVAL_UNTOUCHED (these models never set it). */
+enum { RPA_LCA_DUMMY = 0, RPA_LCA_SIMPLE = 1, RPA_LCA_MEGAN = 2, RPA_LCA_NBEST = 3 };
+typedef struct {
+  int model;               /* RPA_LCA_* */
+  float toppercent;        /* -t, default 0.05 (taxator.cpp:287) */
+  float minscore;          /* -m, default 0 */
+  double maxevalue;        /* -e, default 1000 (narrowed to float by the reference's filter, alignmentsfilter.hh:351) */
+  uint32_t minsupport;     /* -c, default 1 */
+  uint32_t nbest;          /* -n, default 1 */
+  int ignore_unclassified; /* -u */
+  uint32_t reserved;       /* must be zero */
+} rpa_lca_params;
+void rpa_lca_default_params(rpa_lca_params* p);
+int rpa_lca_predict_batch(rpa_engine* e, const rpa_batch* batch, const double* evalue, const uint8_t* node_unclassified,
+                          const rpa_lca_params* params, rpa_prediction* out, int out_mem_kind);
+
 /* Pair-level entry: getAlignment<StringType>(A, B) (taxonpredictionmodelsequence.hh:133-171 DNA, :173-242 protein)
  * for explicit pairs of sequences of a store-shaped arena (letters/offsets as in rpa_store_load; not kept).
  * Used by the parity tests and the kernel benchmark; same kernels as rpa_predict_batch. */

@@ -117,6 +117,23 @@ int orc_predict_batch(const orc_taxonomy* tax, const orc_store* qstore, const or
                       const uint32_t* query_seq, const uint32_t* query_len, const orc_record* recs,
                       orc_prediction* out, orc_stats* stats);
 
+/* ---- alignment-free models (lca_oracle.c; PARITY UNPINNED, see there) ---- */
+enum { ORC_LCA_DUMMY = 0, ORC_LCA_SIMPLE = 1, ORC_LCA_MEGAN = 2, ORC_LCA_NBEST = 3 }; /* taxator -a dummy|simple-lca|megan-lca|n-best-lca */
+typedef struct {
+  int model;
+  float toppercent;  /* -t */
+  float minscore;    /* -m */
+  double maxevalue;  /* -e */
+  uint32_t minsupport; /* -c */
+  uint32_t nbest;      /* -n */
+  int ignore_unclassified; /* -u */
+} orc_lca_params;
+int orc_lca_predict(const orc_taxonomy* tax, const orc_lca_params* p, uint32_t query_len, const orc_record* recs,
+                    const double* evalue, const uint8_t* node_unclassified, uint32_t n, orc_prediction* out);
+int orc_lca_predict_batch(const orc_taxonomy* tax, const orc_lca_params* p, uint32_t n_sets, const uint32_t* set_offsets,
+                          const uint32_t* query_len, const orc_record* recs, const double* evalue,
+                          const uint8_t* node_unclassified, orc_prediction* out);
+
 #ifdef __cplusplus
 }
 #endif

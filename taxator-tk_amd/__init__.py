@@ -32,7 +32,9 @@ ERROR_NAMES = {0: "OK", 1: "INVALID", 2: "DEVICE", 3: "RANGE", 4: "SEQ_ID", 5: "
 # every symbol include/taxator_rpa.h declares (checked by the CPU-side ABI test)
 ABI_SYMBOLS = ["rpa_abi_version", "rpa_default_params", "rpa_create", "rpa_destroy", "rpa_last_error", "rpa_set_stream",
                "rpa_store_load", "rpa_predict_batch", "rpa_align_pairs", "rpa_profile_enable", "rpa_profile_get",
-               "rpa_profile_reset"]
+               "rpa_profile_reset", "rpa_lca_default_params", "rpa_lca_predict_batch"]
+
+LCA_DUMMY, LCA_SIMPLE, LCA_MEGAN, LCA_NBEST = 0, 1, 2, 3  # taxator -a dummy | simple-lca | megan-lca | n-best-lca
 
 
 class RpaError(RuntimeError):
@@ -57,6 +59,11 @@ class _Batch(C.Structure):
                 ("query_len", C.c_void_p), ("qstart", C.c_void_p), ("qstop", C.c_void_p), ("rstart", C.c_void_p),
                 ("rstop", C.c_void_p), ("score", C.c_void_p), ("identities", C.c_void_p), ("alnlen", C.c_void_p),
                 ("ref_seq", C.c_void_p), ("node", C.c_void_p), ("filtered", C.c_void_p), ("mem_kind", C.c_int)]
+
+
+class _LcaParams(C.Structure):
+    _fields_ = [("model", C.c_int), ("toppercent", C.c_float), ("minscore", C.c_float), ("maxevalue", C.c_double),
+                ("minsupport", C.c_uint32), ("nbest", C.c_uint32), ("ignore_unclassified", C.c_int), ("reserved", C.c_uint32)]
 
 
 class _Profile(C.Structure):
@@ -101,6 +108,10 @@ def load_library(path=None):
     L.rpa_align_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int]
     L.rpa_align_pairs.restype = C.c_int
+    L.rpa_lca_default_params.argtypes = [C.POINTER(_LcaParams)]
+    L.rpa_lca_default_params.restype = None
+    L.rpa_lca_predict_batch.argtypes = [C.c_void_p, C.POINTER(_Batch), C.c_void_p, C.c_void_p, C.POINTER(_LcaParams), C.c_void_p, C.c_int]
+    L.rpa_lca_predict_batch.restype = C.c_int
     L.rpa_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.rpa_profile_enable.restype = C.c_int
     L.rpa_profile_get.argtypes = [C.c_void_p, C.POINTER(_Profile)]
@@ -205,6 +216,32 @@ class RPAPredictionModel:
             return rows, st
         self._check(self._L.rpa_predict_batch(self._h, C.byref(b), _ptr(out), _ptr(stats), MEM_DEVICE))
         return out, stats
+
+    def lca_predict(self, batch, model, evalue=None, node_unclassified=None, toppercent=None, minscore=None, maxevalue=None,
+                    minsupport=None, nbest=None, ignore_unclassified=False):
+        """The reference's alignment-free models (taxator -a dummy|simple-lca|megan-lca|n-best-lca) on the device, for a
+        host batch (numpy arrays; only set_offsets, query_len, qstart, qstop, score, node, filtered are read)."""
+        need = {"set_offsets": np.uint32, "query_len": np.uint32, "qstart": np.uint32, "qstop": np.uint32, "score": np.float32,
+                "node": np.uint32}
+        arrs = {k: np.ascontiguousarray(batch[k], dt) for k, dt in need.items()}
+        filt = batch.get("filtered")
+        filt = None if filt is None else np.ascontiguousarray(filt, np.uint8)
+        ev = None if evalue is None else np.ascontiguousarray(evalue, np.float64)
+        un = None if node_unclassified is None else np.ascontiguousarray(node_unclassified, np.uint8)
+        n_sets, n_rec = len(arrs["set_offsets"]) - 1, len(arrs["qstart"])
+        ptrs = [_ptr(arrs[name]) if name in arrs else None for name, _ in BATCH_FIELDS]
+        b = _Batch(n_sets, n_rec, *ptrs, _ptr(filt), MEM_HOST)
+        p = _LcaParams()
+        self._L.rpa_lca_default_params(C.byref(p))
+        p.model = model
+        for name, v in (("toppercent", toppercent), ("minscore", minscore), ("maxevalue", maxevalue), ("minsupport", minsupport),
+                        ("nbest", nbest)):
+            if v is not None:
+                setattr(p, name, v)
+        p.ignore_unclassified = 1 if ignore_unclassified else 0
+        rows = np.zeros(n_sets, PRED_DTYPE)
+        self._check(self._L.rpa_lca_predict_batch(self._h, C.byref(b), _ptr(ev), _ptr(un), C.byref(p), rows.ctypes.data, MEM_HOST))
+        return rows
 
     def align_pairs(self, letters, offsets, pair_a, pair_b):
         """getAlignment(A, B) for explicit pairs of the sequences in (letters, offsets).  Host arrays in, numpy out."""

@@ -210,6 +210,16 @@ hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, cons
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc);
 
+// alignment-free models (lca_kernels.hip): model 0 dummy, 1 simple-lca, 2 megan-lca, 3 n-best-lca
+struct LcaParamsDev {
+  int model;
+  float toppercent, minscore, maxevalue;  // floats in the reference's filter (alignmentsfilter.hh:351)
+  uint32_t minsupport, nbest;
+  int ignore_unclassified;
+};
+hipError_t launch_lca_models(hipStream_t st, const BatchDev& b, const TaxDev& tax, const LcaParamsDev& p, const double* evalue,
+                             const uint8_t* unclassified, void* rows);
+
 // pair-level entry (rpa_align_pairs): segments straight from an arena-shaped store, explicit pair list
 hipError_t launch_plan_plain_segments(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& store);
 hipError_t launch_bin_pairs(hipStream_t st, int alphabet, const WorkDev& w, uint32_t n_pairs);

@@ -65,7 +65,7 @@ struct rpa_engine {
   Store stores[2];
   std::string err;
   // batch staging (host batches) and working set
-  DevBuf in_u32[11], in_f32, in_u8;
+  DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
   DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
       tmp_words, tmp_offsets, protein_ws;
@@ -376,7 +376,7 @@ void rpa_destroy(rpa_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->state, &e->hits,
+  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
@@ -615,6 +615,79 @@ int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, cons
   if (mem_kind == RPA_MEM_HOST) HIP_TRY(e, hipMemcpyAsync(out, out_dev, (size_t)n_pairs * sizeof(rpa_alignment), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return profile_end(e);
+}
+
+void rpa_lca_default_params(rpa_lca_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->model = RPA_LCA_SIMPLE;
+  p->toppercent = 0.05f;   // taxator.cpp:287
+  p->minscore = 0.f;       // :290
+  p->maxevalue = 1000.0;   // :288
+  p->minsupport = 1;       // :289
+  p->nbest = 1;            // :291
+}
+
+int rpa_lca_predict_batch(rpa_engine* e, const rpa_batch* batch, const double* evalue, const uint8_t* node_unclassified,
+                          const rpa_lca_params* params, rpa_prediction* out, int out_mem_kind) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!batch || !params || !out) return fail(e, RPA_ERR_INVALID, "rpa_lca_predict_batch: null argument");
+  if (params->model < RPA_LCA_DUMMY || params->model > RPA_LCA_NBEST) return fail(e, RPA_ERR_INVALID, "rpa_lca_predict_batch: unknown model %d", params->model);
+  const uint32_t S = batch->n_sets, H = batch->n_records;
+  if (S == 0) return RPA_OK;
+  if (!batch->set_offsets || !batch->query_len || (H && (!batch->qstart || !batch->qstop || !batch->score || !batch->node)))
+    return fail(e, RPA_ERR_INVALID, "rpa_lca_predict_batch: null array in batch");
+  if (out_mem_kind != RPA_MEM_HOST && out_mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_lca_predict_batch: bad out_mem_kind");
+  HIP_TRY(e, hipSetDevice(e->device));
+  BatchDev b{};
+  b.n_sets = S; b.n_records = H;
+  const double* ev = evalue;
+  const uint8_t* uncl = node_unclassified;
+  if (batch->mem_kind == RPA_MEM_HOST) {
+    if (batch->set_offsets[0] != 0 || batch->set_offsets[S] != H) return fail(e, RPA_ERR_INVALID, "set_offsets must run from 0 to n_records");
+    for (uint32_t r = 0; r < H; ++r)
+      if (batch->node[r] >= e->tax.n_nodes) return fail(e, RPA_ERR_INVALID, "record %u: taxonomy node index out of range", r);
+    // staging slots shared with rpa_predict_batch: 0 set_offsets, 2 query_len, 3 qstart, 4 qstop, 10 node
+    const void* src[5] = {batch->set_offsets, batch->query_len, batch->qstart, batch->qstop, batch->node};
+    const int slot[5] = {0, 2, 3, 4, 10};
+    const size_t cnt[5] = {(size_t)S + 1, S, H, H, H};
+    for (int k = 0; k < 5; ++k) {
+      HIP_TRY(e, e->in_u32[slot[k]].ensure((cnt[k] ? cnt[k] : 1) * 4));
+      if (cnt[k]) HIP_TRY(e, hipMemcpyAsync(e->in_u32[slot[k]].p, src[k], cnt[k] * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    HIP_TRY(e, e->in_f32.ensure((size_t)(H ? H : 1) * 4));
+    if (H) HIP_TRY(e, hipMemcpyAsync(e->in_f32.p, batch->score, (size_t)H * 4, hipMemcpyHostToDevice, e->stream));
+    if (batch->filtered) {
+      HIP_TRY(e, e->in_u8.ensure(H ? H : 1));
+      if (H) HIP_TRY(e, hipMemcpyAsync(e->in_u8.p, batch->filtered, H, hipMemcpyHostToDevice, e->stream));
+    }
+    if (evalue) {
+      HIP_TRY(e, e->in_f64.ensure((size_t)(H ? H : 1) * 8));
+      if (H) HIP_TRY(e, hipMemcpyAsync(e->in_f64.p, evalue, (size_t)H * 8, hipMemcpyHostToDevice, e->stream));
+      ev = e->in_f64.as<const double>();
+    }
+    if (node_unclassified) {
+      HIP_TRY(e, e->in_uncl.ensure(e->tax.n_nodes));
+      HIP_TRY(e, hipMemcpyAsync(e->in_uncl.p, node_unclassified, e->tax.n_nodes, hipMemcpyHostToDevice, e->stream));
+      uncl = e->in_uncl.as<const uint8_t>();
+    }
+    b.set_offsets = e->in_u32[0].as<uint32_t>(); b.query_len = e->in_u32[2].as<uint32_t>();
+    b.qstart = e->in_u32[3].as<uint32_t>(); b.qstop = e->in_u32[4].as<uint32_t>(); b.node = e->in_u32[10].as<uint32_t>();
+    b.score = e->in_f32.as<float>();
+    b.filtered = batch->filtered ? e->in_u8.as<uint8_t>() : nullptr;
+  } else if (batch->mem_kind == RPA_MEM_DEVICE) {
+    b.set_offsets = batch->set_offsets; b.query_len = batch->query_len; b.qstart = batch->qstart; b.qstop = batch->qstop;
+    b.score = batch->score; b.node = batch->node; b.filtered = batch->filtered;
+  } else return fail(e, RPA_ERR_INVALID, "rpa_lca_predict_batch: bad mem_kind");
+  void* rows_dev = out;
+  if (out_mem_kind == RPA_MEM_HOST) { HIP_TRY(e, e->out_rows.ensure((size_t)S * sizeof(rpa_prediction))); rows_dev = e->out_rows.p; }
+  const LcaParamsDev p{params->model, params->toppercent, params->minscore, (float)params->maxevalue, params->minsupport, params->nbest,
+                       params->ignore_unclassified};
+  HIP_TRY(e, launch_lca_models(e->stream, b, e->tax, p, ev, uncl, rows_dev));
+  if (out_mem_kind == RPA_MEM_HOST) HIP_TRY(e, hipMemcpyAsync(out, rows_dev, (size_t)S * sizeof(rpa_prediction), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return RPA_OK;
 }
 
 int rpa_profile_enable(rpa_engine* e, int on) {

@@ -31,6 +31,13 @@ class Record(C.Structure):
                 ("node", C.c_uint32), ("filtered", C.c_uint32)]
 
 
+class LcaParams(C.Structure):  # orc_lca_params
+    _fields_ = [("model", C.c_int), ("toppercent", C.c_float), ("minscore", C.c_float), ("maxevalue", C.c_double),
+                ("minsupport", C.c_uint32), ("nbest", C.c_uint32), ("ignore_unclassified", C.c_int)]
+
+
+LCA_DUMMY, LCA_SIMPLE, LCA_MEGAN, LCA_NBEST = 0, 1, 2, 3
+
 RECORD_DTYPE = np.dtype([("qstart", "<u4"), ("qstop", "<u4"), ("rstart", "<u4"), ("rstop", "<u4"), ("score", "<f4"),
                          ("identities", "<u4"), ("alnlen", "<u4"), ("ref_seq", "<u4"), ("node", "<u4"),
                          ("filtered", "<u4")])
@@ -90,6 +97,9 @@ def lib():
         L.orc_predict_batch.argtypes = [C.POINTER(Taxonomy), C.POINTER(Store), C.POINTER(Store), C.c_int, C.c_float,
                                         C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
+        L.orc_lca_predict_batch.restype = C.c_int
+        L.orc_lca_predict_batch.argtypes = [C.POINTER(Taxonomy), C.POINTER(LcaParams), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -224,3 +234,19 @@ def predict_batch(tax, qstore, dbstore, alphabet, set_offsets, query_seq, query_
                                  reeval_bandwidth, n, _p(set_offsets), _p(query_seq), _p(query_len), _p(recs), _p(out),
                                  _p(st))
     return rc, out, st
+
+
+def lca_predict_batch(tax, model, set_offsets, query_len, recs, evalue=None, node_unclassified=None, toppercent=0.05, minscore=0.0,
+                      maxevalue=1000.0, minsupport=1, nbest=1, ignore_unclassified=False):
+    """The alignment-free models of the reference (oracle/lca_oracle.c) over a batch; returns (rc, rows)."""
+    set_offsets = np.ascontiguousarray(set_offsets, np.uint32)
+    query_len = np.ascontiguousarray(query_len, np.uint32)
+    recs = np.ascontiguousarray(recs, RECORD_DTYPE)
+    ev = None if evalue is None else np.ascontiguousarray(evalue, np.float64)
+    un = None if node_unclassified is None else np.ascontiguousarray(node_unclassified, np.uint8)
+    n = len(set_offsets) - 1
+    out = np.zeros(n, PRED_DTYPE)
+    p = LcaParams(model, toppercent, minscore, maxevalue, minsupport, nbest, 1 if ignore_unclassified else 0)
+    rc = lib().orc_lca_predict_batch(C.byref(tax.c), C.byref(p), n, _p(set_offsets), _p(query_len), _p(recs),
+                                     None if ev is None else _p(ev), None if un is None else _p(un), _p(out))
+    return rc, out
