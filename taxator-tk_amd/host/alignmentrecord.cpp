@@ -61,7 +61,7 @@ void AlignmentRecordFactory::parse(const std::string& line_in, AlignmentRecordTa
   catch (Exception& e) { throw TaxonMappingNotFound(std::string(e.what()) + " (bad taxon mapping for alignment reference sequence)"); }
   try { rec.reference_node = tax_->getNode(taxid); }
   catch (Exception& e) { throw TaxonNotFound(std::string(e.what()) + " (bad alignment reference taxon)"); }
-  rec.reference_seq = db_->getIndex(rec.reference_identifier);
+  rec.reference_seq = db_ ? db_->getIndex(rec.reference_identifier) : 0u;  // no sequence store with the alignment-free models
 }
 
 RecordSetGenerator::RecordSetGenerator(std::istream& in, const AlignmentRecordFactory& fac, bool split_alignments)

@@ -1,8 +1,9 @@
 // taxator-tk_amd/host/taxator.cpp -- `taxator` driver for the MI355X RPA engine.
 // Mirrors core/taxator.cpp: same option names/defaults (:267-294), taxonomy from $TAXATORTK_TAXONOMY_NCBI pruned to the
 // given ranks (:337-340), seqid->taxid mapping (:342), alignments streamed from stdin, GFF3 to stdout in input order
-// (doPredictionsSerial, :50-77), errors to stderr + EXIT_FAILURE (:381-386).  Only `-a rpa` exists here (the LCA-only
-// models are out of scope); -p sets the number of HOST threads that parse the input and format the output
+// (doPredictionsSerial, :50-77), errors to stderr + EXIT_FAILURE (:381-386).  -a rpa (default) and the alignment-free
+// models dummy | simple-lca | megan-lca | ic-megan-lca | n-best-lca with their options -e -c -m -n -u (:346-361; these
+// need no FASTA files and run through the per-record object loop); -p sets the number of HOST threads that parse the input and format the output
 // (0 or absent = all); -i/-v index files are accepted and ignored (the stores are resident in HBM, no on-disk index is
 // needed); new: --device, --batch, --block-mb, --timing, --record-objects.
 //
@@ -45,7 +46,10 @@ struct Options {
   std::string algorithm = "rpa", mapping, query, query_index, db, db_index, logfile = "/dev/null", dataformat = "nucleotide";
   std::vector<std::string> ranks;
   bool split_alignments = true, alignments_sorted = false, delete_unmarked = true;
-  float filterout = 0.5f, toppercent = 0.05f;
+  float filterout = 0.5f, toppercent = 0.05f, minscore = 0.0f;
+  double maxevalue = 1000.0;
+  unsigned minsupport = 1, nbest = 1;
+  bool ignore_unclassified = false;
   unsigned processors = 0;
   bool record_objects = false;
   double block_mb = 128;
@@ -58,7 +62,7 @@ static void usage(std::ostream& o) {
   o << "Allowed options:\n"
        "  -h [ --help ]                      show help message\n"
        "  -V [ --version ]                   show program version\n"
-       "  -a [ --algorithm ] arg (=rpa)      prediction algorithm (only rpa in this build)\n"
+       "  -a [ --algorithm ] arg (=rpa)      rpa | dummy | simple-lca | megan-lca | ic-megan-lca | n-best-lca\n"
        "  -g [ --seqid-taxid-mapping ] arg   filename of seqid->taxid mapping for reference\n"
        "  -q [ --query-sequences ] arg       query sequences FASTA\n"
        "  -v [ --query-sequences-index ] arg accepted, unused (store is resident in HBM)\n"
@@ -68,7 +72,8 @@ static void usage(std::ostream& o) {
        "  -l [ --logfile ] arg (=/dev/null)  per record set STATS lines are appended here\n"
        "  -b [ --dataformat ] arg (=nucleotide)  nucleotide | protein\n"
        "  advanced: -r ranks..., -s split-alignments (=1), -o alignments-sorted (=0), -d delete-notranks (=1),\n"
-       "            -x heuristic-cutoff (=0.5), -t toppercent (=0.05), --device N (=0), --batch N (record sets per GPU call),\n"
+       "            -x heuristic-cutoff (=0.5), -t toppercent (=0.05), -e max-evalue (=1000), -c min-support (=1), -m minscore (=0),\n"
+       "            -n nbest (=1), -u ignore-unclassified, --device N (=0), --batch N (record sets per GPU call),\n"
        "            --block-mb N (=128, input block parsed at a time), --timing, --record-objects (per-record object loop)\n";
 }
 
@@ -212,6 +217,11 @@ int main(int argc, char** argv) {
     else if (a == "-d" || a == "--delete-notranks") o.delete_unmarked = parse_bool(val("--delete-notranks"));
     else if (a == "-x" || a == "--heuristic-cutoff") o.filterout = (float)atof(val("--heuristic-cutoff").c_str());
     else if (a == "-t" || a == "--toppercent") o.toppercent = (float)atof(val("--toppercent").c_str());
+    else if (a == "-e" || a == "--max-evalue") o.maxevalue = atof(val("--max-evalue").c_str());
+    else if (a == "-c" || a == "--min-support") o.minsupport = (unsigned)atoi(val("--min-support").c_str());
+    else if (a == "-m" || a == "--minscore") o.minscore = (float)atof(val("--minscore").c_str());
+    else if (a == "-n" || a == "--nbest") o.nbest = (unsigned)atoi(val("--nbest").c_str());
+    else if (a == "-u" || a == "--ignore-unclassified") o.ignore_unclassified = true;
     else if (a == "--device") o.device = atoi(val("--device").c_str());
     else if (a == "--timing") o.timing = true;
     else if (a == "--record-objects") o.record_objects = true;
@@ -226,8 +236,10 @@ int main(int argc, char** argv) {
     usage(std::cout);
     return EXIT_FAILURE;
   }
-  if (o.algorithm != "rpa") {
-    std::cout << "classification algorithm can only be rpa in this build (the LCA-only models are not part of the accelerated path)" << std::endl;
+  const bool alignment_free = o.algorithm == "dummy" || o.algorithm == "simple-lca" || o.algorithm == "megan-lca" ||
+                              o.algorithm == "ic-megan-lca" || o.algorithm == "n-best-lca";
+  if (o.algorithm != "rpa" && !alignment_free) {
+    std::cout << "classification algorithm can either be: rpa (default), simple-lca, megan-lca, ic-megan-lca, n-best-lca" << std::endl;  // :376
     return EXIT_FAILURE;
   }
   if (o.dataformat != "nucleotide" && o.dataformat != "protein") {
@@ -242,6 +254,29 @@ int main(int argc, char** argv) {
   try {
     std::unique_ptr<StrIDConverter> seqid2taxid(loadStrIDConverterFromFile(o.mapping, 1000));
     std::ofstream logsink(o.logfile.c_str(), std::ios_base::app);
+    if (alignment_free) {  // taxator.cpp:346-361; doPredictionsSerial (:50-77) in batches
+      std::unique_ptr<TaxonPredictionModel> model;
+      if (o.algorithm == "dummy") model.reset(new DummyPredictionModel(tax.get(), o.device));
+      else if (o.algorithm == "simple-lca") model.reset(new LCASimplePredictionModel(tax.get(), o.device));
+      else if (o.algorithm == "n-best-lca") model.reset(new NBestLCAPredictionModel(tax.get(), (int)o.nbest, o.device));
+      else model.reset(new MeganLCAPredictionModel(tax.get(), o.ignore_unclassified, o.toppercent, o.minscore, (int)o.minsupport, o.maxevalue, o.device));
+      AlignmentRecordFactory fac(*seqid2taxid, tax.get(), nullptr);
+      RecordSetGenerator recgen(std::cin, fac, o.split_alignments);
+      std::vector<RecordSetType> sets;
+      std::vector<PredictionRecord> precs;
+      std::cout << GFF3Header();
+      std::ostringstream outbuf;
+      const size_t batch_sets = o.batch ? o.batch : (size_t)1 << 16;
+      while (recgen.notEmpty()) {
+        sets.clear();
+        while (recgen.notEmpty() && sets.size() < batch_sets) { sets.emplace_back(); recgen.getNext(sets.back()); }
+        model->predict(sets, precs, logsink);
+        outbuf.str("");
+        for (size_t s = 0; s < sets.size(); ++s) outbuf << precs[s];
+        std::cout << outbuf.str();
+      }
+      return EXIT_SUCCESS;
+    }
     SequenceStore query_storage(o.query);
     SequenceStore db_storage(o.db);
     RPAPredictionModel rpa(tax.get(), query_storage, db_storage, o.filterout, o.toppercent, o.dataformat == "protein", o.device);

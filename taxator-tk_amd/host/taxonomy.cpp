@@ -66,9 +66,9 @@ Taxonomy* parseNCBIFlatFiles(const std::string& nodes_filename, const std::strin
 
   Taxonomy* tax = new Taxonomy;
   uint32_t counter = 0;
-  struct Frame { TaxonID id; int32_t kept_parent; uint8_t depth; bool closing; uint32_t idx; };
+  struct Frame { TaxonID id; int32_t kept_parent; uint8_t depth; bool closing; uint32_t idx; bool uncl; };
   std::vector<Frame> stack;
-  stack.push_back({"1", -1, 0, false, 0});
+  stack.push_back({"1", -1, 0, false, 0, false});
   while (!stack.empty()) {
     Frame fr = stack.back();
     stack.pop_back();
@@ -83,15 +83,21 @@ Taxonomy* parseNCBIFlatFiles(const std::string& nodes_filename, const std::strin
       tax->name.push_back(name_of.count(fr.id) ? name_of[fr.id] : std::string());
       tax->parent.push_back(fr.kept_parent >= 0 ? (uint32_t)fr.kept_parent : 0u);
       tax->depth.push_back(fr.depth);
+      tax->is_unclassified.push_back(fr.uncl ? 1 : 0);
       tax->left.push_back(++counter);
       tax->right.push_back(0);
-      stack.push_back({fr.id, fr.kept_parent, fr.depth, true, idx});
+      stack.push_back({fr.id, fr.kept_parent, fr.depth, true, idx, fr.uncl});
       kp = (int32_t)idx;
       kd = (uint8_t)(fr.depth + 1);
     }
     auto it = children.find(fr.id);
     if (it != children.end())
-      for (auto c = it->second.rbegin(); c != it->second.rend(); ++c) stack.push_back({*c, kp, kd, false, 0});
+      for (auto c = it->second.rbegin(); c != it->second.rend(); ++c) {
+        // ncbidata.cpp:119-126: a child inherits the mark, otherwise its own scientific name decides (the root is never marked)
+        bool uncl = fr.uncl;
+        if (!uncl) { auto nm = name_of.find(*c); uncl = nm != name_of.end() && nm->second.find("unclassified") != std::string::npos; }
+        stack.push_back({*c, kp, kd, false, 0, uncl});
+      }
   }
   return tax;
 }

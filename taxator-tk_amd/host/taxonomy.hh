@@ -21,6 +21,9 @@ class Taxonomy {
   std::vector<uint8_t> depth;
   std::vector<TaxonID> taxid;
   std::vector<std::string> name;
+  // Taxon::is_unclassified (core/src/taxontree.hh:68): set while the FULL tree is built, for every node below a taxon
+  // whose scientific name contains "unclassified" and for that taxon itself (core/src/ncbidata.cpp:119-126)
+  std::vector<uint8_t> is_unclassified;
 
   uint32_t getRoot() const { return 0; }
   uint32_t getNode(const TaxonID& id) const;  // throws TaxonNotFound (also for taxa pruned away, taxontree.cpp:59-64)

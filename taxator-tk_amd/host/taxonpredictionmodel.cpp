@@ -93,4 +93,73 @@ void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size
   check(engine_, rpa_predict_batch(engine_, &b, rows, stats, RPA_MEM_HOST));
 }
 
+// ---- alignment-free models ----
+static rpa_lca_params lca_params(int model) {
+  rpa_lca_params p;
+  rpa_lca_default_params(&p);
+  p.model = model;
+  return p;
+}
+
+LCAPredictionModelBase::LCAPredictionModelBase(const Taxonomy* tax, const rpa_lca_params& params, int device)
+    : TaxonPredictionModel(tax), params_(params) {
+  rpa_taxonomy t{(uint32_t)tax->size(), tax->parent.data(), tax->left.data(), tax->right.data(), tax->depth.data()};
+  rpa_params p;
+  rpa_default_params(&p);
+  p.device = device;
+  int rc = rpa_create(&t, &p, &engine_);
+  if (rc != RPA_OK) throw DeviceError(rpa_last_error(nullptr));
+}
+
+LCAPredictionModelBase::~LCAPredictionModelBase() { rpa_destroy(engine_); }
+
+void LCAPredictionModelBase::predict(const std::vector<RecordSetType>& recordsets, std::vector<PredictionRecord>& precs, std::ostream&) {
+  const size_t S = recordsets.size();
+  if (precs.size() < S) precs.resize(S, PredictionRecord(tax_));
+  set_offsets_.assign(1, 0);
+  query_len_.clear(); qstart_.clear(); qstop_.clear(); node_.clear(); score_.clear(); evalue_.clear(); filtered_.clear();
+  for (const RecordSetType& rset : recordsets) {
+    if (rset.empty()) throw GeneralError("empty record set");
+    query_len_.push_back(rset.front().getQueryLength());  // initPredictionRecord: id and length of the first record
+    for (const AlignmentRecordTaxonomy& r : rset) {
+      qstart_.push_back(r.getQueryStart()); qstop_.push_back(r.getQueryStop()); score_.push_back(r.getScore());
+      evalue_.push_back(r.evalue); node_.push_back(r.getReferenceNode()); filtered_.push_back(r.isFiltered() ? 1 : 0);
+    }
+    set_offsets_.push_back((uint32_t)qstart_.size());
+  }
+  rpa_batch b{};
+  b.n_sets = (uint32_t)S; b.n_records = (uint32_t)qstart_.size();
+  b.set_offsets = set_offsets_.data(); b.query_len = query_len_.data(); b.qstart = qstart_.data(); b.qstop = qstop_.data();
+  b.score = score_.data(); b.node = node_.data(); b.filtered = filtered_.data(); b.mem_kind = RPA_MEM_HOST;
+  rows_.resize(S);
+  check(engine_, rpa_lca_predict_batch(engine_, &b, evalue_.data(), tax_->is_unclassified.empty() ? nullptr : tax_->is_unclassified.data(),
+                                       &params_, rows_.data(), RPA_MEM_HOST));
+  for (size_t s = 0; s < S; ++s) {
+    const rpa_prediction& r = rows_[s];
+    PredictionRecord& prec = precs[s];
+    prec.initialize(recordsets[s].front().getQueryIdentifier(), recordsets[s].front().getQueryLength());
+    prec.setQueryFeatureBegin(r.begin);
+    prec.setQueryFeatureEnd(r.end);
+    prec.setNodeRange(r.lower, r.upper, r.support);  // setNodePoint
+    prec.setBestReferenceTaxon(r.rtax);
+    // interpolation value and signal strength keep what the record was constructed with (-1, 0): never printed / "0"
+  }
+}
+
+DummyPredictionModel::DummyPredictionModel(const Taxonomy* tax, int device) : LCAPredictionModelBase(tax, lca_params(RPA_LCA_DUMMY), device) {}
+LCASimplePredictionModel::LCASimplePredictionModel(const Taxonomy* tax, int device)
+    : LCAPredictionModelBase(tax, lca_params(RPA_LCA_SIMPLE), device) {}
+static rpa_lca_params megan_params(bool ignore_unclassified, float toppercent, float minscore, int minsupport, double maxevalue) {
+  rpa_lca_params p = lca_params(RPA_LCA_MEGAN);
+  p.ignore_unclassified = ignore_unclassified ? 1 : 0; p.toppercent = toppercent; p.minscore = minscore;
+  p.minsupport = (uint32_t)minsupport; p.maxevalue = maxevalue;
+  return p;
+}
+MeganLCAPredictionModel::MeganLCAPredictionModel(const Taxonomy* tax, bool ignore_unclassified, float toppercent, float minscore,
+                                                 int minsupport, double maxevalue, int device)
+    : LCAPredictionModelBase(tax, megan_params(ignore_unclassified, toppercent, minscore, minsupport, maxevalue), device) {}
+static rpa_lca_params nbest_params(int n) { rpa_lca_params p = lca_params(RPA_LCA_NBEST); p.nbest = (uint32_t)n; return p; }
+NBestLCAPredictionModel::NBestLCAPredictionModel(const Taxonomy* tax, int n, int device)
+    : LCAPredictionModelBase(tax, nbest_params(n), device) {}
+
 }  // namespace taxator

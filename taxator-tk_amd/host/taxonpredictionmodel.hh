@@ -49,4 +49,38 @@ class RPAPredictionModel : public TaxonPredictionModel {
   std::vector<uint8_t> filtered_;
 };
 
+// The reference's alignment-free models (core/src/taxonpredictionmodel.hh:57-253), selected by taxator -a
+// (core/taxator.cpp:346-361): DummyPredictionModel, LCASimplePredictionModel, MeganLCAPredictionModel (argument order of
+// its ctor kept: ignore_unclassified, toppercent, minscore, minsupport, maxevalue), NBestLCAPredictionModel.  Batched like
+// RPAPredictionModel; the work is done by rpa_lca_predict_batch (hand-written HIP, no CPU path).
+class LCAPredictionModelBase : public TaxonPredictionModel {
+ public:
+  ~LCAPredictionModelBase() override;
+  void predict(const std::vector<RecordSetType>& recordsets, std::vector<PredictionRecord>& precs, std::ostream& logsink) override;
+ protected:
+  LCAPredictionModelBase(const Taxonomy* tax, const rpa_lca_params& params, int device);
+ private:
+  rpa_engine* engine_ = nullptr;
+  rpa_lca_params params_;
+  std::vector<rpa_prediction> rows_;
+  std::vector<uint32_t> set_offsets_, query_len_, qstart_, qstop_, node_;
+  std::vector<float> score_;
+  std::vector<double> evalue_;
+  std::vector<uint8_t> filtered_;
+};
+
+struct DummyPredictionModel : LCAPredictionModelBase {
+  explicit DummyPredictionModel(const Taxonomy* tax, int device = 0);
+};
+struct LCASimplePredictionModel : LCAPredictionModelBase {
+  explicit LCASimplePredictionModel(const Taxonomy* tax, int device = 0);
+};
+struct MeganLCAPredictionModel : LCAPredictionModelBase {
+  MeganLCAPredictionModel(const Taxonomy* tax, bool ignore_unclassified = false, float toppercent = 1.0f, float minscore = 0.0f,
+                          int minsupport = 1, double maxevalue = 1.7976931348623157e308, int device = 0);
+};
+struct NBestLCAPredictionModel : LCAPredictionModelBase {
+  explicit NBestLCAPredictionModel(const Taxonomy* tax, int n = 1, int device = 0);
+};
+
 }  // namespace taxator

@@ -102,6 +102,27 @@ class FlatTaxonomy:
                     fields = line.rstrip("\n").split("\t|\t")
                     if len(fields) >= 4 and fields[3].startswith("scientific name"):
                         self.names[fields[0]] = fields[1]
+        self._parent_of = parent_of
+
+    def unclassified_flags(self):
+        """Taxon::is_unclassified of every kept node (src/ncbidata.cpp:119-126): marked on the FULL tree, before pruning --
+        a node is unclassified if an ancestor is, or if its own scientific name contains "unclassified" (never the root)."""
+        memo = {"1": False}
+
+        def mark(t):
+            chain = []
+            while t not in memo:
+                chain.append(t)
+                t = self._parent_of[t]
+            up = memo[t]
+            for c in reversed(chain):
+                up = up or ("unclassified" in self.names.get(c, ""))
+                memo[c] = up
+            return up
+        out = np.zeros(len(self.taxid), np.uint8)
+        for t, idx in self.index_of.items():
+            out[idx] = 1 if mark(t) else 0
+        return out
 
 
 def read_mapping(path):

@@ -29,8 +29,8 @@ def test_help_and_version(taxator_bin):
 def test_missing_mapping_and_bad_algorithm(taxator_bin):
     r = subprocess.run([taxator_bin], capture_output=True, text=True)
     assert r.returncode == 1 and "Specify a taxonomy mapping file" in r.stdout  # taxator.cpp:328-332
-    r = subprocess.run([taxator_bin, "-g", "x", "-a", "megan-lca"], capture_output=True, text=True)
-    assert r.returncode == 1 and "rpa" in r.stdout
+    r = subprocess.run([taxator_bin, "-g", "x", "-a", "kraken"], capture_output=True, text=True)
+    assert r.returncode == 1 and "classification algorithm can either be: rpa (default), simple-lca, megan-lca" in r.stdout  # :376
 
 
 def test_no_gpu_fails_loudly(taxator_bin, golden_dir):
@@ -44,3 +44,7 @@ def test_no_gpu_fails_loudly(taxator_bin, golden_dir):
     assert r.returncode == 1
     assert "An unrecoverable error occurred" in r.stderr and "no HIP device" in r.stderr
     assert "taxator-tk" not in r.stdout  # no prediction line was produced by some fallback
+    # the alignment-free models run on the device too: same refusal
+    r = subprocess.run([taxator_bin, "-a", "simple-lca", "-g", os.path.join(d, "mapping.tax")], stdin=open(os.path.join(d, "aln_edge.tsv")),
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and "taxator-tk" not in r.stdout

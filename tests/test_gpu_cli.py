@@ -85,3 +85,40 @@ def test_cli_errors_like_the_reference(golden_dir, tmp_path, path):
     (work / "aln_bad.tsv").write_text("e0\t1\t200\t200\tref3\t99999101\t99999300\t400\t0\t150\t200\ne0\t1\t200\t200\tref2\t101\t300\t300\t0\t180\t200\n")
     r = _run(str(work), ".fna", extra=path, aln="aln_bad.tsv", query="query_edge.fna")
     assert r.returncode == 1 and "SequenceRangeError" in r.stderr
+
+
+@pytest.mark.parametrize("algo,extra,kw", [
+    ("dummy", [], {}), ("simple-lca", [], {}), ("megan-lca", [], {}),
+    ("megan-lca", ["-t", "0.3", "-m", "150", "-e", "1e-5", "-c", "2"], dict(toppercent=0.3, minscore=150.0, maxevalue=1e-5, minsupport=2)),
+    ("ic-megan-lca", ["-u", "-t", "1"], dict(toppercent=1.0, ignore_unclassified=True)),
+    ("n-best-lca", ["-n", "2"], dict(nbest=2))])
+def test_cli_alignment_free_models(oracle, golden_dir, tmp_path, algo, extra, kw):
+    """taxator -a dummy | simple-lca | megan-lca | ic-megan-lca | n-best-lca (core/taxator.cpp:346-361) through the host
+    mirror and the device kernel; no FASTA files involved.  Expected GFF3 = the oracle's rows through the GFF3 rules."""
+    folder = _unpack(golden_dir, "survey_dna", ".fna", tmp_path)
+    # give the mock taxonomy an "unclassified" branch so that -u has something to ignore
+    names = os.path.join(folder, "tax", "names.dmp")
+    lines = open(names).read().split("\n")
+    marked = 0
+    for k, l in enumerate(lines):
+        f = l.split("\t|\t")
+        if len(f) >= 4 and f[0] not in ("1",) and marked < 3 and k % 7 == 3:
+            f[1] = "unclassified " + f[1]; lines[k] = "\t|\t".join(f); marked += 1
+    open(names, "w").write("\n".join(lines))
+    env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
+    cmd = [BIN, "-a", algo, "-g", os.path.join(folder, "mapping.tax"), "--batch", "61"] + extra
+    r = subprocess.run(cmd, stdin=open(os.path.join(folder, "aln.tsv")), capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    fds = R.Dataset(folder, 0)
+    b = fds.batch()
+    evalue = np.array([rec.evalue for group in fds.sets for rec in group], np.float64)
+    # Taxon::is_unclassified on the pruned tree, from the full tree (core/src/ncbidata.cpp:119-126)
+    uncl = fds.tax.unclassified_flags()
+    model = {"dummy": oracle.LCA_DUMMY, "simple-lca": oracle.LCA_SIMPLE, "megan-lca": oracle.LCA_MEGAN, "ic-megan-lca": oracle.LCA_MEGAN,
+             "n-best-lca": oracle.LCA_NBEST}[algo]
+    tax = oracle.TaxArrays(fds.tax.parent, fds.tax.left, fds.tax.right, fds.tax.depth)
+    rc, rows = oracle.lca_predict_batch(tax, model, b["offsets"], b["qlen"], b["recs"], evalue, uncl, **kw)
+    assert rc == 0
+    assert r.stdout == fds.gff3(rows, b["qids"], b["qlen"])
+    if algo in ("megan-lca", "n-best-lca"):  # (the LCA over ALL hits of these sets is the superkingdom)
+        assert len(set(rows["lower"])) > 3
