@@ -57,6 +57,110 @@ __device__ __forceinline__ void profile_add(unsigned long long* acc, bool active
   }
 }
 
+// ---- pieces shared by the one-strip kernels ----------------------------------------------------------------
+// The five match masks of pattern word `wi` (32 residues from the stream; residues past the pattern end match nothing).
+__device__ __forceinline__ void peq_word(NtStream& ps, uint32_t wi, uint32_t m, uint32_t (&mask)[5]) {
+#pragma unroll
+  for (int c = 0; c < 5; ++c) mask[c] = 0u;
+  if (wi * 32u < m) {
+    const uint4 x = ps.next32();
+    uint32_t p0, p1, pn;
+    planes32(x, p0, p1, pn);
+    const uint32_t rem = m - wi * 32u;
+    const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+    mask[4] = pn & vm;             // N
+    mask[3] = p1 & p0 & vm;        // T
+    mask[2] = p1 & ~p0 & vm;       // G
+    mask[1] = p0 & ~p1 & ~pn & vm; // C
+    mask[0] = ~(p0 | p1 | pn) & vm;  // A
+  }
+}
+// One text column: NW chained word updates (add carry via v_addc_co, shift carries via v_alignbit); e[wi * STRIDE] is
+// the match mask of word wi for the column's symbol.  10 VALU ops per word: or, and, addc, 3x v_bitop3 (gfx950
+// three-input boolean; truth tables use a=0xF0, b=0xCC, c=0xAA), 2x and, 2x alignbit.
+template <int NW, int STRIDE>
+__device__ __forceinline__ void myers_column(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ e) {
+  uint32_t carry = 0, hp_prev = 0x80000000u /* global alignment: +1 enters row 0 */, hn_prev = 0;
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) {
+    const uint32_t vp = VP[wi], vn = VN[wi];
+    const uint32_t X = e[wi * STRIDE] | vn;
+    uint32_t cout;
+    const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
+    carry = cout;
+    const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);         // (sum ^ vp) | X
+    const uint32_t HN = vp & D0;
+    const uint32_t HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);         // vn | ~(vp | D0)
+    const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);            // (HP << 1) | (hp_prev >> 31)
+    const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+    hp_prev = HP;
+    hn_prev = HN;
+    VN[wi] = Xs & D0;
+    VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);                    // Hs | ~(Xs | D0)
+  }
+}
+// Walk the text front to back and call column(symbol) once per nucleotide.  The n mod 8 leading columns go first (a
+// short loop that every lane of the wave runs at the same time), so that the main loop only ever sees full dwords: 8
+// unrolled columns per dword, no partial-dword branch and no tail in which a wave executes both a fast and a slow
+// path; then full mod 4 single dwords, then 32 nucleotides (one 16-byte load, issued a step ahead) per step.
+template <typename F>
+__device__ __forceinline__ void walk_text(const SegView& txt, F&& column) {
+  const uint32_t n = txt.len, head = n & 7u, full = n >> 3;
+  NtStream ts;
+  ts.init(txt, 0u);
+  if (head) {
+    const uint32_t d = ts.next8();  // positions 0..7; only the first n mod 8 are consumed here
+#pragma unroll 1
+    for (uint32_t k = 0; k < head; ++k) column((d >> (4 * k)) & 7u);
+    if (full) ts.init(txt, head);   // the main loop starts at position n mod 8
+  }
+  if (full) {
+    const uint32_t singles = full & 3u, chunks = full >> 2;
+#pragma unroll 1
+    for (uint32_t k = 0; k < singles; ++k) {
+      const uint32_t d = ts.next8();
+#pragma unroll
+      for (int c = 0; c < 8; ++c) column((d >> (4 * c)) & 7u);
+    }
+    if (chunks) {
+      uint4 pending = ts.load4();
+      for (uint32_t ch = 0; ch < chunks; ++ch) {
+        const uint4 d = ts.take32(pending);
+        if (ch + 1 < chunks) pending = ts.load4();  // prefetch for the next step
+#pragma unroll
+        for (int c = 0; c < 8; ++c) column((d.x >> (4 * c)) & 7u);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) column((d.y >> (4 * c)) & 7u);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) column((d.z >> (4 * c)) & 7u);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) column((d.w >> (4 * c)) & 7u);
+      }
+    }
+  }
+}
+// The score is not tracked per column (the reference adds the horizontal delta of the pattern's last row after every
+// text character, global_alignment_myers_impl.h:120-123): row 0 of a global alignment holds D[0][j] = j, so
+// D[m][n] = n + sum of the vertical deltas of the last column = n + popc(VP & rows<m) - popc(VN & rows<m).
+// This also makes a kernel exact for ANY m <= 32*NW (rows past the pattern match nothing and sit below row m).
+template <int NW>
+__device__ __forceinline__ int32_t myers_distance(const uint32_t (&VP)[NW], const uint32_t (&VN)[NW], uint32_t n, uint32_t m) {
+  int32_t dist = (int32_t)n;
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) {
+    const uint32_t pos = (uint32_t)wi * 32u;
+    const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
+    dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
+  }
+  return dist;
+}
+// distance, similarity = matches = len_short - (d - lendiff) = len_long - d   (:154-164)
+__device__ __forceinline__ void store_dna_result(const WorkDev& w, uint32_t dst, int32_t dist, uint32_t n, uint32_t m) {
+  const uint32_t llong = n > m ? n : m, lshort = n > m ? m : n;
+  w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)llong - dist));
+  if (w.pair_ext) w.pair_ext[dst] = make_uint4(llong - (uint32_t)dist, (uint32_t)dist - (llong - lshort), llong - lshort, llong);  // match+mismatch = len_short, + gap = len_long
+}
+
 // The kernel walks up to two work lists back to back (list, then list2): a pattern-length class with too few pairs
 // to fill the chip rides along with the next wider class instead of paying a serialised launch of its own.
 template <int NW>
@@ -87,109 +191,18 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
   if (active) ps.init(pat, 0u);
 #pragma unroll
   for (int wi = 0; wi < NW; ++wi) {
-    uint32_t A = 0, C = 0, G = 0, T = 0, N = 0;
-    if (active && (uint32_t)wi * 32u < m) {
-      const uint4 x = ps.next32();
-      uint32_t p0, p1, pn;
-      planes32(x, p0, p1, pn);
-      const uint32_t rem = m - wi * 32u;
-      const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);  // residues past the end must match nothing
-      N = pn & vm;
-      T = p1 & p0 & vm;
-      G = p1 & ~p0 & vm;
-      C = p0 & ~p1 & ~pn & vm;
-      A = ~(p0 | p1 | pn) & vm;
-    }
-    peq[(0 * NW + wi) * kBlock + tid] = A;
-    peq[(1 * NW + wi) * kBlock + tid] = C;
-    peq[(2 * NW + wi) * kBlock + tid] = G;
-    peq[(3 * NW + wi) * kBlock + tid] = T;
-    peq[(4 * NW + wi) * kBlock + tid] = N;
+    uint32_t mask[5] = {0u, 0u, 0u, 0u, 0u};
+    if (active) peq_word(ps, (uint32_t)wi, m, mask);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) peq[(c * NW + wi) * kBlock + tid] = mask[c];
   }
   if (!active) return;
 
   uint32_t VP[NW], VN[NW];
 #pragma unroll
   for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
-  // One text column: NW chained word updates (add carry in VCC via v_addc_co, shift carries via v_alignbit).
-  auto column = [&](uint32_t c) {
-    const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
-    uint32_t carry = 0, hp_prev = 0x80000000u /* global alignment: +1 enters row 0 */, hn_prev = 0, HP = 0, HN = 0;
-#pragma unroll
-    for (int wi = 0; wi < NW; ++wi) {
-      // 10 VALU ops per word: or, and, addc, 3x v_bitop3 (gfx950 three-input boolean), 2x and, 2x alignbit.
-      // Truth tables use a=0xF0, b=0xCC, c=0xAA.
-      const uint32_t vp = VP[wi], vn = VN[wi];
-      const uint32_t X = e[wi * kBlock] | vn;
-      uint32_t cout;
-      const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
-      carry = cout;
-      const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);   // (sum ^ vp) | X
-      HN = vp & D0;
-      HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);                  // vn | ~(vp | D0)
-      const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);      // (HP << 1) | (hp_prev >> 31)
-      const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
-      hp_prev = HP;
-      hn_prev = HN;
-      VN[wi] = Xs & D0;
-      VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);              // Hs | ~(Xs | D0)
-    }
-    (void)HP; (void)HN;
-  };
-
-  // Text streaming straight from the resident store (NtStream, rpa_device.h).  The n mod 8 leading columns go first (a
-  // short loop that every lane of the wave runs at the same time), so that the main loop only ever sees full dwords:
-  // 8 unrolled columns per dword with no partial-dword branch, and no tail in which a wave executes both the fast and
-  // the slow path.  Forward and reverse-strand segments run the same instruction stream (selects, no divergence).
-  const uint32_t head = n & 7u, full = n >> 3;
-  NtStream ts;
-  ts.init(txt, 0u);
-  if (head) {
-    const uint32_t d = ts.next8();  // positions 0..7; only the first n mod 8 are consumed here
-#pragma unroll 1
-    for (uint32_t k = 0; k < head; ++k) column((d >> (4 * k)) & 7u);
-    if (full) ts.init(txt, head);   // the main loop starts at position n mod 8
-  }
-  if (full) {
-    // full mod 4 single dwords first, then 32 nucleotides (one 16-byte load, issued a step ahead) per step
-    const uint32_t singles = full & 3u, chunks = full >> 2;
-#pragma unroll 1
-    for (uint32_t k = 0; k < singles; ++k) {
-      const uint32_t d = ts.next8();
-#pragma unroll
-      for (int c = 0; c < 8; ++c) column((d >> (4 * c)) & 7u);
-    }
-    if (chunks) {
-      uint4 pending = ts.load4();
-      for (uint32_t ch = 0; ch < chunks; ++ch) {
-        const uint4 d = ts.take32(pending);
-        if (ch + 1 < chunks) pending = ts.load4();  // prefetch for the next step
-#pragma unroll
-        for (int c = 0; c < 8; ++c) column((d.x >> (4 * c)) & 7u);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) column((d.y >> (4 * c)) & 7u);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) column((d.z >> (4 * c)) & 7u);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) column((d.w >> (4 * c)) & 7u);
-      }
-    }
-  }
-  // The score is not tracked per column (the reference adds the horizontal delta of the pattern's last row after every
-  // text character, global_alignment_myers_impl.h:120-123): row 0 of a global alignment holds D[0][j] = j, so
-  // D[m][n] = n + sum of the vertical deltas of the last column = n + popc(VP & rows<m) - popc(VN & rows<m).
-  // This also makes the kernel exact for ANY m <= 32*NW (rows past the pattern match nothing and sit below row m).
-  int32_t dist = (int32_t)n;
-#pragma unroll
-  for (int wi = 0; wi < NW; ++wi) {
-    const uint32_t pos = (uint32_t)wi * 32u;
-    const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
-    dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
-  }
-  // distance, similarity = matches = len_short - (d - lendiff) = len_long - d   (:154-164)
-  const uint32_t llong = n > m ? n : m, lshort = n > m ? m : n;
-  w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)llong - dist));
-  if (w.pair_ext) w.pair_ext[dst] = make_uint4(llong - (uint32_t)dist, (uint32_t)dist - (llong - lshort), llong - lshort, llong);  // match+mismatch = len_short, + gap = len_long
+  walk_text(txt, [&](uint32_t c) { myers_column<NW, kBlock>(VP, VN, peq + c * (NW * kBlock) + tid); });
+  store_dna_result(w, dst, myers_distance<NW>(VP, VN, n, m), n, m);
 }
 
 hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
