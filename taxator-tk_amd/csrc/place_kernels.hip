@@ -1122,6 +1122,17 @@ hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_
   return hipGetLastError();
 }
 
+// set offsets of a part of a batch, rebased so that its first record is record 0
+__global__ __launch_bounds__(kBlock) void k_rebase_offsets(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = in[i] - in[0];
+}
+hipError_t launch_rebase_offsets(hipStream_t st, const uint32_t* in, uint32_t n, uint32_t* out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rebase_offsets, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
+  return hipGetLastError();
+}
+
 // ---- launchers: P4 = number of 16-byte quads of the taxon path = ceil(max depth / 4) ----
 #define RPA_DISPATCH_P4(P4V, CALL)                 \
   switch (P4V) {                                   \

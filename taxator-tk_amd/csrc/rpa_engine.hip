@@ -3,7 +3,11 @@
 // One engine = one GPU = one RPAPredictionModel instance of the reference (core/src/taxonpredictionmodelsequence.hh:326-339)
 // plus its two sequence stores (core/taxator.cpp:230-249), resident in HBM.  rpa_predict_batch drives the rounds
 //   rank -> plan -> { emit -> align bins -> decide }*      (kernels: place_/align_*_kernels.hip)
-// on one HIP stream.  The host reads one small counter block per round (pairs per bin, live sets, error word).
+// on one HIP stream per PART.  The host reads one small counter block per round (pairs per bin, live sets, error word).
+// A large batch is cut into a few parts of consecutive record sets, each with its own working set, stream and host
+// thread, started one after the other: the alignment kernel is bound by VALU issue and leaves half of every CU's wave
+// slots, registers and LDS free, the placement kernels are bound by memory latency, so the placement rounds of one part
+// run underneath the alignment kernel of another (same results: record sets are independent).
 // There is no CPU compute path: every entry point fails with RPA_ERR_DEVICE when no gfx950 device answers.
 #include <hip/hip_runtime.h>
 
@@ -13,9 +17,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/taxator_rpa.h"
@@ -82,6 +89,14 @@ struct rpa_engine {
   std::vector<std::pair<size_t, size_t>> ev_align;  // (start, stop) indices
   hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
   std::mutex mu;  // submit is serialised per engine (SURVEY 8b threading)
+  // parts of a batch beyond the first run on worker engines: own stream, working set and counters, the owner's
+  // taxonomy / parameters (views, not owned)
+  bool is_worker = false;
+  std::vector<rpa_engine*> workers;     // owner only
+  DevBuf part_offsets;                  // set offsets of this part, rebased to 0
+  hipEvent_t ev_inputs = nullptr;       // owner: everything queued on the owner's stream before the parts start
+  int parts_override = 0;               // RPA_PARTS=n: cut every batch into n parts (tests, A/B); 0 = by size
+  bool part_mode = false;               // running as one of several parts: the call's device time is taken by the owner
 };
 
 namespace {
@@ -200,7 +215,7 @@ int profile_end(rpa_engine* e) {
   HIP_TRY(e, hipEventSynchronize(e->ev_total1));
   float ms = 0.f;
   HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_total0, e->ev_total1));
-  e->prof.total_ms += ms;
+  if (!e->part_mode) e->prof.total_ms += ms;
   for (auto& pr : e->ev_align) {
     HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_pool[pr.first], e->ev_pool[pr.second]));
     e->prof.align_ms += ms;
@@ -268,6 +283,190 @@ int check_device_error(rpa_engine* e, const uint32_t* c) {
   return fail(e, rc, "%s (record set / pair %u)", kernel_error_text(code), c[kCtrErrSet]);
 }
 
+// One part of a batch on engine `e` (the owner for the first part, a worker for the others): everything
+// rpa_predict_batch does on the device for the record sets of `b` (device pointers, set offsets starting at 0).
+struct PartGate {
+  std::mutex m; std::condition_variable cv; bool is_open = false;
+  void open() { { std::lock_guard<std::mutex> lk(m); is_open = true; } cv.notify_all(); }
+  void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return is_open; }); }
+};
+struct GateOpener {  // opens the gate on every way out of predict_part
+  PartGate& g;
+  ~GateOpener() { g.open(); }
+};
+
+int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const StoreDev& db, void* rows_dev, void* stats_dev, PartGate& gate) {
+  GateOpener opener{gate};
+  const uint32_t S = b.n_sets, H = b.n_records, T = H + S;
+  // Row layout.  Tiled (64 record sets side by side, see SetRows in place_kernels.hip) makes the placement kernels'
+  // row accesses coalesced; it pads every tile to its largest set, so batches whose padding would exceed ~50 % of the
+  // rows (wildly different set sizes) keep the linear layout.  The slot count comes back from the device.
+  const uint32_t n_tiles = (S + 63u) / 64u;
+  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 1) * 4));
+  uint32_t P = H;
+  bool tiled = false;
+  if (!e->linear_rows) {
+    HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>()));
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->tile_base.as<uint32_t>() + n_tiles, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const uint64_t slots = e->h_counters[0];
+    if (slots != 0xFFFFFFFFull && slots <= (uint64_t)H + H / 2 + 65536u && slots + S < 0xFFFFFFF0ull) { P = (uint32_t)slots; tiled = true; }
+  }
+  WorkDev w{};
+  int rc = alloc_work(e, S, H, T, T, false, &w, P, tiled);
+  if (rc) return rc;
+
+  rc = profile_begin(e);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * (kNumCounters + 1), e->stream));
+  HIP_TRY(e, hipMemsetAsync(w.seg, 0, (size_t)T * sizeof(SegDesc), e->stream));
+  w.set_offsets = b.set_offsets;
+  w.store_q = q.words; w.store_db = db.words;
+  HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
+  HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev));
+  uint64_t rounds = 0;
+  uint32_t prev_live = S;     // upper bound of the current live list's length (its exact length is counters[kCtrActive])
+  bool list_in_a = true;      // plan wrote the first live list into live_a
+  for (;;) {
+    // plan/decide left, per set, what it wants aligned next (EmitInfo) and appended the set to the live list.
+    // Dense round: scan every row / every set.  Sparse round (few sets left): walk the live list only.
+    uint32_t* cur_list = list_in_a ? e->live_a.as<uint32_t>() : e->live_b.as<uint32_t>();
+    uint32_t* next_list = list_in_a ? e->live_b.as<uint32_t>() : e->live_a.as<uint32_t>();
+    const bool sparse_emit = rounds > 0 && (uint64_t)prev_live * 24 <= S;
+    w.live_in = sparse_emit ? cur_list : nullptr;
+    w.n_live_in = prev_live;  // grid bound only: the kernel reads the exact length from counters[kCtrActive]
+    HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, e->params));
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    rc = check_device_error(e, e->h_counters);
+    if (rc) return rc;
+    const uint32_t live_now = e->h_counters[kCtrActive];
+    if (live_now == 0) break;
+    uint32_t counts[kNumRoundCounters];
+    memcpy(counts, e->h_counters, sizeof(counts));
+    if (e->trace_rounds) {
+      uint64_t pairs = 0;
+      for (int k = 0; k < kNumBins; ++k) pairs += counts[k];
+      fprintf(stderr, "[rpa] round %llu (%s): live sets %u, alignments %llu, per bin:", (unsigned long long)rounds, sparse_emit ? "sparse" : "dense",
+              live_now, (unsigned long long)pairs);
+      for (int k = 0; k < kNumBins; ++k) if (counts[k]) fprintf(stderr, " %d:%u", k, counts[k]);
+      fprintf(stderr, "\n");
+    }
+    rc = run_align_bins(e, w, counts);
+    if (rc) return rc;
+    if (rounds == 1) gate.open();  // the long pass-1 alignment launch is queued: the next part may start underneath it
+    HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kNumRoundCounters, e->stream));  // keep the error words
+    const bool sparse_decide = rounds > 0 && (uint64_t)live_now * 24 <= S;
+    w.live_in = sparse_decide ? cur_list : nullptr;
+    w.n_live_in = live_now;   // exact
+    w.live_out = next_list;
+    HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev,
+                             e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr));
+    prev_live = live_now;
+    list_in_a = !list_in_a;
+    ++rounds;
+    if (rounds > (uint64_t)H + S + 8) return fail(e, RPA_ERR_INVALID, "placement state machine did not terminate");
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->prof.rounds += rounds;
+  return profile_end(e);
+}
+
+// Worker engine for the parts of a batch beyond the first: the owner's taxonomy and parameters by view, everything
+// else (stream, working set, counters, profiling accumulators) its own.
+rpa_engine* make_worker(rpa_engine* e) {
+  rpa_engine* w = new (std::nothrow) rpa_engine();
+  if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
+  w->is_worker = true;
+  w->device = e->device; w->params = e->params; w->tax = e->tax;
+  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
+  hipError_t err = hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipHostMalloc((void**)&w->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault);
+  if (err == hipSuccess) err = w->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(w->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long));
+  if (err != hipSuccess) { fail(e, RPA_ERR_DEVICE, "worker engine: %s", hipGetErrorString(err)); rpa_destroy(w); return nullptr; }
+  w->stream = w->own_stream;
+  return w;
+}
+
+// How many parts a batch of S record sets is cut into: ONE unless RPA_PARTS asks for more.  Measured on MI355X with
+// config 2 (1 M record sets): 2 parts 15.5 ms, 3 parts 15.3 ms against 16.7 ms whole (4 and more: slower again, every
+// part pays its own ramp-up and its own tail of sparse rounds) -- but the alignment kernels of different parts then run
+// side by side and each launch takes longer (0.68-0.79 ms instead of 1.11 ms on average at 2-3 parts), which is what
+// the per-kernel roofline figure is quoted on; routing all alignment launches through one stream instead kept them
+// apart but stalled the parts behind each other's long launches (16.2 / 17.5 ms).  Left as an opt-in.
+int parts_for(const rpa_engine* e, uint32_t S) {
+  int k = e->parts_override > 0 ? e->parts_override : 1;
+  if ((uint32_t)k > S) k = (int)S;
+  return k < 1 ? 1 : k;
+}
+
+// All parts of one batch.  h_offsets: the host copy of set_offsets when the caller's batch lives on the host, else null
+// (the part boundaries are then read back from the device).
+int run_parts(rpa_engine* e, const BatchDev& b, const uint32_t* h_offsets, void* rows_dev, void* stats_dev) {
+  const uint32_t S = b.n_sets;
+  const StoreDev q = e->stores[RPA_STORE_QUERY].view(), db = e->stores[RPA_STORE_DB].view();
+  const int K = parts_for(e, S);
+  if (K == 1) {
+    PartGate g;
+    return predict_part(e, b, q, db, rows_dev, stats_dev, g);
+  }
+  std::vector<uint32_t> s_lo(K + 1), r_lo(K + 1);
+  for (int k = 0; k <= K; ++k) s_lo[k] = (uint32_t)((uint64_t)S * k / K);
+  r_lo[0] = 0; r_lo[K] = b.n_records;
+  for (int k = 1; k < K; ++k) {
+    if (h_offsets) r_lo[k] = h_offsets[s_lo[k]];
+    else HIP_TRY(e, hipMemcpyAsync(&r_lo[k], b.set_offsets + s_lo[k], 4, hipMemcpyDeviceToHost, e->stream));
+  }
+  if (!h_offsets) HIP_TRY(e, hipStreamSynchronize(e->stream));
+  while ((int)e->workers.size() < K - 1) {
+    rpa_engine* w = make_worker(e);
+    if (!w) return RPA_ERR_DEVICE;
+    e->workers.push_back(w);
+  }
+  if (!e->ev_inputs) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_inputs, hipEventDisableTiming));
+  HIP_TRY(e, hipEventRecord(e->ev_inputs, e->stream));  // staged inputs / the caller's earlier work on this stream
+  std::vector<PartGate> gates(K);
+  std::vector<int> rcs(K, RPA_OK);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto run = [&](int k) -> int {
+    rpa_engine* pe = k == 0 ? e : e->workers[k - 1];
+    GateOpener opener{gates[k]};  // whatever happens, the part after this one must not wait forever
+    pe->part_mode = true;
+    if (k) {
+      pe->err.clear();
+      pe->profiling = e->profiling;
+      HIP_TRY(pe, hipSetDevice(pe->device));
+      HIP_TRY(pe, hipStreamWaitEvent(pe->stream, e->ev_inputs, 0));
+      gates[k - 1].wait();  // start underneath the previous part's long alignment launch
+    }
+    BatchDev pb = b;
+    pb.n_sets = s_lo[k + 1] - s_lo[k]; pb.n_records = r_lo[k + 1] - r_lo[k];
+    HIP_TRY(pe, pe->part_offsets.ensure((size_t)(pb.n_sets + 1) * 4));
+    HIP_TRY(pe, launch_rebase_offsets(pe->stream, b.set_offsets + s_lo[k], pb.n_sets + 1, pe->part_offsets.as<uint32_t>()));
+    pb.set_offsets = pe->part_offsets.as<uint32_t>();
+    pb.query_seq += s_lo[k]; pb.query_len += s_lo[k];
+    pb.qstart += r_lo[k]; pb.qstop += r_lo[k]; pb.rstart += r_lo[k]; pb.rstop += r_lo[k]; pb.score += r_lo[k];
+    pb.identities += r_lo[k]; pb.alnlen += r_lo[k]; pb.ref_seq += r_lo[k]; pb.node += r_lo[k];
+    if (pb.filtered) pb.filtered += r_lo[k];
+    return predict_part(pe, pb, q, db, (char*)rows_dev + (size_t)s_lo[k] * sizeof(rpa_prediction),
+                        stats_dev ? (char*)stats_dev + (size_t)s_lo[k] * sizeof(rpa_stats) : nullptr, gates[k]);
+  };
+  std::vector<std::thread> threads;
+  for (int k = 1; k < K; ++k) threads.emplace_back([&, k] { rcs[k] = run(k); });
+  rcs[0] = run(0);
+  for (auto& t : threads) t.join();
+  e->part_mode = false;
+  for (rpa_engine* w : e->workers) w->part_mode = false;
+  if (e->profiling) e->prof.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (int k = 0; k < K; ++k)
+    if (rcs[k] != RPA_OK) {
+      if (k) e->err = e->workers[k - 1]->err;
+      return rcs[k];
+    }
+  return RPA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -316,6 +515,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 6u) : params->speculation_pass2;  // tools/spec_sweep.sh
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
   if (const char* v = getenv("RPA_ROW_LAYOUT")) e->linear_rows = !strcmp(v, "linear");
+  if (const char* v = getenv("RPA_PARTS")) e->parts_override = atoi(v);
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
@@ -374,19 +574,22 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
 
 void rpa_destroy(rpa_engine* e) {
   if (!e) return;
+  for (rpa_engine* w : e->workers) rpa_destroy(w);
+  e->workers.clear();
   (void)hipSetDevice(e->device);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
-                    &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc};
+                    &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc, &e->part_offsets};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
   for (auto& s : e->stores) { s.words.release(); s.offsets.release(); }
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_total0) (void)hipEventDestroy(e->ev_total0);
   if (e->ev_total1) (void)hipEventDestroy(e->ev_total1);
+  if (e->ev_inputs) (void)hipEventDestroy(e->ev_inputs);
   if (e->h_counters) (void)hipHostFree(e->h_counters);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -459,7 +662,6 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
     return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: null array in batch");
   if ((uint64_t)S + H >= 0xFFFFFFF0ull) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: batch too large");
   HIP_TRY(e, hipSetDevice(e->device));
-  const uint32_t T = H + S;
   BatchDev b{};
   b.n_sets = S; b.n_records = H;
   if (batch->mem_kind == RPA_MEM_HOST) {
@@ -490,23 +692,6 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
     b.filtered = batch->filtered;
   } else return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: bad mem_kind");
 
-  // Row layout.  Tiled (64 record sets side by side, see SetRows in place_kernels.hip) makes the placement kernels'
-  // row accesses coalesced; it pads every tile to its largest set, so batches whose padding would exceed ~50 % of the
-  // rows (wildly different set sizes) keep the linear layout.  The slot count comes back from the device.
-  const uint32_t n_tiles = (S + 63u) / 64u;
-  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 1) * 4));
-  uint32_t P = H;
-  bool tiled = false;
-  if (!e->linear_rows) {
-    HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>()));
-    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->tile_base.as<uint32_t>() + n_tiles, 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    const uint64_t slots = e->h_counters[0];
-    if (slots != 0xFFFFFFFFull && slots <= (uint64_t)H + H / 2 + 65536u && slots + S < 0xFFFFFFF0ull) { P = (uint32_t)slots; tiled = true; }
-  }
-  WorkDev w{};
-  int rc = alloc_work(e, S, H, T, T, false, &w, P, tiled);
-  if (rc) return rc;
   void* rows_dev = out;
   void* stats_dev = stats;
   if (out_mem_kind == RPA_MEM_HOST) {
@@ -514,65 +699,14 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
     rows_dev = e->out_rows.p;
     if (stats) { HIP_TRY(e, e->out_stats.ensure((size_t)S * sizeof(rpa_stats))); stats_dev = e->out_stats.p; }
   } else if (out_mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: bad out_mem_kind");
-
-  rc = profile_begin(e);
+  int rc = run_parts(e, b, batch->mem_kind == RPA_MEM_HOST ? batch->set_offsets : nullptr, rows_dev, stats_dev);
   if (rc) return rc;
-  HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * (kNumCounters + 1), e->stream));
-  HIP_TRY(e, hipMemsetAsync(w.seg, 0, (size_t)T * sizeof(SegDesc), e->stream));
-  const StoreDev q = e->stores[RPA_STORE_QUERY].view(), db = e->stores[RPA_STORE_DB].view();
-  w.set_offsets = b.set_offsets;
-  w.store_q = q.words; w.store_db = db.words;
-  HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
-  HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev));
-  uint64_t rounds = 0;
-  uint32_t prev_live = S;     // upper bound of the current live list's length (its exact length is counters[kCtrActive])
-  bool list_in_a = true;      // plan wrote the first live list into live_a
-  for (;;) {
-    // plan/decide left, per set, what it wants aligned next (EmitInfo) and appended the set to the live list.
-    // Dense round: scan every row / every set.  Sparse round (few sets left): walk the live list only.
-    uint32_t* cur_list = list_in_a ? e->live_a.as<uint32_t>() : e->live_b.as<uint32_t>();
-    uint32_t* next_list = list_in_a ? e->live_b.as<uint32_t>() : e->live_a.as<uint32_t>();
-    const bool sparse_emit = rounds > 0 && (uint64_t)prev_live * 24 <= S;
-    w.live_in = sparse_emit ? cur_list : nullptr;
-    w.n_live_in = prev_live;  // grid bound only: the kernel reads the exact length from counters[kCtrActive]
-    HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, e->params));
-    HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    rc = check_device_error(e, e->h_counters);
-    if (rc) return rc;
-    const uint32_t live_now = e->h_counters[kCtrActive];
-    if (live_now == 0) break;
-    uint32_t counts[kNumRoundCounters];
-    memcpy(counts, e->h_counters, sizeof(counts));
-    if (e->trace_rounds) {
-      uint64_t pairs = 0;
-      for (int k = 0; k < kNumBins; ++k) pairs += counts[k];
-      fprintf(stderr, "[rpa] round %llu (%s): live sets %u, alignments %llu, per bin:", (unsigned long long)rounds, sparse_emit ? "sparse" : "dense",
-              live_now, (unsigned long long)pairs);
-      for (int k = 0; k < kNumBins; ++k) if (counts[k]) fprintf(stderr, " %d:%u", k, counts[k]);
-      fprintf(stderr, "\n");
-    }
-    rc = run_align_bins(e, w, counts);
-    if (rc) return rc;
-    HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kNumRoundCounters, e->stream));  // keep the error words
-    const bool sparse_decide = rounds > 0 && (uint64_t)live_now * 24 <= S;
-    w.live_in = sparse_decide ? cur_list : nullptr;
-    w.n_live_in = live_now;   // exact
-    w.live_out = next_list;
-    HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev,
-                             e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr));
-    prev_live = live_now;
-    list_in_a = !list_in_a;
-    ++rounds;
-    if (rounds > (uint64_t)H + S + 8) return fail(e, RPA_ERR_INVALID, "placement state machine did not terminate");
-  }
   if (out_mem_kind == RPA_MEM_HOST) {
     HIP_TRY(e, hipMemcpyAsync(out, rows_dev, (size_t)S * sizeof(rpa_prediction), hipMemcpyDeviceToHost, e->stream));
     if (stats) HIP_TRY(e, hipMemcpyAsync(stats, stats_dev, (size_t)S * sizeof(rpa_stats), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  e->prof.rounds += rounds;
-  return profile_end(e);
+  return RPA_OK;
 }
 
 int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, uint32_t n_pairs,
@@ -694,6 +828,7 @@ int rpa_profile_enable(rpa_engine* e, int on) {
   if (!e) return RPA_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);
   e->profiling = on != 0;
+  for (rpa_engine* w : e->workers) w->profiling = e->profiling;
   return RPA_OK;
 }
 
@@ -703,6 +838,10 @@ int rpa_profile_reset(rpa_engine* e) {
   HIP_TRY(e, hipSetDevice(e->device));
   memset(&e->prof, 0, sizeof(e->prof));
   HIP_TRY(e, hipMemset(e->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
+  for (rpa_engine* w : e->workers) {
+    memset(&w->prof, 0, sizeof(w->prof));
+    HIP_TRY(e, hipMemset(w->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
+  }
   return RPA_OK;
 }
 
@@ -710,6 +849,11 @@ int rpa_profile_get(rpa_engine* e, rpa_profile* out) {
   if (!e || !out) return RPA_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);
   *out = e->prof;
+  for (const rpa_engine* w : e->workers) {  // parts of a batch that ran on worker engines
+    out->launches += w->prof.launches; out->pairs += w->prof.pairs; out->residue_bytes += w->prof.residue_bytes;
+    out->cells += w->prof.cells; out->align_ms += w->prof.align_ms; out->demanded += w->prof.demanded;
+    out->rounds = out->rounds > w->prof.rounds ? out->rounds : w->prof.rounds;
+  }
   return RPA_OK;
 }
 

@@ -452,3 +452,28 @@ def test_row_layouts_tiled_and_linear(pkg, oracle, synth, layout, monkeypatch):
     even = copy.copy(ds)
     even.batch = _subset_batch(ds, np.full(ds.n_sets, 7))
     _engine_vs_oracle(pkg, oracle, synth, even, 0, speculation=(3, 2))
+
+
+@pytest.mark.parametrize("parts", ["2", "5"])
+def test_batch_cut_into_parts(pkg, oracle, synth, parts, monkeypatch):
+    """RPA_PARTS=n: the record sets of a batch go through n worker engines (own streams, working sets and host threads,
+    started one after the other so that one part's placement rounds run underneath another's alignment kernel).  Record
+    sets are independent: rows and counters must be those of the whole batch, for host and for device-resident batches."""
+    monkeypatch.setenv("RPA_PARTS", parts)
+    ds = synth.make_dataset(n_sets=2500, n_hits=14, seg_len=120, branching=4, genome_len=3000, seed=51, variety=True)
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    import torch
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=0)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).cuda()
+           for k, v in ds.batch.items()}
+    out = torch.zeros((ds.n_sets, 8), dtype=torch.int32, device="cuda")
+    st = torch.zeros((ds.n_sets, 4), dtype=torch.int32, device="cuda")
+    model.profile(enable=True, reset=True)
+    model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=out, stats=st)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == rows.view(np.int32).reshape(-1, 8).tobytes()
+    assert st.cpu().numpy().tobytes() == stats.view(np.int32).reshape(-1, 4).tobytes()
+    prof = model.profile()
+    assert prof["demanded"] == int(stats["pass0"].sum() + stats["pass1"].sum() + stats["pass2"].sum())
