@@ -81,6 +81,7 @@ Taxonomy* parseNCBIFlatFiles(const std::string& nodes_filename, const std::strin
       tax->index_[fr.id] = idx;
       tax->taxid.push_back(fr.id);
       tax->name.push_back(name_of.count(fr.id) ? name_of[fr.id] : std::string());
+      tax->rank.push_back(rank_of.count(fr.id) ? rank_of[fr.id] : std::string());
       tax->parent.push_back(fr.kept_parent >= 0 ? (uint32_t)fr.kept_parent : 0u);
       tax->depth.push_back(fr.depth);
       tax->is_unclassified.push_back(fr.uncl ? 1 : 0);
@@ -113,7 +114,12 @@ Taxonomy* loadTaxonomyFromEnvironment(const std::vector<std::string>* ranks_to_m
   const std::string nodes = folder + "/nodes.dmp", names = folder + "/names.dmp";
   if (!file_exists(nodes)) { std::cerr << " \"" << nodes << "\" not found" << std::endl; return nullptr; }
   if (!file_exists(names)) { std::cerr << " \"" << names << "\" not found" << std::endl; return nullptr; }
-  return parseNCBIFlatFiles(nodes, names, ranks_to_mark, delete_unmarked);
+  Taxonomy* tax = parseNCBIFlatFiles(nodes, names, ranks_to_mark, delete_unmarked);
+  if (tax) {  // optional version file (ncbidata.cpp:201-207)
+    std::ifstream versionfile(folder + "/version.txt");
+    if (versionfile) std::getline(versionfile, tax->version);
+  }
+  return tax;
 }
 
 }  // namespace taxator

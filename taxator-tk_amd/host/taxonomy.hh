@@ -21,11 +21,15 @@ class Taxonomy {
   std::vector<uint8_t> depth;
   std::vector<TaxonID> taxid;
   std::vector<std::string> name;
+  std::vector<std::string> rank;   // TaxonAnnotation::rank of every kept node (nodes.dmp column 3)
+  std::string version;             // first line of $TAXATORTK_TAXONOMY_NCBI/version.txt if present (ncbidata.cpp:201-207)
   // Taxon::is_unclassified (core/src/taxontree.hh:68): set while the FULL tree is built, for every node below a taxon
   // whose scientific name contains "unclassified" and for that taxon itself (core/src/ncbidata.cpp:119-126)
   std::vector<uint8_t> is_unclassified;
 
   uint32_t getRoot() const { return 0; }
+  bool isParentOf(uint32_t a, uint32_t b) const { return right[a] > left[b] && left[a] < left[b]; }  // taxonomyinterface.cpp:52-55
+  uint8_t getMaxDepth() const { uint8_t m = 0; for (uint8_t d : depth) m = d > m ? d : m; return m; }
   uint32_t getNode(const TaxonID& id) const;  // throws TaxonNotFound (also for taxa pruned away, taxontree.cpp:59-64)
   size_t size() const { return parent.size(); }
 
