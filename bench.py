@@ -190,10 +190,15 @@ def main():
     stream = torch.cuda.current_stream()
     model.set_stream(stream.cuda_stream)
 
+    # X1: PredictionRecord rows of every rank to rank 0 over xGMI (RCCL gather); shard sizes are equal and known, the
+    # receive buffers on rank 0 are allocated once
+    gather_sizes = [ds.n_sets] * world
+    gather_out = [torch.empty_like(rows) for _ in range(world)] if (world > 1 and rank == 0) else None
+
     def step():
         model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
         if world > 1:
-            sharding.gather_rows(rows, dst=0)  # X1: PredictionRecord rows of every rank to rank 0 over xGMI (RCCL)
+            sharding.gather_rows(rows, dst=0, sizes=gather_sizes, out=gather_out)
 
     for _ in range(args.warmup):
         step()

@@ -33,24 +33,31 @@ def slice_batch(batch, lo, hi):
     return out
 
 
-def gather_rows(rows, dst=0, group=None):
+def gather_rows(rows, dst=0, group=None, sizes=None, out=None):
     """rows: (n_local, 8) int32 tensor (any device).  Returns the rows of all ranks concatenated in rank order on `dst`
-    (None elsewhere).  Shards may differ in size: sizes are exchanged first, rows are padded to the largest shard."""
+    (None elsewhere).  Shards may differ in size: sizes are exchanged first, rows are padded to the largest shard.
+    A caller that gathers the same shapes every step passes `sizes` (rows per rank, known up front) to skip the size
+    exchange, and on `dst` `out` = a list of world_size preallocated (max(sizes), 8) tensors to skip the allocation."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
         return rows
-    n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+        gathered = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(gathered, n_local, group=group)
+        sizes = [int(s.item()) for s in gathered]
     n_max = max(sizes)
     padded = rows
     if rows.shape[0] != n_max:
         padded = torch.zeros((n_max,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
         padded[: rows.shape[0]] = rows
-    bufs = [torch.zeros_like(padded) for _ in range(world)] if rank == dst else None
+    bufs = None
+    if rank == dst:
+        bufs = out if out is not None else [torch.empty_like(padded) for _ in range(world)]
     dist.gather(padded.contiguous(), bufs, dst=dst, group=group)
     if rank != dst:
         return None
+    if all(n == n_max for n in sizes) and out is not None:
+        return bufs  # equal shards, caller-owned buffers: no concatenation copy
     return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)

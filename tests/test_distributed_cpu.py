@@ -48,6 +48,14 @@ def _worker(rank, world, port, out_path, uneven):
     t = torch.from_numpy(rows.view(np.int32).reshape(-1, 8).copy())
     allrows = sharding.gather_rows(t, dst=0)
     dist.barrier()
+    # the path bench.py takes: shard sizes known up front (no size exchange), receive buffers allocated once
+    sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
+    outb = [torch.empty((max(sizes), 8), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+    again = sharding.gather_rows(t, dst=0, sizes=sizes, out=outb)
+    if rank == 0:
+        again = torch.cat(list(again), dim=0) if isinstance(again, list) else again
+        assert again.numpy().tobytes() == allrows.numpy().tobytes()
+    dist.barrier()
     if rank == 0:
         rc, full, _ = O.predict_batch(tax, q, db, 0, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
                                       synth.records_aos(ds.batch, O.RECORD_DTYPE))
