@@ -78,7 +78,9 @@ void rpa_destroy(rpa_engine* e);
 const char* rpa_last_error(const rpa_engine* e);
 
 /* Run on a caller-provided hipStream_t (e.g. the current stream of the framework that owns the device buffers).
- * NULL restores the engine's own stream. */
+ * NULL restores the engine's own stream.  The engine's own stream is independent (non-blocking): device-resident
+ * inputs (RPA_MEM_DEVICE batches, stores) must be complete before a call unless the engine has been put on the stream
+ * that produces them. */
 int rpa_set_stream(rpa_engine* e, void* hip_stream);
 
 /* Sequence stores, resident in HBM -- replaces RandomSeqStoreROInterface::getSequence /

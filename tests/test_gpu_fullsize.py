@@ -1,0 +1,80 @@
+"""BASELINE config 2 at its full size (1 M record sets x 20 hits x 200 bp on one MI355X) through properties that do not
+need the CPU oracle to finish a million sets: determinism, independence of record sets (a batch in reversed set order
+gives the reversed rows), structural invariants of every row, and bit-exact agreement with the oracle on two 10 k-set
+windows of the same batch (front and back).  The device batch is generated on the GPU exactly as bench.py does."""
+import importlib
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+from helpers import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_full_size_properties():
+    import torch
+    pkg = graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    S, NH = 1_000_000, 20
+    ds = synth.make_dataset(n_sets=S, n_hits=NH, seg_len=200, branching=4, genome_len=4000, seed=2, device="cuda")
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).cuda()
+           for k, v in ds.batch.items()}
+
+    def run(batch):
+        rows = torch.zeros((S, 8), dtype=torch.int32, device="cuda")
+        stats = torch.zeros((S, 4), dtype=torch.int32, device="cuda")
+        model.predict(batch, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
+        torch.cuda.synchronize()
+        return rows, stats
+
+    rows, stats = run(dev)
+    rows2, stats2 = run(dev)
+    assert torch.equal(rows, rows2) and torch.equal(stats, stats2)                      # deterministic
+
+    # independence: the same record sets in reversed order (every set has NH records here)
+    rev = {}
+    for k, v in dev.items():
+        if k == "set_offsets":
+            rev[k] = v
+        elif v.numel() == S:
+            rev[k] = torch.flip(v, dims=[0]).contiguous()
+        else:
+            rev[k] = torch.flip(v.view(S, NH), dims=[0]).contiguous().view(-1)
+    torch.cuda.synchronize()  # the engine runs on its own stream: the flips above (torch's stream) must have finished
+    rrows, rstats = run(rev)
+    assert torch.equal(torch.flip(rrows, dims=[0]), rows) and torch.equal(torch.flip(rstats, dims=[0]), stats)
+
+    r = rows.cpu().numpy().view(pkg.PRED_DTYPE).reshape(-1)
+    st = stats.cpu().numpy().view(pkg.STATS_DTYPE).reshape(-1)
+    tax = ds.tax
+    # every row: upper is lower or an ancestor of it, rtax lies at or below lower's lineage start, ranges inside the query
+    left, right, depth = np.asarray(tax.left), np.asarray(tax.right), np.asarray(tax.depth)
+    lo, up = r["lower"], r["upper"]
+    assert ((left[up] <= left[lo]) & (right[up] >= right[lo])).all() and (depth[up] <= depth[lo]).all()
+    assert ((left[lo] <= left[r["rtax"]]) & (right[lo] >= right[r["rtax"]]) | (r["flags"] != 0)).all()   # rtax at or below lower (multi-hit rows)
+    qlen = np.asarray(ds.batch["query_len"])
+    assert (r["begin"] >= 1).all() and (r["end"] <= qlen).all() and (r["begin"] <= r["end"]).all()
+    ival = r["ival"][r["flags"] == 0]
+    assert ((ival >= 0) & (ival <= 1)).all()
+    assert (st["n"] == NH).all() and int(st["pass0"].sum()) > S // 2 and int(st["pass1"].sum()) > 10 * S
+    demanded = int(st["pass0"].astype(np.int64).sum() + st["pass1"].astype(np.int64).sum() + st["pass2"].astype(np.int64).sum())
+    assert 20_000_000 < demanded < 40_000_000
+
+    # two windows against the oracle, bit for bit
+    otax = O.TaxArrays(tax.parent, tax.left, tax.right, tax.depth)
+    q = O.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+    db = O.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+    b = ds.batch
+    for w0 in (0, S - 10_000):
+        w1 = w0 + 10_000
+        r0, r1 = int(b["set_offsets"][w0]), int(b["set_offsets"][w1])
+        sub = {k: (v[r0:r1] if len(v) == len(b["qstart"]) else v) for k, v in b.items()}
+        offs = (b["set_offsets"][w0:w1 + 1] - b["set_offsets"][w0]).astype(np.uint32)
+        rc, exp, est = O.predict_batch(otax, q, db, 0, offs, b["query_seq"][w0:w1], b["query_len"][w0:w1], synth.records_aos(sub, O.RECORD_DTYPE))
+        assert rc == 0
+        assert r[w0:w1].tobytes() == exp.tobytes() and st[w0:w1].tobytes() == est.tobytes()
