@@ -82,6 +82,7 @@ struct rpa_engine {
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
+  bool fixed_speculation = false;  // the caller (or RPA_SPEC1/2) fixed the chunk sizes: keep them in the sparse rounds too
   DevBuf prof_acc;
   rpa_profile prof{};
   std::vector<hipEvent_t> ev_pool;
@@ -360,7 +361,12 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     w.live_in = sparse_decide ? cur_list : nullptr;
     w.n_live_in = live_now;   // exact
     w.live_out = next_list;
-    HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev,
+    // In the sparse rounds at the end of a batch a round costs ~150 us whatever it carries, so the loops that pause there
+    // ask for everything they could still need at once (speculation chunk 0) instead of 10 hits per round: a few hundred
+    // speculative alignments more, several rounds fewer.  (Chunk sizes never change results, only who computes what when.)
+    Params pr = e->params;
+    if (sparse_decide && !e->fixed_speculation) { pr.spec1 = 0; pr.spec2 = 0; }
+    HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, pr, rows_dev, stats_dev,
                              e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr));
     prev_live = live_now;
     list_in_a = !list_in_a;
@@ -380,6 +386,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
   w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
+  w->fixed_speculation = e->fixed_speculation;
   hipError_t err = hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipHostMalloc((void**)&w->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault);
   if (err == hipSuccess) err = w->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long));
@@ -519,8 +526,9 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
-  if (const char* v = getenv("RPA_SPEC1")) e->params.spec1 = (uint32_t)atoi(v);
-  if (const char* v = getenv("RPA_SPEC2")) e->params.spec2 = (uint32_t)atoi(v);
+  e->fixed_speculation = params->speculation_pass1 != RPA_SPECULATION_DEFAULT || params->speculation_pass2 != RPA_SPECULATION_DEFAULT;
+  if (const char* v = getenv("RPA_SPEC1")) { e->params.spec1 = (uint32_t)atoi(v); e->fixed_speculation = true; }
+  if (const char* v = getenv("RPA_SPEC2")) { e->params.spec2 = (uint32_t)atoi(v); e->fixed_speculation = true; }
   auto bail = [&](int code) { g_create_error = e->err; rpa_destroy(e); return code; };
 #define CREATE_TRY(call)                                                                                  \
   do {                                                                                                    \
