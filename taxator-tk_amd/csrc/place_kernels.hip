@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   w.res_slot[pos] = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);  // where the alignment kernels put this hit's result
   if (sp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); sp.x = 0; }
   // compact per-row word for k_emit: segment length + "pass 0 re-aligns this hit" (:511-518, threshold :499)
-  w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u);
+  w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u) | (perfect ? kLitePerfect : 0u);
   R.store_quad(rank, 0, make_uint4(__float_as_uint(sc), id, node, r));
   R.store_quad(rank, 1, make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta));
   const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
@@ -369,7 +369,9 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
   const uint32_t H = b.n_records;
   const uint32_t seglen = lite & kLiteLenMask;
   bool want = false;
+  const bool vs_query = info.mode == 1 || (info.mode == 4 && pos - lo == info.anchor);
   if (info.mode == 1) want = (lite & kLiteWant0) != 0u;
+  else if (info.mode == 4) want = vs_query ? (lite & kLiteWant0) != 0u : !(lite & kLiteZeroQd);
   else if (info.mode == 2) want = !(lite & kLiteZeroQd);
   else {
     const SetRows<P4> R = set_rows<P4>(w, s, lo);
@@ -383,8 +385,8 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
     }
   }
   if (!want) return -1;
-  const uint32_t other_len = info.mode == 1 ? info.qseglen : info.anchor_len;
-  const uint32_t other_seg = info.mode == 1 ? H + s : lo + info.anchor;
+  const uint32_t other_len = vs_query ? info.qseglen : info.anchor_len;
+  const uint32_t other_seg = vs_query ? H + s : lo + info.anchor;
   int bin = pair_bin(p, seglen, other_len);
   maxlen = p.alphabet == 0 ? max(seglen, other_len) : seglen;  // DNA: text = the longer one; protein: A
   entry = make_uint2(pos, other_seg);
@@ -419,20 +421,21 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(BatchDev b, WorkDev w, P
 #pragma unroll
   for (int k = 0; k < kEmitRows; ++k) {
     const uint32_t pos = pos0 + k * kEmitBlock;
-    const uint32_t mode = desc[k].x & 3u, anchor = desc[k].x >> 2;
+    const uint32_t mode = desc[k].x & 7u, anchor = desc[k].x >> 3;
     const uint32_t i = pos - lo[k];
     bin[k] = -1;
     entry[k] = make_uint2(0u, 0u);
     uint32_t ml = 0;
     if (pos < H) {
-      if (mode != 0u && i >= desc[k].y && i < desc[k].z && (mode == 1u || i != anchor)) {
+      if (mode != 0u && (mode == 4u || i >= desc[k].y) && i < desc[k].z && (mode == 1u || mode == 4u || i != anchor)) {
         if (mode != 3u) {  // passes 0 and 1: the lite word decides
-          const bool want = mode == 1u ? (lite[k] & kLiteWant0) != 0u : !(lite[k] & kLiteZeroQd);
+          const bool vs_query = mode == 1u || (mode == 4u && i == anchor);
+          const bool want = vs_query ? (lite[k] & kLiteWant0) != 0u : !(lite[k] & kLiteZeroQd);
           if (want) {
-            const uint32_t seglen = lite[k] & kLiteLenMask, other_len = desc[k].w;
+            const uint32_t seglen = lite[k] & kLiteLenMask, other_len = (mode == 4u && vs_query) ? desc[k].y : desc[k].w;
             bin[k] = pair_bin(p, seglen, other_len);
             ml = p.alphabet == 0 ? max(seglen, other_len) : seglen;  // DNA: text = the longer one; protein: A
-            entry[k] = make_uint2(pos, mode == 1u ? H + set_of[k] : lo[k] + anchor);
+            entry[k] = make_uint2(pos, vs_query ? H + set_of[k] : lo[k] + anchor);
             if (bin[k] >= kNumBins) { raise_error(w, kErrUnsupported, set_of[k]); bin[k] = -1; }
           }
         } else {
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, P
     const uint32_t i = i0 + (uint32_t)lane;
     int bin = -1;
     uint2 entry = make_uint2(0u, 0u);
-    if (i < i_hi && (info.mode == 1 || i != info.anchor)) {
+    if (i < i_hi && (info.mode == 1 || info.mode == 4 || i != info.anchor)) {
       uint32_t ml = 0;
       bin = sparse_bin(p, emit_predicate<P4>(b, w, p, info, s, lo, lo + i, w.lite[lo + i], entry, ml));
       maxlen = max(maxlen, ml);
@@ -595,6 +598,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
     st.qseglen = qseg.x; st.qsegerr = qseg.y;
     st.support = 0; st.best = 0; st.d_lca_all = 0; st.d_rtax = 0; st.d_lnode_g = 0; st.d_unode_g = 0; st.ival_g = 0.f;
     st.bf_max = 1.f; st.lrd_min = 255; st.anchor = 0; st.cnt0 = st.cnt1 = st.cnt2 = 0; st.loop_live = 0; st.chunk_hi = 0; st.i_next = 0;
+    st.combined = 0; st.pad_ = 0;
     OutRow row;
     row.begin = 1; row.end = b.query_len[s];  // initPredictionRecord, core/src/taxonpredictionmodel.hh:42-44
     row.lower = row.upper = row.rtax = kRoot; row.support = 0; row.ival = 0.f; row.flags = 0;
@@ -644,6 +648,19 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
         st.phase = kPass0Wait;
         em.mode = 1; em.n = n; em.L = st.L; em.qseglen = st.qseglen; em.i_lo = 0; em.i_hi = n;
         em.fcut = p.reeval_factor * h0.score;  // dbalignment_searchscore_threshold, :499
+        // Pass 0 and the first pass-1 loop in ONE round.  qgroup = the perfect hits + the hits above the threshold
+        // (:511-518).  If that is a single (not perfect) hit -- it is then hit 0, the top score -- every other hit
+        // comes out of pass 0 with distance FLT_MAX, so index_best and the first pass-1 anchor are hit 0 whatever its
+        // distance turns out to be (:542-546,553-562,582-583).  The pass-1 pairs (hit i, hit 0) can therefore be asked for
+        // together with the pass-0 pair (hit 0, query range): mode 4; k_decide consumes pass 0 and, the anchor being as
+        // predicted, the pass-1 loop in the same call.  Typical data (one hit within 5 % of the best score): one round,
+        // one decide launch and one small alignment launch less per batch.
+        uint32_t members = 0;
+        for (uint32_t i = 0; i < n; ++i) members += (w.lite[lo + i] & (kLiteWant0 | kLitePerfect)) ? 1u : 0u;
+        if (members == 1 && (w.lite[lo] & kLiteWant0) && !p.no_combined) {
+          em.mode = 4; em.anchor = 0; em.anchor_len = h0.seglen;
+          st.combined = 1;
+        }
       }
     }
     if (done) {
@@ -752,6 +769,10 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     uint32_t* fo = fq + nw;        // outgroup bits
     bool failed = false;
 
+    // Normally one trip: consume the results of the phase the set waited for, then choose what to align next.  A set
+    // whose pass 0 and first pass-1 loop were requested together (mode 4) takes a second trip through the pass-1 branch
+    // right away when the anchor it then selects is the predicted one (hit 0).
+    for (int trip = 0; trip < 2; ++trip) {
     if (st.phase == kPass0Wait) {  // ---- pass 0, :497-566 ----
       uint32_t path0[4 * P4];
       uint32_t d0 = 0;
@@ -1072,6 +1093,12 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         if (st.d_unode_g > st.d_lnode_g) raise_error(w, kErrAssert, s);  // setNodeRange assert, predictionrecord.hh:153
         st.phase = kDone;
       }
+    }
+    if (failed || trip == 1 || !st.combined) break;
+    st.combined = 0;
+    if (!(st.phase == kPass1Wait && st.anchor == 0)) break;  // (cannot happen with a single member; the results are then simply not used)
+    st.chunk_hi = n;   // every pass-1 pair of this anchor was part of the request
+    em.mode = 0;       // nothing asked for yet: the second trip decides
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
     w.emit[s] = em;

@@ -83,6 +83,8 @@ struct SetState {
   float ldist, udist;
   int32_t scut;        // qsearchscore_thresh_heuristic (:602)
   double qpid_upper, cut_g, cut_h;
+  uint32_t combined;   // pass 0 and the pass-1 loop of hit 0 were requested together (EmitInfo mode 4)
+  uint32_t pad_;
 };
 
 // One hit of a record set at its SortFilter position: 32 bytes of fields + the taxon path (4*path_quads words),
@@ -97,7 +99,8 @@ struct HitCore {
   uint32_t seglen;   // length of the reference segment
   uint32_t meta;     // kMeta* bits (static after k_rank_records)
 };
-constexpr uint32_t kLiteLenMask = 0x3FFFFFFFu;  // reference segments of 2^30 residues and more are refused
+constexpr uint32_t kLiteLenMask = 0x1FFFFFFFu;  // reference segments of 2^29 residues and more are refused
+constexpr uint32_t kLitePerfect = 0x20000000u;  // alnlen == L && identities == L: a member of qgroup with distance 0 (:511-517)
 constexpr uint32_t kLiteWant0 = 0x80000000u;    // pass 0 aligns this hit to the query range (not perfect, score >= threshold)
 constexpr uint32_t kLiteZeroQd = 0x40000000u;   // querydistance[i] == 0 after pass 0: pass 1 never aligns it (:620)
 constexpr uint32_t kMetaPerfect = 4u;  // perfect: alnlen == L && identities == L
@@ -112,7 +115,9 @@ struct SegDesc {
 
 // What a record set wants aligned in the coming round (written by plan/decide, read by k_emit and the alignment kernels).
 struct EmitInfo {
-  uint32_t mode;        // 0 nothing, 1 pass 0 (vs query range), 2 pass 1 (vs anchor), 3 pass 2 (vs anchor)
+  uint32_t mode;        // 0 nothing, 1 pass 0 (vs query range), 2 pass 1 (vs anchor), 3 pass 2 (vs anchor),
+                        // 4 pass 0 + pass 1 in one round: the only hit pass 0 aligns (hit `anchor` = 0) vs the query range,
+                        //   every other hit vs that hit (see k_plan_sets)
   uint32_t anchor;      // index_anchor
   uint32_t n;           // active hits
   uint32_t L;           // qrlength
@@ -127,9 +132,10 @@ struct EmitInfo {
 };
 
 // The 16 bytes of EmitInfo that k_emit needs in passes 0 and 1 (one load instead of the 56-byte struct):
-// x = mode | anchor << 2, y = i_lo, z = i_hi (<= n), w = length of the other segment (query range in pass 0, anchor in pass 1/2)
+// x = mode | anchor << 3, y = i_lo (mode 4: length of the query range), z = i_hi (<= n), w = length of the other segment
+// (query range in pass 0, anchor in pass 1/2 and in mode 4)
 __host__ __device__ __forceinline__ uint4 emit_desc(const EmitInfo& e) {
-  return uint4{e.mode | (e.anchor << 2), e.i_lo, e.i_hi < e.n ? e.i_hi : e.n, e.mode == 1u ? e.qseglen : e.anchor_len};
+  return uint4{e.mode | (e.anchor << 3), e.mode == 4u ? e.qseglen : e.i_lo, e.i_hi < e.n ? e.i_hi : e.n, e.mode == 1u ? e.qseglen : e.anchor_len};
 }
 
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
@@ -189,6 +195,7 @@ struct Params {
   float reeval_factor;    // reeval_bandwidth_factor_ = (float)(1. - reeval_bandwidth)
   uint32_t spec1, spec2;  // speculation chunk (hits per round) of the pass-1 / pass-2 loops; 0 = the whole set at once
   int force_bin;          // >= 0: put every pair into this bin (experiments: RPA_FORCE_BIN); -1 normally
+  int no_combined;        // 1: never ask for pass 0 and the first pass-1 loop in one round (A/B: RPA_NO_COMBINED)
 };
 
 struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells

@@ -525,6 +525,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_PARTS")) e->parts_override = atoi(v);
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
+  e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
   e->fixed_speculation = params->speculation_pass1 != RPA_SPECULATION_DEFAULT || params->speculation_pass2 != RPA_SPECULATION_DEFAULT;
   if (const char* v = getenv("RPA_SPEC1")) { e->params.spec1 = (uint32_t)atoi(v); e->fixed_speculation = true; }
