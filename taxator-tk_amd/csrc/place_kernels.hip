@@ -659,6 +659,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
         for (uint32_t i = 0; i < n; ++i) members += (w.lite[lo + i] & (kLiteWant0 | kLitePerfect)) ? 1u : 0u;
         if (members == 1 && (w.lite[lo] & kLiteWant0) && !p.no_combined) {
           em.mode = 4; em.anchor = 0; em.anchor_len = h0.seglen;
+          em.i_hi = p.spec1 ? min(n, p.spec1) : n;  // the first speculation chunk of the pass-1 loop (hit 0 is part of it)
           st.combined = 1;
         }
       }
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     if (failed || trip == 1 || !st.combined) break;
     st.combined = 0;
     if (!(st.phase == kPass1Wait && st.anchor == 0)) break;  // (cannot happen with a single member; the results are then simply not used)
-    st.chunk_hi = n;   // every pass-1 pair of this anchor was part of the request
+    // (st.chunk_hi, just set by the anchor selection, is the chunk k_plan_sets asked for: same speculation parameter)
     em.mode = 0;       // nothing asked for yet: the second trip decides
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
