@@ -197,3 +197,39 @@ def test_device_models_match_oracle(case):
     rows = model.lca_predict(batch, c["model"], evalue=evalue, node_unclassified=uncl, toppercent=c["toppercent"], minscore=c["minscore"],
                              maxevalue=c["maxevalue"], minsupport=c["minsupport"], nbest=c["nbest"], ignore_unclassified=c["ignore_unclassified"])
     assert rows.tobytes() == exp.tobytes()
+
+
+@pytest.mark.gpu
+def test_device_resident_batch():
+    """rpa_lca_predict_batch with every array already in HBM (RPA_MEM_DEVICE), rows written to a device tensor."""
+    import ctypes as C
+    import torch
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    rng = np.random.default_rng(6)
+    tree = Tree(rng, n_nodes=1000)
+    uncl = (rng.random(len(tree.parent)) < 0.2).astype(np.uint8)
+    offs, qlen, recs, evalue = random_batch(rng, tree, 5000, 30)
+    tax = O.TaxArrays(tree.parent, tree.left, tree.right, tree.depth)
+    rc, exp = O.lca_predict_batch(tax, O.LCA_MEGAN, offs, qlen, recs, evalue, uncl, toppercent=0.2, minsupport=2, ignore_unclassified=True)
+    assert rc == 0
+    model = pkg.RPAPredictionModel(tree, alphabet=pkg.DNA)
+    dev = dict(set_offsets=torch.from_numpy(offs.view(np.int32)).cuda(), query_len=torch.from_numpy(qlen.view(np.int32)).cuda(),
+               qstart=torch.from_numpy(recs["qstart"].copy().view(np.int32)).cuda(), qstop=torch.from_numpy(recs["qstop"].copy().view(np.int32)).cuda(),
+               score=torch.from_numpy(recs["score"].copy()).cuda(), node=torch.from_numpy(recs["node"].copy().view(np.int32)).cuda(),
+               filtered=torch.from_numpy(recs["filtered"].astype(np.uint8)).cuda())
+    ev = torch.from_numpy(evalue).cuda()
+    un = torch.from_numpy(uncl).cuda()
+    out = torch.zeros((len(qlen), 8), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # the engine runs on its own stream
+    L = model._L
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    b = pkg._Batch(len(qlen), len(recs), dev["set_offsets"].data_ptr(), None, dev["query_len"].data_ptr(), dev["qstart"].data_ptr(),
+                   dev["qstop"].data_ptr(), None, None, dev["score"].data_ptr(), None, None, None, dev["node"].data_ptr(),
+                   dev["filtered"].data_ptr(), pkg.MEM_DEVICE)
+    p = pkg._LcaParams()
+    L.rpa_lca_default_params(C.byref(p))
+    p.model, p.toppercent, p.minsupport, p.ignore_unclassified = pkg.LCA_MEGAN, 0.2, 2, 1
+    rc = L.rpa_lca_predict_batch(model._h, C.byref(b), ptr(ev), ptr(un), C.byref(p), ptr(out), pkg.MEM_DEVICE)
+    assert rc == 0, L.rpa_last_error(model._h)
+    assert out.cpu().numpy().tobytes() == exp.tobytes()
