@@ -194,8 +194,11 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   __shared__ uint32_t s_first;
   // the fields the per-set scan below compares, for the block's own records: the scan of a 20-hit set is 20 x 4 loads
   // per thread, nearly all of them to records of this block -> LDS (broadcast reads) instead of the vector memory path
-  __shared__ uint4 s_rec[kBlock];      // score bits, identities, qstart, qstop
-  __shared__ uint8_t s_filt[kBlock];
+  // (+ kHalo records on either side: the sets that straddle the block's ends would otherwise take the global path for
+  // up to a whole set's worth of iterations -- 45 vector loads per wave on config 2 instead of 15)
+  constexpr uint32_t kHalo = 64, kWin = kBlock + 2 * kHalo;
+  __shared__ uint4 s_rec[kWin];      // score bits, identities, qstart, qstop
+  __shared__ uint8_t s_filt[kWin];
   // Rows are written in the tiled layout: the 64-byte row of a record lands 16 bytes at a time in lines it shares with
   // the same row of the 63 neighbouring record sets, i.e. with records handled by this and the next few workgroups.
   // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so consecutive LOGICAL blocks are mapped
@@ -204,11 +207,12 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   const uint32_t lblock = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
   const uint32_t r0 = lblock * kBlock;
   if (r0 >= b.n_records) return;  // padding blocks of the grid (whole workgroup)
-  {
-    const uint32_t rr = r0 + threadIdx.x;
+  const uint32_t w0 = r0 >= kHalo ? r0 - kHalo : 0u;  // first record of the staged window
+  for (uint32_t k = threadIdx.x; k < kWin; k += kBlock) {
+    const uint32_t rr = w0 + k;
     if (rr < b.n_records) {
-      s_rec[threadIdx.x] = make_uint4(__float_as_uint(b.score[rr]), b.identities[rr], b.qstart[rr], b.qstop[rr]);
-      s_filt[threadIdx.x] = rec_filtered(b, rr) ? 1 : 0;
+      s_rec[k] = make_uint4(__float_as_uint(b.score[rr]), b.identities[rr], b.qstart[rr], b.qstop[rr]);
+      s_filt[k] = rec_filtered(b, rr) ? 1 : 0;
     }
   }
   if (threadIdx.x < 64) {
@@ -251,16 +255,17 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   if (s >= b.n_sets) s = b.n_sets - 1;  // clamped window entries (cannot be selected: set_offsets[n_sets] > r)
   w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
   const uint32_t beg = b.set_offsets[s], end = b.set_offsets[s + 1];
-  const bool me_filtered = s_filt[threadIdx.x] != 0;
-  const float sc = __uint_as_float(s_rec[threadIdx.x].x);
-  const uint32_t id = s_rec[threadIdx.x].y;
+  const uint32_t me = r - w0;  // my record inside the window
+  const bool me_filtered = s_filt[me] != 0;
+  const float sc = __uint_as_float(s_rec[me].x);
+  const uint32_t id = s_rec[me].y;
   uint32_t rank = 0, n = 0, qrstart = 0xFFFFFFFFu, qrstop = 0;
   float smax = 0.f;  // score of the set's best record (its first one in SortFilter order)
   for (uint32_t j = beg; j < end; ++j) {
     uint4 v;
     bool filt;
-    const uint32_t jl = j - r0;  // wraps for j < r0
-    if (jl < (uint32_t)kBlock) { v = s_rec[jl]; filt = s_filt[jl] != 0; }
+    const uint32_t jl = j - w0;  // wraps for j < w0
+    if (jl < kWin) { v = s_rec[jl]; filt = s_filt[jl] != 0; }
     else { v = make_uint4(__float_as_uint(b.score[j]), b.identities[j], b.qstart[j], b.qstop[j]); filt = rec_filtered(b, j); }
     if (filt) continue;
     const float sj = __uint_as_float(v.x);
