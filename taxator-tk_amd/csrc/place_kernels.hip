@@ -665,6 +665,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
         if (members == 1 && (w.lite[lo] & kLiteWant0) && !p.no_combined) {
           em.mode = 4; em.anchor = 0; em.anchor_len = h0.seglen;
           em.i_hi = p.spec1 ? min(n, p.spec1) : n;  // the first speculation chunk of the pass-1 loop (hit 0 is part of it)
+          st.chunk_hi = em.i_hi;                    // remembered: k_decide may run with another chunk size by then
           st.combined = 1;
         }
       }
@@ -778,6 +779,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     // Normally one trip: consume the results of the phase the set waited for, then choose what to align next.  A set
     // whose pass 0 and first pass-1 loop were requested together (mode 4) takes a second trip through the pass-1 branch
     // right away when the anchor it then selects is the predicted one (hit 0).
+    const uint32_t combined_hi = st.chunk_hi;  // mode 4: the pass-1 chunk that was requested together with pass 0
     for (int trip = 0; trip < 2; ++trip) {
     if (st.phase == kPass0Wait) {  // ---- pass 0, :497-566 ----
       uint32_t path0[4 * P4];
@@ -1103,8 +1105,8 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     if (failed || trip == 1 || !st.combined) break;
     st.combined = 0;
     if (!(st.phase == kPass1Wait && st.anchor == 0)) break;  // (cannot happen with a single member; the results are then simply not used)
-    // (st.chunk_hi, just set by the anchor selection, is the chunk k_plan_sets asked for: same speculation parameter)
-    em.mode = 0;       // nothing asked for yet: the second trip decides
+    st.chunk_hi = combined_hi;  // what was actually requested (the anchor selection just set it from the current chunk size)
+    em.mode = 0;                // nothing asked for yet: the second trip decides
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
     w.emit[s] = em;

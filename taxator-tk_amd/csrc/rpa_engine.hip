@@ -142,6 +142,7 @@ const char* kernel_error_text(uint32_t code) {
 // one-strip class also has work: its list is appended to that launch (a sparse launch costs ~60 us whatever its size,
 // and the wider kernel is exact for the narrower patterns at the price of the extra rows).
 constexpr uint32_t kRideAlongPairs = 262144;
+constexpr uint32_t kResidentLanes = 256u * 4u * 256u;  // one-pair-per-lane kernels: 256 CUs x 4 workgroups (LDS) x 256 lanes
 
 int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
   unsigned long long* acc = e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr;
@@ -364,8 +365,18 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     // In the sparse rounds at the end of a batch a round costs ~150 us whatever it carries, so the loops that pause there
     // ask for everything they could still need at once (speculation chunk 0) instead of 10 hits per round: a few hundred
     // speculative alignments more, several rounds fewer.  (Chunk sizes never change results, only who computes what when.)
+    // Likewise when the record sets still running cannot fill the chip with a default-sized chunk each (one pair per lane,
+    // ~262 k lanes resident): lanes that would idle anyway take the next hits of the loop, and a 50-hit pass-2 loop needs
+    // 2-3 rounds instead of 5 (config 5: rounds of 100 k pairs on a chip that holds 262 k).
     Params pr = e->params;
-    if (sparse_decide && !e->fixed_speculation) { pr.spec1 = 0; pr.spec2 = 0; }
+    if (!e->fixed_speculation) {
+      if (sparse_decide) { pr.spec1 = 0; pr.spec2 = 0; }
+      else {
+        const uint32_t fill = kResidentLanes / (live_now ? live_now : 1u);
+        if (pr.spec1 && fill > pr.spec1) pr.spec1 = fill;
+        if (pr.spec2 && fill > pr.spec2) pr.spec2 = fill;
+      }
+    }
     HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, pr, rows_dev, stats_dev,
                              e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr));
     prev_live = live_now;
