@@ -379,8 +379,9 @@ static size_t strip_words_per_thread(uint32_t max_len) { return 2 * (((size_t)ma
 size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len) {
   size_t threads = ((size_t)n_pairs + kBlock - 1) / kBlock * kBlock;
   // at most 32 GiB of boundary bytes in flight (of 288 GB of HBM), and never fewer than one workgroup.  The cap decides
-  // into how many launches a list is cut, and every launch ends with a partly filled last wave of workgroups: 700 k
-  // pairs of 10 kbp (config 5) took 4 such waves in two launches under a 4 GiB cap, 3 in one launch now.
+  // into how many launches a list is cut, and every launch has a tail in which most of the chip waits for its last
+  // workgroups (a 10 kbp pair keeps a lane busy for ~0.2 s): config 5 ran its 700 k-pair rounds as two launches under
+  // a 4 GiB cap and 4 % faster as one.
   const size_t cap = (((size_t)1 << 33) / strip_words_per_thread(max_len)) / kBlock * kBlock;
   if (threads > cap) threads = cap ? cap : kBlock;
   return threads * strip_words_per_thread(max_len);
