@@ -16,6 +16,31 @@ def shard_bounds(n_sets, world_size):
     return [(n_sets * r) // world_size for r in range(world_size + 1)]
 
 
+def set_costs(batch):
+    """Estimated alignment cells per record set: the cost of the path is quadratic in segment length (every demanded
+    realignment is ~ query range x reference range cells), so a set costs ~ sum over its hits of
+    (query range length) x (reference range length)."""
+    so = np.asarray(batch["set_offsets"]).astype(np.int64)
+    qspan = np.abs(np.asarray(batch["qstop"]).astype(np.int64) - np.asarray(batch["qstart"]).astype(np.int64)) + 1
+    rspan = np.abs(np.asarray(batch["rstop"]).astype(np.int64) - np.asarray(batch["rstart"]).astype(np.int64)) + 1
+    cells = np.concatenate([[0], np.cumsum(qspan * rspan)])
+    return cells[so[1:]] - cells[so[:-1]]
+
+
+def shard_bounds_by_cost(costs, world_size):
+    """Contiguous blocks of record sets with (nearly) equal summed cost per rank -- for batches of mixed lengths such as
+    BASELINE config 5, where equal counts leave ranks unevenly loaded.  Returns world_size+1 non-decreasing bounds; a set
+    goes to the rank whose cost interval contains the midpoint of the set's own cost span."""
+    costs = np.asarray(costs, dtype=np.float64)
+    n = len(costs)
+    total = float(costs.sum())
+    if n == 0 or total <= 0.0:
+        return shard_bounds(n, world_size)
+    mid = np.cumsum(costs) - 0.5 * costs
+    cuts = total * np.arange(1, world_size) / world_size
+    return [0] + [int(x) for x in np.searchsorted(mid, cuts, side="left")] + [n]
+
+
 def slice_batch(batch, lo, hi):
     """Record sets [lo, hi) of a host batch (dict of numpy arrays in rpa_batch layout), offsets rebased to 0."""
     so = np.asarray(batch["set_offsets"])

@@ -81,3 +81,28 @@ def test_shard_bounds_and_slices():
              qstart=np.arange(6, dtype=np.uint32), filtered=None)
     s = sharding.slice_batch(b, 1, 3)
     assert list(s["set_offsets"]) == [0, 3, 4] and list(s["qstart"]) == [2, 3, 4, 5] and list(s["query_len"]) == [8, 7]
+
+
+def test_shard_bounds_by_cost():
+    """batches of mixed lengths are cut by summed alignment cells, not by count."""
+    graft.load_package()
+    sharding = importlib.import_module("taxator_tk_amd.sharding")
+    # equal costs -> the same cut as by count (up to rounding at the boundary set)
+    assert sharding.shard_bounds_by_cost(np.ones(8), 4) == [0, 2, 4, 6, 8]
+    # one heavy set gets a rank to itself, the light ones share the others
+    b = sharding.shard_bounds_by_cost([1, 1, 1, 1, 100, 1, 1, 1, 1], 3)
+    assert b[0] == 0 and b[-1] == 9 and b == sorted(b) and b[1] <= 4 < b[2]
+    rng = np.random.default_rng(5)
+    for world in (2, 3, 8):
+        costs = rng.integers(1, 1000, 5000).astype(np.float64) ** 2
+        b = sharding.shard_bounds_by_cost(costs, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == 5000 and b == sorted(b)
+        loads = np.array([costs[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert loads.max() <= costs.sum() / world + costs.max()          # never worse than one set over the even share
+        by_count = sharding.shard_bounds(5000, world)
+        assert loads.max() <= max(costs[by_count[r]:by_count[r + 1]].sum() for r in range(world)) + costs.max()
+    assert sharding.shard_bounds_by_cost([], 4) == [0, 0, 0, 0, 0] and sharding.shard_bounds_by_cost([0, 0, 0], 2) == sharding.shard_bounds(3, 2)
+    # costs of a batch: query range x reference range, summed per record set
+    batch = dict(set_offsets=np.array([0, 2, 3], np.uint32), qstart=np.array([1, 1, 5], np.uint32), qstop=np.array([10, 20, 14], np.uint32),
+                 rstart=np.array([100, 50, 9], np.uint32), rstop=np.array([91, 69, 18], np.uint32))
+    assert list(sharding.set_costs(batch)) == [10 * 10 + 20 * 20, 10 * 10]
