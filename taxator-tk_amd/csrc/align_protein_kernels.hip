@@ -176,8 +176,203 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint2* __restrict__
   if (w.pair_ext) w.pair_ext[dst] = make_uint4(nmatch, mismatch, gap, len);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K3p: the same recurrence for pairs whose two sequences are at most kPackedMaxLen residues (every pair of the 67 aa
+// workload), with a cell packed into ONE 32-bit word so that the three-way choice AND its tie order are a single
+// unsigned maximum:
+//     bits 20..31  M[i][j] + i + bias  (row-relative score; bias = la + 32 keeps every candidate non-negative; <= 3347 < 4096)
+//     bits 18..19  which move produced the candidate: 2 diagonal, 1 vertical, 0 horizontal
+//     bits  9..17  #matches            (<= 255)
+//     bits  0..8   #diagonal steps     (<= 255)
+// max() orders candidates by score first and, on equal scores, by the move field = diagonal over vertical over
+// horizontal, the reference's order (dp_formula.h:153-163); the counters ride in the low bits of whichever wins.
+// Cells are kept with the move field SET TO 1 ("as a vertical candidate") and scores carry + i, so that
+//     vertical   candidate of the cell below = the cell itself               (gap -1 and row +1 cancel)  -- no instruction
+//     horizontal candidate = left + (-1 score, move 1 -> 0)                                              -- one add
+//     diagonal   candidate = diag + T(a,b),  T = (s(a,b) + 1) << 20 | (move 1 -> 2) | (a == b) << 9 | 1  -- one add
+// T is a ready-made 32-bit LDS table entry, the table replicated over the 32 banks (27 x 27 x 32 x 4 B = 91 KB) so
+// that a lane always reads its own bank.  Per cell: address add, ds_read_b32, two adds, v_max3_u32, v_and_or_b32 -- five
+// VALU instructions with a dependent chain of two (max3 -> and_or), against ~17 with compares and selects through SGPR
+// masks in K3, and half the strip-boundary traffic (4 B per column).
+// One 1024-lane workgroup per CU holds the table; its wavefronts are persistent and draw runs of 64 pairs from a
+// counter until the list is empty, so a long pair never keeps a whole workgroup's table waiting.
+// Same results as K3 bit for bit (same recurrence; no field can overflow at these lengths).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kPackedBlock = 1024;
+constexpr uint32_t kPkScore = 20, kPkMove = 18, kPkMatch = 9;
+constexpr uint32_t kPkMoveMask = 3u << kPkMove;
+constexpr uint32_t kPackedScratchHead = 64;  // words in front of the boundary rows: [0] = the work counter
+
+template <int R>
+__global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
+                                                                    uint32_t* __restrict__ scratch, uint32_t col_stride,
+                                                                    unsigned long long* prof_acc) {
+  __shared__ uint32_t tab[kAA * kAA * 32];  // [b][a][bank] -> T(a,b)
+  __shared__ int32_t selfdiag[32];
+  __shared__ int8_t blosum[kAA * kAA];       // the 729 scores once, then the expansion reads LDS
+  if (threadIdx.x < kAA * kAA) blosum[threadIdx.x] = c_blosum62[threadIdx.x];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < kAA * kAA * 32; idx += kPackedBlock) {
+    const int bres = idx / (kAA * 32), a = (idx / 32) % kAA;
+    const int sc = blosum[a * kAA + bres];
+    tab[idx] = ((uint32_t)(sc + 1) << kPkScore) + (1u << kPkMove) + (a == bres ? 1u << kPkMatch : 0u) + 1u;
+  }
+  if (threadIdx.x < 32) selfdiag[threadIdx.x] = threadIdx.x < kAA ? blosum[threadIdx.x * kAA + threadIdx.x] : 0;
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t bank4 = (threadIdx.x & 31u) * 4u;
+  const uint8_t* __restrict__ tabb = reinterpret_cast<const uint8_t*>(tab);
+  // my boundary row: columns 4g+1 .. 4g+4 at sc4[g * col_stride] (16 bytes per lane and group: coalesced)
+  uint4* __restrict__ sc4 = reinterpret_cast<uint4*>(scratch + kPackedScratchHead) + blockIdx.x * kPackedBlock + threadIdx.x;
+  // the constants of a cell live in VGPRs (literal / SGPR operands issue at half rate on gfx950)
+  uint32_t c_horiz = 0u - (1u << kPkScore) - (1u << kPkMove);  // score - 1, move 1 -> 0
+  uint32_t c_keep = ~kPkMoveMask, c_one = 1u << kPkMove;
+  asm volatile("" : "+v"(c_horiz), "+v"(c_keep), "+v"(c_one));
+
+  // The first run of a wavefront is fixed -- wavefront v of workgroup g takes run v * gridDim.x + g, so a short list is
+  // dealt one run per CU before any CU gets a second -- the following ones come from the counter (which starts behind
+  // the fixed runs).  Every wavefront leaves through the break: the counter only grows.
+  uint32_t base = ((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64u;
+  for (;; ) {
+    if (base >= n_list) break;
+    const uint32_t run = base;
+    if (lane == 0) base = atomicAdd(scratch, 64u);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t t = run + lane;
+    const bool active = t < n_list;
+    uint32_t dst = 0, la = 0, lb = 0;
+    const uint8_t* __restrict__ pa = nullptr;
+    const uint8_t* __restrict__ pb = nullptr;
+    if (active) {
+      uint32_t sa, sb;
+      resolve_pair(w, list[t], sa, sb, dst);
+      const SegView va = seg_view(w, sa), vb = seg_view(w, sb);
+      la = va.len; lb = vb.len;
+      pa = reinterpret_cast<const uint8_t*>(va.words) + va.src;
+      pb = reinterpret_cast<const uint8_t*>(vb.words) + vb.src;
+    }
+    if (prof_acc) {  // same accounting as the other alignment kernels: pairs, len_a+len_b+8, cells
+      unsigned long long v0 = active ? 1ull : 0ull, v1 = active ? (unsigned long long)la + lb + 8ull : 0ull,
+                         v2 = active ? (unsigned long long)la * lb : 0ull;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); v2 += __shfl_down(v2, d, 64); }
+      if (lane == 0) {
+        unsigned long long* acc = prof_acc + ((run >> 6) & (kProfParts - 1)) * 4;
+        atomicAdd(&acc[0], v0); atomicAdd(&acc[1], v1); atomicAdd(&acc[2], v2);
+      }
+    }
+    if (!active) continue;  // the last run of a list; nothing below is wave-collective
+
+    int32_t selfscore = 0;  // NW(A,A) + NW(B,B) = sums of s(x,x) (:190-191), gathered while the residues pass by
+    const uint32_t bias = la + 32u;
+    const uint32_t nstrips = (lb + R - 1) / R;
+    uint32_t res = bias << kPkScore;  // no rows: K3's answer (score 0, no steps)
+    if (nstrips == 0)
+      for (uint32_t j = 0; j < la; ++j) selfscore += selfdiag[pa[j]];
+    for (uint32_t k = 0; k < nstrips; ++k) {
+      const bool first = k == 0, last = k + 1 == nstrips;
+      uint32_t rowoff[R];  // LDS byte offset of the table row of each strip row's residue
+      {
+        uint32_t bw[R / 4];  // unaligned dword loads; reads run at most R - 1 bytes past the segment (store slack)
+#pragma unroll
+        for (int q = 0; q < R / 4; ++q) __builtin_memcpy(&bw[q], pb + (size_t)k * R + 4 * q, 4);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t bres = (bw[r >> 2] >> (8 * (r & 3))) & 0xFFu;  // rows past lb are never used
+          rowoff[r] = bres * (kAA * 128u) + bank4;
+          if (k * R + r < lb) selfscore += selfdiag[bres];
+        }
+      }
+      uint32_t L[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) L[r] = (bias << kPkScore) | c_one;  // column 0: M[i][0] + i = 0
+      uint32_t dtop = (bias << kPkScore) | c_one;                      // (row k*R, column 0)
+      // one column: residue a, the cell above the strip; returns the strip's bottom cell
+      auto column = [&](uint32_t a, uint32_t top) -> uint32_t {
+        const uint32_t colterm = a * 128u;
+        uint32_t up = top, dg = dtop;
+        dtop = top;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t tv = *reinterpret_cast<const uint32_t*>(tabb + rowoff[r] + colterm);
+          const uint32_t left = L[r];
+          const uint32_t raw = max(max(dg + tv, up), left + c_horiz);
+          const uint32_t cell = __builtin_amdgcn_bitop3_b32(raw, c_keep, c_one, 0xEA);  // (raw & keep) | one: v_bitop3 issues at full rate, v_and_or at half
+          dg = left;
+          L[r] = cell;
+          up = cell;
+        }
+        return up;
+      };
+      // Columns go in groups of four: the residues of A come as unaligned dwords asked for two groups ahead, the
+      // boundary cells of the strip above as one 16-byte load per group asked for one group ahead, and the strip's own
+      // bottom cells leave as one 16-byte store per group.  (Memory operations retire in order on gfx9: with a byte
+      // load and a 4-byte store per column, every column waited for the previous column's store to reach memory.)
+      uint32_t ad_cur = 0u, ad_nxt = 0u;
+      if (la) __builtin_memcpy(&ad_cur, pa, 4);
+      if (la > 4u) __builtin_memcpy(&ad_nxt, pa + 4, 4);
+      uint4 t_cur = make_uint4(0u, 0u, 0u, 0u);
+      if (!first && la) t_cur = sc4[0];
+      const uint32_t full = la & ~3u;
+      uint32_t jb = 0;
+      for (; jb < full; jb += 4u) {  // columns jb+1 .. jb+4
+        const uint32_t g = jb >> 2;
+        uint4 t_nxt = make_uint4(0u, 0u, 0u, 0u);
+        if (!first && jb + 4u < la) t_nxt = sc4[(size_t)(g + 1u) * col_stride];
+        uint32_t ad_far = 0u;
+        if (jb + 8u < la) __builtin_memcpy(&ad_far, pa + jb + 8u, 4);
+        const uint32_t a0 = ad_cur & 0xFFu, a1 = (ad_cur >> 8) & 0xFFu, a2 = (ad_cur >> 16) & 0xFFu, a3 = ad_cur >> 24;
+        uint4 top = t_cur;
+        if (first) {  // row 0: M[0][j] = -j
+          const uint32_t t0 = ((bias - (jb + 1u)) << kPkScore) | c_one;
+          top = make_uint4(t0, t0 - (1u << kPkScore), t0 - (2u << kPkScore), t0 - (3u << kPkScore));
+          selfscore += selfdiag[a0] + selfdiag[a1] + selfdiag[a2] + selfdiag[a3];
+        }
+        uint4 out;
+        out.x = column(a0, top.x);
+        out.y = column(a1, top.y);
+        out.z = column(a2, top.z);
+        out.w = column(a3, top.w);
+        if (!last) sc4[(size_t)g * col_stride] = out;
+        t_cur = t_nxt; ad_cur = ad_nxt; ad_nxt = ad_far;
+      }
+      if (jb < la) {  // the last one to three columns, one at a time
+        uint4 out = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t ncol = la - jb;
+#pragma unroll 1
+        for (uint32_t c = 0; c < ncol; ++c) {
+          const uint32_t a = (ad_cur >> (8u * c)) & 0xFFu;
+          uint32_t top = c == 0u ? t_cur.x : c == 1u ? t_cur.y : t_cur.z;
+          if (first) { top = ((bias - (jb + c + 1u)) << kPkScore) | c_one; selfscore += selfdiag[a]; }
+          const uint32_t bottom = column(a, top);
+          if (c == 0u) out.x = bottom; else if (c == 1u) out.y = bottom; else out.z = bottom;
+        }
+        if (!last) sc4[(size_t)(jb >> 2) * col_stride] = out;
+      }
+      if (last) {
+        const uint32_t rr = lb - k * R - 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if ((uint32_t)r == rr) res = L[r];
+      }
+    }
+    const int32_t mutual = (int32_t)(res >> kPkScore) - (int32_t)(bias + lb);
+    const uint32_t ndiag = res & 0x1FFu, nmatch = (res >> kPkMatch) & 0x1FFu;
+    const uint32_t gap = (la - ndiag) + (lb - ndiag);
+    const uint32_t mismatch = ndiag - nmatch;
+    const uint32_t len = gap + nmatch + mismatch;                       // :227
+    const float normfactor = (float)len / (float)selfscore;             // :228
+    float distance = (float)(selfscore - 2 * mutual) * normfactor;      // :232
+    const float similarity = (float)(2 * mutual) * normfactor;          // :233
+    if (!(selfscore >= mutual) || !(distance >= 0.f)) distance = __builtin_nanf("");
+    w.pair_res[res_index(w, dst)] = make_float2(distance, similarity);
+    if (w.pair_ext) w.pair_ext[dst] = make_uint4(nmatch, mismatch, gap, len);
+  }
+}
+
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len) {
-  size_t threads = ((size_t)n_pairs + kBlock - 1) / kBlock * kBlock;
+  size_t threads = ((size_t)n_pairs + kPackedBlock - 1) / kPackedBlock * kPackedBlock;
   const size_t cap = (size_t)1 << 20;  // at most 1 Mi alignments in flight per launch
   if (threads > cap) threads = cap;
   return threads * 2 * ((size_t)max_len + 2);
@@ -208,6 +403,37 @@ hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* lis
 #undef RPA_LAUNCH_NW
     done += chunk;
   }
+  return hipGetLastError();
+}
+
+// K3p over a list of pairs that protein_bin() found eligible (both sequences <= kPackedMaxLen).  One persistent
+// workgroup per CU; the boundary rows need (max_len + 1) words per resident lane.
+hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
+                                       size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc) {
+  if (n == 0) return hipSuccess;
+  hipError_t e = upload_blosum();
+  if (e != hipSuccess) return e;
+  if (max_len > kPackedMaxLen) return hipErrorInvalidValue;
+  static int cus[64] = {0};
+  int dev = 0;
+  e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  int n_cu = dev < 64 ? cus[dev] : 0;
+  if (!n_cu) {
+    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64) cus[dev] = n_cu;
+  }
+  // one workgroup per CU as long as there is a run of 64 pairs for it: a short list is spread over the chip (one busy
+  // wavefront per CU runs ~3.5x faster than four per SIMD); wavefronts that find the counter exhausted leave at once
+  uint32_t blocks = (n + 63u) / 64u;
+  if (blocks > (uint32_t)n_cu) blocks = (uint32_t)n_cu;
+  const size_t per_lane_words = ((size_t)max_len + 3) / 4 * 4;  // whole groups of four columns
+  while (blocks > 1 && kPackedScratchHead + (size_t)blocks * kPackedBlock * per_lane_words > scratch_words) --blocks;
+  if (kPackedScratchHead + (size_t)blocks * kPackedBlock * per_lane_words > scratch_words) return hipErrorOutOfMemory;
+  e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch), (int)(blocks * (kPackedBlock / 64) * 64u), 1, st);  // the work counter starts behind the fixed first runs
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_nw_protein_packed<24>, dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
   return hipGetLastError();
 }
 

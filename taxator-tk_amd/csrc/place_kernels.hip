@@ -345,7 +345,7 @@ __device__ __forceinline__ int pair_bin(const Params& p, uint32_t la, uint32_t l
   if (p.alphabet == 0) return dna_bin(la < lb ? la : lb);
   (void)la;
   if (p.force_bin >= 0) return p.force_bin;
-  return protein_bin(lb);  // protein: B (second segment) is the vertical sequence cut into register strips
+  return protein_bin(la, lb);  // protein: B (second segment) is the vertical sequence cut into register strips
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         st.loop_live = 1; st.i_next = i; st.nog = nog; st.d_lnode = d_lnode; st.ldist = ldist; st.udist = udist;
         st.qpid_upper = qpid_upper; st.cut_g = cut_g; st.cut_h = cut_h; st.scut = scut;
         band.save(w.band_save + (size_t)s * 2 * (kMaxDepth + 1));
-        st.chunk_hi = p.spec1 ? min(n, i + p.spec1) : n;
+        st.chunk_hi = p.spec1 ? min(n, i + (p.grow ? max(p.spec1, i) : p.spec1)) : n;
         em.mode = 2; em.anchor = a; em.anchor_len = ha.seglen; em.i_lo = i; em.i_hi = st.chunk_hi;
       } else
       if (!failed) {
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       }
       if (paused) {
         st.loop_live = 1; st.i_next = i;
-        st.chunk_hi = p.spec2 ? min(n, i + p.spec2) : n;
+        st.chunk_hi = p.spec2 ? min(n, i + (p.grow ? max(p.spec2, i) : p.spec2)) : n;
         em = sel; em.mode = 3; em.i_lo = i; em.i_hi = st.chunk_hi; em.emit_query = 0; em.d_unode_g = st.d_unode_g;
       } else if (!failed) { st.phase = kPass2Select; st.loop_live = 0; }
     }

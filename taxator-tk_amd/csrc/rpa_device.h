@@ -196,6 +196,8 @@ struct Params {
   uint32_t spec1, spec2;  // speculation chunk (hits per round) of the pass-1 / pass-2 loops; 0 = the whole set at once
   int force_bin;          // >= 0: put every pair into this bin (experiments: RPA_FORCE_BIN); -1 normally
   int no_combined;        // 1: never ask for pass 0 and the first pass-1 loop in one round (A/B: RPA_NO_COMBINED)
+  int grow;               // 1: a loop that pauses asks for as many hits again as it has already walked (chunks 2,2,4,8,...):
+                          //    a loop that has not stopped early so far probably will not; log2(n) rounds instead of n/chunk
 };
 
 struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells
@@ -245,6 +247,8 @@ hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint2
                                  unsigned long long* prof_acc);
 hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
+hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
+                                       size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
 
 // Work-list entry -> (segment A, segment B, result index).  Order matters for protein (A is the horizontal sequence):
@@ -271,9 +275,12 @@ __device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
 // 67 aa (tools/ab_protein.sh, same device): R = 16 and 24 tie, R = 32 is 17 % slower (172 VGPRs -> 2 waves per SIMD),
 // R = 8 is 50 % slower (per-column overhead); choosing 16 or 24 per pair costs 7 % more than either alone (two
 // half-filled launches per round).  RPA_FORCE_BIN selects another height for experiments.
-__host__ __device__ __forceinline__ int protein_bin(uint32_t lb) {
-  (void)lb;
-  return 2;
+// Bin 4: both sequences short enough for the packed-cell kernel (K3p, align_protein_kernels.hip).
+constexpr uint32_t kPackedMaxLen = 255;
+constexpr int kProteinBins = 5;
+constexpr int kProteinPackedBin = 4;
+__host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb) {
+  return la <= kPackedMaxLen && lb <= kPackedMaxLen ? kProteinPackedBin : 2;
 }
 
 // ---- reading a segment out of the packed store --------------------------------------------------------------

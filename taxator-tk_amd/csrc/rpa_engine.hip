@@ -191,7 +191,11 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
     } else {
       const uint32_t max_len = counts[kCtrMaxLen];
       HIP_TRY(e, e->protein_ws.ensure(protein_scratch_words(n, max_len) * 4));
-      HIP_TRY(e, launch_align_protein(e->stream, 8 * (bin + 1), list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
+      if (bin == kProteinPackedBin)  // in this list both sequences of every pair are <= kPackedMaxLen (protein_bin)
+        HIP_TRY(e, launch_align_protein_packed(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4,
+                                               std::min(max_len, kPackedMaxLen), acc));
+      else
+        HIP_TRY(e, launch_align_protein(e->stream, 8 * (bin + 1), list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
     }
     if (e->profiling) {
       HIP_TRY(e, hipEventRecord(e->ev_pool[i1], e->stream));
@@ -251,7 +255,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   const size_t n_res = (size_t)(want_ext ? (T > T2 ? T : T2) : (size_t)P + S) + 1;  // predict: one per row slot + one per set; align_pairs: one per pair
   HIP_TRY(e, e->pair_res.ensure(n_res * 8));
   if (want_ext) HIP_TRY(e, e->pair_ext.ensure(n_res * 16));
-  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kNumBins : 4)));
+  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kNumBins : kProteinBins)));
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
   HIP_TRY(e, e->live_a.ensure((size_t)(S ? S : 1) * 4));
   HIP_TRY(e, e->live_b.ensure((size_t)(S ? S : 1) * 4));
@@ -529,18 +533,21 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.reeval_factor = (float)(1. - params->reeval_bandwidth);  // reeval_bandwidth_factor_(1. - reeval_bandwidth), :334
   // speculation chunks (hits whose alignment is requested per round of a pass-1 / pass-2 loop): results never depend on
   // them, only the number of alignments computed beyond what the reference demands and the number of rounds
-  e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 0u : 8u) : params->speculation_pass1;
-  e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 6u) : params->speculation_pass2;  // tools/spec_sweep.sh
+  e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 0u : 2u) : params->speculation_pass1;
+  e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 10u) : params->speculation_pass2;  // tools/spec_sweep.sh, tools/spec_sweep4.sh
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
   if (const char* v = getenv("RPA_ROW_LAYOUT")) e->linear_rows = !strcmp(v, "linear");
   if (const char* v = getenv("RPA_PARTS")) e->parts_override = atoi(v);
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
   e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
+  e->params.grow = 0;
+  if (const char* v = getenv("RPA_SPEC_GROW")) e->params.grow = atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
   e->fixed_speculation = params->speculation_pass1 != RPA_SPECULATION_DEFAULT || params->speculation_pass2 != RPA_SPECULATION_DEFAULT;
   if (const char* v = getenv("RPA_SPEC1")) { e->params.spec1 = (uint32_t)atoi(v); e->fixed_speculation = true; }
   if (const char* v = getenv("RPA_SPEC2")) { e->params.spec2 = (uint32_t)atoi(v); e->fixed_speculation = true; }
+  if (getenv("RPA_SPEC_ADAPTIVE")) e->fixed_speculation = false;  // sweeps of the default chunk sizes: keep the per-round adaptation
   auto bail = [&](int code) { g_create_error = e->err; rpa_destroy(e); return code; };
 #define CREATE_TRY(call)                                                                                  \
   do {                                                                                                    \

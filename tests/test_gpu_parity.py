@@ -167,6 +167,22 @@ def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir):
                 b = a.copy()
             a_codes.append(a)
             b_codes.append(b.astype(np.uint8))
+    # the packed-cell kernel takes pairs of <= 255 x <= 255 residues, the two-register one the rest: both sides of the
+    # switch, the extreme scores the packed score field must hold (255 x W/W = +2805, nothing in common = all gaps /
+    # mismatches), and lopsided pairs
+    w_code = int(np.nonzero(LETTERS_AA == ord("W"))[0][0])
+    c_code, g_code = (int(np.nonzero(LETTERS_AA == ord(ch))[0][0]) for ch in "CG")
+    for la, lb in [(255, 255), (256, 256), (255, 256), (256, 255), (254, 255), (255, 1), (1, 255), (256, 1), (1, 256), (255, 24), (24, 255),
+                   (255, 25), (72, 72), (48, 49)]:
+        a_codes.append(np.full(la, w_code, np.uint8)); b_codes.append(np.full(lb, w_code, np.uint8))
+        a_codes.append(np.full(la, w_code, np.uint8)); b_codes.append(np.full(lb, c_code, np.uint8))
+        a_codes.append(np.full(la, g_code, np.uint8)); b_codes.append(np.full(lb, c_code, np.uint8))
+        a_codes.append(rng.integers(0, 20, la).astype(np.uint8)); b_codes.append(rng.integers(0, 20, lb).astype(np.uint8))
+        a = rng.integers(0, 20, la).astype(np.uint8)
+        b = np.resize(a, lb).copy()
+        mm = rng.random(lb) < 0.15
+        b[mm] = rng.integers(0, 20, int(mm.sum()))
+        a_codes.append(a); b_codes.append(b)
     seqs = [LETTERS_AA[x] for pair in zip(a_codes, b_codes) for x in pair]
     letters, offsets = _pack(seqs)
     n = len(a_codes)
