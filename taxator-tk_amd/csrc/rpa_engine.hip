@@ -533,7 +533,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.reeval_factor = (float)(1. - params->reeval_bandwidth);  // reeval_bandwidth_factor_(1. - reeval_bandwidth), :334
   // speculation chunks (hits whose alignment is requested per round of a pass-1 / pass-2 loop): results never depend on
   // them, only the number of alignments computed beyond what the reference demands and the number of rounds
-  e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 0u : 2u) : params->speculation_pass1;
+  e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 0u : 4u) : params->speculation_pass1;
   e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 10u) : params->speculation_pass2;  // tools/spec_sweep.sh, tools/spec_sweep4.sh
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
   if (const char* v = getenv("RPA_ROW_LAYOUT")) e->linear_rows = !strcmp(v, "linear");
