@@ -258,8 +258,9 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
 
   const uint32_t words = (m + 31u) / 32u;
   const uint32_t nstrips = (words + NW - 1u) / NW;
-  uint32_t* __restrict__ sc = scratch + t;  // message dword g (columns 4g .. 4g+3) at sc[g * stride]
-  const uint32_t n_dwords = (n + 7u) >> 3;
+  // boundary messages: 4 bits per column (3 used), 32 columns = one 16-byte word per lane, group g at sc4[g * stride]
+  uint4* __restrict__ sc4 = reinterpret_cast<uint4*>(scratch) + t;
+  const uint32_t n_groups = (n + 31u) >> 5;
 
   uint32_t VP[NW], VN[NW];
   int32_t bottom = 0;
@@ -320,46 +321,39 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
       return carry | (hp << 1) | (hn << 2);
     };
 
-    // the text: 32 nucleotides (one 16-byte load, issued four dwords ahead) per four steps
+    // Per 32 columns: one 16-byte load of text, one of the messages of the strip above (both asked for a group ahead)
+    // and one 16-byte store of this strip's messages.  Memory operations retire in order on gfx9, so a load and a
+    // store every four columns made each wait for the previous store to reach HBM; the strips of a 10 kbp pair move
+    // ~400 KB of messages per lane, which is also why a column's message is a nibble and not a byte.
     NtStream ts;
     ts.init(txt, 0u);
     uint4 pending = ts.load4();
-    uint4 buf = make_uint4(0u, 0u, 0u, 0u);
     // row 0 of the matrix: +1 enters every column (HP carry 1), no add carry, no HN
-    uint32_t min0 = 0x02020202u, min1 = 0x02020202u;
-    if (!first) { min0 = sc[0]; if (n > 4u) min1 = sc[stride]; }
-    for (uint32_t dw = 0; dw < n_dwords; ++dw) {
-      if ((dw & 3u) == 0u) {
-        buf = ts.take32(pending);
-        if (dw + 4 < n_dwords) pending = ts.load4();
-      }
-      const uint32_t in0 = min0, in1 = min1;
-      if (dw + 1 < n_dwords) {
-        if (!first) {  // boundary messages of the next 8 columns
-          min0 = sc[(size_t)(2u * dw + 2u) * stride];
-          if (n > (dw + 1u) * 8u + 4u) min1 = sc[(size_t)(2u * dw + 3u) * stride];
-        }
-      }
-      const uint32_t q4 = dw & 3u;
-      const uint32_t d = q4 == 0u ? buf.x : q4 == 1u ? buf.y : q4 == 2u ? buf.z : buf.w;
-      const uint32_t cols = n - dw * 8u;
-      uint32_t out0 = 0, out1 = 0;
-      if (cols >= 8u) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out0 |= column((d >> (4 * k)) & 7u, in0 >> (8 * k)) << (8 * k);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out1 |= column((d >> (4 * k + 16)) & 7u, in1 >> (8 * k)) << (8 * k);
-      } else {
+    uint4 m_nxt = make_uint4(0x22222222u, 0x22222222u, 0x22222222u, 0x22222222u);
+    if (!first) m_nxt = sc4[0];
+    for (uint32_t g = 0; g < n_groups; ++g) {
+      const uint4 buf = ts.take32(pending);
+      if (g + 1u < n_groups) pending = ts.load4();
+      const uint4 m_in = m_nxt;
+      if (!first && g + 1u < n_groups) m_nxt = sc4[(size_t)(g + 1u) * stride];
+      const uint32_t cols = n - g * 32u;
+      uint4 out = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 1
-        for (uint32_t k = 0; k < cols; ++k) {
-          const uint32_t o = column((d >> (4 * k)) & 7u, (k < 4u ? in0 : in1) >> (8 * (k & 3u)));
-          if (k < 4u) out0 |= o << (8 * k); else out1 |= o << (8 * (k - 4u));
+      for (uint32_t q = 0; q < 4u && q * 8u < cols; ++q) {  // eight columns: one dword of text, one of messages
+        const uint32_t d = q == 0u ? buf.x : q == 1u ? buf.y : q == 2u ? buf.z : buf.w;
+        const uint32_t mi = q == 0u ? m_in.x : q == 1u ? m_in.y : q == 2u ? m_in.z : m_in.w;
+        const uint32_t left = cols - q * 8u;
+        uint32_t o = 0;
+        if (left >= 8u) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o |= column((d >> (4 * k)) & 7u, mi >> (4 * k)) << (4 * k);
+        } else {
+#pragma unroll 1
+          for (uint32_t k = 0; k < left; ++k) o |= column((d >> (4u * k)) & 7u, mi >> (4u * k)) << (4u * k);
         }
+        if (q == 0u) out.x = o; else if (q == 1u) out.y = o; else if (q == 2u) out.z = o; else out.w = o;
       }
-      if (!last) {
-        sc[(size_t)(2u * dw) * stride] = out0;
-        if (cols > 4u) sc[(size_t)(2u * dw + 1u) * stride] = out1;
-      }
+      if (!last) sc4[(size_t)g * stride] = out;
     }
   }
   // phantom rows below the pattern in the last strip: take their vertical deltas off the bottom score
@@ -374,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
   if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
 }
 
-static size_t strip_words_per_thread(uint32_t max_len) { return 2 * (((size_t)max_len + 7) / 8) + 2; }
+static size_t strip_words_per_thread(uint32_t max_len) { return 4 * (((size_t)max_len + 31) / 32) + 4; }  // 16 bytes per 32 columns
 
 size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len) {
   size_t threads = ((size_t)n_pairs + kBlock - 1) / kBlock * kBlock;
