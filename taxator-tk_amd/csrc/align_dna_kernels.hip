@@ -229,12 +229,12 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
 // The delta vectors of a strip of NW words (NW in 5..8, chosen per pair to waste the fewest rows) live in VGPRs and
 // the strip's match masks in LDS exactly as in K1; the lane sweeps the whole text once per strip.  What a strip hands
 // to the one below is, per text column, the add carry and the two shift carries out of its last word -- 3 bits, the
-// same message K2 passes between lanes -- kept as one byte per column in an HBM scratch laid out
-// [4 columns][thread] (a wave reads/writes 256 contiguous bytes per 4 columns; one dword load + store per 4 columns
-// against ~600 VALU issue slots).  Rows past the end of the pattern (the last strip is rarely full) match nothing,
+// same message K2 passes between lanes -- kept as three bit planes of 32 columns in an HBM scratch laid out
+// [group of 32 columns][plane][thread] (a wave reads/writes 256 contiguous bytes per plane and group; three dword loads
+// + stores per 32 columns against ~4000 VALU issue slots).  Rows past the end of the pattern (the last strip is rarely full) match nothing,
 // which leaves rows <= m untouched; the score is tracked at the static bottom bit of the last strip and corrected at
 // the end by the vertical deltas of those phantom rows: D[m][n] = D[bottom][n] - (popc(VP & tail) - popc(VN & tail)).
-// Same bound as K1 (integer VALU issue); per-column strip overhead ~12 %.  Any pattern length fits.
+// Same bound as K1 (integer VALU issue); per-column strip overhead ~9 instructions of ~90.  Any pattern length fits.
 // ------------------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
 
   const uint32_t words = (m + 31u) / 32u;
   const uint32_t nstrips = (words + NW - 1u) / NW;
-  // boundary messages: 4 bits per column (3 used), 32 columns = one 16-byte word per lane, group g at sc4[g * stride]
-  uint4* __restrict__ sc4 = reinterpret_cast<uint4*>(scratch) + t;
+  // boundary bit planes: group g (32 columns) of plane p at sc[(3g + p) * stride]
+  uint32_t* __restrict__ sc = scratch + t;
   const uint32_t n_groups = (n + 31u) >> 5;
 
   uint32_t VP[NW], VN[NW];
@@ -295,10 +295,14 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
     }
     bottom = (int32_t)((wbase + NW) * 32u);  // D[bottom row of this strip][0]
 
-    // One column.  `in`: bit 0 add carry, bit 1 HP, bit 2 HN entering word 0 (higher bits are ignored); returns the same for the strip below.
-    auto column = [&](uint32_t c, uint32_t in) -> uint32_t {
+    // What a strip hands to the one below per column is 3 bits: the add carry and the HP / HN shift carries out of its
+    // last word.  They travel as three bit planes of 32 columns (column k of a group at bit 31-k): leaving, a column
+    // shifts its bit into each plane with one funnel shift; entering, the carries of column k are the top bits of the
+    // planes shifted left by k (only bit 31 of hp_prev / hn_prev is ever used).
+    uint32_t Cout = 0, Pout = 0, Nout = 0;
+    auto column = [&](uint32_t c, uint32_t carry, uint32_t hp_prev, uint32_t hn_prev) {
       const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
-      uint32_t carry = in & 1u, hp_prev = in << 30, hn_prev = in << 29, HP = 0, HN = 0;
+      uint32_t HP = 0, HN = 0;
 #pragma unroll
       for (int wi = 0; wi < NW; ++wi) {
         const uint32_t vp = VP[wi], vn = VN[wi];
@@ -316,44 +320,53 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
         VN[wi] = Xs & D0;
         VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);              // Hs | ~(Xs | D0)
       }
-      const uint32_t hp = HP >> 31, hn = HN >> 31;
-      bottom += (int32_t)hp - (int32_t)hn;
-      return carry | (hp << 1) | (hn << 2);
+      Pout = __builtin_amdgcn_alignbit(Pout, HP, 31);  // (Pout << 1) | (HP >> 31)
+      Nout = __builtin_amdgcn_alignbit(Nout, HN, 31);
+      Cout = (Cout << 1) | carry;
     };
 
-    // Per 32 columns: one 16-byte load of text, one of the messages of the strip above (both asked for a group ahead)
-    // and one 16-byte store of this strip's messages.  Memory operations retire in order on gfx9, so a load and a
-    // store every four columns made each wait for the previous store to reach HBM; the strips of a 10 kbp pair move
-    // ~400 KB of messages per lane, which is also why a column's message is a nibble and not a byte.
+    // Per 32 columns: one 16-byte load of text and three dword loads of the planes of the strip above (all asked for a
+    // group ahead), three dword stores of this strip's planes, [plane][group][lane] so that a wavefront's accesses are
+    // contiguous.  (Memory operations retire in order on gfx9: with a load and a store every four columns each load
+    // waited for the previous store to reach HBM; the strips of a 10 kbp pair move ~250 KB of planes per lane.)
     NtStream ts;
     ts.init(txt, 0u);
     uint4 pending = ts.load4();
     // row 0 of the matrix: +1 enters every column (HP carry 1), no add carry, no HN
-    uint4 m_nxt = make_uint4(0x22222222u, 0x22222222u, 0x22222222u, 0x22222222u);
-    if (!first) m_nxt = sc4[0];
+    uint32_t Cn = 0u, Pn = 0xFFFFFFFFu, Nn = 0u;
+    if (!first) { Cn = sc[0]; Pn = sc[stride]; Nn = sc[(size_t)2 * stride]; }
     for (uint32_t g = 0; g < n_groups; ++g) {
       const uint4 buf = ts.take32(pending);
       if (g + 1u < n_groups) pending = ts.load4();
-      const uint4 m_in = m_nxt;
-      if (!first && g + 1u < n_groups) m_nxt = sc4[(size_t)(g + 1u) * stride];
+      uint32_t Cin = Cn, Pin = Pn, Nin = Nn;
+      if (!first && g + 1u < n_groups) {
+        const uint32_t* __restrict__ nx = sc + (size_t)(3u * (g + 1u)) * stride;
+        Cn = nx[0]; Pn = nx[stride]; Nn = nx[(size_t)2 * stride];
+      }
       const uint32_t cols = n - g * 32u;
-      uint4 out = make_uint4(0u, 0u, 0u, 0u);
+      Cout = 0u; Pout = 0u; Nout = 0u;
 #pragma unroll 1
-      for (uint32_t q = 0; q < 4u && q * 8u < cols; ++q) {  // eight columns: one dword of text, one of messages
+      for (uint32_t q = 0; q < 4u && q * 8u < cols; ++q) {  // eight columns: one dword of text, one byte of each plane
         const uint32_t d = q == 0u ? buf.x : q == 1u ? buf.y : q == 2u ? buf.z : buf.w;
-        const uint32_t mi = q == 0u ? m_in.x : q == 1u ? m_in.y : q == 2u ? m_in.z : m_in.w;
         const uint32_t left = cols - q * 8u;
-        uint32_t o = 0;
         if (left >= 8u) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) o |= column((d >> (4 * k)) & 7u, mi >> (4 * k)) << (4 * k);
+          for (int k = 0; k < 8; ++k) column((d >> (4 * k)) & 7u, (Cin >> (31 - k)) & 1u, Pin << k, Nin << k);
+          Cin <<= 8; Pin <<= 8; Nin <<= 8;
         } else {
 #pragma unroll 1
-          for (uint32_t k = 0; k < left; ++k) o |= column((d >> (4u * k)) & 7u, mi >> (4u * k)) << (4u * k);
+          for (uint32_t k = 0; k < left; ++k) {
+            column((d >> (4u * k)) & 7u, Cin >> 31, Pin, Nin);
+            Cin <<= 1; Pin <<= 1; Nin <<= 1;
+          }
         }
-        if (q == 0u) out.x = o; else if (q == 1u) out.y = o; else if (q == 2u) out.z = o; else out.w = o;
       }
-      if (!last) sc4[(size_t)g * stride] = out;
+      bottom += (int32_t)__popc(Pout) - (int32_t)__popc(Nout);  // D[bottom row][j] - D[bottom row][j-1] summed over the group
+      if (cols < 32u) { const uint32_t sh = 32u - cols; Cout <<= sh; Pout <<= sh; Nout <<= sh; }
+      if (!last) {
+        uint32_t* __restrict__ o = sc + (size_t)(3u * g) * stride;
+        o[0] = Cout; o[stride] = Pout; o[(size_t)2 * stride] = Nout;
+      }
     }
   }
   // phantom rows below the pattern in the last strip: take their vertical deltas off the bottom score
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict
   if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
 }
 
-static size_t strip_words_per_thread(uint32_t max_len) { return 4 * (((size_t)max_len + 31) / 32) + 4; }  // 16 bytes per 32 columns
+static size_t strip_words_per_thread(uint32_t max_len) { return 3 * (((size_t)max_len + 31) / 32) + 3; }  // three bit planes per 32 columns
 
 size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len) {
   size_t threads = ((size_t)n_pairs + kBlock - 1) / kBlock * kBlock;
