@@ -82,6 +82,9 @@ struct rpa_engine {
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
+  // a round goes through the live list once live sets x this <= all sets (tools/sparse_sweep.sh: decide from 1/6 on is
+  // 5 % of a config-4 step, neutral on config 2; emit only pays from 1/24 on)
+  uint32_t sparse_div_emit = 24, sparse_div_decide = 6;
   bool fixed_speculation = false;  // the caller (or RPA_SPEC1/2) fixed the chunk sizes: keep them in the sparse rounds too
   DevBuf prof_acc;
   rpa_profile prof{};
@@ -338,7 +341,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     // Dense round: scan every row / every set.  Sparse round (few sets left): walk the live list only.
     uint32_t* cur_list = list_in_a ? e->live_a.as<uint32_t>() : e->live_b.as<uint32_t>();
     uint32_t* next_list = list_in_a ? e->live_b.as<uint32_t>() : e->live_a.as<uint32_t>();
-    const bool sparse_emit = rounds > 0 && (uint64_t)prev_live * 24 <= S;
+    const bool sparse_emit = rounds > 0 && (uint64_t)prev_live * e->sparse_div_emit <= S;
     w.live_in = sparse_emit ? cur_list : nullptr;
     w.n_live_in = prev_live;  // grid bound only: the kernel reads the exact length from counters[kCtrActive]
     HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, e->params));
@@ -362,7 +365,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     if (rc) return rc;
     if (rounds == 1) gate.open();  // the long pass-1 alignment launch is queued: the next part may start underneath it
     HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kNumRoundCounters, e->stream));  // keep the error words
-    const bool sparse_decide = rounds > 0 && (uint64_t)live_now * 24 <= S;
+    const bool sparse_decide = rounds > 0 && (uint64_t)live_now * e->sparse_div_decide <= S;
     w.live_in = sparse_decide ? cur_list : nullptr;
     w.n_live_in = live_now;   // exact
     w.live_out = next_list;
@@ -402,6 +405,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   w->device = e->device; w->params = e->params; w->tax = e->tax;
   w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
   w->fixed_speculation = e->fixed_speculation;
+  w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide;
   hipError_t err = hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipHostMalloc((void**)&w->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault);
   if (err == hipSuccess) err = w->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long));
@@ -547,6 +551,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->fixed_speculation = params->speculation_pass1 != RPA_SPECULATION_DEFAULT || params->speculation_pass2 != RPA_SPECULATION_DEFAULT;
   if (const char* v = getenv("RPA_SPEC1")) { e->params.spec1 = (uint32_t)atoi(v); e->fixed_speculation = true; }
   if (const char* v = getenv("RPA_SPEC2")) { e->params.spec2 = (uint32_t)atoi(v); e->fixed_speculation = true; }
+  if (const char* v = getenv("RPA_SPARSE_EMIT")) e->sparse_div_emit = (uint32_t)atoi(v);
+  if (const char* v = getenv("RPA_SPARSE_DECIDE")) e->sparse_div_decide = (uint32_t)atoi(v);
   if (getenv("RPA_SPEC_ADAPTIVE")) e->fixed_speculation = false;  // sweeps of the default chunk sizes: keep the per-round adaptation
   auto bail = [&](int code) { g_create_error = e->err; rpa_destroy(e); return code; };
 #define CREATE_TRY(call)                                                                                  \
