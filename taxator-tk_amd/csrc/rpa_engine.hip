@@ -176,11 +176,14 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
         // Patterns of more than 256 nt.  Many pairs: one per lane, register strips (K1s).  Few pairs (not enough to give
         // every SIMD a few waves of lanes): one per wavefront (K2), as long as the pattern fits its 64 x 8 words.
         const uint32_t max_len = counts[kCtrMaxLen];  // longest sequence of any emitted pair: bounds text and pattern
-        // Measured on MI355X (tools/pairs_bench.py): K1s reaches ~66 T cell updates/s once ~160 k lanes are busy and
-        // ~0.4 G/s per lane below that; K2 ~50 T/s x (pattern words / (64 x words per lane)) from ~8 k waves on.
+        // Measured on MI355X (config 5 rounds, 10 kbp pairs, both kernels on the same lists): K1s runs a lane at ~1.0 G
+        // cell updates/s while a SIMD holds one or two of its waves (0.9 k pairs: 99 ms, 115 k pairs: 134 ms = 86 T/s)
+        // and levels off near 90 T/s as the chip fills (217 k pairs: 240 ms; 115 T/s over several rounds of lanes);
+        // K2 reaches 17 T/s at 0.9 k pairs, 29 T/s at 2.2 k and ~50 T/s x (pattern words / (64 x words per lane)) from
+        // ~4 k waves on (115 k pairs: 230 ms).  The cross-over is near 50 k pairs.
         const double words = (max_len + 31u) / 32u, wpl = (uint32_t)((words + 63) / 64);
-        const double tp_lane = std::min(66e12, n * 0.4e9);
-        const double tp_wave = std::min(1.0, n / 8192.0) * 50e12 * words / (64.0 * wpl);
+        const double tp_lane = std::min(88e12, n * 1.0e9);
+        const double tp_wave = std::min(1.0, n / 4096.0) * 50e12 * words / (64.0 * wpl);
         bool wave = max_len <= kWaveMaxPattern && tp_wave > tp_lane;
         if (e->long_kernel == 1 && max_len <= kWaveMaxPattern) wave = true;
         if (e->long_kernel == 2) wave = false;
