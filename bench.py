@@ -161,7 +161,7 @@ CONFIGS = {
     "c2": dict(sets=1_000_000, hits=20, seg_len=200, alphabet=0, genome_len=4000, level_rate=0.03, query_rate=0.05,
                name="BASELINE config 2", kernel="k_myers_short (batched bit-parallel edit distance, one alignment per lane)"),
     "c4": dict(sets=500_000, hits=20, seg_len=67, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08,
-               name="BASELINE config 4 (protein, 67 aa)", kernel="k_nw_protein (BLOSUM62 global DP with forward-carried path counters, one alignment per lane)"),
+               name="BASELINE config 4 (protein, 67 aa)", kernel="k_nw_protein_packed (BLOSUM62 global DP, score + tie order + path counters in one 32-bit cell, one alignment per lane)"),
     "c5": dict(sets=12_500, hits=50, seg_len=10_000, alphabet=0, genome_len=40_000, level_rate=0.03, query_rate=0.05,
                name="BASELINE config 5 (10 kbp contigs, per-GPU share of 100 k)", kernel="k_myers_strips (bit-parallel edit distance, one alignment per lane, pattern in register strips of 5-8 words)"),
 }
