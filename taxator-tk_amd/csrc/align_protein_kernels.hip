@@ -198,7 +198,14 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint2* __restrict__
 // counter until the list is empty, so a long pair never keeps a whole workgroup's table waiting.
 // Same results as K3 bit for bit (same recurrence; no field can overflow at these lengths).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kPackedBlock = 1024;
+#ifndef RPA_PACKED_BLOCK
+#define RPA_PACKED_BLOCK 1024
+#endif
+#ifndef RPA_PACKED_ROWS
+#define RPA_PACKED_ROWS 24
+#endif
+constexpr int kPackedBlock = RPA_PACKED_BLOCK;
+constexpr int kPackedRows = RPA_PACKED_ROWS;
 constexpr uint32_t kPkScore = 20, kPkMove = 18, kPkMatch = 9;
 constexpr uint32_t kPkMoveMask = 3u << kPkMove;
 constexpr uint32_t kPackedScratchHead = 64;  // words in front of the boundary rows: [0] = the work counter
@@ -433,7 +440,7 @@ hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32
   if (kPackedScratchHead + (size_t)blocks * kPackedBlock * per_lane_words > scratch_words) return hipErrorOutOfMemory;
   e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch), (int)(blocks * (kPackedBlock / 64) * 64u), 1, st);  // the work counter starts behind the fixed first runs
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_nw_protein_packed<24>, dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
+  hipLaunchKernelGGL(k_nw_protein_packed<kPackedRows>, dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
   return hipGetLastError();
 }
 
