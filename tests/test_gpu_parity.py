@@ -241,6 +241,25 @@ def test_speculation_chunks_never_change_results(pkg, oracle, synth, speculation
     _engine_vs_oracle(pkg, oracle, synth, dp, 1, speculation=speculation)
 
 
+@pytest.mark.parametrize("env", [
+    {"RPA_SPEC1": "2", "RPA_SPEC2": "3", "RPA_SPEC_GROW": "1"},                 # paused loops double their chunk
+    {"RPA_SPEC1": "3", "RPA_SPEC2": "2", "RPA_SPEC_ADAPTIVE": "1"},             # fixed start, per-round adaptation on
+    {"RPA_SPARSE_DECIDE": "1", "RPA_SPARSE_EMIT": "1"},                         # every round after the first through the live list
+    {"RPA_SPARSE_DECIDE": "1000000", "RPA_SPARSE_EMIT": "1000000"},             # never
+    {"RPA_NO_COMBINED": "1", "RPA_SPARSE_DECIDE": "2", "RPA_SPARSE_EMIT": "50"},
+], ids=["grow", "adaptive", "always-sparse", "never-sparse", "split-rounds"])
+def test_round_scheduling_knobs_never_change_results(pkg, oracle, synth, env, monkeypatch):
+    """How the rounds are cut (chunk growth, when a round walks the live list instead of every row, pass 0 and pass 1 in
+    one round or two) decides who computes what when -- never the rows or the demanded-alignment counters."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ds = synth.make_dataset(n_sets=1200, n_hits=20, seg_len=150, branching=4, genome_len=3000, seed=23, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    dp = synth.make_dataset(n_sets=300, n_hits=16, seg_len=60, branching=3, genome_len=1500, seed=24, alphabet=1,
+                            level_rate=0.06, query_rate=0.08, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, dp, 1)
+
+
 def test_predict_dna_ragged_sets_and_lengths(pkg, oracle, synth):
     """Record sets of different sizes (1..40 records) and segment lengths from 40 to 700 bp in one batch."""
     parts = [synth.make_dataset(n_sets=150, n_hits=h, seg_len=L, branching=3, genome_len=2500, seed=10 + k, variety=True)
