@@ -276,6 +276,12 @@ def test_predict_protein(pkg, oracle, synth):
     ds = synth.make_dataset(n_sets=60, n_hits=10, seg_len=200, branching=2, genome_len=1500, seed=5, alphabet=1,
                             level_rate=0.06, query_rate=0.08)
     _engine_vs_oracle(pkg, oracle, synth, ds, 1)
+    # segments around the 255-residue limit of the packed-cell kernel: one batch feeds both protein kernels
+    ds = synth.make_dataset(n_sets=60, n_hits=10, seg_len=253, branching=2, genome_len=1500, seed=6, alphabet=1,
+                            level_rate=0.06, query_rate=0.08)
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 1)
+    lens = np.abs(ds.batch["rstop"].astype(np.int64) - ds.batch["rstart"].astype(np.int64)) + 1
+    assert (lens <= 255).any() and (lens > 255).any()
 
 
 def test_predict_long_contigs(pkg, oracle, synth):
