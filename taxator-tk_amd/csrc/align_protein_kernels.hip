@@ -177,13 +177,13 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint2* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K3p: the same recurrence for pairs whose two sequences are at most kPackedMaxLen residues (every pair of the 67 aa
+// K3p: the same recurrence for pairs that pass protein_fits_packed() (up to 312 x 312 residues; every pair of the 67 aa
 // workload), with a cell packed into ONE 32-bit word so that the three-way choice AND its tie order are a single
 // unsigned maximum:
-//     bits 20..31  M[i][j] + i + bias  (row-relative score; bias = la + 32 keeps every candidate non-negative; <= 3347 < 4096)
+//     bits 20..31  M[i][j] + i + bias  (row-relative score; bias = la + 32 keeps every candidate non-negative; <= 4095 by the bin's test)
 //     bits 18..19  which move produced the candidate: 2 diagonal, 1 vertical, 0 horizontal
-//     bits  9..17  #matches            (<= 255)
-//     bits  0..8   #diagonal steps     (<= 255)
+//     bits  9..17  #matches            (<= 511)
+//     bits  0..8   #diagonal steps     (<= 511)
 // max() orders candidates by score first and, on equal scores, by the move field = diagonal over vertical over
 // horizontal, the reference's order (dp_formula.h:153-163); the counters ride in the low bits of whichever wins.
 // Cells are kept with the move field SET TO 1 ("as a vertical candidate") and scores carry + i, so that

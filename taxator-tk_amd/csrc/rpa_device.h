@@ -275,13 +275,16 @@ __device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
 // 67 aa (tools/ab_protein.sh, same device): R = 16 and 24 tie, R = 32 is 17 % slower (172 VGPRs -> 2 waves per SIMD),
 // R = 8 is 50 % slower (per-column overhead); choosing 16 or 24 per pair costs 7 % more than either alone (two
 // half-filled launches per round).  RPA_FORCE_BIN selects another height for experiments.
-// Bin 4: both sequences short enough for the packed-cell kernel (K3p, align_protein_kernels.hip).
-constexpr uint32_t kPackedMaxLen = 255;
+// Bin 4: the pair fits the packed-cell kernel (K3p, align_protein_kernels.hip): its two 9-bit path counters hold up to
+// 511 steps and its 12-bit score field holds la + lb + 11 * min(la, lb) + 32 (row-relative score + bias, BLOSUM62's
+// largest entry is 11) -- 312 x 312 residues, or e.g. 511 x 100.
+constexpr uint32_t kPackedMaxLen = 511;
 constexpr int kProteinBins = 5;
 constexpr int kProteinPackedBin = 4;
-__host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb) {
-  return la <= kPackedMaxLen && lb <= kPackedMaxLen ? kProteinPackedBin : 2;
+__host__ __device__ __forceinline__ bool protein_fits_packed(uint32_t la, uint32_t lb) {
+  return la <= kPackedMaxLen && lb <= kPackedMaxLen && la + lb + 11u * (la < lb ? la : lb) + 32u <= 4095u;
 }
+__host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb) { return protein_fits_packed(la, lb) ? kProteinPackedBin : 2; }
 
 // ---- reading a segment out of the packed store --------------------------------------------------------------
 __device__ __forceinline__ uint32_t revcomp8(uint32_t x) {  // 8 packed nt: reverse the nibble order, A<->T, C<->G, N stays

@@ -167,13 +167,13 @@ def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir):
                 b = a.copy()
             a_codes.append(a)
             b_codes.append(b.astype(np.uint8))
-    # the packed-cell kernel takes pairs of <= 255 x <= 255 residues, the two-register one the rest: both sides of the
-    # switch, the extreme scores the packed score field must hold (255 x W/W = +2805, nothing in common = all gaps /
-    # mismatches), and lopsided pairs
+    # the packed-cell kernel takes pairs whose score and counter fields cannot overflow (312 x 312, 511 x 100, ...), the
+    # two-register one the rest: both sides of the switch, the extreme scores the packed score field must hold (W/W =
+    # +11 per residue, nothing in common = all gaps / mismatches), and lopsided pairs
     w_code = int(np.nonzero(LETTERS_AA == ord("W"))[0][0])
     c_code, g_code = (int(np.nonzero(LETTERS_AA == ord(ch))[0][0]) for ch in "CG")
     for la, lb in [(255, 255), (256, 256), (255, 256), (256, 255), (254, 255), (255, 1), (1, 255), (256, 1), (1, 256), (255, 24), (24, 255),
-                   (255, 25), (72, 72), (48, 49)]:
+                   (255, 25), (72, 72), (48, 49), (312, 312), (313, 313), (313, 312), (511, 100), (100, 511), (512, 100), (511, 101), (340, 280)]:
         a_codes.append(np.full(la, w_code, np.uint8)); b_codes.append(np.full(lb, w_code, np.uint8))
         a_codes.append(np.full(la, w_code, np.uint8)); b_codes.append(np.full(lb, c_code, np.uint8))
         a_codes.append(np.full(la, g_code, np.uint8)); b_codes.append(np.full(lb, c_code, np.uint8))
@@ -276,12 +276,12 @@ def test_predict_protein(pkg, oracle, synth):
     ds = synth.make_dataset(n_sets=60, n_hits=10, seg_len=200, branching=2, genome_len=1500, seed=5, alphabet=1,
                             level_rate=0.06, query_rate=0.08)
     _engine_vs_oracle(pkg, oracle, synth, ds, 1)
-    # segments around the 255-residue limit of the packed-cell kernel: one batch feeds both protein kernels
-    ds = synth.make_dataset(n_sets=60, n_hits=10, seg_len=253, branching=2, genome_len=1500, seed=6, alphabet=1,
+    # segments around the ~312 x 312 limit of the packed-cell kernel: one batch feeds both protein kernels
+    ds = synth.make_dataset(n_sets=60, n_hits=10, seg_len=312, branching=2, genome_len=1500, seed=6, alphabet=1,
                             level_rate=0.06, query_rate=0.08)
     rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 1)
     lens = np.abs(ds.batch["rstop"].astype(np.int64) - ds.batch["rstart"].astype(np.int64)) + 1
-    assert (lens <= 255).any() and (lens > 255).any()
+    assert (13 * lens + 32 <= 4095).any() and (13 * lens + 32 > 4095).any()
 
 
 def test_predict_long_contigs(pkg, oracle, synth):
