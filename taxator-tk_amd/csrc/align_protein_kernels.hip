@@ -1,4 +1,6 @@
-// taxator-tk_amd/csrc/align_protein_kernels.hip -- protein re-alignment kernel (K3) for gfx950.
+// taxator-tk_amd/csrc/align_protein_kernels.hip -- protein re-alignment kernels for gfx950: K3 (any length) and K3p (the
+// packed-cell form of the same recurrence for pairs up to ~312 x 312 residues, further down; the engine bins pairs by
+// protein_fits_packed(), rpa_device.h).
 //
 // What it replaces: getAlignmentProtein (core/src/taxonpredictionmodelsequence.hh:173-242) = three SeqAn calls
 //   selfscore = NW(A,A) + NW(B,B)                 (:190-191, full DP in the reference)
@@ -413,7 +415,7 @@ hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* lis
   return hipGetLastError();
 }
 
-// K3p over a list of pairs that protein_bin() found eligible (both sequences <= kPackedMaxLen).  One persistent
+// K3p over a list of pairs that protein_bin() found eligible (protein_fits_packed).  One persistent
 // workgroup per CU; the boundary rows need (max_len + 1) words per resident lane.
 hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                        size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc) {

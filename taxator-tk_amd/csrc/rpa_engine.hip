@@ -197,7 +197,7 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
     } else {
       const uint32_t max_len = counts[kCtrMaxLen];
       HIP_TRY(e, e->protein_ws.ensure(protein_scratch_words(n, max_len) * 4));
-      if (bin == kProteinPackedBin)  // in this list both sequences of every pair are <= kPackedMaxLen (protein_bin)
+      if (bin == kProteinPackedBin)  // every pair of this list passed protein_fits_packed(): no sequence above kPackedMaxLen
         HIP_TRY(e, launch_align_protein_packed(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4,
                                                std::min(max_len, kPackedMaxLen), acc));
       else
