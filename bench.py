@@ -258,9 +258,12 @@ def main():
         # HBM traffic of the alignment kernels cannot be read from inside the process: it comes from the committed
         # rocprofv3 PMC passes of this same command (profiles/*traffic.json, see profiles/README.md)
         traffic, traffic_src = None, None
-        if args.config == "c2":
+        if args.sets == cfg["sets"] and args.hits == cfg["hits"] and args.seg_len == cfg["seg_len"]:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+            # profiles/<round>_traffic.json = config 2 (the headline), profiles/<round>_cN_traffic.json = config N
+            tagged = lambda f, c: ("_%s_" % c) in os.path.basename(f)
+            cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))
+                           if (tagged(f, args.config) if args.config != "c2" else not any(tagged(f, c) for c in CONFIGS)))
             if cands:
                 tj = json.load(open(cands[-1]))
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
