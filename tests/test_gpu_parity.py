@@ -503,6 +503,9 @@ def test_batch_cut_into_parts(pkg, oracle, synth, parts, monkeypatch):
     monkeypatch.setenv("RPA_PARTS", parts)
     ds = synth.make_dataset(n_sets=2500, n_hits=14, seg_len=120, branching=4, genome_len=3000, seed=51, variety=True)
     rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    dp = synth.make_dataset(n_sets=700, n_hits=12, seg_len=67, branching=3, genome_len=1500, seed=52, alphabet=1,
+                            level_rate=0.06, query_rate=0.08, variety=True)  # every worker has its own protein workspace / work counter
+    _engine_vs_oracle(pkg, oracle, synth, dp, 1)
     import torch
     model = pkg.RPAPredictionModel(ds.tax, alphabet=0)
     model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
