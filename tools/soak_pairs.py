@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""tools/soak_pairs.py [N_BATCHES] -- pair-level differential soak on the GPU box: batches of random nucleotide / protein
+pairs of random lengths (every kernel: one-strip Myers classes, register strips, wave-per-pair, both protein kernels) and
+similarity (identical, point mutations + indels, unrelated, reversed, N-rich) through rpa_align_pairs and the CPU oracle.
+Test infrastructure (uses oracle/)."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as graft
+from helpers import oracle as O
+from helpers import refio as R
+
+pkg = graft.load_package()
+LET = {0: np.frombuffer(b"ACGTN", np.uint8), 1: np.frombuffer(R.AA_LETTERS.encode(), np.uint8)}
+
+
+class OneNodeTax:
+    parent = np.zeros(1, np.uint32); left = np.array([1], np.uint32); right = np.array([2], np.uint32); depth = np.zeros(1, np.uint8)
+
+
+def mutate(a, rng, asize, rate):
+    b = a.copy()
+    mm = rng.random(len(b)) < rate
+    b[mm] = rng.integers(0, asize, int(mm.sum()))
+    for _ in range(int(rng.integers(0, 1 + len(a) // 16))):
+        if len(b) > 1 and rng.random() < 0.5:
+            b = np.delete(b, rng.integers(0, len(b)))
+        else:
+            b = np.insert(b, rng.integers(0, len(b) + 1), rng.integers(0, asize))
+    return b.astype(np.uint8)
+
+
+n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(777)
+t0 = time.time()
+total = 0
+for k in range(n_batches):
+    alphabet = int(rng.random() < 0.4)
+    asize = 5 if alphabet == 0 else 27
+    if alphabet == 0:
+        top = int(rng.choice([64, 256, 300, 700, 2000, 5000, 18000]))
+        n = int(rng.integers(200, 3000)) if top <= 700 else int(rng.integers(20, 200)) if top <= 5000 else int(rng.integers(4, 20))
+        os.environ.pop("RPA_LONG_KERNEL", None)
+        lk = rng.choice(["", "wave", "lane"])
+        if lk: os.environ["RPA_LONG_KERNEL"] = str(lk)
+    else:
+        top = int(rng.choice([30, 80, 260, 330, 520, 800]))
+        n = int(rng.integers(100, 1500)) if top <= 330 else int(rng.integers(20, 200))
+        lk = ""
+    a_codes, b_codes = [], []
+    for _ in range(n):
+        la = int(rng.integers(1, top + 1))
+        a = rng.integers(0, asize if rng.random() < 0.3 else (4 if alphabet == 0 else 20), la).astype(np.uint8)
+        mode = rng.integers(0, 5)
+        if mode == 0: b = a.copy()
+        elif mode == 1: b = mutate(a, rng, asize, float(rng.choice([0.02, 0.1, 0.3])))
+        elif mode == 2: b = rng.integers(0, asize, int(rng.integers(1, top + 1))).astype(np.uint8)
+        elif mode == 3: b = a[::-1].copy()
+        else: b = mutate(a[: max(1, la // 2)], rng, asize, 0.05)
+        a_codes.append(a); b_codes.append(b)
+    seqs = [LET[alphabet][x] for pair in zip(a_codes, b_codes) for x in pair]
+    offsets = np.zeros(len(seqs) + 1, np.uint64); offsets[1:] = np.cumsum([len(s) for s in seqs])
+    letters = np.concatenate(seqs)
+    m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=alphabet)
+    out = m.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    bad = -1
+    for i in range(n):
+        if alphabet == 0:
+            o = O.align_dna(a_codes[i], b_codes[i]); rc = 0
+        else:
+            rc, o = O.align_protein(a_codes[i], b_codes[i])
+        g = out[i]
+        same = (g["matches"], g["mismatches"], g["gaps"], g["length"]) == (o["matches"], o["mismatches"], o["gaps"], o["length"]) \
+            and np.float32(g["similarity"]).tobytes() == np.float32(o["similarity"]).tobytes() \
+            and (rc != 0 or np.float32(g["distance"]).tobytes() == np.float32(o["distance"]).tobytes()) \
+            and (rc == 0 or np.isnan(g["distance"]))
+        if not same:
+            bad = i
+            break
+    total += n
+    print("batch %d: %s pairs=%d max_len=%d kernel=%s -> %s  (%.0f s)" % (k, "protein" if alphabet else "dna", n, top, lk or "auto",
+                                                                    "ok" if bad < 0 else "MISMATCH at pair %d (%d x %d)" % (bad, len(a_codes[bad]), len(b_codes[bad])),
+                                                                    time.time() - t0), flush=True)
+    if bad >= 0:
+        print("  engine", out[bad], "\n  oracle", o)
+        sys.exit(1)
+print("pair soak ok: %d batches, %d pairs" % (n_batches, total))
