@@ -85,6 +85,7 @@ struct rpa_engine {
   // a round goes through the live list once live sets x this <= all sets (tools/sparse_sweep.sh: decide from 1/6 on is
   // 5 % of a config-4 step, neutral on config 2; emit only pays from 1/24 on)
   uint32_t sparse_div_emit = 24, sparse_div_decide = 6;
+  uint32_t fill_lanes = 0;  // pairs a round should at least ask for when few record sets are left (set in rpa_create)
   bool fixed_speculation = false;  // the caller (or RPA_SPEC1/2) fixed the chunk sizes: keep them in the sparse rounds too
   DevBuf prof_acc;
   rpa_profile prof{};
@@ -376,13 +377,14 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     // ask for everything they could still need at once (speculation chunk 0) instead of 10 hits per round: a few hundred
     // speculative alignments more, several rounds fewer.  (Chunk sizes never change results, only who computes what when.)
     // Likewise when the record sets still running cannot fill the chip with a default-sized chunk each (one pair per lane,
-    // ~262 k lanes resident): lanes that would idle anyway take the next hits of the loop, and a 50-hit pass-2 loop needs
-    // 2-3 rounds instead of 5 (config 5: rounds of 100 k pairs on a chip that holds 262 k).
+    // ~262 k lanes resident): lanes that would idle anyway take the next hits of the loop.  The target is three times the
+    // resident lanes: a round of long alignments costs a whole chip-round (~240 ms for 10 kbp pairs) however few lanes
+    // it fills, and a launch of 1.7 rounds of lanes runs faster than two of 0.85 (config 5: 3 rounds instead of 6).
     Params pr = e->params;
     if (!e->fixed_speculation) {
       if (sparse_decide) { pr.spec1 = 0; pr.spec2 = 0; }
       else {
-        const uint32_t fill = kResidentLanes / (live_now ? live_now : 1u);
+        const uint32_t fill = e->fill_lanes / (live_now ? live_now : 1u);
         if (pr.spec1 && fill > pr.spec1) pr.spec1 = fill;
         if (pr.spec2 && fill > pr.spec2) pr.spec2 = fill;
       }
@@ -408,7 +410,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   w->device = e->device; w->params = e->params; w->tax = e->tax;
   w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
   w->fixed_speculation = e->fixed_speculation;
-  w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide;
+  w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipHostMalloc((void**)&w->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault);
   if (err == hipSuccess) err = w->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long));
@@ -554,6 +556,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->fixed_speculation = params->speculation_pass1 != RPA_SPECULATION_DEFAULT || params->speculation_pass2 != RPA_SPECULATION_DEFAULT;
   if (const char* v = getenv("RPA_SPEC1")) { e->params.spec1 = (uint32_t)atoi(v); e->fixed_speculation = true; }
   if (const char* v = getenv("RPA_SPEC2")) { e->params.spec2 = (uint32_t)atoi(v); e->fixed_speculation = true; }
+  e->fill_lanes = 3u * kResidentLanes;  // RPA_FILL_LANES sweep: config 5 1174 / 1137 / 1053 ms at 1x / 2x / 3x, configs 2 and 4 indifferent
+  if (const char* v = getenv("RPA_FILL_LANES")) e->fill_lanes = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SPARSE_EMIT")) e->sparse_div_emit = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SPARSE_DECIDE")) e->sparse_div_decide = (uint32_t)atoi(v);
   if (getenv("RPA_SPEC_ADAPTIVE")) e->fixed_speculation = false;  // sweeps of the default chunk sizes: keep the per-round adaptation
