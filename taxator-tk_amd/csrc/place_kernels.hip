@@ -185,13 +185,13 @@ __device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, co
 // ------------------------------------------------------------------------------------------------------------
 template <int P4>
 __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, TaxDev tax, StoreDev qstore, StoreDev dbstore, Params p) {
-  // Record -> record set.  The records of a workgroup are consecutive, so their sets are consecutive too: the first
-  // wave finds the set of the block's first record with a 64-ary search over set_offsets (4 dependent probes for 1 M
-  // sets instead of 20 per thread), the block stages the next kBlock+1 offsets in LDS and every thread finishes with a
-  // search in LDS.  Only a block whose range holds more than kBlock set boundaries (runs of empty sets) falls back to
-  // the global search.  "Set of r" = largest s with set_offsets[s] <= r (empty sets share an offset: take the last).
+  // Record -> record set.  The records of a workgroup are consecutive, so their sets are consecutive too: the set of
+  // the block's first record comes from k_block_first (one binary search per workgroup, all of them in one small launch
+  // instead of 4 dependent probes at the head of every workgroup), the block stages the next kBlock+1 offsets in LDS and
+  // every thread finishes with a search in LDS.  Only a block whose range holds more than kBlock set boundaries (runs
+  // of empty sets) falls back to the global search.  "Set of r" = largest s with set_offsets[s] <= r (empty sets share
+  // an offset: take the last).
   __shared__ uint32_t s_off[kBlock + 1];
-  __shared__ uint32_t s_first;
   // the fields the per-set scan below compares, for the block's own records: the scan of a 20-hit set is 20 x 4 loads
   // per thread, nearly all of them to records of this block -> LDS (broadcast reads) instead of the vector memory path
   // (+ kHalo records on either side: the sets that straddle the block's ends would otherwise take the global path for
@@ -215,22 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
       s_filt[k] = rec_filtered(b, rr) ? 1 : 0;
     }
   }
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    uint32_t lo = 0, hi = b.n_sets;  // set_offsets[lo] <= r0 < set_offsets[hi]
-    while (hi - lo > 1) {
-      const uint32_t step = (hi - lo + 63u) / 64u;
-      const uint64_t probe = (uint64_t)lo + (uint64_t)(lane + 1) * step;
-      const bool ok = probe < hi && b.set_offsets[probe] <= r0;  // monotone over the lanes
-      const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));
-      const uint64_t nhi = (uint64_t)lo + (uint64_t)(cnt + 1u) * step;
-      lo += cnt * step;
-      hi = nhi < hi ? (uint32_t)nhi : hi;
-    }
-    if (lane == 0) s_first = lo;
-  }
-  __syncthreads();
-  const uint32_t first = s_first;
+  const uint32_t first = w.block_first[lblock];
   for (uint32_t k = threadIdx.x; k <= (uint32_t)kBlock; k += kBlock) {
     const uint64_t idx = (uint64_t)first + k;
     s_off[k] = b.set_offsets[idx < b.n_sets ? idx : b.n_sets];
@@ -244,6 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     if (s_off[mid] <= r) lo = mid; else hi = mid;
   }
   uint32_t s = first + lo;
+  bool in_window = lo < (uint32_t)kBlock;  // the set's two offsets are s_off[lo], s_off[lo + 1]
   if (lo == (uint32_t)kBlock && s < b.n_sets) {  // window exhausted: more than kBlock boundaries in this block's range
     uint32_t glo = s, ghi = b.n_sets;
     while (ghi - glo > 1) {
@@ -252,9 +238,11 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     }
     s = glo;
   }
-  if (s >= b.n_sets) s = b.n_sets - 1;  // clamped window entries (cannot be selected: set_offsets[n_sets] > r)
+  if (s >= b.n_sets) { s = b.n_sets - 1; in_window = false; }  // clamped window entries (cannot be selected: set_offsets[n_sets] > r)
   w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
-  const uint32_t beg = b.set_offsets[s], end = b.set_offsets[s + 1];
+  uint32_t beg, end;
+  if (in_window) { beg = s_off[lo]; end = s_off[lo + 1]; }  // staged above: no second trip to memory
+  else { beg = b.set_offsets[s]; end = b.set_offsets[s + 1]; }
   const uint32_t me = r - w0;  // my record inside the window
   const bool me_filtered = s_filt[me] != 0;
   const float sc = __uint_as_float(s_rec[me].x);
@@ -1178,10 +1166,25 @@ hipError_t launch_rebase_offsets(hipStream_t st, const uint32_t* in, uint32_t n,
     default: return hipErrorInvalidValue;          \
   }
 
+// record set of the first record of every k_rank_records workgroup: largest s with set_offsets[s] <= block * kBlock
+__global__ __launch_bounds__(kBlock) void k_block_first(const uint32_t* __restrict__ set_offsets, uint32_t n_sets, uint32_t n_blocks,
+                                                        uint32_t* __restrict__ block_first) {
+  const uint32_t blk = blockIdx.x * kBlock + threadIdx.x;
+  if (blk >= n_blocks) return;
+  const uint64_t r0 = (uint64_t)blk * kBlock;
+  uint32_t lo = 0, hi = n_sets;  // set_offsets[lo] <= r0 (set_offsets[0] = 0); set_offsets[hi] > r0 or hi == n_sets
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (set_offsets[mid] <= r0) lo = mid; else hi = mid;
+  }
+  block_first[blk] = lo;
+}
+
 hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
                                const StoreDev& db, const Params& p) {
   if (b.n_records == 0) return hipSuccess;
   const dim3 grid(((b.n_records + kBlock - 1) / kBlock + 7u) / 8u * 8u);  // multiple of 8: see the XCD mapping in the kernel
+  hipLaunchKernelGGL(k_block_first, dim3((grid.x + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b.set_offsets, b.n_sets, grid.x, w.block_first);
   RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_rank_records<P4>, grid, dim3(kBlock), 0, st, b, w, tax, q, db, p));
   return hipGetLastError();
 }

@@ -150,6 +150,7 @@ struct WorkDev {
   EmitInfo* emit;       // S
   uint4* emit_lite;     // S   emit_desc(emit[s])
   uint32_t* hit_set;    // H   row position -> record set
+  uint32_t* block_first;  // per workgroup of k_rank_records (logical order): record set of its first record
   // qgroup / outgroup membership (:480-481,:578) as bit sets: for a set with n >= 2 active hits at rows [lo, lo+n),
   // words flags[lo .. lo+nw) hold the qgroup bits and flags[lo+nw .. lo+2nw) the outgroup bits, nw = ceil(n/32) (2nw <= n)
   uint32_t* flags;      // H

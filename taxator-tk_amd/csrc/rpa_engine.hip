@@ -73,7 +73,7 @@ struct rpa_engine {
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
-  DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
+  DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
       tmp_words, tmp_offsets, protein_ws;
   uint32_t* h_counters = nullptr;  // pinned
@@ -252,6 +252,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->emit.ensure((size_t)(S ? S : 1) * sizeof(EmitInfo)));
   HIP_TRY(e, e->emit_lite.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
   HIP_TRY(e, e->hit_set.ensure((size_t)(H ? H : 1) * 4));
+  HIP_TRY(e, e->block_first.ensure(((size_t)H / kBlock + 16) * 4));  // one word per k_rank_records workgroup (grid rounded up to 8)
   HIP_TRY(e, e->flags.ensure((size_t)(H ? H : 1) * 4));
   HIP_TRY(e, e->lite.ensure((size_t)(H ? H : 1) * 4));
   HIP_TRY(e, e->seg.ensure((size_t)(T ? T : 1) * sizeof(SegDesc)));
@@ -270,7 +271,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
   w->state = e->state.as<SetState>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
-  w->set_qseg = e->set_qseg.as<uint2>(); w->emit = e->emit.as<EmitInfo>(); w->emit_lite = e->emit_lite.as<uint4>(); w->hit_set = e->hit_set.as<uint32_t>();
+  w->set_qseg = e->set_qseg.as<uint2>(); w->emit = e->emit.as<EmitInfo>(); w->emit_lite = e->emit_lite.as<uint4>(); w->hit_set = e->hit_set.as<uint32_t>(); w->block_first = e->block_first.as<uint32_t>();
   w->flags = e->flags.as<uint32_t>();
   w->lite = e->lite.as<uint32_t>();
   w->seg = e->seg.as<SegDesc>(); w->store_q = nullptr; w->store_db = nullptr;
@@ -620,7 +621,7 @@ void rpa_destroy(rpa_engine* e) {
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
-                    &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
+                    &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
                     &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc, &e->part_offsets};
   for (DevBuf* b : bufs) b->release();
