@@ -290,7 +290,9 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   const uint32_t L = qrstop - qrstart + 1;
   const bool perfect = b.alnlen[r] == L && id == L;  // :431,511
   const uint32_t meta = (perfect ? kMetaPerfect : 0u) | (sp.y << kMetaErrShift) | ((uint32_t)tax.depth[node] << kMetaDepthShift);
-  float qd = FLT_MAX, qs = 0.f;  // :475-476
+  // :475-476 start at (FLT_MAX, 0); pass 0 then gives every hit it does not re-align (FLT_MAX, identities) before anything
+  // reads the pair (:535-537) -- written here so that k_decide only stores the pairs of the hits pass 0 does align
+  float qd = FLT_MAX, qs = (float)id;
   if (n == 1) { qd = __uint_as_float(b.qstart[r]); qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
   const SetRows<P4> R = set_rows<P4>(w, s, beg);
   w.res_slot[pos] = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);  // where the alignment kernels put this hit's result
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         } else {
           dist = FLT_MAX; sim = (float)h.ident;
         }
-        R.store_qdqs(i, dist, sim);
+        if (member) R.store_qdqs(i, dist, sim);  // the others keep what k_rank_records wrote: (FLT_MAX, identities)
         if (dist == 0.f) w.lite[lo + i] = h.seglen | kLiteZeroQd;  // pass 1 will not align this hit (:620-621)
         if (member) qword |= 1u << (i & 31u);
         if ((i & 31u) == 31u || i + 1 == n) { fq[i >> 5] = qword; qword = 0; }
