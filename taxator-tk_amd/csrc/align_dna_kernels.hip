@@ -225,186 +225,242 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1s: pattern longer than 256 nt, many pairs -- still ONE ALIGNMENT PER LANE, the pattern cut into register strips.
-// The delta vectors of a strip of NW words (NW in 5..8, chosen per pair to waste the fewest rows) live in VGPRs and
-// the strip's match masks in LDS exactly as in K1; the lane sweeps the whole text once per strip.  What a strip hands
-// to the one below is, per text column, the add carry and the two shift carries out of its last word -- 3 bits, the
-// same message K2 passes between lanes -- kept as three bit planes of 32 columns in an HBM scratch laid out
-// [group of 32 columns][plane][thread] (a wave reads/writes 256 contiguous bytes per plane and group; three dword loads
-// + stores per 32 columns against ~4000 VALU issue slots).  Rows past the end of the pattern (the last strip is rarely full) match nothing,
-// which leaves rows <= m untouched; the score is tracked at the static bottom bit of the last strip and corrected at
-// the end by the vertical deltas of those phantom rows: D[m][n] = D[bottom][n] - (popc(VP & tail) - popc(VN & tail)).
-// Same bound as K1 (integer VALU issue); per-column strip overhead ~9 instructions of ~90.  Any pattern length fits.
+// K1s: pattern longer than 256 nt, many pairs -- still ONE ALIGNMENT PER LANE, the pattern cut into register strips,
+// and only the cells inside Ukkonen's band are computed.
+//
+// Strips.  The delta vectors of a strip of NW words (NW in 5..8, chosen per pair to waste the fewest rows) live in
+// VGPRs and the strip's match masks in LDS exactly as in K1; the lane sweeps the text once per strip.  What a strip
+// hands to the one below is, per text column, the HP and HN bits of its last row -- two bit planes of 32 columns in an
+// HBM scratch laid out [group of 32 columns][plane][thread] (a wave reads/writes 256 contiguous bytes per plane and
+// group).  The add carry into the strip below needs no plane of its own: the carry out of a word's top bit is set
+// exactly when vp & D0 is at that bit, i.e. it IS the HN bit (tools/band_model.py asserts it on every column).
+// Rows past the end of the pattern (the last strip is rarely full) match nothing, which leaves rows <= m untouched;
+// the score is tracked at the static bottom row of the strip and corrected at the end by the vertical deltas of those
+// phantom rows: D[m][n] = D[bottom][n] - (popc(VP & tail) - popc(VN & tail)).
+//
+// Band.  An alignment of cost <= k of a pattern of m rows with a text of n >= m columns never leaves the diagonals
+// -h <= j - i <= (n - m) + h, h = (k - (n - m)) / 2 (Ukkonen 1985: a cell on diagonal e costs at least |e| to reach
+// and |n - m - e| to leave).  A strip therefore sweeps only the column groups that band touches: it starts at its
+// first group from VP = all ones on top of the value the strip above had in that column (an upper bound of the true
+// column), and where the strip above never got to, "+1 per column" comes down (again an upper bound).  Every value
+// D' computed this way is >= the true D, and equal to it along any path that stays inside the band, so
+//     D'[m][n] <= k  =>  D'[m][n] is the distance;      D'[m][n] > k  =>  the distance is > k.
+// A pair that fails the test goes onto a retry list and is re-run with the band wide open (by K2 when the pattern fits
+// a wavefront, else by this kernel): results are those of the unbanded recurrence the reference runs
+// (global_alignment_myers_impl.h:129-191), bit for bit, whatever k was.  k comes from a probe: the first strip over
+// the first columns gives min_j D[HS][j], the edits the first HS rows need; scaled to m rows with a 31 % margin.  h is
+// made uniform over the wavefront (its lanes run the same group loop anyway), so the planes stay coalesced.
+// With the 10 kbp pairs of config 5 (distances 0.21-0.29 n) a strip sweeps about a third of the columns.
+// Same bound as K1 (integer VALU issue); per-column strip overhead ~7 instructions of ~90.  Any pattern length fits.
 // ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kProbeMarginDen = 16;  // k = probe rate x m x margin/16 + slack (margin: launcher argument, 21 by default)
+constexpr uint32_t kProbeSlack = 48;
+
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_myers_strips(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
-                                                          uint32_t* __restrict__ scratch, uint32_t stride,
-                                                          unsigned long long* prof_acc) {
+__global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__ list, uint32_t n_list,
+                                                        const uint32_t* __restrict__ n_list_dev, WorkDev w,
+                                                        uint32_t* __restrict__ scratch, uint32_t stride, uint32_t wide_open,
+                                                        uint32_t margin, uint2* __restrict__ retry, uint32_t* __restrict__ retry_n,
+                                                        unsigned long long* prof_acc) {
   extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
+  constexpr uint32_t HS = NW * 32u;
   const int tid = threadIdx.x;
-  const uint32_t t = blockIdx.x * kBlock + tid;
-  const bool active = t < n_list;
-  uint32_t dst = 0, m = 0, n = 0;
-  SegView pat{}, txt{};
-  if (active) {
-    uint32_t a, b;
-    resolve_pair(w, list[t], a, b, dst);
-    SegView va = seg_view(w, a), vb = seg_view(w, b);
-    if (va.len < vb.len) { txt = vb; pat = va; } else { txt = va; pat = vb; }
-    n = txt.len; m = pat.len;
-  }
-  if (prof_acc) profile_add(prof_acc, active, n, m);
-  if (!active) return;  // no barrier below: a lane only ever touches its own LDS column
-
-  const uint32_t words = (m + 31u) / 32u;
-  const uint32_t nstrips = (words + NW - 1u) / NW;
-  // boundary bit planes: group g (32 columns) of plane p at sc[(3g + p) * stride]
-  uint32_t* __restrict__ sc = scratch + t;
-  const uint32_t n_groups = (n + 31u) >> 5;
-
-  uint32_t VP[NW], VN[NW];
-  int32_t bottom = 0;
-  for (uint32_t s = 0; s < nstrips; ++s) {
-    const bool first = s == 0, last = s + 1u == nstrips;
-    const uint32_t wbase = s * NW;
-    NtStream ps;  // the strip's part of the pattern, 16 bytes per word (NtStream, rpa_device.h)
-    ps.init(pat, wbase * 32u);
-#pragma unroll
-    for (int wi = 0; wi < NW; ++wi) {
-      uint32_t A = 0, C = 0, G = 0, T = 0, N = 0;
-      const uint32_t pos = (wbase + wi) * 32u;
-      if (pos < m) {
-        const uint4 x = ps.next32();
-        uint32_t p0, p1, pn;
-        planes32(x, p0, p1, pn);
-        const uint32_t rem = m - pos;
-        const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
-        N = pn & vm;
-        T = p1 & p0 & vm;
-        G = p1 & ~p0 & vm;
-        C = p0 & ~p1 & ~pn & vm;
-        A = ~(p0 | p1 | pn) & vm;
-      }
-      peq[(0 * NW + wi) * kBlock + tid] = A;
-      peq[(1 * NW + wi) * kBlock + tid] = C;
-      peq[(2 * NW + wi) * kBlock + tid] = G;
-      peq[(3 * NW + wi) * kBlock + tid] = T;
-      peq[(4 * NW + wi) * kBlock + tid] = N;
-      VP[wi] = 0xFFFFFFFFu;
-      VN[wi] = 0u;
+  const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
+  uint32_t* __restrict__ sc = scratch + (blockIdx.x * kBlock + tid);  // boundary planes: group g, plane p at sc[(2g + p) * stride]
+  for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {  // retry launches are sized before the count is known
+    const uint32_t t = base + tid;
+    const bool active = t < total;
+    uint32_t dst = 0, m = 0, n = 0;
+    SegView pat{}, txt{};
+    uint2 entry = make_uint2(0u, 0u);
+    if (active) {
+      uint32_t a, b;
+      entry = list[t];
+      resolve_pair(w, entry, a, b, dst);
+      SegView va = seg_view(w, a), vb = seg_view(w, b);
+      if (va.len < vb.len) { txt = vb; pat = va; } else { txt = va; pat = vb; }
+      n = txt.len; m = pat.len;
     }
-    bottom = (int32_t)((wbase + NW) * 32u);  // D[bottom row of this strip][0]
+    if (prof_acc) profile_add(prof_acc, active, n, m);
+    if (!active) continue;  // no barrier below: a lane only ever touches its own LDS column
 
-    // What a strip hands to the one below per column is 3 bits: the add carry and the HP / HN shift carries out of its
-    // last word.  They travel as three bit planes of 32 columns (column k of a group at bit 31-k): leaving, a column
-    // shifts its bit into each plane with one funnel shift; entering, the carries of column k are the top bits of the
-    // planes shifted left by k (only bit 31 of hp_prev / hn_prev is ever used).
-    uint32_t Cout = 0, Pout = 0, Nout = 0;
-    auto column = [&](uint32_t c, uint32_t carry, uint32_t hp_prev, uint32_t hn_prev) {
-      const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
-      uint32_t HP = 0, HN = 0;
+    const uint32_t words = (m + 31u) / 32u;
+    const uint32_t nstrips = (words + NW - 1u) / NW;
+    const uint32_t n_groups = (n + 31u) >> 5;
+    const uint32_t delta = n - m;
+    uint32_t h = n;  // band half width beyond the corridor [0, delta]; n = wide open
+    uint32_t probe_min = 0xFFFFFFFFu;
+    int32_t bottom = 0, next_top = 0;
+    uint32_t VP[NW], VN[NW];
+    // it = -1: the probe (strip 0 over the first columns, nothing stored); it >= 0: strip `it`
+    for (int32_t it = wide_open ? 0 : -1; it < (int32_t)nstrips; ++it) {
+      const bool probe = it < 0;
+      const uint32_t s = probe ? 0u : (uint32_t)it;
+      const bool first = s == 0, last = !probe && s + 1u == nstrips;
+      const uint32_t wbase = s * NW, R = wbase * 32u;
+      NtStream ps;  // the strip's part of the pattern, 16 bytes per word (NtStream, rpa_device.h)
+      ps.init(pat, R);
 #pragma unroll
       for (int wi = 0; wi < NW; ++wi) {
-        const uint32_t vp = VP[wi], vn = VN[wi];
-        const uint32_t X = e[wi * kBlock] | vn;
-        uint32_t cout;
-        const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
-        carry = cout;
-        const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);   // (sum ^ vp) | X
-        HN = vp & D0;
-        HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);                  // vn | ~(vp | D0)
-        const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
-        const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
-        hp_prev = HP;
-        hn_prev = HN;
-        VN[wi] = Xs & D0;
-        VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);              // Hs | ~(Xs | D0)
-      }
-      Pout = __builtin_amdgcn_alignbit(Pout, HP, 31);  // (Pout << 1) | (HP >> 31)
-      Nout = __builtin_amdgcn_alignbit(Nout, HN, 31);
-      Cout = (Cout << 1) | carry;
-    };
-
-    // Per 32 columns: one 16-byte load of text and three dword loads of the planes of the strip above (all asked for a
-    // group ahead), three dword stores of this strip's planes, [plane][group][lane] so that a wavefront's accesses are
-    // contiguous.  (Memory operations retire in order on gfx9: with a load and a store every four columns each load
-    // waited for the previous store to reach HBM; the strips of a 10 kbp pair move ~250 KB of planes per lane.)
-    NtStream ts;
-    ts.init(txt, 0u);
-    uint4 pending = ts.load4();
-    // row 0 of the matrix: +1 enters every column (HP carry 1), no add carry, no HN
-    uint32_t Cn = 0u, Pn = 0xFFFFFFFFu, Nn = 0u;
-    if (!first) { Cn = sc[0]; Pn = sc[stride]; Nn = sc[(size_t)2 * stride]; }
-    for (uint32_t g = 0; g < n_groups; ++g) {
-      const uint4 buf = ts.take32(pending);
-      if (g + 1u < n_groups) pending = ts.load4();
-      uint32_t Cin = Cn, Pin = Pn, Nin = Nn;
-      if (!first && g + 1u < n_groups) {
-        const uint32_t* __restrict__ nx = sc + (size_t)(3u * (g + 1u)) * stride;
-        Cn = nx[0]; Pn = nx[stride]; Nn = nx[(size_t)2 * stride];
-      }
-      const uint32_t cols = n - g * 32u;
-      Cout = 0u; Pout = 0u; Nout = 0u;
-#pragma unroll 1
-      for (uint32_t q = 0; q < 4u && q * 8u < cols; ++q) {  // eight columns: one dword of text, one byte of each plane
-        const uint32_t d = q == 0u ? buf.x : q == 1u ? buf.y : q == 2u ? buf.z : buf.w;
-        const uint32_t left = cols - q * 8u;
-        if (left >= 8u) {
+        uint32_t mask[5];
+        peq_word(ps, wbase + wi, m, mask);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) column((d >> (4 * k)) & 7u, (Cin >> (31 - k)) & 1u, Pin << k, Nin << k);
-          Cin <<= 8; Pin <<= 8; Nin <<= 8;
-        } else {
+        for (int c = 0; c < 5; ++c) peq[(c * NW + wi) * kBlock + tid] = mask[c];
+        VP[wi] = 0xFFFFFFFFu;
+        VN[wi] = 0u;
+      }
+      // column groups this strip sweeps: [g_lo, g_hi); the strip below starts at g_next; the strip above ended at ga_hi
+      uint32_t g_lo, g_hi, g_next = 0xFFFFFFFFu, ga_hi = 0u;
+      if (probe) {
+        g_lo = 0u;
+        g_hi = (3u * NW) / 2u < n_groups ? (3u * NW) / 2u : n_groups;  // 1.5 x the strip's height in columns
+      } else {
+        g_lo = R > h ? (R - h) >> 5 : 0u;
+        const uint64_t hi = (uint64_t)R + HS + delta + h - 1u;
+        g_hi = (hi >> 5) + 1u < (uint64_t)n_groups ? (uint32_t)(hi >> 5) + 1u : n_groups;
+        if (!last) g_next = R + HS > h ? (R + HS - h) >> 5 : 0u;
+        if (!first) {
+          const uint64_t ahi = (uint64_t)R + delta + h - 1u;
+          ga_hi = (ahi >> 5) + 1u < (uint64_t)n_groups ? (uint32_t)(ahi >> 5) + 1u : n_groups;
+        }
+      }
+      bottom = (first ? 0 : next_top) + (int32_t)HS;  // D'[bottom row of the strip][32 g_lo]: VP = all ones below the row above
+      if (g_next == g_lo) next_top = bottom;
+
+      uint32_t Pout = 0, Nout = 0;
+      auto column = [&](uint32_t c, uint32_t hp_prev, uint32_t hn_prev) {
+        const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
+        uint32_t HP = 0, HN = 0;
+        uint32_t carry = hn_prev >> 31;  // the add carry out of the strip above == its HN bit
+#pragma unroll
+        for (int wi = 0; wi < NW; ++wi) {
+          const uint32_t vp = VP[wi], vn = VN[wi];
+          const uint32_t X = e[wi * kBlock] | vn;
+          uint32_t cout;
+          const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
+          carry = cout;
+          const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);   // (sum ^ vp) | X
+          HN = vp & D0;
+          HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);                  // vn | ~(vp | D0)
+          const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
+          const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+          hp_prev = HP;
+          hn_prev = HN;
+          VN[wi] = Xs & D0;
+          VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);              // Hs | ~(Xs | D0)
+        }
+        Pout = __builtin_amdgcn_alignbit(Pout, HP, 31);  // (Pout << 1) | (HP >> 31): column k of a group ends up at bit 31-k
+        Nout = __builtin_amdgcn_alignbit(Nout, HN, 31);
+      };
+
+      // Per 32 columns: one 16-byte load of text and two dword loads of the planes of the strip above (all asked for a
+      // group ahead), two dword stores of this strip's planes.  (Memory operations retire in order on gfx9: with a load
+      // and a store every four columns each load waited for the previous store to reach HBM.)
+      if (g_lo < g_hi) {
+        NtStream ts;
+        ts.init(txt, g_lo * 32u);
+        uint4 pending = ts.load4();
+        // no strip above, or it never got to these columns: +1 enters every column (HP 1, HN 0)
+        uint32_t Pn = 0xFFFFFFFFu, Nn = 0u;
+        if (g_lo < ga_hi) { Pn = sc[(size_t)(2u * g_lo) * stride]; Nn = sc[(size_t)(2u * g_lo + 1u) * stride]; }
+        for (uint32_t g = g_lo; g < g_hi; ++g) {
+          const uint4 buf = ts.take32(pending);
+          if (g + 1u < g_hi) pending = ts.load4();
+          uint32_t Pin = Pn, Nin = Nn;
+          Pn = 0xFFFFFFFFu; Nn = 0u;
+          if (g + 1u < ga_hi && g + 1u < g_hi) {
+            const uint32_t* __restrict__ nx = sc + (size_t)(2u * (g + 1u)) * stride;
+            Pn = nx[0]; Nn = nx[stride];
+          }
+          const uint32_t cols = n - g * 32u;
+          Pout = 0u; Nout = 0u;
 #pragma unroll 1
-          for (uint32_t k = 0; k < left; ++k) {
-            column((d >> (4u * k)) & 7u, Cin >> 31, Pin, Nin);
-            Cin <<= 1; Pin <<= 1; Nin <<= 1;
+          for (uint32_t q = 0; q < 4u && q * 8u < cols; ++q) {  // eight columns: one dword of text, one byte of each plane
+            const uint32_t d = q == 0u ? buf.x : q == 1u ? buf.y : q == 2u ? buf.z : buf.w;
+            const uint32_t left = cols - q * 8u;
+            if (left >= 8u) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) column((d >> (4 * k)) & 7u, Pin << k, Nin << k);
+              Pin <<= 8; Nin <<= 8;
+            } else {
+#pragma unroll 1
+              for (uint32_t k = 0; k < left; ++k) {
+                column((d >> (4u * k)) & 7u, Pin, Nin);
+                Pin <<= 1; Nin <<= 1;
+              }
+            }
+          }
+          bottom += (int32_t)__popc(Pout) - (int32_t)__popc(Nout);  // D'[bottom row][j] - D'[bottom row][j-1] summed over the group
+          if (g + 1u == g_next) next_top = bottom;                  // what the strip below starts on top of
+          if (probe) probe_min = (uint32_t)bottom < probe_min ? (uint32_t)bottom : probe_min;
+          if (cols < 32u) { const uint32_t sh = 32u - cols; Pout <<= sh; Nout <<= sh; }
+          if (!last && !probe) {
+            uint32_t* __restrict__ o = sc + (size_t)(2u * g) * stride;
+            o[0] = Pout; o[stride] = Nout;
           }
         }
       }
-      bottom += (int32_t)__popc(Pout) - (int32_t)__popc(Nout);  // D[bottom row][j] - D[bottom row][j-1] summed over the group
-      if (cols < 32u) { const uint32_t sh = 32u - cols; Cout <<= sh; Pout <<= sh; Nout <<= sh; }
-      if (!last) {
-        uint32_t* __restrict__ o = sc + (size_t)(3u * g) * stride;
-        o[0] = Cout; o[stride] = Pout; o[(size_t)2 * stride] = Nout;
+      if (probe) {
+        // edits of the first HS rows -> a budget for all m rows; then one half width for the whole wavefront
+        const uint64_t est = (uint64_t)probe_min * m * margin / ((uint64_t)HS * kProbeMarginDen) + kProbeSlack;
+        const uint32_t mine = est / 2u < (uint64_t)n ? (uint32_t)(est / 2u) : n;
+        uint32_t hmax = 0u;  // every lane that has a pair is here (the probe is its first iteration): scalar loop over them
+        for (unsigned long long mk = __ballot(1); mk; mk &= mk - 1ull) {
+          const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)mk) - 1);
+          hmax = o > hmax ? o : hmax;
+        }
+        h = hmax;
       }
     }
-  }
-  // phantom rows below the pattern in the last strip: take their vertical deltas off the bottom score
-  int32_t dist = bottom;
+    // phantom rows below the pattern in the last strip: take their vertical deltas off the bottom score
+    int32_t dist = bottom;
 #pragma unroll
-  for (int wi = 0; wi < NW; ++wi) {
-    const uint32_t pos = ((nstrips - 1u) * NW + wi) * 32u;
-    const uint32_t tail = pos >= m ? 0xFFFFFFFFu : (m - pos >= 32u ? 0u : ~((1u << (m - pos)) - 1u));
-    dist -= (int32_t)__popc(VP[wi] & tail) - (int32_t)__popc(VN[wi] & tail);
+    for (int wi = 0; wi < NW; ++wi) {
+      const uint32_t pos = ((nstrips - 1u) * NW + wi) * 32u;
+      const uint32_t tail = pos >= m ? 0xFFFFFFFFu : (m - pos >= 32u ? 0u : ~((1u << (m - pos)) - 1u));
+      dist -= (int32_t)__popc(VP[wi] & tail) - (int32_t)__popc(VN[wi] & tail);
+    }
+    const uint64_t k = 2ull * h + delta;
+    if ((uint64_t)(uint32_t)dist <= k) {  // inside the band: this IS the distance (always, when the band is wide open)
+      w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)n - dist));
+      if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
+    } else {
+      retry[atomicAdd(retry_n, 1u)] = entry;
+    }
   }
-  w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)n - dist));
-  if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
 }
 
-static size_t strip_words_per_thread(uint32_t max_len) { return 3 * (((size_t)max_len + 31) / 32) + 3; }  // three bit planes per 32 columns
+static size_t strip_words_per_thread(uint32_t max_len) { return 2 * (((size_t)max_len + 31) / 32) + 2; }  // two bit planes per 32 columns
 
 size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len) {
   size_t threads = ((size_t)n_pairs + kBlock - 1) / kBlock * kBlock;
   // at most 32 GiB of boundary bytes in flight (of 288 GB of HBM), and never fewer than one workgroup.  The cap decides
   // into how many launches a list is cut, and every launch has a tail in which most of the chip waits for its last
-  // workgroups (a 10 kbp pair keeps a lane busy for ~0.2 s): config 5 ran its 700 k-pair rounds as two launches under
-  // a 4 GiB cap and 4 % faster as one.
+  // workgroups: config 5 ran its 700 k-pair rounds as two launches under a 4 GiB cap and 4 % faster as one.
   const size_t cap = (((size_t)1 << 33) / strip_words_per_thread(max_len)) / kBlock * kBlock;
   if (threads > cap) threads = cap ? cap : kBlock;
   return threads * strip_words_per_thread(max_len);
 }
 
-hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2* list, uint32_t n, const WorkDev& w,
-                                   uint32_t* scratch, size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc) {
+// n_dev != null: the list's length is read on the device (a retry list filled by the launch before); `n` then only
+// bounds it, and the grid is `grid_blocks` workgroups that stride over the list.
+hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2* list, uint32_t n, const uint32_t* n_dev,
+                                   uint32_t grid_blocks, const WorkDev& w, uint32_t* scratch, size_t scratch_words, uint32_t max_len,
+                                   bool wide_open, uint32_t margin, uint2* retry, uint32_t* retry_n, unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
+  if (!retry || !retry_n) wide_open = true;  // nowhere to put a pair that leaves its band
   size_t threads = scratch_words / strip_words_per_thread(max_len) / kBlock * kBlock;
   if (threads == 0) return hipErrorOutOfMemory;
   const size_t lds = (size_t)5 * strip_words * kBlock * sizeof(uint32_t);
   for (uint32_t done = 0; done < n;) {
-    const uint32_t chunk = (uint32_t)((size_t)(n - done) < threads ? (n - done) : threads);
-    const uint32_t blocks = (chunk + kBlock - 1) / kBlock;
+    uint32_t chunk = (uint32_t)((size_t)(n - done) < threads ? (n - done) : threads);
+    uint32_t blocks = (chunk + kBlock - 1) / kBlock;
+    if (n_dev) {  // one launch that strides over whatever the device-side count turns out to be
+      chunk = n;
+      if (grid_blocks && blocks > grid_blocks) blocks = grid_blocks;
+    }
 #define RPA_LAUNCH_STRIPS(NWV) \
-  case NWV: hipLaunchKernelGGL(k_myers_strips<NWV>, dim3(blocks), dim3(kBlock), lds, st, list + done, chunk, w, scratch, blocks * kBlock, prof_acc); break;
+  case NWV: hipLaunchKernelGGL(k_myers_band<NWV>, dim3(blocks), dim3(kBlock), lds, st, list + done, chunk, n_dev, w, scratch, blocks * kBlock, wide_open ? 1u : 0u, margin, retry, retry_n, prof_acc); break;
     switch (strip_words) {
       RPA_LAUNCH_STRIPS(5) RPA_LAUNCH_STRIPS(6) RPA_LAUNCH_STRIPS(7) RPA_LAUNCH_STRIPS(8)
       default: return hipErrorInvalidValue;
@@ -428,11 +484,13 @@ hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2*
 // v_readlane).  Reference: the multi-block branch of the same SeqAn routine (global_alignment_myers_impl.h:129-191).
 // ------------------------------------------------------------------------------------------------------------
 template <int WPL>
-__global__ __launch_bounds__(64) void k_myers_long(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
+__global__ __launch_bounds__(64) void k_myers_long(const uint2* __restrict__ list, uint32_t n_list,
+                                                    const uint32_t* __restrict__ n_list_dev, WorkDev w,
                                                     unsigned long long* prof_acc) {
-  const uint32_t t = blockIdx.x;
-  if (t >= n_list) return;
+  // n_list_dev != null: a retry list whose length only the device knows (n_list bounds it); the grid strides over it
+  const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
   const int lane = threadIdx.x;
+  for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
   uint32_t a, b, dst;
   resolve_pair(w, list[t], a, b, dst);
   SegView txt = seg_view(w, a), pat = seg_view(w, b);
@@ -511,13 +569,15 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint2* __restrict__ lis
     w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)n - dist));
     if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
   }
+  }
 }
 
-hipError_t launch_align_dna_long(hipStream_t st, int wpl, const uint2* list, uint32_t n, const WorkDev& w,
-                                 unsigned long long* prof_acc) {
+hipError_t launch_align_dna_long(hipStream_t st, int wpl, const uint2* list, uint32_t n, const uint32_t* n_dev, uint32_t grid_blocks,
+                                 const WorkDev& w, unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
+  const uint32_t blocks = n_dev && grid_blocks && grid_blocks < n ? grid_blocks : n;
 #define RPA_LAUNCH_LONG(V) \
-  case V: hipLaunchKernelGGL(k_myers_long<V>, dim3(n), dim3(64), 0, st, list, n, w, prof_acc); break;
+  case V: hipLaunchKernelGGL(k_myers_long<V>, dim3(blocks), dim3(64), 0, st, list, n, n_dev, w, prof_acc); break;
   switch (wpl) {
     RPA_LAUNCH_LONG(1) RPA_LAUNCH_LONG(2) RPA_LAUNCH_LONG(3) RPA_LAUNCH_LONG(4)
     RPA_LAUNCH_LONG(5) RPA_LAUNCH_LONG(6) RPA_LAUNCH_LONG(7) RPA_LAUNCH_LONG(8)

@@ -186,9 +186,10 @@ struct WorkDev {
   uint32_t T;    // number of segments
   uint32_t T2;   // number of pair slots = stride of each bin list
 };
-// counters: [0..kNumBins) pairs per bin | live sets | longest horizontal sequence among emitted pairs | error code | error set/pair
-constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrErr = kNumBins + 2, kCtrErrSet = kNumBins + 3,
-              kNumCounters = kNumBins + 4, kNumRoundCounters = kNumBins + 2;  // the first kNumRoundCounters are reset every round
+// counters: [0..kNumBins) pairs per bin | live sets | longest horizontal sequence among emitted pairs | pairs on the
+// retry list (banded alignments whose distance turned out to lie outside their band) | error code | error set/pair
+constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNumBins + 2, kCtrErr = kNumBins + 3, kCtrErrSet = kNumBins + 4,
+              kNumCounters = kNumBins + 5, kNumRoundCounters = kNumBins + 3;  // the first kNumRoundCounters are reset every round
 
 struct Params {
   int alphabet;
@@ -240,12 +241,16 @@ hipError_t launch_export_alignments(hipStream_t st, const WorkDev& w, uint32_t n
 // walks `list` then `list2` (n2 may be 0): pairs of a narrower class may ride along, the kernel is exact for any pattern <= 32*words
 hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
                                   const WorkDev& w, unsigned long long* prof_acc);
-// multi-strip per-lane kernel; scratch holds one boundary byte per text column per thread in flight
+// multi-strip per-lane kernel inside Ukkonen's band; scratch holds two boundary bits per text column per thread in
+// flight.  A pair whose distance lies outside its band is appended to retry[*retry_n] (wide_open: never happens).
+// margin / 16 = safety factor on the probe's distance estimate (21 by default; tests use tiny ones to force retries).
+// n_dev != null: the length of `list` is read on the device (bounded by n) and grid_blocks workgroups stride over it.
 size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len);
-hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2* list, uint32_t n, const WorkDev& w,
-                                   uint32_t* scratch, size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
-hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint2* list, uint32_t n, const WorkDev& w,
-                                 unsigned long long* prof_acc);
+hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2* list, uint32_t n, const uint32_t* n_dev,
+                                   uint32_t grid_blocks, const WorkDev& w, uint32_t* scratch, size_t scratch_words, uint32_t max_len,
+                                   bool wide_open, uint32_t margin, uint2* retry, uint32_t* retry_n, unsigned long long* prof_acc);
+hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint2* list, uint32_t n, const uint32_t* n_dev,
+                                 uint32_t grid_blocks, const WorkDev& w, unsigned long long* prof_acc);
 hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,

@@ -75,13 +75,16 @@ struct rpa_engine {
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
   DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
-      tmp_words, tmp_offsets, protein_ws;
+      tmp_words, tmp_offsets, protein_ws, retry_list;
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
   bool profiling = false;
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
+  bool band_long = true;      // RPA_BAND=0: the strip kernel computes every cell (A/B; results are the same either way)
+  uint32_t band_margin = 21;  // x/16: safety factor on the probe's distance estimate (RPA_BAND_MARGIN; tests force retries with 1)
+  double band_gain = 2.5;     // K1s-vs-K2 cost model: what the band is worth on K1s (RPA_BAND_GAIN)
   // a round goes through the live list once live sets x this <= all sets (tools/sparse_sweep.sh: decide from 1/6 on is
   // 5 % of a config-4 step, neutral on config 2; emit only pays from 1/24 on)
   uint32_t sparse_div_emit = 24, sparse_div_decide = 6;
@@ -148,10 +151,37 @@ const char* kernel_error_text(uint32_t code) {
 constexpr uint32_t kRideAlongPairs = 262144;
 constexpr uint32_t kResidentLanes = 256u * 4u * 256u;  // one-pair-per-lane kernels: 256 CUs x 4 workgroups (LDS) x 256 lanes
 
+// Timed launch bracket for the profile (HIP events on the engine's stream).
+struct LaunchTimer {
+  rpa_engine* e; size_t i0 = 0, i1 = 0; bool on = false;
+  int begin() {
+    if (!e->profiling) return RPA_OK;
+    hipEvent_t a = get_event(e), b = get_event(e);
+    if (!a || !b) return fail(e, RPA_ERR_DEVICE, "hipEventCreate failed");
+    i0 = e->ev_used - 2; i1 = e->ev_used - 1; on = true;
+    HIP_TRY(e, hipEventRecord(a, e->stream));
+    return RPA_OK;
+  }
+  int end() {
+    if (!on) return RPA_OK;
+    HIP_TRY(e, hipEventRecord(e->ev_pool[i1], e->stream));
+    e->ev_align.emplace_back(i0, i1);
+    e->prof.launches += 1;
+    on = false;
+    return RPA_OK;
+  }
+};
+
 int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
   unsigned long long* acc = e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr;
   const uint32_t* counts = counts_in;
   int rider = -1;  // a narrower one-strip class waiting for the next launch
+  uint64_t banded_pairs = 0;  // pairs that went through the banded strip kernel this round: the retry list's bound
+  if (e->params.alphabet == RPA_DNA && e->band_long) {
+    uint64_t strip_pairs = 0;
+    for (int bin = kShortWords; bin < kNumBins; ++bin) strip_pairs += counts[bin];
+    if (strip_pairs) HIP_TRY(e, e->retry_list.ensure((size_t)strip_pairs * sizeof(uint2)));
+  }
   for (int bin = 0; bin < kNumBins; ++bin) {
     const uint32_t n = counts[bin];
     if (!n) continue;
@@ -164,35 +194,36 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
       if (rider < 0 && n < kRideAlongPairs && wider) { rider = bin; continue; }  // picked up by the next one-strip launch
       if (rider >= 0) { list2 = w.bin_list + (size_t)rider * w.T2; n2 = counts[rider]; rider = -1; }
     }
-    size_t i0 = 0, i1 = 0;
-    if (e->profiling) {
-      hipEvent_t a = get_event(e), b = get_event(e);
-      if (!a || !b) return fail(e, RPA_ERR_DEVICE, "hipEventCreate failed");
-      i0 = e->ev_used - 2; i1 = e->ev_used - 1;
-      HIP_TRY(e, hipEventRecord(a, e->stream));
-    }
+    LaunchTimer timer{e};
+    int trc = timer.begin();
+    if (trc) return trc;
     if (e->params.alphabet == RPA_DNA) {
       if (bin < kShortWords) HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, list2, n2, w, acc));
       else {
-        // Patterns of more than 256 nt.  Many pairs: one per lane, register strips (K1s).  Few pairs (not enough to give
-        // every SIMD a few waves of lanes): one per wavefront (K2), as long as the pattern fits its 64 x 8 words.
+        // Patterns of more than 256 nt.  Many pairs: one per lane, register strips inside Ukkonen's band (K1s).  Few pairs
+        // (not enough to give every SIMD a few waves of lanes): one per wavefront (K2, every cell), as long as the pattern
+        // fits its 64 x 8 words.
         const uint32_t max_len = counts[kCtrMaxLen];  // longest sequence of any emitted pair: bounds text and pattern
-        // Measured on MI355X (config 5 rounds, 10 kbp pairs, both kernels on the same lists): K1s runs a lane at ~1.0 G
-        // cell updates/s while a SIMD holds one or two of its waves (0.9 k pairs: 99 ms, 115 k pairs: 134 ms = 86 T/s)
-        // and levels off near 90 T/s as the chip fills (217 k pairs: 240 ms; 115 T/s over several rounds of lanes);
-        // K2 reaches 17 T/s at 0.9 k pairs, 29 T/s at 2.2 k and ~50 T/s x (pattern words / (64 x words per lane)) from
-        // ~4 k waves on (115 k pairs: 230 ms).  The cross-over is near 50 k pairs.
+        // Measured on MI355X (config 5 rounds, 10 kbp pairs, both kernels on the same lists, every cell computed): K1s runs
+        // a lane at ~1.0 G cell updates/s while a SIMD holds one or two of its waves (0.9 k pairs: 99 ms, 115 k pairs:
+        // 134 ms = 86 T/s) and levels off near 90 T/s as the chip fills (217 k pairs: 240 ms; 115 T/s over several rounds
+        // of lanes); K2 reaches 17 T/s at 0.9 k pairs, 29 T/s at 2.2 k and ~50 T/s x (pattern words / (64 x words per
+        // lane)) from ~4 k waves on (115 k pairs: 230 ms).  The band leaves K1s about a third of the cells on pairs
+        // that differ by 20-30 % (less on closer ones): its rates are scaled by e->band_gain.
         const double words = (max_len + 31u) / 32u, wpl = (uint32_t)((words + 63) / 64);
-        const double tp_lane = std::min(88e12, n * 1.0e9);
+        const double gain = e->band_long ? e->band_gain : 1.0;
+        const double tp_lane = std::min(88e12, n * 1.0e9) * gain;
         const double tp_wave = std::min(1.0, n / 4096.0) * 50e12 * words / (64.0 * wpl);
         bool wave = max_len <= kWaveMaxPattern && tp_wave > tp_lane;
         if (e->long_kernel == 1 && max_len <= kWaveMaxPattern) wave = true;
         if (e->long_kernel == 2) wave = false;
-        if (wave) HIP_TRY(e, launch_align_dna_long(e->stream, (int)wpl, list, n, w, acc));
+        if (wave) HIP_TRY(e, launch_align_dna_long(e->stream, (int)wpl, list, n, nullptr, 0, w, acc));
         else {
           HIP_TRY(e, e->protein_ws.ensure(dna_strip_scratch_words(n, max_len) * 4));
-          HIP_TRY(e, launch_align_dna_strips(e->stream, bin - kShortWords + kStripMinWords, list, n, w, e->protein_ws.as<uint32_t>(),
-                                             e->protein_ws.cap / 4, max_len, acc));
+          HIP_TRY(e, launch_align_dna_strips(e->stream, bin - kShortWords + kStripMinWords, list, n, nullptr, 0, w, e->protein_ws.as<uint32_t>(),
+                                             e->protein_ws.cap / 4, max_len, !e->band_long, e->band_margin, e->retry_list.as<uint2>(),
+                                             w.counters + kCtrRetry, acc));
+          if (e->band_long) banded_pairs += n;
         }
       }
     } else {
@@ -204,11 +235,30 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
       else
         HIP_TRY(e, launch_align_protein(e->stream, 8 * (bin + 1), list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
     }
-    if (e->profiling) {
-      HIP_TRY(e, hipEventRecord(e->ev_pool[i1], e->stream));
-      e->ev_align.emplace_back(i0, i1);
-      e->prof.launches += 1;
+    trc = timer.end();
+    if (trc) return trc;
+  }
+  if (banded_pairs) {
+    // The pairs whose distance lies outside their band, with the band wide open.  How many there are only the device
+    // knows (counters[kCtrRetry]): the launch is sized for "a few" and strides over the list.  One pair per wavefront
+    // when the pattern fits (a lone lane needs ~0.1 s for 10 kbp x 10 kbp), else the strip kernel again.  Not counted
+    // into the profile's pairs / bytes a second time (its time is).
+    const uint32_t bound = banded_pairs > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)banded_pairs;
+    const uint32_t max_len = counts[kCtrMaxLen];
+    LaunchTimer timer{e};
+    int trc = timer.begin();
+    if (trc) return trc;
+    if (max_len <= kWaveMaxPattern) {
+      const uint32_t wpl = ((max_len + 31u) / 32u + 63u) / 64u;
+      HIP_TRY(e, launch_align_dna_long(e->stream, (int)(wpl ? wpl : 1u), e->retry_list.as<uint2>(), bound, w.counters + kCtrRetry, 16384u, w, nullptr));
+    } else {
+      const uint32_t blocks = 1024u;  // 4 workgroups per CU
+      HIP_TRY(e, e->protein_ws.ensure(dna_strip_scratch_words(std::min(bound, blocks * (uint32_t)kBlock), max_len) * 4));
+      HIP_TRY(e, launch_align_dna_strips(e->stream, kShortWords, e->retry_list.as<uint2>(), bound, w.counters + kCtrRetry, blocks, w,
+                                         e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, true, 0u, nullptr, nullptr, nullptr));
     }
+    trc = timer.end();
+    if (trc) return trc;
   }
   return RPA_OK;
 }
@@ -409,7 +459,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
+  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
   w->fixed_speculation = e->fixed_speculation;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking);
@@ -553,6 +603,9 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
   e->params.grow = 0;
   if (const char* v = getenv("RPA_SPEC_GROW")) e->params.grow = atoi(v);
+  if (const char* v = getenv("RPA_BAND")) e->band_long = atoi(v) != 0;
+  if (const char* v = getenv("RPA_BAND_GAIN")) e->band_gain = atof(v);
+  if (const char* v = getenv("RPA_BAND_MARGIN")) e->band_margin = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
   e->fixed_speculation = params->speculation_pass1 != RPA_SPECULATION_DEFAULT || params->speculation_pass2 != RPA_SPECULATION_DEFAULT;
   if (const char* v = getenv("RPA_SPEC1")) { e->params.spec1 = (uint32_t)atoi(v); e->fixed_speculation = true; }
@@ -623,7 +676,7 @@ void rpa_destroy(rpa_engine* e) {
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
-                    &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->prof_acc, &e->part_offsets};
+                    &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->retry_list, &e->prof_acc, &e->part_offsets};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
   for (auto& s : e->stores) { s.words.release(); s.offsets.release(); }

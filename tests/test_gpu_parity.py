@@ -107,6 +107,46 @@ def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
     assert out.tobytes() == out2.tobytes()
 
 
+@pytest.mark.parametrize("band", ["default", "tight", "off"])
+def test_dna_long_pairs_band(pkg, oracle, band, monkeypatch):
+    """The strip kernel only computes the cells inside Ukkonen's band around a probed distance estimate; a pair whose
+    distance lies outside its band is re-run with the band wide open (one pair per wavefront up to 16384 nt, the strip
+    kernel beyond).  Results must not depend on the band: default margin, a margin so tight that nearly every pair is
+    retried, and no band at all, on pairs from identical to unrelated, with length differences, up to 20 kbp."""
+    monkeypatch.setenv("RPA_LONG_KERNEL", "lane")
+    if band == "tight": monkeypatch.setenv("RPA_BAND_MARGIN", "1")
+    if band == "off": monkeypatch.setenv("RPA_BAND", "0")
+    rng = np.random.default_rng(11)
+    m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
+    a_codes, b_codes = [], []
+    for la in [257, 300, 511, 777, 1024, 1500, 2049, 3000, 5000, 8192, 10000, 16384, 17000, 20000]:
+        for rate in [0.0, 0.01, 0.05, 0.15, 0.3, 0.6]:
+            a = rng.integers(0, 4, la).astype(np.uint8)
+            r = rng.random(la)
+            b = a.copy()
+            sub = r < rate * 0.6
+            b[sub] = rng.integers(0, 5, int(sub.sum()))
+            keep = ~((r >= rate * 0.6) & (r < rate * 0.8))            # deletions
+            ins = (r >= rate * 0.8) & (r < rate)                      # insertions (a random base behind the position)
+            counts = keep.astype(np.int64) + ins.astype(np.int64)
+            out = np.repeat(b, counts)
+            second = np.cumsum(counts)[ins & keep] - 1
+            out[second] = rng.integers(0, 4, len(second))
+            if rate == 0.05:   # a divergent stretch in the middle of an otherwise close pair: the probe underestimates
+                lo = len(out) // 2
+                out[lo:lo + len(out) // 8] = rng.integers(0, 4, len(out[lo:lo + len(out) // 8]))
+            if rate == 0.15:   # plus a length difference
+                out = np.concatenate([out, rng.integers(0, 4, la // 10).astype(np.uint8)])
+            if len(out) == 0: out = a[:1].copy()
+            a_codes.append(a)
+            b_codes.append(out.astype(np.uint8))
+    seqs = [LETTERS_DNA[x] for pair in zip(a_codes, b_codes) for x in pair]
+    letters, offsets = _pack(seqs)
+    n = len(a_codes)
+    out = m.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    _check_dna(oracle, out, a_codes, b_codes)
+
+
 def test_dna_pairs_many_200bp(pkg, oracle):
     """The benchmark shape: 200 bp x 200 bp, ~10 % divergence, checked against the oracle on a sample and through
     a size-independent property on all of them: d(a,b) == d(b,a) and |len diff| <= d <= max len."""
