@@ -163,30 +163,141 @@ __device__ __forceinline__ void store_dna_result(const WorkDev& w, uint32_t dst,
 
 // The kernel walks up to two work lists back to back (list, then list2): a pattern-length class with too few pairs
 // to fill the chip rides along with the next wider class instead of paying a serialised launch of its own.
+// n_list_dev != null: `list` is a retry list whose length only the device knows (n_list bounds it) and the grid strides.
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict__ list, uint32_t n_list,
+__global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict__ list, uint32_t n_list, const uint32_t* __restrict__ n_list_dev,
                                                          const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
                                                          unsigned long long* prof_acc) {
+  extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
+  const int tid = threadIdx.x;
+  if (n_list_dev) {
+    n_list = *n_list_dev < n_list ? *n_list_dev : n_list;
+    if (blockIdx.x == 0 && tid == 0 && n_list) atomicAdd(&w.counters[kCtrRetryShortTotal], n_list);  // what the band cost this batch
+  }
+  const uint32_t total = n_list + n_list2;
+  for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
+    const uint32_t t = base + tid;
+    const bool active = t < total;
+    uint32_t dst = 0, m = 0, n = 0;
+    SegView pat{}, txt{};
+    if (active) {
+      uint32_t a, b;
+      resolve_pair(w, t < n_list ? list[t] : list2[t - n_list], a, b, dst);
+      SegView va = seg_view(w, a), vb = seg_view(w, b);
+      // The reference takes the shorter sequence as the pattern (:144-147); the distance is symmetric, so any choice is
+      // exact.  Cost = words(pattern) x columns(text): when both need the same number of 32-row words the LONGER one
+      // becomes the pattern, and the lane walks the shorter one's columns (2-3 % fewer on ~200 nt segments).
+      const bool a_pat = (va.len + 31u) / 32u == (vb.len + 31u) / 32u ? va.len >= vb.len : va.len < vb.len;
+      if (a_pat) { txt = vb; pat = va; } else { txt = va; pat = vb; }
+      n = txt.len; m = pat.len;
+    }
+    if (prof_acc) profile_add(prof_acc, active, n, m);
+
+    // ---- Peq build (bit planes -> five match masks per 32-residue word); the pattern is read 16 bytes per word ----
+    NtStream ps;
+    if (active) ps.init(pat, 0u);
+#pragma unroll
+    for (int wi = 0; wi < NW; ++wi) {
+      uint32_t mask[5] = {0u, 0u, 0u, 0u, 0u};
+      if (active) peq_word(ps, (uint32_t)wi, m, mask);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) peq[(c * NW + wi) * kBlock + tid] = mask[c];
+    }
+    if (!active) continue;  // (no barrier anywhere: a lane only ever touches its own LDS column)
+
+    uint32_t VP[NW], VN[NW];
+#pragma unroll
+    for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
+    walk_text(txt, [&](uint32_t c) { myers_column<NW, kBlock>(VP, VN, peq + c * (NW * kBlock) + tid); });
+    store_dna_result(w, dst, myers_distance<NW>(VP, VN, n, m), n, m);
+  }
+}
+
+// K1 inside Ukkonen's band: the same lane-per-pair kernel, but the 32 columns of text group g only update the pattern
+// words g - HW .. g + HW (a window that slides down one word per group; compile-time word indices, the loop over the
+// groups is fully unrolled).  Words below the window keep the VP = all ones they started with until the window reaches
+// them (an upper bound of the true column), words above it are dropped and "+1 per column" comes down from there.  As
+// in k_myers_band every value D' is >= the true D and equal to it along paths inside the band, which here is
+//     min(0, delta) - h <= j - i <= max(0, delta) + h,   h = 32 HW - |delta|,   delta = n - m,
+// so D'[m][n] <= k = 2 h + |delta| = 64 HW - |delta| is the distance, and anything larger proves the distance is > k: such
+// pairs (and pairs with |delta| >= 32 HW) go onto the retry list and through k_myers_short.  The score is followed at the
+// top of the window: T = D'[row above the window][column] grows by 1 per column and by the dropped word's vertical
+// deltas when the window moves; at the end the vertical deltas of the words from the window's top down are added
+// (tools/band_model.py: banded_window).  HW = 2 covers distances up to ~120 on 200 nt pairs: config 2's pass-1 pairs
+// (55-65 edits) update 4.3 of their 7 words per column on average.
+template <int NW, int WLO, int WHI>
+__device__ __forceinline__ void myers_column_window(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ e) {
+  uint32_t carry = 0, hp_prev = 0x80000000u, hn_prev = 0;
+#pragma unroll
+  for (int wi = WLO; wi <= WHI; ++wi) {
+    const uint32_t vp = VP[wi], vn = VN[wi];
+    const uint32_t X = e[wi * kBlock] | vn;
+    uint32_t cout;
+    const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
+    carry = cout;
+    const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);         // (sum ^ vp) | X
+    const uint32_t HN = vp & D0;
+    const uint32_t HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);         // vn | ~(vp | D0)
+    const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
+    const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+    hp_prev = HP;
+    hn_prev = HN;
+    VN[wi] = Xs & D0;
+    VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);                    // Hs | ~(Xs | D0)
+  }
+}
+
+template <int NW, int HW, int G>
+struct BandGroups {  // text group G and the ones after it (compile-time recursion: the word window is a constant per group)
+  static __device__ __forceinline__ void run(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ peq_lane,
+                                             NtStream& ts, uint4& pending, uint32_t n, uint32_t n_groups, int32_t& T) {
+    if ((uint32_t)G >= n_groups) return;
+    constexpr int WLO = G - HW > 0 ? G - HW : 0, WHI = G + HW < NW - 1 ? G + HW : NW - 1;
+    const uint4 buf = ts.take32(pending);
+    if ((uint32_t)G + 1u < n_groups) pending = ts.load4();
+    const uint32_t cols = n - (uint32_t)G * 32u < 32u ? n - (uint32_t)G * 32u : 32u;
+#pragma unroll 1
+    for (uint32_t q = 0; q < 4u && q * 8u < cols; ++q) {
+      const uint32_t d = q == 0u ? buf.x : q == 1u ? buf.y : q == 2u ? buf.z : buf.w;
+      const uint32_t left = cols - q * 8u;
+      if (left >= 8u) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) myers_column_window<NW, WLO, WHI>(VP, VN, peq_lane + ((d >> (4 * k)) & 7u) * (NW * kBlock));
+      } else {
+#pragma unroll 1
+        for (uint32_t k = 0; k < left; ++k) myers_column_window<NW, WLO, WHI>(VP, VN, peq_lane + ((d >> (4u * k)) & 7u) * (NW * kBlock));
+      }
+    }
+    T += (int32_t)cols;
+    if constexpr (G - HW >= 0 && G - HW <= NW - 1) {
+      if ((uint32_t)G + 1u < n_groups) T += (int32_t)__popc(VP[G - HW]) - (int32_t)__popc(VN[G - HW]);  // the window moves down a word
+    }
+    if constexpr (G + 1 < NW + HW) BandGroups<NW, HW, G + 1>::run(VP, VN, peq_lane, ts, pending, n, n_groups, T);
+  }
+};
+
+template <int NW, int HW>
+__global__ __launch_bounds__(kBlock) void k_myers_short_band(const uint2* __restrict__ list, uint32_t n_list,
+                                                              const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
+                                                              uint2* __restrict__ retry, uint32_t* __restrict__ retry_n,
+                                                              unsigned long long* prof_acc) {
   extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
   const int tid = threadIdx.x;
   const uint32_t t = blockIdx.x * kBlock + tid;
   const bool active = t < n_list + n_list2;
   uint32_t dst = 0, m = 0, n = 0;
   SegView pat{}, txt{};
+  uint2 entry = make_uint2(0u, 0u);
   if (active) {
     uint32_t a, b;
-    resolve_pair(w, t < n_list ? list[t] : list2[t - n_list], a, b, dst);
+    entry = t < n_list ? list[t] : list2[t - n_list];
+    resolve_pair(w, entry, a, b, dst);
     SegView va = seg_view(w, a), vb = seg_view(w, b);
-    // The reference takes the shorter sequence as the pattern (:144-147); the distance is symmetric, so any choice is
-    // exact.  Cost = words(pattern) x columns(text): when both need the same number of 32-row words the LONGER one
-    // becomes the pattern, and the lane walks the shorter one's columns (2-3 % fewer on ~200 nt segments).
-    const bool a_pat = (va.len + 31u) / 32u == (vb.len + 31u) / 32u ? va.len >= vb.len : va.len < vb.len;
+    const bool a_pat = (va.len + 31u) / 32u == (vb.len + 31u) / 32u ? va.len >= vb.len : va.len < vb.len;  // as in k_myers_short
     if (a_pat) { txt = vb; pat = va; } else { txt = va; pat = vb; }
     n = txt.len; m = pat.len;
   }
   if (prof_acc) profile_add(prof_acc, active, n, m);
-
-  // ---- Peq build (bit planes -> five match masks per 32-residue word); the pattern is read 16 bytes per word ----
   NtStream ps;
   if (active) ps.init(pat, 0u);
 #pragma unroll
@@ -197,30 +308,66 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
     for (int c = 0; c < 5; ++c) peq[(c * NW + wi) * kBlock + tid] = mask[c];
   }
   if (!active) return;
-
+  const uint32_t ad = n > m ? n - m : m - n;
+  if (ad >= 32u * HW) { retry[atomicAdd(retry_n, 1u)] = entry; return; }  // no band of this shape holds the corridor
   uint32_t VP[NW], VN[NW];
 #pragma unroll
   for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
-  walk_text(txt, [&](uint32_t c) { myers_column<NW, kBlock>(VP, VN, peq + c * (NW * kBlock) + tid); });
-  store_dna_result(w, dst, myers_distance<NW>(VP, VN, n, m), n, m);
+  const uint32_t n_groups = (n + 31u) >> 5;  // <= NW + HW: n < m + 32 HW <= 32 (NW + HW)
+  int32_t T = 0;
+  if (n_groups) {
+    NtStream ts;
+    ts.init(txt, 0u);
+    uint4 pending = ts.load4();
+    BandGroups<NW, HW, 0>::run(VP, VN, peq + tid, ts, pending, n, n_groups, T);
+  }
+  const int32_t wlo_final = (int32_t)n_groups - 1 - HW;  // first word of the last group's window (<= 0: from word 0)
+  int32_t dist = T;
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) {
+    const uint32_t pos = (uint32_t)wi * 32u;
+    const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
+    if (wi >= wlo_final) dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
+  }
+  if ((uint32_t)dist <= 64u * HW - ad) store_dna_result(w, dst, dist, n, m);
+  else retry[atomicAdd(retry_n, 1u)] = entry;
 }
 
-hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
-                                  const WorkDev& w, unsigned long long* prof_acc) {
+hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint32_t* n_dev, uint32_t grid_blocks,
+                                  const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc) {
   if ((uint64_t)n + n2 == 0) return hipSuccess;
   if ((uint64_t)n + n2 > 0xFFFFFF00ull) return hipErrorInvalidValue;
-  const uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
+  uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
+  if (n_dev && grid_blocks && blocks > grid_blocks) blocks = grid_blocks;
   size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
   static const size_t lds_pad = getenv("RPA_LDS_PAD") ? (size_t)atoi(getenv("RPA_LDS_PAD")) : 0;  // occupancy experiments only
   lds += lds_pad;
 #define RPA_LAUNCH_MYERS(NWV) \
-  case NWV: hipLaunchKernelGGL(k_myers_short<NWV>, dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, prof_acc); break;
+  case NWV: hipLaunchKernelGGL(k_myers_short<NWV>, dim3(blocks), dim3(kBlock), lds, st, list, n, n_dev, list2, n2, w, prof_acc); break;
   switch (words) {
     RPA_LAUNCH_MYERS(1) RPA_LAUNCH_MYERS(2) RPA_LAUNCH_MYERS(3) RPA_LAUNCH_MYERS(4)
     RPA_LAUNCH_MYERS(5) RPA_LAUNCH_MYERS(6) RPA_LAUNCH_MYERS(7) RPA_LAUNCH_MYERS(8)
     default: return hipErrorInvalidValue;
   }
 #undef RPA_LAUNCH_MYERS
+  return hipGetLastError();
+}
+
+bool dna_short_band_available(int words) { return words >= 5 && words <= kShortWords; }
+
+hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
+                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, unsigned long long* prof_acc) {
+  if ((uint64_t)n + n2 == 0) return hipSuccess;
+  if ((uint64_t)n + n2 > 0xFFFFFF00ull || !retry || !retry_n) return hipErrorInvalidValue;
+  const uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
+  const size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
+#define RPA_LAUNCH_MYERS_BAND(NWV) \
+  case NWV: hipLaunchKernelGGL((k_myers_short_band<NWV, 2>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); break;
+  switch (words) {
+    RPA_LAUNCH_MYERS_BAND(5) RPA_LAUNCH_MYERS_BAND(6) RPA_LAUNCH_MYERS_BAND(7) RPA_LAUNCH_MYERS_BAND(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef RPA_LAUNCH_MYERS_BAND
   return hipGetLastError();
 }
 
@@ -266,6 +413,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
   constexpr uint32_t HS = NW * 32u;
   const int tid = threadIdx.x;
   const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
+  if (n_list_dev && blockIdx.x == 0 && tid == 0 && total) atomicAdd(&w.counters[kCtrRetryTotal], total);
   uint32_t* __restrict__ sc = scratch + (blockIdx.x * kBlock + tid);  // boundary planes: group g, plane p at sc[(2g + p) * stride]
   for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {  // retry launches are sized before the count is known
     const uint32_t t = base + tid;
@@ -277,8 +425,10 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
       uint32_t a, b;
       entry = list[t];
       resolve_pair(w, entry, a, b, dst);
-      SegView va = seg_view(w, a), vb = seg_view(w, b);
-      if (va.len < vb.len) { txt = vb; pat = va; } else { txt = va; pat = vb; }
+      // Segment B is the text, whichever is longer (the distance is symmetric and the cost is rows x columns either way):
+      // in a placement round B is the anchor of the record set, i.e. the SAME segment for ~50 consecutive lanes, and the
+      // lanes of a wavefront sweep the same column groups -- their text loads hit the same 16 bytes.
+      pat = seg_view(w, a); txt = seg_view(w, b);
       n = txt.len; m = pat.len;
     }
     if (prof_acc) profile_add(prof_acc, active, n, m);
@@ -287,8 +437,12 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
     const uint32_t words = (m + 31u) / 32u;
     const uint32_t nstrips = (words + NW - 1u) / NW;
     const uint32_t n_groups = (n + 31u) >> 5;
-    const uint32_t delta = n - m;
-    uint32_t h = n;  // band half width beyond the corridor [0, delta]; n = wide open
+    const int64_t delta = (int64_t)n - (int64_t)m, dlo = delta < 0 ? delta : 0, dhi = delta > 0 ? delta : 0;  // rows may outnumber columns
+    const uint32_t h_open = n > m ? n : m;
+    // band half width beyond the corridor [min(0, delta), max(0, delta)] (h_open = wide open) of the strip above / this strip / the strip below:
+    // the estimate is refreshed after every strip (more rows seen, less margin needed) and takes effect two strips on,
+    // because a strip must know where the strip below will start while it sweeps
+    uint32_t h_prev = h_open, h_cur = h_open, h_next = h_open, h_min = h_open;
     uint32_t probe_min = 0xFFFFFFFFu;
     int32_t bottom = 0, next_top = 0;
     uint32_t VP[NW], VN[NW];
@@ -315,15 +469,17 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
         g_lo = 0u;
         g_hi = (3u * NW) / 2u < n_groups ? (3u * NW) / 2u : n_groups;  // 1.5 x the strip's height in columns
       } else {
-        g_lo = R > h ? (R - h) >> 5 : 0u;
-        const uint64_t hi = (uint64_t)R + HS + delta + h - 1u;
-        g_hi = (hi >> 5) + 1u < (uint64_t)n_groups ? (uint32_t)(hi >> 5) + 1u : n_groups;
-        if (!last) g_next = R + HS > h ? (R + HS - h) >> 5 : 0u;
+        const int64_t lo = (int64_t)R + dlo - (int64_t)h_cur, hi = (int64_t)R + HS + dhi + (int64_t)h_cur - 1;
+        g_lo = lo > 0 ? (uint32_t)(lo >> 5) : 0u;
+        g_hi = (hi >> 5) + 1 < (int64_t)n_groups ? (uint32_t)(hi >> 5) + 1u : n_groups;
+        if (!last) { const int64_t nlo = (int64_t)R + HS + dlo - (int64_t)h_next; g_next = nlo > 0 ? (uint32_t)(nlo >> 5) : 0u; }
         if (!first) {
-          const uint64_t ahi = (uint64_t)R + delta + h - 1u;
-          ga_hi = (ahi >> 5) + 1u < (uint64_t)n_groups ? (uint32_t)(ahi >> 5) + 1u : n_groups;
+          const int64_t ahi = (int64_t)R + dhi + (int64_t)h_prev - 1;
+          ga_hi = ahi < 0 ? 1u : ((ahi >> 5) + 1 < (int64_t)n_groups ? (uint32_t)(ahi >> 5) + 1u : n_groups);
         }
+        h_min = h_cur < h_min ? h_cur : h_min;
       }
+      probe_min = 0xFFFFFFFFu;
       bottom = (first ? 0 : next_top) + (int32_t)HS;  // D'[bottom row of the strip][32 g_lo]: VP = all ones below the row above
       if (g_next == g_lo) next_top = bottom;
 
@@ -392,24 +548,30 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
           }
           bottom += (int32_t)__popc(Pout) - (int32_t)__popc(Nout);  // D'[bottom row][j] - D'[bottom row][j-1] summed over the group
           if (g + 1u == g_next) next_top = bottom;                  // what the strip below starts on top of
-          if (probe) probe_min = (uint32_t)bottom < probe_min ? (uint32_t)bottom : probe_min;
+          probe_min = (uint32_t)bottom < probe_min ? (uint32_t)bottom : probe_min;
           if (cols < 32u) { const uint32_t sh = 32u - cols; Pout <<= sh; Nout <<= sh; }
-          if (!last && !probe) {
+          if (!last && !probe && g >= g_next) {  // the strip below starts at g_next: nobody reads the groups before it
             uint32_t* __restrict__ o = sc + (size_t)(2u * g) * stride;
             o[0] = Pout; o[stride] = Nout;
           }
         }
       }
-      if (probe) {
-        // edits of the first HS rows -> a budget for all m rows; then one half width for the whole wavefront
-        const uint64_t est = (uint64_t)probe_min * m * margin / ((uint64_t)HS * kProbeMarginDen) + kProbeSlack;
-        const uint32_t mine = est / 2u < (uint64_t)n ? (uint32_t)(est / 2u) : n;
-        uint32_t hmax = 0u;  // every lane that has a pair is here (the probe is its first iteration): scalar loop over them
+      if (!wide_open) {
+        // The cheapest way to have consumed the rows seen so far (min over the swept columns of the strip's bottom row)
+        // -> a budget for all m rows, with a margin that shrinks as the square root of the rows seen (margin / 16 after
+        // one strip); then ONE half width for the whole wavefront (its lanes run the same group loop anyway, and the
+        // planes stay coalesced).  D' >= D: a band that was too narrow can only raise the estimate.
+        const uint32_t rows = R + HS;
+        const float f = 1.0f + (float)((int32_t)margin - (int32_t)kProbeMarginDen) * (1.0f / kProbeMarginDen) * __builtin_sqrtf((float)HS / (float)rows);
+        const float est = (float)probe_min * ((float)m / (float)rows) * f + (float)kProbeSlack;
+        const uint32_t mine = est * 0.5f < (float)h_open ? (uint32_t)(est * 0.5f) : h_open;
+        uint32_t hmax = 0u;  // the lanes that are here are on the same strip: scalar loop over them
         for (unsigned long long mk = __ballot(1); mk; mk &= mk - 1ull) {
           const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)mk) - 1);
           hmax = o > hmax ? o : hmax;
         }
-        h = hmax;
+        if (probe) { h_prev = hmax; h_cur = hmax; h_next = hmax; }
+        else { h_prev = h_cur; h_cur = h_next; h_next = hmax < h_cur + HS ? hmax : h_cur + HS; }  // the strip below never starts left of this one
       }
     }
     // phantom rows below the pattern in the last strip: take their vertical deltas off the bottom score
@@ -420,13 +582,9 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
       const uint32_t tail = pos >= m ? 0xFFFFFFFFu : (m - pos >= 32u ? 0u : ~((1u << (m - pos)) - 1u));
       dist -= (int32_t)__popc(VP[wi] & tail) - (int32_t)__popc(VN[wi] & tail);
     }
-    const uint64_t k = 2ull * h + delta;
-    if ((uint64_t)(uint32_t)dist <= k) {  // inside the band: this IS the distance (always, when the band is wide open)
-      w.pair_res[res_index(w, dst)] = make_float2((float)dist, (float)((int32_t)n - dist));
-      if (w.pair_ext) w.pair_ext[dst] = make_uint4(n - (uint32_t)dist, (uint32_t)dist - (n - m), n - m, n);
-    } else {
-      retry[atomicAdd(retry_n, 1u)] = entry;
-    }
+    const uint64_t k = 2ull * h_min + (uint64_t)(delta < 0 ? -delta : delta);
+    if ((uint64_t)(uint32_t)dist <= k) store_dna_result(w, dst, dist, n, m);  // inside the band: this IS the distance (always, when the band is wide open)
+    else retry[atomicAdd(retry_n, 1u)] = entry;
   }
 }
 
@@ -490,6 +648,7 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint2* __restrict__ lis
   // n_list_dev != null: a retry list whose length only the device knows (n_list bounds it); the grid strides over it
   const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
   const int lane = threadIdx.x;
+  if (n_list_dev && blockIdx.x == 0 && lane == 0 && total) atomicAdd(&w.counters[kCtrRetryTotal], total);
   for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
   uint32_t a, b, dst;
   resolve_pair(w, list[t], a, b, dst);

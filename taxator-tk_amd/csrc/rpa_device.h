@@ -187,9 +187,12 @@ struct WorkDev {
   uint32_t T2;   // number of pair slots = stride of each bin list
 };
 // counters: [0..kNumBins) pairs per bin | live sets | longest horizontal sequence among emitted pairs | pairs on the
-// retry list (banded alignments whose distance turned out to lie outside their band) | error code | error set/pair
-constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNumBins + 2, kCtrErr = kNumBins + 3, kCtrErrSet = kNumBins + 4,
-              kNumCounters = kNumBins + 5, kNumRoundCounters = kNumBins + 3;  // the first kNumRoundCounters are reset every round
+// retry lists (banded alignments whose distance turned out to lie outside their band;
+// (kCtrRetry: the strip kernel's, kCtrRetryShort: the one-strip kernels') | error code | error set/pair
+// | retried pairs so far in this batch (long, short: added up by the retry launches; the host reads them a round later)
+constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNumBins + 2, kCtrRetryShort = kNumBins + 3, kCtrErr = kNumBins + 4,
+              kCtrErrSet = kNumBins + 5, kCtrRetryTotal = kNumBins + 6, kCtrRetryShortTotal = kNumBins + 7, kNumCounters = kNumBins + 8,
+              kNumRoundCounters = kNumBins + 4;  // the first kNumRoundCounters are reset every round
 
 struct Params {
   int alphabet;
@@ -239,8 +242,14 @@ hipError_t launch_export_alignments(hipStream_t st, const WorkDev& w, uint32_t n
 
 // alignment kernels over one bin list
 // walks `list` then `list2` (n2 may be 0): pairs of a narrower class may ride along, the kernel is exact for any pattern <= 32*words
-hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
-                                  const WorkDev& w, unsigned long long* prof_acc);
+// n_dev != null: `list` is a retry list whose length is read on the device (bounded by n); grid_blocks workgroups stride over it
+hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint32_t* n_dev, uint32_t grid_blocks,
+                                  const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc);
+// the same inside a band of 2 words either side of the diagonal (patterns of 5..8 words); pairs whose distance lies
+// outside it are appended to retry[*retry_n] instead of being answered
+bool dna_short_band_available(int words);
+hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
+                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, unsigned long long* prof_acc);
 // multi-strip per-lane kernel inside Ukkonen's band; scratch holds two boundary bits per text column per thread in
 // flight.  A pair whose distance lies outside its band is appended to retry[*retry_n] (wide_open: never happens).
 // margin / 16 = safety factor on the probe's distance estimate (21 by default; tests use tiny ones to force retries).

@@ -75,13 +75,19 @@ struct rpa_engine {
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
   DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
-      tmp_words, tmp_offsets, protein_ws, retry_list;
+      tmp_words, tmp_offsets, protein_ws, retry_list, retry_short;
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
   bool profiling = false;
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
+  // what the bands cost: pairs sent through the banded kernels / re-run wide open, per batch.  A band that sends more
+  // than a quarter of its pairs to the retry list (unrelated sequences) is switched off for the next 16 batches.
+  uint64_t banded_short_batch = 0, banded_long_batch = 0;
+  int band_short_pause = 0, band_long_pause = 0;
+  bool band_short = true;     // RPA_BAND_SHORT=0: the one-strip kernel computes every cell of 5..8-word patterns too
+  uint32_t band_short_min = 65536;  // fewer pairs than this in a launch: not worth a second (retry) launch
   bool band_long = true;      // RPA_BAND=0: the strip kernel computes every cell (A/B; results are the same either way)
   uint32_t band_margin = 21;  // x/16: safety factor on the probe's distance estimate (RPA_BAND_MARGIN; tests force retries with 1)
   double band_gain = 2.5;     // K1s-vs-K2 cost model: what the band is worth on K1s (RPA_BAND_GAIN)
@@ -177,10 +183,18 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
   const uint32_t* counts = counts_in;
   int rider = -1;  // a narrower one-strip class waiting for the next launch
   uint64_t banded_pairs = 0;  // pairs that went through the banded strip kernel this round: the retry list's bound
-  if (e->params.alphabet == RPA_DNA && e->band_long) {
+  uint64_t banded_short = 0;  // ... through the banded one-strip kernel (its own retry list and counter)
+  int widest_short = 0;       // widest pattern class (in words) among the banded one-strip launches
+  const bool use_band_long = e->band_long && e->band_long_pause == 0, use_band_short = e->band_short && e->band_short_pause == 0;
+  if (e->params.alphabet == RPA_DNA && use_band_long) {
     uint64_t strip_pairs = 0;
     for (int bin = kShortWords; bin < kNumBins; ++bin) strip_pairs += counts[bin];
     if (strip_pairs) HIP_TRY(e, e->retry_list.ensure((size_t)strip_pairs * sizeof(uint2)));
+  }
+  if (e->params.alphabet == RPA_DNA && use_band_short) {
+    uint64_t short_pairs = 0;
+    for (int bin = 0; bin < kShortWords; ++bin) short_pairs += counts[bin];
+    if (short_pairs) HIP_TRY(e, e->retry_short.ensure((size_t)short_pairs * sizeof(uint2)));
   }
   for (int bin = 0; bin < kNumBins; ++bin) {
     const uint32_t n = counts[bin];
@@ -198,8 +212,16 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
     int trc = timer.begin();
     if (trc) return trc;
     if (e->params.alphabet == RPA_DNA) {
-      if (bin < kShortWords) HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, list2, n2, w, acc));
-      else {
+      if (bin < kShortWords) {
+        // Patterns of 5..8 words inside a band of two words either side of the diagonal (exact: what falls outside goes
+        // onto a retry list).  A launch of the dense rounds only: the sparse rounds put every class into one list.
+        if (use_band_short && dna_short_band_available(bin + 1) && (uint64_t)n + n2 >= e->band_short_min) {
+          HIP_TRY(e, launch_align_dna_short_band(e->stream, bin + 1, list, n, list2, n2, w, e->retry_short.as<uint2>(),
+                                                 w.counters + kCtrRetryShort, acc));
+          banded_short += (uint64_t)n + n2;
+          widest_short = bin + 1;
+        } else HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, nullptr, 0, list2, n2, w, acc));
+      } else {
         // Patterns of more than 256 nt.  Many pairs: one per lane, register strips inside Ukkonen's band (K1s).  Few pairs
         // (not enough to give every SIMD a few waves of lanes): one per wavefront (K2, every cell), as long as the pattern
         // fits its 64 x 8 words.
@@ -211,7 +233,7 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
         // lane)) from ~4 k waves on (115 k pairs: 230 ms).  The band leaves K1s about a third of the cells on pairs
         // that differ by 20-30 % (less on closer ones): its rates are scaled by e->band_gain.
         const double words = (max_len + 31u) / 32u, wpl = (uint32_t)((words + 63) / 64);
-        const double gain = e->band_long ? e->band_gain : 1.0;
+        const double gain = use_band_long ? e->band_gain : 1.0;
         const double tp_lane = std::min(88e12, n * 1.0e9) * gain;
         const double tp_wave = std::min(1.0, n / 4096.0) * 50e12 * words / (64.0 * wpl);
         bool wave = max_len <= kWaveMaxPattern && tp_wave > tp_lane;
@@ -221,9 +243,9 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
         else {
           HIP_TRY(e, e->protein_ws.ensure(dna_strip_scratch_words(n, max_len) * 4));
           HIP_TRY(e, launch_align_dna_strips(e->stream, bin - kShortWords + kStripMinWords, list, n, nullptr, 0, w, e->protein_ws.as<uint32_t>(),
-                                             e->protein_ws.cap / 4, max_len, !e->band_long, e->band_margin, e->retry_list.as<uint2>(),
+                                             e->protein_ws.cap / 4, max_len, !use_band_long, e->band_margin, e->retry_list.as<uint2>(),
                                              w.counters + kCtrRetry, acc));
-          if (e->band_long) banded_pairs += n;
+          if (use_band_long) banded_pairs += n;
         }
       }
     } else {
@@ -235,6 +257,18 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
       else
         HIP_TRY(e, launch_align_protein(e->stream, 8 * (bin + 1), list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
     }
+    trc = timer.end();
+    if (trc) return trc;
+  }
+  if (banded_short) {
+    // One-strip pairs outside their band: every cell, by the kernel of the widest class that was launched (exact for
+    // the narrower ones).  The count lives on the device; 2048 workgroups (two rounds of the chip) stride over the list.
+    const uint32_t bound = banded_short > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)banded_short;
+    LaunchTimer timer{e};
+    int trc = timer.begin();
+    if (trc) return trc;
+    HIP_TRY(e, launch_align_dna_short(e->stream, widest_short, e->retry_short.as<uint2>(), bound, w.counters + kCtrRetryShort, 2048u,
+                                      nullptr, 0, w, nullptr));
     trc = timer.end();
     if (trc) return trc;
   }
@@ -260,6 +294,8 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
     trc = timer.end();
     if (trc) return trc;
   }
+  e->banded_short_batch += banded_short;
+  e->banded_long_batch += banded_pairs;
   return RPA_OK;
 }
 
@@ -405,7 +441,14 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     rc = check_device_error(e, e->h_counters);
     if (rc) return rc;
     const uint32_t live_now = e->h_counters[kCtrActive];
-    if (live_now == 0) break;
+    if (live_now == 0) {  // the batch is done: what did the bands cost? (totals added up by the retry launches)
+      if (e->banded_short_batch >= 65536 && (uint64_t)e->h_counters[kCtrRetryShortTotal] * 4 > e->banded_short_batch) e->band_short_pause = 16;
+      else if (e->band_short_pause) --e->band_short_pause;
+      if (e->banded_long_batch >= 1024 && (uint64_t)e->h_counters[kCtrRetryTotal] * 4 > e->banded_long_batch) e->band_long_pause = 16;
+      else if (e->band_long_pause) --e->band_long_pause;
+      e->banded_short_batch = 0; e->banded_long_batch = 0;
+      break;
+    }
     uint32_t counts[kNumRoundCounters];
     memcpy(counts, e->h_counters, sizeof(counts));
     if (e->trace_rounds) {
@@ -418,6 +461,15 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     }
     rc = run_align_bins(e, w, counts);
     if (rc) return rc;
+    if (e->trace_rounds) {  // (a synchronisation the normal path does not have)
+      uint32_t retried = 0;
+      HIP_TRY(e, hipMemcpyAsync(&retried, w.counters + kCtrRetry, 4, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      uint32_t retried_short = 0;
+      HIP_TRY(e, hipMemcpyAsync(&retried_short, w.counters + kCtrRetryShort, 4, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      if (retried || retried_short) fprintf(stderr, "[rpa]   banded alignments that left their band and were re-run wide open: %u long, %u short\n", retried, retried_short);
+    }
     if (rounds == 1) gate.open();  // the long pass-1 alignment launch is queued: the next part may start underneath it
     HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kNumRoundCounters, e->stream));  // keep the error words
     const bool sparse_decide = rounds > 0 && (uint64_t)live_now * e->sparse_div_decide <= S;
@@ -459,7 +511,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
+  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
   w->fixed_speculation = e->fixed_speculation;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking);
@@ -604,6 +656,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.grow = 0;
   if (const char* v = getenv("RPA_SPEC_GROW")) e->params.grow = atoi(v);
   if (const char* v = getenv("RPA_BAND")) e->band_long = atoi(v) != 0;
+  if (const char* v = getenv("RPA_BAND_SHORT")) e->band_short = atoi(v) != 0;
+  if (const char* v = getenv("RPA_BAND_SHORT_MIN")) e->band_short_min = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_GAIN")) e->band_gain = atof(v);
   if (const char* v = getenv("RPA_BAND_MARGIN")) e->band_margin = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
@@ -676,7 +730,7 @@ void rpa_destroy(rpa_engine* e) {
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
-                    &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->retry_list, &e->prof_acc, &e->part_offsets};
+                    &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->retry_list, &e->retry_short, &e->prof_acc, &e->part_offsets};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
   for (auto& s : e->stores) { s.words.release(); s.offsets.release(); }

@@ -68,13 +68,14 @@ def test_dna_pairs_golden(pkg, oracle, golden_dir):
             v["dist"], v["match"], v["mismatch"], v["gap"], v["length"]), (len(v["a"]), len(v["b"]))
 
 
-@pytest.mark.parametrize("long_kernel", ["wave", "lane", None])
+@pytest.mark.parametrize("long_kernel", ["wave", "lane", None, "short-band"])
 def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
     """Every length bin of the nucleotide kernels against the oracle.  Patterns above 256 nt have two kernels (one pair
     per wavefront for few pairs, register strips per lane for many, chosen by a cost model): both are forced in turn;
     above 16384 nt only the strip kernel applies."""
-    if long_kernel: monkeypatch.setenv("RPA_LONG_KERNEL", long_kernel)
-    else: monkeypatch.delenv("RPA_LONG_KERNEL", raising=False)
+    monkeypatch.delenv("RPA_LONG_KERNEL", raising=False)
+    if long_kernel == "short-band": monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")  # banded one-strip kernel for launches of any size
+    elif long_kernel: monkeypatch.setenv("RPA_LONG_KERNEL", long_kernel)
     rng = np.random.default_rng(42)
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
     a_codes, b_codes = [], []
@@ -105,6 +106,41 @@ def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
     # argument order must not matter for DNA (getAlignmentDNA orders by length itself)
     out2 = m.align_pairs(letters, offsets, np.arange(n) * 2 + 1, np.arange(n) * 2)
     assert out.tobytes() == out2.tobytes()
+
+
+@pytest.mark.parametrize("band", ["forced", "off"])
+def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
+    """Patterns of 5..8 words (129..256 nt) go through a one-strip kernel that only updates the pattern words within two
+    words of the diagonal; pairs whose distance lies outside that band (or whose lengths differ by 64 and more) are
+    re-run by the full kernel.  Forced on for launches of any size / switched off: the same bytes either way, and both
+    equal to the oracle -- from identical pairs to unrelated ones, with N's, and every length difference class."""
+    monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")
+    if band == "off": monkeypatch.setenv("RPA_BAND_SHORT", "0")
+    rng = np.random.default_rng(12)
+    m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
+    a_codes, b_codes = [], []
+    for la in [129, 150, 159, 160, 161, 180, 191, 192, 193, 200, 210, 223, 224, 225, 240, 255, 256]:
+        for rate in [0.0, 0.02, 0.1, 0.25, 0.32, 0.4, 0.6, 1.0]:
+            for extra in [0, 3, 31, 40, 63, 64, 65, 100]:
+                a = rng.integers(0, 5 if rate > 0.3 else 4, la).astype(np.uint8)
+                r = rng.random(la)
+                b = a.copy()
+                sub = r < rate * 0.7
+                b[sub] = rng.integers(0, 4, int(sub.sum()))
+                b = b[~((r >= rate * 0.7) & (r < rate * 0.85))]
+                ins = np.nonzero((r >= rate * 0.85) & (r < rate))[0]
+                b = np.insert(b, np.minimum(ins, len(b)), rng.integers(0, 4, len(ins)).astype(np.uint8)) if len(b) else a[:1].copy()
+                if extra:
+                    tail = rng.integers(0, 4, extra).astype(np.uint8)
+                    b = np.concatenate([tail, b]) if rng.random() < 0.5 else np.concatenate([b, tail])
+                if rng.random() < 0.5: a, b = b, a
+                a_codes.append(a.astype(np.uint8))
+                b_codes.append(b.astype(np.uint8))
+    seqs = [LETTERS_DNA[x] for pair in zip(a_codes, b_codes) for x in pair]
+    letters, offsets = _pack(seqs)
+    n = len(a_codes)
+    out = m.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    _check_dna(oracle, out, a_codes, b_codes)
 
 
 @pytest.mark.parametrize("band", ["default", "tight", "off"])

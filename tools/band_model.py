@@ -2,12 +2,12 @@
 """Bit-level model of the banded strip kernel (k_myers_band, csrc/align_dna_kernels.hip) with small words, checked
 against plain Levenshtein.  Design aid + CPU test of the exactness argument (tests/test_band_model_cpu.py):
 
-  * a strip of HS rows sweeps only the column groups [g_lo, g_hi) that Ukkonen's band  -h <= j - i <= delta + h  touches;
+  * a strip of HS rows sweeps only the column groups [g_lo, g_hi) that Ukkonen's band  min(0, delta) - h <= j - i <= max(0, delta) + h  touches;
   * a strip that starts at a column > 0 starts from VP = all ones on top of the value the strip above had there
     (an upper bound of the true column), column groups the strip above never computed hand down "+1 per column";
   * what crosses a strip boundary per column is HP and HN of the strip's last row; the add carry into the strip below
     IS the HN bit (carry out of the top bit <=> vp & D0 at the top bit), so no third plane;
-  * the result D' is >= the true distance d, and D' == d whenever d <= k = 2 h + delta; D' > k proves d > k.
+  * the result D' is >= the true distance d, and D' == d whenever d <= k = 2 h + |delta|; D' > k proves d > k.
 """
 import random
 
@@ -23,12 +23,16 @@ def levenshtein(a, b):
 
 
 def banded_strips(pat, txt, h, HS=8, G=4, probe_groups=None):
-    """pat = rows (shorter), txt = columns.  Returns (D', ok, probe_min).  HS rows per strip, G columns per group."""
+    """pat = rows (shorter), txt = columns.  Returns (D', ok).  HS rows per strip, G columns per group.
+    h: one half width, or one per strip (each at most HS above the one before: a strip never starts left of the one above)."""
     m, n = len(pat), len(txt)
-    assert n >= m >= 1
-    delta = n - m
+    assert m >= 1 and n >= 1
+    delta = n - m                       # may be negative: more rows than columns
+    dlo, dhi = min(0, delta), max(0, delta)
     mask = (1 << HS) - 1
     nstrips = (m + HS - 1) // HS
+    hs = list(h) if isinstance(h, (list, tuple)) else [h] * (nstrips + 1)
+    hs += [hs[-1]] * (nstrips + 1 - len(hs))
     n_groups = (n + G - 1) // G
     planes = {}          # (strip, group) -> (P bits list, N bits list) per column of the group
     saved_next = 0
@@ -44,10 +48,12 @@ def banded_strips(pat, txt, h, HS=8, G=4, probe_groups=None):
                 if R + r < m and pat[R + r] == c:
                     e |= 1 << r
             eq[c] = e
-        g_lo = (R - h) // G if R > h else 0
-        g_hi = min(n_groups, (R + HS + delta + h - 1) // G + 1)
-        g_next = (R + HS - h) // G if R + HS > h else 0
-        ga_hi = min(n_groups, (R + delta + h - 1) // G + 1) if not first else 0   # window end of the strip above
+        h, h_nxt, h_prv = hs[s], hs[s + 1], hs[s - 1] if s else 0
+        g_lo = max(0, R + dlo - h) // G
+        g_hi = min(n_groups, (R + HS + dhi + h - 1) // G + 1)
+        g_next = max(0, R + HS + dlo - h_nxt) // G
+        ga_hi = min(n_groups, max(0, R + dhi + h_prv - 1) // G + 1) if not first else 0   # window end of the strip above
+        assert g_lo < g_hi
         VP, VN = mask, 0
         bottom = (0 if first else saved_next) + HS
         if first:
@@ -92,7 +98,7 @@ def banded_strips(pat, txt, h, HS=8, G=4, probe_groups=None):
     dist = bottom
     for r in range(HS - tail_rows, HS):
         dist -= ((VP >> r) & 1) - ((VN >> r) & 1)
-    k = 2 * h + delta
+    k = 2 * min(hs[:nstrips]) + abs(delta)
     return dist, dist <= k
 
 
@@ -115,18 +121,120 @@ def check(trials=3000, seed=1):
         if rng.random() < 0.3:
             b += [rng.randrange(3) for _ in range(rng.randint(0, 10))]
         if not b: b = [0]
-        pat, txt = (a, b) if len(a) <= len(b) else (b, a)
+        pat, txt = (a, b) if rng.random() < 0.5 else (b, a)   # rows / columns: either may be the longer one
         d = levenshtein(pat, txt)
         for h in (0, 1, 2, 3, 5, 8, 13, 100):
             dp, ok = banded_strips(pat, txt, h, HS, G)
-            k = 2 * h + len(txt) - len(pat)
+            k = 2 * h + abs(len(txt) - len(pat))
             assert dp >= d, (pat, txt, h, dp, d)
             if d <= k:
                 assert ok and dp == d, (pat, txt, h, HS, G, dp, d)
             else:
                 assert not ok, (pat, txt, h, dp, d, k)
+        # a different half width per strip (the kernel refreshes its estimate after every strip)
+        for _ in range(4):
+            nstrips = (len(pat) + HS - 1) // HS
+            hs = [rng.randint(0, 12)]
+            for _s in range(nstrips):
+                hs.append(rng.randint(0, hs[-1] + HS))
+            dp, ok = banded_strips(pat, txt, hs, HS, G)
+            k = 2 * min(hs[:nstrips]) + abs(len(txt) - len(pat))
+            assert dp >= d, (pat, txt, hs, dp, d)
+            if d <= k:
+                assert ok and dp == d, (pat, txt, hs, HS, G, dp, d)
+            else:
+                assert not ok, (pat, txt, hs, dp, d, k)
     return trials
 
 
 if __name__ == "__main__":
     print("ok", check())
+
+
+# ---- K1 form: the whole pattern in registers, a STATIC window of words per column group ---------------------------
+def banded_window(pat, txt, NW, HW, W=4):
+    """k_myers_short_band (align_dna_kernels.hip): pattern rows in NW words of W bits, text in groups of W columns; group g
+    updates only the words [g - HW, g + HW] (clipped).  Words below the window keep their initial VP = all ones until the
+    window reaches them, words above it are dropped ("+1 per column" comes down from there).  The score is followed at
+    the top of the window: T = D'[row above the window's first word][column], +1 per column, plus the dropped word's
+    vertical deltas whenever the window moves down.  Returns (D', applicable, ok)."""
+    m, n = len(pat), len(txt)
+    assert 1 <= m <= NW * W
+    delta = n - m
+    ad = abs(delta)
+    if ad >= W * HW:
+        return None, False, False
+    h = W * HW - ad
+    k = 2 * h + ad
+    mask = (1 << W) - 1
+    eq = {}
+    for c in set(txt):
+        eq[c] = [sum(1 << r for r in range(W) if wi * W + r < m and pat[wi * W + r] == c) for wi in range(NW)]
+    VP = [mask] * NW
+    VN = [0] * NW
+    T = 0
+    n_groups = (n + W - 1) // W
+    assert n_groups <= NW + HW
+    for g in range(n_groups):
+        wlo, whi = max(0, g - HW), min(NW - 1, g + HW)
+        cols = min(W, n - g * W)
+        for kcol in range(cols):
+            e = eq[txt[g * W + kcol]]
+            hp_in, hn_in = 1, 0
+            for wi in range(wlo, whi + 1):
+                vp, vn = VP[wi], VN[wi]
+                X = e[wi] | vn
+                sm = vp + (X & vp) + hn_in
+                D0 = ((sm ^ vp) | X) & mask
+                HN = vp & D0
+                HP = (vn | ~(vp | D0)) & mask
+                Xs = ((HP << 1) | hp_in) & mask
+                Hs = ((HN << 1) | hn_in) & mask
+                VN[wi] = Xs & D0
+                VP[wi] = (Hs | ~(Xs | D0)) & mask
+                hp_in, hn_in = (HP >> (W - 1)) & 1, (HN >> (W - 1)) & 1
+        T += cols
+        if g + 1 < n_groups and g - HW >= 0 and g - HW <= NW - 1:   # the window's first word moves down: fold the dropped word in
+            w0 = g - HW
+            T += bin(VP[w0]).count("1") - bin(VN[w0]).count("1")
+    wlo_final = max(0, (n_groups - 1) - HW) if n_groups else 0
+    dist = T
+    for wi in range(wlo_final, NW):
+        for r in range(W):
+            if wi * W + r < m:
+                dist += ((VP[wi] >> r) & 1) - ((VN[wi] >> r) & 1)
+    return dist, True, dist <= k
+
+
+def check_window(trials=3000, seed=2):
+    rng = random.Random(seed)
+    for t in range(trials):
+        W = rng.choice([3, 4, 8]); NW = rng.randint(1, 7); HW = rng.randint(1, 3)
+        m = rng.randint(1, NW * W)
+        a = [rng.randrange(3) for _ in range(m)]
+        b = []
+        rate = rng.choice([0.0, 0.05, 0.2, 0.5, 0.9])
+        for c in a:
+            r = rng.random()
+            if r < rate / 3: continue
+            if r < 2 * rate / 3: b.append(rng.randrange(3)); b.append(c); continue
+            if r < rate: b.append(rng.randrange(3)); continue
+            b.append(c)
+        if rng.random() < 0.3:
+            b += [rng.randrange(3) for _ in range(rng.randint(0, 6))]
+        if not b: b = [0]
+        d = levenshtein(a, b)
+        dp, applicable, ok = banded_window(a, b, NW, HW, W)
+        if not applicable:
+            continue
+        k = 2 * (W * HW - abs(len(b) - m)) + abs(len(b) - m)
+        assert dp >= d, (a, b, NW, HW, W, dp, d)
+        if d <= k:
+            assert ok and dp == d, (a, b, NW, HW, W, dp, d, k)
+        else:
+            assert not ok, (a, b, NW, HW, W, dp, d, k)
+    return trials
+
+
+if __name__ == "__main__":
+    print("window ok", check_window())
