@@ -608,6 +608,9 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
     } else {
       const SetRows<P4> R = set_rows<P4>(w, s, lo);
       const HitCore h0 = R.core(0u);
+      // the reference fetches the query range (:415) BEFORE it looks at the best hit: an unreadable range aborts the run
+      // even where the shortcut below would not have needed the sequence
+      if (st.qsegerr) raise_error(w, st.qsegerr, s);
       if (h0.meta & kMetaPerfect) {  // :431-472: lnode / unode are points on hit 0's path
         uint32_t path0[4 * P4];
         R.path(0u, path0);
@@ -1144,6 +1147,26 @@ hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_
   if (n_tiles == 0) return hipSuccess;
   hipLaunchKernelGGL(k_tile_caps, dim3((n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, st, set_offsets, n_sets, n_tiles, tile_base);
   hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, n_tiles, tile_base);
+  return hipGetLastError();
+}
+
+// Batch sanity, before any kernel follows an index of the caller's (the C ABI takes device pointers: nothing else stands
+// between a bad index and a page fault): set_offsets runs from 0 to n_records without ever decreasing, every taxonomy node
+// index is inside the taxonomy.  err[0] = error code (first one wins), err[1] = offending set / record.
+__global__ __launch_bounds__(kBlock) void k_validate_batch(BatchDev b, uint32_t n_nodes, uint32_t* __restrict__ err) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t bad = 0xFFFFFFFFu;
+  if (t < b.n_sets) {
+    const uint32_t lo = b.set_offsets[t], hi = b.set_offsets[t + 1];
+    if (lo > hi || hi > b.n_records || (t == 0 && lo != 0u) || (t + 1u == b.n_sets && hi != b.n_records)) bad = t;
+  }
+  if (bad == 0xFFFFFFFFu && t < b.n_records && b.node[t] >= n_nodes) bad = t;
+  if (bad != 0xFFFFFFFFu && atomicCAS(&err[0], 0u, (uint32_t)kErrInvalid) == 0u) err[1] = bad;
+}
+hipError_t launch_validate_batch(hipStream_t st, const BatchDev& b, uint32_t n_nodes, uint32_t* err) {
+  const uint32_t n = b.n_sets > b.n_records ? b.n_sets : b.n_records;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_validate_batch, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, n_nodes, err);
   return hipGetLastError();
 }
 

@@ -216,6 +216,8 @@ hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* lett
 // count), tile_base[n_tiles] = total slots.  Two small launches; the caller reads the total back to size the buffers.
 hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t* tile_base);
 
+// err[0..1] (zeroed by the caller) <- kErrInvalid + index when set_offsets / node indices of the batch are not usable
+hipError_t launch_validate_batch(hipStream_t st, const BatchDev& b, uint32_t n_nodes, uint32_t* err);
 hipError_t launch_rebase_offsets(hipStream_t st, const uint32_t* in, uint32_t n, uint32_t* out);
 hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
                                const StoreDev& db, const Params& p);

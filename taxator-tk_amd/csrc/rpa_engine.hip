@@ -402,15 +402,19 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   // row accesses coalesced; it pads every tile to its largest set, so batches whose padding would exceed ~50 % of the
   // rows (wildly different set sizes) keep the linear layout.  The slot count comes back from the device.
   const uint32_t n_tiles = (S + 63u) / 64u;
-  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 1) * 4));
+  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 4) * 4));  // + total slots, + the two words of k_validate_batch
   uint32_t P = H;
   bool tiled = false;
-  if (!e->linear_rows) {
-    HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>()));
-    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->tile_base.as<uint32_t>() + n_tiles, 4, hipMemcpyDeviceToHost, e->stream));
+  {
+    uint32_t* tail = e->tile_base.as<uint32_t>() + n_tiles;
+    HIP_TRY(e, hipMemsetAsync(tail, 0, 12, e->stream));
+    HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, tail + 1));
+    if (!e->linear_rows) HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>()));
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, tail, 12, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->h_counters[1]) return fail(e, RPA_ERR_INVALID, "batch rejected: set_offsets must run from 0 to n_records without decreasing and every node index must lie inside the taxonomy (set / record %u)", e->h_counters[2]);
     const uint64_t slots = e->h_counters[0];
-    if (slots != 0xFFFFFFFFull && slots <= (uint64_t)H + H / 2 + 65536u && slots + S < 0xFFFFFFF0ull) { P = (uint32_t)slots; tiled = true; }
+    if (!e->linear_rows && slots != 0xFFFFFFFFull && slots <= (uint64_t)H + H / 2 + 65536u && slots + S < 0xFFFFFFF0ull) { P = (uint32_t)slots; tiled = true; }
   }
   WorkDev w{};
   int rc = alloc_work(e, S, H, T, T, false, &w, P, tiled);
@@ -544,6 +548,14 @@ int run_parts(rpa_engine* e, const BatchDev& b, const uint32_t* h_offsets, void*
   if (K == 1) {
     PartGate g;
     return predict_part(e, b, q, db, rows_dev, stats_dev, g);
+  }
+  {  // the part boundaries below are read out of set_offsets: check the batch first (predict_part does it for K == 1)
+    HIP_TRY(e, e->tile_base.ensure(16));
+    HIP_TRY(e, hipMemsetAsync(e->tile_base.p, 0, 8, e->stream));
+    HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, e->tile_base.as<uint32_t>()));
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->tile_base.p, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->h_counters[0]) return fail(e, RPA_ERR_INVALID, "batch rejected: set_offsets must run from 0 to n_records without decreasing and every node index must lie inside the taxonomy (set / record %u)", e->h_counters[1]);
   }
   std::vector<uint32_t> s_lo(K + 1), r_lo(K + 1);
   for (int k = 0; k <= K; ++k) s_lo[k] = (uint32_t)((uint64_t)S * k / K);
@@ -964,6 +976,14 @@ int rpa_lca_predict_batch(rpa_engine* e, const rpa_batch* batch, const double* e
   } else return fail(e, RPA_ERR_INVALID, "rpa_lca_predict_batch: bad mem_kind");
   void* rows_dev = out;
   if (out_mem_kind == RPA_MEM_HOST) { HIP_TRY(e, e->out_rows.ensure((size_t)S * sizeof(rpa_prediction))); rows_dev = e->out_rows.p; }
+  {  // a bad node index or offset must not reach the kernel (host batches were checked above; this covers device batches too)
+    HIP_TRY(e, e->tile_base.ensure(16));
+    HIP_TRY(e, hipMemsetAsync(e->tile_base.p, 0, 8, e->stream));
+    HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, e->tile_base.as<uint32_t>()));
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->tile_base.p, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->h_counters[0]) return fail(e, RPA_ERR_INVALID, "batch rejected: set_offsets must run from 0 to n_records without decreasing and every node index must lie inside the taxonomy (set / record %u)", e->h_counters[1]);
+  }
   const LcaParamsDev p{params->model, params->toppercent, params->minscore, (float)params->maxevalue, params->minsupport, params->nbest,
                        params->ignore_unclassified};
   HIP_TRY(e, launch_lca_models(e->stream, b, e->tax, p, ev, uncl, rows_dev));

@@ -597,3 +597,48 @@ def test_batch_cut_into_parts(pkg, oracle, synth, parts, monkeypatch):
     assert st.cpu().numpy().tobytes() == stats.view(np.int32).reshape(-1, 4).tobytes()
     prof = model.profile()
     assert prof["demanded"] == int(stats["pass0"].sum() + stats["pass1"].sum() + stats["pass2"].sum())
+
+
+def test_bad_batches_rejected(pkg, oracle, synth):
+    """What must not reach a kernel through the C ABI: a taxonomy node index outside the taxonomy, set offsets that
+    decrease or do not end at n_records (host and device batches alike: RPA_ERR_INVALID, no page fault); and the
+    reference's order of events around the perfect-hit shortcut: the query range is fetched first (:415), so an unknown
+    query sequence aborts the run even for a set the shortcut would have finished without looking at it."""
+    import torch
+    ds = synth.make_dataset(n_sets=92, n_hits=6, seg_len=120, branching=2, seed=9, variety=True)
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    rows, _ = model.predict(ds.batch)
+    shortcut = np.nonzero(rows["flags"] & 2)[0]
+    assert len(shortcut), "the variety generator plants perfect-hit sets"
+    tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    q = oracle.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+    db = oracle.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+    bad = {k: v.copy() for k, v in ds.batch.items()}
+    bad["query_seq"][int(shortcut[0])] = 10 ** 6            # SequenceNotFound before the shortcut is even considered
+    rc, _, _ = oracle.predict_batch(tax, q, db, 0, bad["set_offsets"], bad["query_seq"], bad["query_len"], synth.records_aos(bad, oracle.RECORD_DTYPE))
+    assert rc == 2                                            # ORC_ERR_SEQ_ID
+    with pytest.raises(pkg.RpaError) as ei:
+        model.predict(bad)
+    assert ei.value.code == 4                                 # RPA_ERR_SEQ_ID
+
+    def as_dev(b):
+        return {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).cuda() for k, v in b.items()}
+
+    for kind in ("node", "offsets_decrease", "offsets_end"):
+        bad = {k: v.copy() for k, v in ds.batch.items()}
+        if kind == "node": bad["node"][17] = len(ds.tax.parent) + 5
+        elif kind == "offsets_decrease": bad["set_offsets"][40] = bad["set_offsets"][39] - 1
+        else: bad["set_offsets"][-1] += 3
+        for device in (False, True):
+            with pytest.raises(pkg.RpaError) as ei:
+                if device:
+                    out = torch.zeros((ds.n_sets, 8), dtype=torch.int32, device="cuda")
+                    model.predict(as_dev(bad), mem_kind=pkg.MEM_DEVICE, out=out)
+                else:
+                    model.predict(bad)
+            assert ei.value.code == 1, (kind, device)
+    rows2, _ = model.predict(ds.batch)                        # the engine is still usable
+    assert rows2.tobytes() == rows.tobytes()
+
