@@ -156,14 +156,19 @@ def cpu_reference_pairs(synth, ds, seconds_target=4.0, n_pairs=20000):
                       % (n_pairs, reps, done, dt, "DNA" if ds.alphabet == 0 else "Protein")}
 
 
-# BASELINE.json configs that fit one GPU per rank (per-GPU sizes; c5 is 100 k contigs over 8 GPUs = 12.5 k per GPU)
+# BASELINE.json configs, per-GPU sizes (weak scaling: the whole job is sets x N).  c2: 1 M sets on one GPU (the headline);
+# c3: 10 M sets over 8 GPUs = 1.25 M per GPU, one seed per shard (3 + rank: SURVEY 8d "seeds 3..10 per shard");
+# c5: 100 k contigs over 8 GPUs = 12.5 k per GPU -- with N > 1 ONE workload of 12.5 k x N contigs is generated (same
+# seed on every rank) and cut into N contiguous shards of equal summed alignment cells (sharding.shard_bounds_by_cost).
 CONFIGS = {
-    "c2": dict(sets=1_000_000, hits=20, seg_len=200, alphabet=0, genome_len=4000, level_rate=0.03, query_rate=0.05,
-               name="BASELINE config 2", kernel="k_myers_short (batched bit-parallel edit distance, one alignment per lane)"),
-    "c4": dict(sets=500_000, hits=20, seg_len=67, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08,
+    "c2": dict(sets=1_000_000, hits=20, seg_len=200, alphabet=0, genome_len=4000, level_rate=0.03, query_rate=0.05, seed=2,
+               name="BASELINE config 2", kernel="k_myers_short_band / k_myers_short (batched bit-parallel edit distance, one alignment per lane, pattern words within two words of the diagonal)"),
+    "c3": dict(sets=1_250_000, hits=20, seg_len=200, alphabet=0, genome_len=4000, level_rate=0.03, query_rate=0.05, seed=3,
+               name="BASELINE config 3 (10 M record sets over 8 GPUs: 1.25 M per GPU)", kernel="k_myers_short_band / k_myers_short (batched bit-parallel edit distance, one alignment per lane, pattern words within two words of the diagonal)"),
+    "c4": dict(sets=500_000, hits=20, seg_len=67, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08, seed=2,
                name="BASELINE config 4 (protein, 67 aa)", kernel="k_nw_protein_packed (BLOSUM62 global DP, score + tie order + path counters in one 32-bit cell, one alignment per lane)"),
-    "c5": dict(sets=12_500, hits=50, seg_len=10_000, alphabet=0, genome_len=40_000, level_rate=0.03, query_rate=0.05,
-               name="BASELINE config 5 (10 kbp contigs, per-GPU share of 100 k)", kernel="k_myers_strips (bit-parallel edit distance, one alignment per lane, pattern in register strips of 5-8 words)"),
+    "c5": dict(sets=12_500, hits=50, seg_len=10_000, alphabet=0, genome_len=40_000, level_rate=0.03, query_rate=0.05, seed=2, cut_by_cost=True,
+               name="BASELINE config 5 (10 kbp contigs, per-GPU share of 100 k)", kernel="k_myers_band (bit-parallel edit distance inside Ukkonen's band, one alignment per lane, pattern in register strips of 5-8 words)"),
 }
 
 
@@ -173,7 +178,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
-                    help="c2 = the headline configuration (BASELINE config 2); c4 protein, c5 long contigs are extra measurements")
+                    help="c2 = the headline configuration (BASELINE config 2); c3 = config 3's per-GPU share (for --gpus 8), c4 protein, "
+                         "c5 long contigs are extra measurements")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) and run the gather path even with one rank (hardware rehearsal of the N > 1 code)")
     ap.add_argument("--sets", type=int, default=None, help="record sets per GPU (default: the configuration's)")
     ap.add_argument("--hits", type=int, default=None)
     ap.add_argument("--seg-len", type=int, default=None)
@@ -199,15 +207,31 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the RPA engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = graft.load_package()
     synth = importlib.import_module("taxator_tk_amd.synth")
     t_gen = time.perf_counter()
-    ds = synth.make_dataset(n_sets=args.sets, n_hits=args.hits, seg_len=args.seg_len, branching=4, genome_len=cfg["genome_len"],
-                            seed=2 + rank, device="cuda", alphabet=cfg["alphabet"], level_rate=cfg["level_rate"],
-                            query_rate=cfg["query_rate"])
+    sharding = importlib.import_module("taxator_tk_amd.sharding")
+    cut_by_cost = bool(cfg.get("cut_by_cost")) and world > 1
+    if cut_by_cost:
+        # ONE workload for the whole job (every rank generates the same one), cut where the summed alignment cells are equal
+        ds = synth.make_dataset(n_sets=args.sets * world, n_hits=args.hits, seg_len=args.seg_len, branching=4, genome_len=cfg["genome_len"],
+                                seed=cfg["seed"], device="cuda", alphabet=cfg["alphabet"], level_rate=cfg["level_rate"],
+                                query_rate=cfg["query_rate"])
+        bounds = sharding.shard_bounds_by_cost(sharding.set_costs(ds.batch), world)
+        ds.batch = sharding.slice_batch(ds.batch, bounds[rank], bounds[rank + 1])  # query_seq keeps pointing into the whole query store
+        ds.n_sets = bounds[rank + 1] - bounds[rank]
+        gather_sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
+    else:
+        ds = synth.make_dataset(n_sets=args.sets, n_hits=args.hits, seg_len=args.seg_len, branching=4, genome_len=cfg["genome_len"],
+                                seed=cfg["seed"] + rank, device="cuda", alphabet=cfg["alphabet"], level_rate=cfg["level_rate"],
+                                query_rate=cfg["query_rate"])
+        gather_sizes = [ds.n_sets] * world
     t_gen = time.perf_counter() - t_gen
 
     model = pkg.RPAPredictionModel(ds.tax, alphabet=cfg["alphabet"], device=local_rank)
@@ -217,14 +241,13 @@ def main():
            for k, v in ds.batch.items()}
     rows = torch.zeros((ds.n_sets, 8), dtype=torch.int32, device="cuda")
     stats = torch.zeros((ds.n_sets, 4), dtype=torch.int32, device="cuda")
-    sharding = importlib.import_module("taxator_tk_amd.sharding")
     stream = torch.cuda.current_stream()
     model.set_stream(stream.cuda_stream)
 
     # X1: PredictionRecord rows of every rank to rank 0 over xGMI (RCCL gather); shard sizes are equal and known, the
     # receive buffers on rank 0 are allocated once
-    gather_sizes = [ds.n_sets] * world
-    gather_out = [torch.empty_like(rows) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_out = ([torch.empty((max(gather_sizes), 8), dtype=torch.int32, device="cuda") for _ in range(world)]
+                  if (use_dist and rank == 0) else None)
 
     def step():
         if args.host_buffers:
@@ -235,22 +258,22 @@ def main():
                 step.copied = True
         else:
             model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
-        if world > 1:
-            sharding.gather_rows(rows, dst=0, sizes=gather_sizes, out=gather_out)
+        if use_dist:
+            sharding.gather_rows(rows, dst=0, sizes=gather_sizes, out=gather_out, force=True)
 
     step.copied = False
     for _ in range(args.warmup):
         step()
     model.profile(enable=True, reset=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -259,9 +282,11 @@ def main():
     demanded = int(stats[:, 1:].to(torch.int64).sum().item())  # per step, this rank
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     d = torch.tensor([demanded], dtype=torch.int64, device="cuda")
-    if world > 1:
+    n_sets_all = torch.tensor([ds.n_sets], dtype=torch.int64, device="cuda")
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(d, op=dist.ReduceOp.SUM)
+        dist.all_reduce(n_sets_all, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     demanded_all = int(d.item())
 
@@ -269,12 +294,16 @@ def main():
         # HBM traffic of the alignment kernels cannot be read from inside the process: it comes from the committed
         # rocprofv3 PMC passes of this same command (profiles/*traffic.json, see profiles/README.md)
         traffic, traffic_src = None, None
+        if use_dist and rank == 0:  # the gathered rows of this rank's own shard must be the rows it computed
+            own = gather_out[0][: gather_sizes[0]] if isinstance(gather_out, list) else None
+            assert own is None or torch.equal(own, rows), "gathered rows differ from the computed ones"
         if args.sets == cfg["sets"] and args.hits == cfg["hits"] and args.seg_len == cfg["seg_len"]:
             import glob
             # profiles/<round>_traffic.json = config 2 (the headline), profiles/<round>_cN_traffic.json = config N
             tagged = lambda f, c: ("_%s_" % c) in os.path.basename(f)
+            tcfg = "c2" if args.config == "c3" else args.config  # config 3 runs config 2's kernels on config 2's shapes
             cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))
-                           if (tagged(f, args.config) if args.config != "c2" else not any(tagged(f, c) for c in CONFIGS)))
+                           if (tagged(f, tcfg) if tcfg != "c2" else not any(tagged(f, c) for c in CONFIGS)))
             if cands:
                 tj = json.load(open(cands[-1]))
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
@@ -291,9 +320,10 @@ def main():
                                    % (cfg["name"], args.sets, args.hits, args.seg_len, "bp nucleotide" if cfg["alphabet"] == 0 else "aa protein")
                                    + (" -- HOST BUFFERS: batch copied to the device and rows back inside every step (PCIe-inclusive, not the headline)" if args.host_buffers else ""),
                        "record_sets_per_gpu": args.sets, "hits_per_set": args.hits, "segment_bp": args.seg_len,
-                       "parallelism": "record sets sharded over %d GPU(s); RCCL gather of 32-byte rows" % world if world > 1 else "single GPU",
+                       "parallelism": ("record sets sharded over %d GPU(s)%s; RCCL gather of 32-byte rows to rank 0 every step"
+                                       % (world, ", ONE workload cut by summed alignment cells" if cut_by_cost else "")) if use_dist else "single GPU",
                        "unit_counted": "alignments demanded by the reference control flow (STATS gcounter), not speculative ones"},
-            "record_sets_per_s": ds.n_sets * world * args.steps / elapsed,
+            "record_sets_per_s": int(n_sets_all.item()) * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC)",
                          "traffic_source": traffic_src,
@@ -313,7 +343,7 @@ def main():
             if ref is not None:
                 out["cpu_reference"] = ref
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -58,14 +58,14 @@ def slice_batch(batch, lo, hi):
     return out
 
 
-def gather_rows(rows, dst=0, group=None, sizes=None, out=None):
+def gather_rows(rows, dst=0, group=None, sizes=None, out=None, force=False):
     """rows: (n_local, 8) int32 tensor (any device).  Returns the rows of all ranks concatenated in rank order on `dst`
     (None elsewhere).  Shards may differ in size: sizes are exchanged first, rows are padded to the largest shard.
-    A caller that gathers the same shapes every step passes `sizes` (rows per rank, known up front) to skip the size
+    Shards need not be equal (config 5 is cut by cost).  A caller that gathers the same shapes every step passes `sizes` (rows per rank, known up front) to skip the size
     exchange, and on `dst` `out` = a list of world_size preallocated (max(sizes), 8) tensors to skip the allocation."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not force:  # force: run the collective anyway (a one-rank rehearsal of the N > 1 path on hardware)
         return rows
     if sizes is None:
         n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)

@@ -1,0 +1,39 @@
+"""The N > 1 code path of bench.py on the one GPU of the test box: torch.distributed.run with ONE rank and the RCCL
+(`nccl`) backend forced on -- init_process_group on a device, the engine on torch's current stream, the gather of the
+32-byte rows through RCCL, the barrier / all_reduce bracketing of the timed region.  The child is a fresh process (never a
+re-exec of the test runner).  Multi-rank plumbing itself (shard bounds, uneven gathers) is covered on CPU with gloo in
+tests/test_distributed_cpu.py; the 8-GPU curve is the driver's to measure."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("config,extra", [("c3", ["--sets", "30000"]), ("c5", ["--sets", "40", "--seg-len", "3000"])])
+def test_bench_one_rank_over_rccl(config, extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", config, "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--force-dist"] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
+    assert "RCCL gather" in out["config"]["parallelism"]
+    assert out["roofline"]["achieved"] > 0 and out["roofline"]["launches"] > 0
