@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RPA_ABI_VERSION 1
+#define RPA_ABI_VERSION 2
 
 enum { RPA_DNA = 0, RPA_PROTEIN = 1 };              /* taxator -b nucleotide|protein, core/taxator.cpp:280,362-371 */
 enum { RPA_STORE_QUERY = 0, RPA_STORE_DB = 1 };      /* query_sequences_ / db_sequences_, taxonpredictionmodelsequence.hh:842-843 */
@@ -92,6 +92,24 @@ int rpa_set_stream(rpa_engine* e, void* hip_stream);
  * reference's: 1-based inclusive; rstart > rstop means reverse strand. */
 int rpa_store_load(rpa_engine* e, int which, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets,
                    int mem_kind);
+
+/* Indexed stores.  The reference's RandomIndexedSeqstoreRO (core/src/sequencestorage.hh:318-406) keeps
+ * nothing in memory and reads every region through the .fai index (core/src/faidx.h:315-350).  The counterpart here:
+ * rpa_store_reserve makes a store of n_seqs sequences of which none is resident yet (sequence indices = positions in
+ * the index file); rpa_store_append packs the letters of the sequences `seq_index[0..n)` (host memory, `offsets` = n + 1
+ * entries from 0, as in rpa_store_load) behind what is resident and makes them readable.  The host driver appends the
+ * sequences a block of the alignment stream refers to before it submits the block, so HBM and load time scale with the
+ * sequences touched, not with the collection.  A record that points at a sequence that was never appended sees an
+ * empty sequence (RPA_ERR_RANGE).  Appending an index twice wastes arena space but is harmless. */
+int rpa_store_reserve(rpa_engine* e, int which, uint32_t n_seqs);
+int rpa_store_append(rpa_engine* e, int which, uint32_t n, const uint32_t* seq_index, const uint8_t* letters, const uint64_t* offsets);
+typedef struct {
+  uint32_t n_seqs;       /* sequences the store knows */
+  uint32_t n_resident;   /* of which resident in HBM */
+  uint64_t residues;     /* residues resident */
+  uint64_t device_bytes; /* HBM bytes held by the store (packed arena incl. growth slack + extent table) */
+} rpa_store_info;
+int rpa_store_info_get(rpa_engine* e, int which, rpa_store_info* out);
 
 /* One batch of record sets = what RecordSetGenerator*::getNext hands to predict() one at a time
  * (core/src/alignmentrecord.hh:457-631), as structure-of-arrays.  Record fields are exactly those predict() reads

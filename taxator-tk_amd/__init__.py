@@ -32,7 +32,8 @@ ERROR_NAMES = {0: "OK", 1: "INVALID", 2: "DEVICE", 3: "RANGE", 4: "SEQ_ID", 5: "
 # every symbol include/taxator_rpa.h declares (checked by the CPU-side ABI test)
 ABI_SYMBOLS = ["rpa_abi_version", "rpa_default_params", "rpa_create", "rpa_destroy", "rpa_last_error", "rpa_set_stream",
                "rpa_store_load", "rpa_predict_batch", "rpa_align_pairs", "rpa_profile_enable", "rpa_profile_get",
-               "rpa_profile_reset", "rpa_lca_default_params", "rpa_lca_predict_batch"]
+               "rpa_profile_reset", "rpa_lca_default_params", "rpa_lca_predict_batch", "rpa_store_reserve", "rpa_store_append",
+               "rpa_store_info_get"]
 
 LCA_DUMMY, LCA_SIMPLE, LCA_MEGAN, LCA_NBEST = 0, 1, 2, 3  # taxator -a dummy | simple-lca | megan-lca | n-best-lca
 
@@ -108,6 +109,12 @@ def load_library(path=None):
     L.rpa_align_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int]
     L.rpa_align_pairs.restype = C.c_int
+    L.rpa_store_reserve.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    L.rpa_store_reserve.restype = C.c_int
+    L.rpa_store_append.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rpa_store_append.restype = C.c_int
+    L.rpa_store_info_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.rpa_store_info_get.restype = C.c_int
     L.rpa_lca_default_params.argtypes = [C.POINTER(_LcaParams)]
     L.rpa_lca_default_params.restype = None
     L.rpa_lca_predict_batch.argtypes = [C.c_void_p, C.POINTER(_Batch), C.c_void_p, C.c_void_p, C.POINTER(_LcaParams), C.c_void_p, C.c_int]
@@ -191,6 +198,24 @@ class RPAPredictionModel:
         self._keep = (letters, offsets)
         self._check(self._L.rpa_store_load(self._h, which, n, _ptr(letters), _ptr(offsets), mem_kind))
         self._keep = None
+
+    def reserve_store(self, which, n_seqs):
+        """An indexed store (sequencestorage.hh:318-406): n_seqs sequences known, none resident yet."""
+        self._check(self._L.rpa_store_reserve(self._h, which, int(n_seqs)))
+
+    def append_store(self, which, seq_index, letters, offsets):
+        """Make the sequences seq_index[k] resident: letters back to back (uint8), offsets uint64 [n+1] from 0."""
+        idx = np.ascontiguousarray(seq_index, np.uint32)
+        letters = np.ascontiguousarray(letters, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        self._check(self._L.rpa_store_append(self._h, which, len(idx), _ptr(idx), _ptr(letters), _ptr(offsets)))
+
+    def store_info(self, which):
+        class _Info(C.Structure):
+            _fields_ = [("n_seqs", C.c_uint32), ("n_resident", C.c_uint32), ("residues", C.c_uint64), ("device_bytes", C.c_uint64)]
+        out = _Info()
+        self._check(self._L.rpa_store_info_get(self._h, which, C.byref(out)))
+        return {k: int(getattr(out, k)) for k, _ in _Info._fields_}
 
     def predict(self, batch, mem_kind=MEM_HOST, want_stats=True, out=None, stats=None):
         """batch: dict with the rpa_batch arrays (numpy for MEM_HOST, torch cuda tensors for MEM_DEVICE).

@@ -162,8 +162,8 @@ __device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, co
   uint64_t src = 0;
   if (seq >= store.n_seqs) err = kErrSeqId;
   else {
-    const uint64_t off = store.offsets[seq];
-    const uint64_t slen = store.offsets[seq + 1] - off;
+    const ulonglong2 ex = store.extent[seq];
+    const uint64_t off = ex.x, slen = ex.y;
     if (start > stop) err = kErrAssert;
     else {
       if ((uint64_t)stop > slen) stop = (uint32_t)slen;
@@ -1251,8 +1251,8 @@ hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, co
 __global__ __launch_bounds__(kBlock) void k_plan_plain_segments(WorkDev w, StoreDev store) {
   const uint32_t seg = blockIdx.x * kBlock + threadIdx.x;
   if (seg >= w.T) return;
-  const uint64_t off = store.offsets[seg];
-  w.seg[seg] = SegDesc{(uint32_t)off, (uint32_t)(off >> 32), (uint32_t)(store.offsets[seg + 1] - off), 0u};
+  const ulonglong2 ex = store.extent[seg];
+  w.seg[seg] = SegDesc{(uint32_t)ex.x, (uint32_t)(ex.x >> 32), (uint32_t)ex.y, 0u};
 }
 
 hipError_t launch_plan_plain_segments(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& store) {

@@ -37,7 +37,7 @@ struct TaxDev {
 // Resident sequence store: residues packed little-endian into 32-bit words, 4 bit (DNA) or 8 bit (protein) each.
 struct StoreDev {
   const uint32_t* words;
-  const uint64_t* offsets;  // residue index of sequence i = offsets[i]; n_seqs+1 entries
+  const ulonglong2* extent;  // sequence i = residues [extent[i].x, extent[i].x + extent[i].y) of the arena; y == 0: not resident
   uint32_t n_seqs;
 };
 
@@ -211,6 +211,9 @@ struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells
 
 // ---- launchers (each enqueues on `st`, returns the hipError of the launch) ----
 hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* letters, uint64_t n_residues, uint32_t* words);
+// extent table of a store: from an offsets table (n_seqs + 1 entries, sequence i at base + offsets[i]) for all sequences,
+// or scattered for the sequences `index[k]` (k < n) of an append
+hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const uint32_t* index, uint32_t n, uint64_t base, ulonglong2* extent);
 
 // tiled row layout: tile_base[t] = first row slot of tile t (64 record sets, each padded to the tile's largest record
 // count), tile_base[n_tiles] = total slots.  Two small launches; the caller reads the total back to size the buffers.

@@ -53,12 +53,14 @@ struct DevBuf {
 constexpr size_t kLeadWords = 16, kTailWords = 64;  // slack around the packed residues (16-byte text loads, funnel shifts)
 
 struct Store {
-  DevBuf words, offsets;
-  uint32_t n_seqs = 0;
-  uint64_t n_residues = 0;
+  DevBuf words, extent, tmp_offsets, tmp_index;
+  uint32_t n_seqs = 0, n_resident = 0;
+  uint64_t n_residues = 0;   // residues of the arena in use (appends start at multiples of 8 residues)
+  uint64_t cap_words = 0;    // packed words the arena holds (without the slack in front and behind)
   bool loaded = false;
   // the packed words sit behind kLeadWords zero words: a reverse-strand reader may fetch a few words below its segment
-  StoreDev view() const { return StoreDev{words.as<const uint32_t>() + kLeadWords, offsets.as<const uint64_t>(), n_seqs}; }
+  StoreDev view() const { return StoreDev{words.as<const uint32_t>() + kLeadWords, extent.as<const ulonglong2>(), n_seqs}; }
+  void release() { words.release(); extent.release(); tmp_offsets.release(); tmp_index.release(); n_seqs = n_resident = 0; n_residues = cap_words = 0; loaded = false; }
 };
 
 }  // namespace
@@ -70,6 +72,7 @@ struct rpa_engine {
   DevBuf tax_parent, tax_left, tax_right, tax_depth, tax_anc;
   TaxDev tax{};
   Store stores[2];
+  Store pair_store;  // rpa_align_pairs
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
@@ -745,7 +748,8 @@ void rpa_destroy(rpa_engine* e) {
                     &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->retry_list, &e->retry_short, &e->prof_acc, &e->part_offsets};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
-  for (auto& s : e->stores) { s.words.release(); s.offsets.release(); }
+  for (auto& s : e->stores) s.release();
+  e->pair_store.release();
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_total0) (void)hipEventDestroy(e->ev_total0);
   if (e->ev_total1) (void)hipEventDestroy(e->ev_total1);
@@ -762,27 +766,59 @@ int rpa_set_stream(rpa_engine* e, void* hip_stream) {
   return RPA_OK;
 }
 
-static int pack_store(rpa_engine* e, Store* st, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, int mem_kind,
-                      DevBuf* letters_buf) {
-  // offsets -> host copy of the total, device copy of the table
+// Make room for `more` residues behind the ones in use (rounded up to whole words); the arena grows by doubling, its
+// contents move with a device-to-device copy.  Returns the residue index the new residues start at (a multiple of 8).
+static int store_grow(rpa_engine* e, Store* st, uint64_t more, uint64_t* first_residue) {
+  const int bits = e->params.alphabet == RPA_DNA ? 4 : 8;
+  const uint64_t start = (st->n_residues + 7u) & ~7ull;
+  const uint64_t need_words = ((start + more) * bits + 31) / 32;
+  if (need_words > st->cap_words || !st->words.p) {
+    uint64_t cap = st->cap_words ? st->cap_words : 0;
+    while (cap < need_words) cap = cap ? cap * 2 : need_words;
+    DevBuf bigger;
+    HIP_TRY(e, bigger.ensure((size_t)(cap + kLeadWords + kTailWords) * 4));
+    cap = (bigger.cap / 4) - kLeadWords - kTailWords;  // what ensure() really gave
+    HIP_TRY(e, hipMemsetAsync(bigger.p, 0, kLeadWords * 4, e->stream));
+    const uint64_t used_words = (st->n_residues * bits + 31) / 32;
+    if (used_words) HIP_TRY(e, hipMemcpyAsync(bigger.as<uint32_t>() + kLeadWords, st->words.as<uint32_t>() + kLeadWords, (size_t)used_words * 4, hipMemcpyDeviceToDevice, e->stream));
+    // everything behind the words in use reads as zero (slack for 16-byte text loads and funnel shifts)
+    HIP_TRY(e, hipMemsetAsync(bigger.as<uint32_t>() + kLeadWords + used_words, 0, (size_t)(cap - used_words + kTailWords) * 4, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    st->words.release();
+    st->words = bigger;
+    st->cap_words = cap;
+  }
+  *first_residue = start;
+  return RPA_OK;
+}
+
+// letters of `n` sequences (offsets: n + 1 entries from 0) -> packed behind the arena's residues in use; extent table
+// entries index[k] (or k when index is null) point at them.
+static int store_add(rpa_engine* e, Store* st, uint32_t n, const uint32_t* index, const uint8_t* letters, const uint64_t* offsets, int mem_kind,
+                     DevBuf* letters_buf) {
   uint64_t total = 0;
-  HIP_TRY(e, st->offsets.ensure((size_t)(n_seqs + 1) * 8));
+  HIP_TRY(e, st->tmp_offsets.ensure((size_t)(n + 1) * 8));
   if (mem_kind == RPA_MEM_HOST) {
-    for (uint32_t i = 0; i < n_seqs; ++i)
+    for (uint32_t i = 0; i < n; ++i)
       if (offsets[i + 1] < offsets[i]) return fail(e, RPA_ERR_INVALID, "store offsets must be non-decreasing (sequence %u)", i);
     if (offsets[0] != 0) return fail(e, RPA_ERR_INVALID, "store offsets[0] must be 0");
-    total = offsets[n_seqs];
-    HIP_TRY(e, hipMemcpyAsync(st->offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, e->stream));
+    total = offsets[n];
+    HIP_TRY(e, hipMemcpyAsync(st->tmp_offsets.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, e->stream));
   } else {
-    HIP_TRY(e, hipMemcpyAsync(st->offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyDeviceToDevice, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(&total, offsets + n_seqs, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(st->tmp_offsets.p, offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&total, offsets + n, 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
+  const uint32_t* dev_index = nullptr;
+  if (index) {
+    HIP_TRY(e, st->tmp_index.ensure((size_t)n * 4));
+    HIP_TRY(e, hipMemcpyAsync(st->tmp_index.p, index, (size_t)n * 4, mem_kind == RPA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, e->stream));
+    dev_index = st->tmp_index.as<const uint32_t>();
+  }
+  uint64_t first = 0;
+  int rc = store_grow(e, st, total, &first);
+  if (rc) return rc;
   const int bits = e->params.alphabet == RPA_DNA ? 4 : 8;
-  const uint64_t n_words = (total * bits + 31) / 32;
-  HIP_TRY(e, st->words.ensure((size_t)(n_words + kLeadWords + kTailWords) * 4));  // slack: kernels may read a few words around a segment
-  HIP_TRY(e, hipMemsetAsync(st->words.p, 0, kLeadWords * 4, e->stream));
-  HIP_TRY(e, hipMemsetAsync(st->words.as<uint32_t>() + kLeadWords + n_words, 0, kTailWords * 4, e->stream));
   const uint8_t* dev_letters = letters;
   if (mem_kind == RPA_MEM_HOST && total) {
     HIP_TRY(e, letters_buf->ensure((size_t)total + 8));
@@ -791,9 +827,21 @@ static int pack_store(rpa_engine* e, Store* st, uint32_t n_seqs, const uint8_t* 
   } else if (total && ((uintptr_t)letters & 7u)) {
     return fail(e, RPA_ERR_INVALID, "device letter buffer must be 8-byte aligned");
   }
-  HIP_TRY(e, launch_pack_letters(e->stream, e->params.alphabet, dev_letters, total, st->words.as<uint32_t>() + kLeadWords));
+  HIP_TRY(e, launch_pack_letters(e->stream, e->params.alphabet, dev_letters, total, st->words.as<uint32_t>() + kLeadWords + first * bits / 32));
+  HIP_TRY(e, launch_store_extents(e->stream, st->tmp_offsets.as<const uint64_t>(), dev_index, n, first, st->extent.as<ulonglong2>()));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  st->n_seqs = n_seqs; st->n_residues = total; st->loaded = true;
+  st->n_residues = first + total;
+  st->n_resident += n;
+  return RPA_OK;
+}
+
+static int pack_store(rpa_engine* e, Store* st, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, int mem_kind,
+                      DevBuf* letters_buf) {
+  st->n_residues = 0; st->n_resident = 0; st->n_seqs = n_seqs;
+  HIP_TRY(e, st->extent.ensure((size_t)(n_seqs ? n_seqs : 1) * sizeof(ulonglong2)));
+  int rc = store_add(e, st, n_seqs, nullptr, letters, offsets, mem_kind, letters_buf);
+  if (rc) return rc;
+  st->loaded = true;
   return RPA_OK;
 }
 
@@ -807,6 +855,48 @@ int rpa_store_load(rpa_engine* e, int which, uint32_t n_seqs, const uint8_t* let
   int rc = pack_store(e, &e->stores[which], n_seqs, letters, offsets, mem_kind, &e->tmp_letters);
   e->tmp_letters.release();  // the raw letters are not kept: the packed store is the resident copy
   return rc;
+}
+
+int rpa_store_reserve(rpa_engine* e, int which, uint32_t n_seqs) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_reserve: bad store id");
+  HIP_TRY(e, hipSetDevice(e->device));
+  Store* st = &e->stores[which];
+  st->n_residues = 0; st->n_resident = 0; st->n_seqs = n_seqs;
+  HIP_TRY(e, st->extent.ensure((size_t)(n_seqs ? n_seqs : 1) * sizeof(ulonglong2)));
+  HIP_TRY(e, hipMemsetAsync(st->extent.p, 0, (size_t)(n_seqs ? n_seqs : 1) * sizeof(ulonglong2), e->stream));  // nothing resident: every length 0
+  uint64_t first = 0;
+  int rc = store_grow(e, st, 0, &first);  // an (empty) arena with its slack words, so that a view exists
+  if (rc) return rc;
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  st->loaded = true;
+  return RPA_OK;
+}
+
+int rpa_store_append(rpa_engine* e, int which, uint32_t n, const uint32_t* seq_index, const uint8_t* letters, const uint64_t* offsets) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_append: bad store id");
+  Store* st = &e->stores[which];
+  if (!st->loaded) return fail(e, RPA_ERR_INVALID, "rpa_store_append: reserve (or load) the store first");
+  if (n == 0) return RPA_OK;
+  if (!seq_index || !offsets || !letters) return fail(e, RPA_ERR_INVALID, "rpa_store_append: null argument");
+  for (uint32_t k = 0; k < n; ++k)
+    if (seq_index[k] >= st->n_seqs) return fail(e, RPA_ERR_INVALID, "rpa_store_append: sequence index %u outside the store (%u sequences)", seq_index[k], st->n_seqs);
+  HIP_TRY(e, hipSetDevice(e->device));
+  int rc = store_add(e, st, n, seq_index, letters, offsets, RPA_MEM_HOST, &e->tmp_letters);
+  return rc;
+}
+
+int rpa_store_info_get(rpa_engine* e, int which, rpa_store_info* out) {
+  if (!e || !out) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_info_get: bad store id");
+  const Store& st = e->stores[which];
+  out->n_seqs = st.n_seqs; out->n_resident = st.n_resident; out->residues = st.n_residues;
+  out->device_bytes = (uint64_t)st.words.cap + st.extent.cap;
+  return RPA_OK;
 }
 
 int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind) {
@@ -877,10 +967,8 @@ int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, cons
   if (mem_kind != RPA_MEM_HOST && mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_align_pairs: bad mem_kind");
   if (n_pairs == 0) return RPA_OK;
   HIP_TRY(e, hipSetDevice(e->device));
-  Store tmp;
-  tmp.words = e->tmp_words; tmp.offsets = e->tmp_offsets;  // reuse the engine's scratch buffers
+  Store& tmp = e->pair_store;  // a store of its own, rebuilt per call (its buffers are kept and reused)
   int rc = pack_store(e, &tmp, n_seqs, letters, offsets, mem_kind, &e->tmp_letters);
-  e->tmp_words = tmp.words; e->tmp_offsets = tmp.offsets;
   if (rc) return rc;
   WorkDev w{};
   rc = alloc_work(e, 1, 1, n_seqs, n_pairs, true, &w, 1, false);

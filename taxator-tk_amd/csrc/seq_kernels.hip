@@ -75,4 +75,18 @@ hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* lett
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(kBlock) void k_store_extents(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ index, uint32_t n,
+                                                          uint64_t base, ulonglong2* __restrict__ extent) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const uint64_t lo = offsets[k], hi = offsets[k + 1];
+  extent[index ? index[k] : k] = make_ulonglong2(base + lo, hi - lo);
+}
+
+hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const uint32_t* index, uint32_t n, uint64_t base, ulonglong2* extent) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_store_extents, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, offsets, index, n, base, extent);
+  return hipGetLastError();
+}
+
 }  // namespace rpa

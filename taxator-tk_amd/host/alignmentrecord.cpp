@@ -64,8 +64,8 @@ void AlignmentRecordFactory::parse(const std::string& line_in, AlignmentRecordTa
   rec.reference_seq = db_ ? db_->getIndex(rec.reference_identifier) : 0u;  // no sequence store with the alignment-free models
 }
 
-RecordSetGenerator::RecordSetGenerator(std::istream& in, const AlignmentRecordFactory& fac, bool split_alignments)
-    : in_(in), fac_(fac), split_(split_alignments) {
+RecordSetGenerator::RecordSetGenerator(std::istream& in, const AlignmentRecordFactory& fac, bool split_alignments, bool alignments_sorted)
+    : in_(in), fac_(fac), split_(split_alignments), sorted_(alignments_sorted) {
   have_next_ = feed();
 }
 
@@ -91,7 +91,7 @@ void RecordSetGenerator::getNext(RecordSetType& rset) {
       pending_.push_back(next_);
       have_next_ = feed();
     } while (have_next_ && next_.query_identifier == qid);
-    if (split_)
+    if (split_ && !sorted_)  // -o 1 (RecordSetGeneratorSorted, :569-631): same cut rule, input order
       std::stable_sort(pending_.begin(), pending_.end(), [](const AlignmentRecordTaxonomy& a, const AlignmentRecordTaxonomy& b) {
         if (a.query_start != b.query_start) return a.query_start < b.query_start;
         return a.query_stop < b.query_stop;

@@ -56,7 +56,7 @@ class AlignmentRecordFactory {
 
 class RecordSetGenerator {
  public:
-  RecordSetGenerator(std::istream& in, const AlignmentRecordFactory& fac, bool split_alignments);
+  RecordSetGenerator(std::istream& in, const AlignmentRecordFactory& fac, bool split_alignments, bool alignments_sorted = false);
   bool notEmpty() const { return have_next_ || pending_pos_ < pending_.size(); }
   void getNext(RecordSetType& rset);  // appends one record set
  private:
@@ -64,6 +64,7 @@ class RecordSetGenerator {
   std::istream& in_;
   const AlignmentRecordFactory& fac_;
   bool split_;
+  bool sorted_;
   AlignmentRecordTaxonomy next_;
   bool have_next_ = false;
   unsigned line_num_ = 0;

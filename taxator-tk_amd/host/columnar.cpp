@@ -131,8 +131,8 @@ static bool field_f64_valid(const char* p, const char* e) {
 // ---- reader ----
 
 ColumnarReader::ColumnarReader(FILE* in, const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db,
-                               const SequenceStore* query, bool split_alignments, unsigned threads, size_t block_bytes)
-    : in_(in), legacy_(acc2taxid, tax, db), query_(query), split_(split_alignments), threads_(threads), block_bytes_(block_bytes) {
+                               const SequenceStore* query, bool split_alignments, unsigned threads, size_t block_bytes, bool alignments_sorted)
+    : in_(in), legacy_(acc2taxid, tax, db), query_(query), split_(split_alignments), sorted_(alignments_sorted), threads_(threads), block_bytes_(block_bytes) {
   if (threads_ == 0) threads_ = std::max(1u, std::thread::hardware_concurrency());
   if (block_bytes_ < 4096) block_bytes_ = 4096;
   // reference identifier -> (taxonomy node, index in the reference store); identifiers with a broken link are left out
@@ -333,7 +333,8 @@ void ColumnarReader::emit_groups(ColumnarBatch& out) {
       if (qseq == FlatStringMap::npos) { part.unknown = g; return; }  // SequenceStore::getIndex in RPAPredictionModel::predict's staging
       order.resize(n);
       for (size_t k = 0; k < n; ++k) order[k] = (uint32_t)(lo + k);
-      if (split_) {  // stable by (qstart, qstop), ties keep input order (alignmentrecord.hh:476-481)
+      if (split_ && !sorted_) {  // stable by (qstart, qstop), ties keep input order (alignmentrecord.hh:476-481); -o 1: the input is
+                                 // taken as sorted and cut in input order (RecordSetGeneratorSorted, :569-631)
         if (n <= 64) {  // groups are short and mostly sorted already
           for (size_t k = 1; k < n; ++k) {
             const uint32_t x = order[k];

@@ -51,7 +51,7 @@ class ColumnarReader {
  public:
   // threads = 0: all hardware threads.  block_bytes: how much of the stream is parsed (and becomes one batch) at a time.
   ColumnarReader(FILE* in, const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db, const SequenceStore* query,
-                 bool split_alignments, unsigned threads, size_t block_bytes);
+                 bool split_alignments, unsigned threads, size_t block_bytes, bool alignments_sorted = false);
   // Fills `out` with the record sets of the next block; false when the stream is exhausted (out is then empty).
   // Throws what RecordSetGenerator would throw (ParsingError ... [line N]) or what RPAPredictionModel::predict's staging
   // would throw (SequenceNotFound for an unknown query identifier), but only after every record set that precedes the
@@ -69,6 +69,7 @@ class ColumnarReader {
   AlignmentRecordFactory legacy_;  // error texts
   const SequenceStore* query_;
   bool split_;
+  bool sorted_;  // -o 1: groups are not sorted before they are cut (core/src/alignmentrecord.hh:569-631)
   unsigned threads_;
   size_t block_bytes_;
   FlatStringMap ref_map_, query_map_;

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <vector>
 
 #include "columnar.hh"
 
@@ -25,7 +26,36 @@ static void print_rec(bool filt, uint32_t qs, uint32_t qe, uint32_t rs, uint32_t
   printf("%d\t%u\t%u\t%u\t%u\t%08x\t%u\t%u\t%u\t%u\n", filt ? 1 : 0, qs, qe, rs, re, bits, ident, alnlen, ref_seq, node);
 }
 
+// parsecheck --fasta <file.fasta> <file.fai | -> : the indexed store (memory-mapped FASTA + .fai, or an index built by a
+// scan when "-" is given) against the in-memory store: same identifiers, same lengths, same residues.
+static int fasta_check(const char* fasta, const char* fai) {
+  try {
+    SequenceStore mem(fasta);
+    SequenceStore idx(fasta, strcmp(fai, "-") ? fai : "");
+    if (mem.size() != idx.size()) { printf("MISMATCH sequences %u vs %u\n", mem.size(), idx.size()); return 1; }
+    uint64_t total = 0;
+    std::vector<uint8_t> buf;
+    for (uint32_t i = 0; i < mem.size(); ++i) {
+      if (mem.ids()[i] != idx.ids()[i] || idx.getIndex(idx.ids()[i]) != mem.getIndex(mem.ids()[i])) { printf("MISMATCH id %u\n", i); return 1; }
+      if (mem.length(i) != idx.length(i)) { printf("MISMATCH length of %s: %llu vs %llu\n", mem.ids()[i].c_str(), (unsigned long long)mem.length(i), (unsigned long long)idx.length(i)); return 1; }
+      buf.assign((size_t)idx.length(i) + 1, 0xEE);
+      idx.fetch(i, buf.data());
+      if (buf[(size_t)idx.length(i)] != 0xEE || memcmp(buf.data(), mem.letters().data() + mem.offsets()[i], (size_t)mem.length(i)) != 0) {
+        printf("MISMATCH residues of %s\n", mem.ids()[i].c_str());
+        return 1;
+      }
+      total += mem.length(i);
+    }
+    printf("OK %u %llu\n", mem.size(), (unsigned long long)total);
+    return 0;
+  } catch (Exception& e) {
+    printf("ERROR %s\n", e.what());
+    return 1;
+  }
+}
+
 int main(int argc, char** argv) {
+  if (argc == 4 && !strcmp(argv[1], "--fasta")) return fasta_check(argv[2], argv[3]);
   if (argc < 6) { fprintf(stderr, "usage: parsecheck mapping query.fasta ref.fasta objects|columnar split [threads] [block_bytes]\n"); return 2; }
   const std::string mode = argv[4];
   const bool split = atoi(argv[5]) != 0;
@@ -38,7 +68,7 @@ int main(int argc, char** argv) {
     SequenceStore query(argv[2]), db(argv[3]);
     if (mode == "objects") {
       AlignmentRecordFactory fac(acc, tax.get(), &db);
-      RecordSetGenerator gen(std::cin, fac, split);
+      RecordSetGenerator gen(std::cin, fac, split, getenv("PARSECHECK_SORTED") != nullptr);
       RecordSetType rset;
       while (gen.notEmpty()) {
         rset.clear();
@@ -50,7 +80,7 @@ int main(int argc, char** argv) {
                     r.alignment_length, r.reference_seq, r.reference_node);
       }
     } else {
-      ColumnarReader reader(stdin, acc, tax.get(), &db, &query, split, threads, block);
+      ColumnarReader reader(stdin, acc, tax.get(), &db, &query, split, threads, block, getenv("PARSECHECK_SORTED") != nullptr);
       ColumnarBatch b;
       const bool quiet = getenv("PARSECHECK_QUIET") != nullptr;  // timing runs: parse only
       size_t sets = 0, recs = 0;

@@ -1,8 +1,15 @@
 // taxator-tk_amd/host/sequencestorage.cpp -- FASTA reader for the resident stores (see sequencestorage.hh).
 #include "sequencestorage.hh"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 
 namespace taxator {
 
@@ -28,8 +35,7 @@ SequenceStore::SequenceStore(const std::string& fasta_filename) {
       if (isspace((unsigned char)*s)) break;
       id.push_back(*s);
     }
-    index_.emplace(id, (uint32_t)ids_.size());  // first occurrence wins, like the .fai name lookup
-    ids_.push_back(id);
+    add_id(id);
   };
   auto add_line = [&](const char* s, const char* e) {
     if (s == e) return;
@@ -64,6 +70,105 @@ SequenceStore::SequenceStore(const std::string& fasta_filename) {
   }
   fclose(f);
   if (have_record) offsets_.push_back(letters_.size());
+}
+
+SequenceStore::~SequenceStore() {
+  if (map_) munmap(const_cast<char*>(map_), map_len_);
+}
+
+void SequenceStore::add_id(const std::string& id) {
+  index_.emplace(id, (uint32_t)ids_.size());  // first occurrence wins, like the .fai name lookup
+  ids_.push_back(id);
+}
+
+// Indexed store: map the FASTA, take the per-sequence geometry from the .fai (samtools format, five tab-separated
+// columns: name, length, offset of the first residue, residues per line, bytes per line; core/src/faidx.h:438-476).
+SequenceStore::SequenceStore(const std::string& fasta_filename, const std::string& fai_filename) : indexed_(true) {
+  const int fd = open(fasta_filename.c_str(), O_RDONLY);
+  if (fd < 0) throw FileNotFound(fasta_filename);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); throw FileNotFound(fasta_filename); }
+  map_len_ = (size_t)sb.st_size;
+  if (map_len_) {
+    void* m = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { close(fd); throw FileNotFound(fasta_filename + " (mmap failed)"); }
+    map_ = (const char*)m;
+    madvise(m, map_len_, MADV_RANDOM);  // regions are read where the alignment stream points, not front to back
+  }
+  close(fd);
+  std::ifstream fai(fai_filename.c_str());
+  if (!fai_filename.empty() && fai) {
+    std::string line;
+    while (std::getline(fai, line)) {
+      if (line.empty()) continue;
+      const size_t t1 = line.find('\t');
+      if (t1 == std::string::npos) throw ParsingError("fasta index line without columns: " + line);
+      FaiEntry e{0, 0, 0, 0};
+      unsigned long long len = 0, off = 0, lb = 0, lw = 0;
+      if (sscanf(line.c_str() + t1 + 1, "%llu\t%llu\t%llu\t%llu", &len, &off, &lb, &lw) != 4)
+        throw ParsingError("fasta index line is not name, length, offset, line bases, line width: " + line);
+      e.length = len; e.offset = off; e.linebases = (uint32_t)lb; e.linewidth = (uint32_t)lw;
+      if (e.offset > map_len_ || (e.length && (e.linebases == 0 || e.linewidth < e.linebases)))
+        throw ParsingError("fasta index does not fit the fasta file: " + line);
+      add_id(line.substr(0, t1));
+      entries_.push_back(e);
+    }
+  } else {
+    build_index_by_scan();
+  }
+}
+
+// No .fai next to the FASTA: one pass over the mapped file finds what `samtools faidx` would have written.  A sequence
+// whose lines are not all of one length (except the last) is marked irregular and fetched by scanning.
+void SequenceStore::build_index_by_scan() {
+  const char* p = map_;
+  const char* end = map_ + map_len_;
+  while (p < end) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    const char* le = nl ? nl : end;
+    if (*p == '>') {
+      std::string id;
+      for (const char* s = p + 1; s < le && !isspace((unsigned char)*s); ++s) id.push_back(*s);
+      add_id(id);
+      FaiEntry e{0, (uint64_t)((nl ? nl + 1 : end) - map_), 0, 0};
+      entries_.push_back(e);
+    } else if (!entries_.empty()) {
+      FaiEntry& e = entries_.back();
+      size_t bases = 0;
+      bool blank_inside = false;
+      for (const char* s = p; s < le; ++s) { if (*s == '\r' || *s == ' ' || *s == '\t') blank_inside = blank_inside || *s != '\r'; else ++bases; }
+      const uint32_t width = (uint32_t)((nl ? nl + 1 : end) - p);
+      if (e.length == 0 && e.linewidth == 0) { e.linebases = (uint32_t)bases; e.linewidth = width; if (blank_inside || bases == 0) e.linebases = 0; }
+      else if (e.linebases && (e.length % e.linebases != 0 || bases > e.linebases || blank_inside)) e.linebases = 0;  // a short line that is not the last, or a longer one
+      e.length += bases;
+      if (e.linewidth == 0) e.linewidth = width ? width : 1;
+    }
+    p = nl ? nl + 1 : end;
+  }
+}
+
+void SequenceStore::fetch(uint32_t i, uint8_t* dst) const {
+  const FaiEntry& e = entries_[i];
+  uint64_t remaining = e.length;
+  const char* p = map_ + e.offset;
+  const char* end = map_ + map_len_;
+  if (e.linebases) {
+    while (remaining) {
+      const uint64_t take = remaining < e.linebases ? remaining : e.linebases;
+      if (p + take > end) throw ParsingError("fasta index points beyond the end of the fasta file (sequence " + ids_[i] + ")");
+      if (memchr(p, ' ', take) || memchr(p, '\t', take)) break;  // blanks inside a line: readRegion skips them -> scan the rest
+      memcpy(dst, p, take);
+      dst += take; p += e.linewidth; remaining -= take;
+    }
+    if (!remaining) return;
+  }
+  for (; remaining && p < end; ++p) {  // irregular lines: every non-blank byte up to `length` of them (faidx.h:340-347)
+    const char c = *p;
+    if (c == '\n' || c == '\r' || c == ' ' || c == '\t') continue;
+    *dst++ = (uint8_t)c;
+    --remaining;
+  }
+  if (remaining) throw ParsingError("fasta file ends inside sequence " + ids_[i]);
 }
 
 }  // namespace taxator

@@ -4,8 +4,11 @@
 // (doPredictionsSerial, :50-77), errors to stderr + EXIT_FAILURE (:381-386).  -a rpa (default) and the alignment-free
 // models dummy | simple-lca | megan-lca | ic-megan-lca | n-best-lca with their options -e -c -m -n -u (:346-361; these
 // need no FASTA files and run through the per-record object loop); -p sets the number of HOST threads that parse the input and format the output
-// (0 or absent = all); -i/-v index files are accepted and ignored (the stores are resident in HBM, no on-disk index is
-// needed); new: --device, --batch, --block-mb, --timing, --record-objects.
+// (0 or absent = all); -i / -v select the indexed store (sequencestorage.hh): the FASTA is memory-mapped and a sequence
+// goes to HBM when the alignment stream first refers to it, instead of the whole file being loaded up front;
+// new: --device N | --devices a,b,... (one engine and one host thread per GPU, batches dealt to whichever is free,
+// output in input order: the replacement of doPredictionsParallel, :181-210), --batch, --block-mb, --timing,
+// --record-objects.
 //
 // Default data path (no per-record objects): a reader thread turns blocks of the TSV stream into columnar batches
 // (columnar.hh) while the main thread runs the previous batch on the GPU and a writer thread formats the one before
@@ -20,6 +23,7 @@
 #include <exception>
 #include <fstream>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <sstream>
@@ -53,6 +57,7 @@ struct Options {
   unsigned processors = 0;
   bool record_objects = false;
   double block_mb = 128;
+  std::vector<int> devices;  // --devices a,b,...; empty: --device
   int device = 0;
   bool timing = false;
   size_t batch = 0;  // 0: one GPU call per parsed block (columnar path) / 65536 record sets (record-object path)
@@ -65,15 +70,15 @@ static void usage(std::ostream& o) {
        "  -a [ --algorithm ] arg (=rpa)      rpa | dummy | simple-lca | megan-lca | ic-megan-lca | n-best-lca\n"
        "  -g [ --seqid-taxid-mapping ] arg   filename of seqid->taxid mapping for reference\n"
        "  -q [ --query-sequences ] arg       query sequences FASTA\n"
-       "  -v [ --query-sequences-index ] arg accepted, unused (store is resident in HBM)\n"
+       "  -v [ --query-sequences-index ] arg query sequences FASTA index (.fai): sequences go to HBM when first referred to\n"
        "  -f [ --ref-sequences ] arg         reference sequences FASTA\n"
-       "  -i [ --ref-sequences-index ] arg   accepted, unused (store is resident in HBM)\n"
+       "  -i [ --ref-sequences-index ] arg   reference sequences FASTA index (.fai): sequences go to HBM when first referred to\n"
        "  -p [ --processors ] arg (=0)       host threads for parsing and output formatting, 0 = all\n"
        "  -l [ --logfile ] arg (=/dev/null)  per record set STATS lines are appended here\n"
        "  -b [ --dataformat ] arg (=nucleotide)  nucleotide | protein\n"
        "  advanced: -r ranks..., -s split-alignments (=1), -o alignments-sorted (=0), -d delete-notranks (=1),\n"
        "            -x heuristic-cutoff (=0.5), -t toppercent (=0.05), -e max-evalue (=1000), -c min-support (=1), -m minscore (=0),\n"
-       "            -n nbest (=1), -u ignore-unclassified, --device N (=0), --batch N (record sets per GPU call),\n"
+       "            -n nbest (=1), -u ignore-unclassified, --device N (=0), --devices a,b,... (several GPUs), --batch N (record sets per GPU call),\n"
        "            --block-mb N (=128, input block parsed at a time), --timing, --record-objects (per-record object loop)\n";
 }
 
@@ -83,8 +88,10 @@ struct Work {
   ColumnarBatch batch;
   std::vector<rpa_prediction> rows;
   std::vector<rpa_stats> stats;
-  bool last = false;            // end of stream (or failure): no batch inside
+  bool last = false;            // end of stream (or a failure of the reader): no batch inside
+  bool failed = false;          // a GPU call failed on this block: nothing from here on is printed
   std::exception_ptr err;
+  uint64_t seq = 0;             // position in the input: the writer prints in this order
 };
 
 struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, records = 0; };
@@ -92,98 +99,130 @@ struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, recor
 typedef std::chrono::steady_clock Clock;
 double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
 
-// reader thread -> main thread (GPU) -> writer thread, three Work objects in circulation
-void run_columnar(ColumnarReader& reader, RPAPredictionModel& rpa, const Taxonomy& tax, std::ostream* logsink, size_t max_sets,
+// reader thread -> one GPU thread per engine -> writer thread; 2 x engines + 1 Work objects in circulation.  The
+// reference's doPredictionsParallel (core/taxator.cpp:181-210) has N consumer threads call predict() on one model and
+// prints in whatever order they finish; here a parsed block goes to whichever GPU is free and the writer puts the
+// blocks back into input order (what the reference's serial loop prints, :69-74).
+void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& models, const Taxonomy& tax, std::ostream* logsink, size_t max_sets,
                   unsigned threads, Timing& tm) {
-  Work works[3];
+  const size_t n_gpu = models.size();
+  std::vector<Work> works(2 * n_gpu + 1);
   Channel<Work*> free_q, parsed_q, predicted_q;
   for (Work& w : works) free_q.push(&w);
   std::atomic<bool> stop(false);
   std::thread reader_thread([&] {
+    uint64_t seq = 0;
     for (;;) {
       Work* w = free_q.pop();
-      if (stop.load()) return;
-      w->last = false; w->err = nullptr;
+      if (!w) break;
+      w->last = false; w->failed = false; w->err = nullptr; w->seq = seq++;
+      if (stop.load()) { w->last = true; parsed_q.push(w); break; }  // a GPU call failed: end the stream here
       const Clock::time_point t0 = Clock::now();
       try { if (!reader.next(w->batch)) w->last = true; }
       catch (...) { w->err = std::current_exception(); w->last = true; }
       tm.parse += secs(t0, Clock::now());
       parsed_q.push(w);
-      if (w->last) return;
+      if (w->last) break;
     }
+    for (size_t k = 1; k < n_gpu; ++k) parsed_q.push(nullptr);  // every other GPU thread sees the end of the stream too
   });
   float stale_ival = -1.f;  // predictionrecord.hh:40; the reference reuses one PredictionRecord (taxator.cpp:66)
   std::thread writer_thread([&] {
     std::vector<float> ival;
     std::vector<std::string> parts, log_parts;
-    for (;;) {
-      Work* w = predicted_q.pop();
-      if (w->last) return;
-      const Clock::time_point t0 = Clock::now();
-      const ColumnarBatch& b = w->batch;
-      const size_t S = b.n_sets();
-      ival.resize(S);
-      for (size_t s = 0; s < S; ++s) {
-        if (!(w->rows[s].flags & RPA_FLAG_IVAL_UNTOUCHED)) stale_ival = w->rows[s].ival;
-        ival[s] = stale_ival;
-      }
-      const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, S / 4096 + 1));
-      parts.assign(T, std::string());
-      log_parts.assign(T, std::string());
-      auto format = [&](unsigned t) {
-        const size_t lo = S * t / T, hi = S * (t + 1) / T;
-        std::string& out = parts[t];
-        out.reserve((hi - lo) * 112);
-        for (size_t s = lo; s < hi; ++s)
-          append_gff3(out, tax, b.qid_arena.data() + b.qid_off[s], b.qid_len[s], b.query_len[s], w->rows[s], ival[s]);
-        if (logsink) {  // the STATS line of the reference log (:837), timing columns left out
-          std::string& lg = log_parts[t];
-          for (size_t s = lo; s < hi; ++s) {
-            const rpa_stats& st = w->stats[s];
-            lg.append("STATS\t"); lg.append(b.qid_arena.data() + b.qid_off[s], b.qid_len[s]);
-            const uint32_t v[5] = {st.n, st.pass0, st.pass1, st.pass2, st.pass0 + st.pass1 + st.pass2};
-            for (uint32_t x : v) { lg.push_back('\t'); append_u32(lg, x); }
-            lg.push_back('\n');
-          }
+    std::map<uint64_t, Work*> waiting;  // blocks that finished ahead of their turn
+    uint64_t next_seq = 0;
+    bool finished = false, discard = false;
+    while (!finished) {
+      Work* got = predicted_q.pop();
+      waiting[got->seq] = got;
+      while (!waiting.empty() && waiting.begin()->first == next_seq) {
+        Work* w = waiting.begin()->second;
+        waiting.erase(waiting.begin());
+        ++next_seq;
+        if (w->last) { finished = true; break; }  // end of stream (or the reader's failure): everything before it has been printed
+        if (w->failed) discard = true;            // the serial loop would have died here: blocks behind it are recycled unprinted
+        if (discard) { free_q.push(w); continue; }
+        const Clock::time_point t0 = Clock::now();
+        const ColumnarBatch& b = w->batch;
+        const size_t S = b.n_sets();
+        ival.resize(S);
+        for (size_t s = 0; s < S; ++s) {
+          if (!(w->rows[s].flags & RPA_FLAG_IVAL_UNTOUCHED)) stale_ival = w->rows[s].ival;
+          ival[s] = stale_ival;
         }
-      };
-      std::vector<std::thread> th;
-      for (unsigned t = 1; t < T; ++t) th.emplace_back(format, t);
-      format(0);
-      for (auto& x : th) x.join();
-      for (const std::string& p : parts) fwrite(p.data(), 1, p.size(), stdout);
-      if (logsink) for (const std::string& p : log_parts) logsink->write(p.data(), (std::streamsize)p.size());
-      tm.write += secs(t0, Clock::now());
-      free_q.push(w);
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, S / 4096 + 1));
+        parts.assign(T, std::string());
+        log_parts.assign(T, std::string());
+        auto format = [&](unsigned t) {
+          const size_t lo = S * t / T, hi = S * (t + 1) / T;
+          std::string& out = parts[t];
+          out.reserve((hi - lo) * 112);
+          for (size_t s = lo; s < hi; ++s)
+            append_gff3(out, tax, b.qid_arena.data() + b.qid_off[s], b.qid_len[s], b.query_len[s], w->rows[s], ival[s]);
+          if (logsink) {  // the STATS line of the reference log (:837), timing columns left out
+            std::string& lg = log_parts[t];
+            for (size_t s = lo; s < hi; ++s) {
+              const rpa_stats& st = w->stats[s];
+              lg.append("STATS\t"); lg.append(b.qid_arena.data() + b.qid_off[s], b.qid_len[s]);
+              const uint32_t v[5] = {st.n, st.pass0, st.pass1, st.pass2, st.pass0 + st.pass1 + st.pass2};
+              for (uint32_t x : v) { lg.push_back('\t'); append_u32(lg, x); }
+              lg.push_back('\n');
+            }
+          }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(format, t);
+        format(0);
+        for (auto& x : th) x.join();
+        for (const std::string& p : parts) fwrite(p.data(), 1, p.size(), stdout);
+        if (logsink) for (const std::string& p : log_parts) logsink->write(p.data(), (std::streamsize)p.size());
+        tm.write += secs(t0, Clock::now());
+        free_q.push(w);
+      }
     }
   });
   std::exception_ptr failure;
-  for (;;) {
-    Work* w = parsed_q.pop();
-    if (w->last) { failure = w->err; predicted_q.push(w); break; }
-    const Clock::time_point t0 = Clock::now();
-    const size_t S = w->batch.n_sets();
-    w->rows.resize(S);
-    w->stats.resize(S);
-    try {
-      const size_t step = max_sets ? max_sets : S;
-      for (size_t lo = 0; lo < S; lo += step) {
-        const size_t hi = std::min(S, lo + step);
-        rpa.predictColumns(w->batch, lo, hi, w->rows.data() + lo, w->stats.data() + lo);
+  std::mutex failure_mu;
+  std::atomic<uint64_t> fail_seq(~0ull);  // the earliest block that failed: what the serial loop would have died on
+  auto gpu_loop = [&](size_t g) {
+    RPAPredictionModel& rpa = *models[g];
+    for (;;) {
+      Work* w = parsed_q.pop();
+      if (!w) return;
+      if (w->last) {
+        if (w->err) { std::lock_guard<std::mutex> lk(failure_mu); if (w->seq < fail_seq.load()) { fail_seq = w->seq; failure = w->err; } }
+        predicted_q.push(w);
+        return;
       }
-    } catch (...) {
-      failure = std::current_exception();
-      w->last = true;
+      const Clock::time_point t0 = Clock::now();
+      const size_t S = w->batch.n_sets();
+      w->rows.resize(S);
+      w->stats.resize(S);
+      try {
+        const size_t step = max_sets ? max_sets : S;
+        for (size_t lo = 0; lo < S; lo += step) {
+          const size_t hi = std::min(S, lo + step);
+          rpa.predictColumns(w->batch, lo, hi, w->rows.data() + lo, w->stats.data() + lo);
+        }
+      } catch (...) {
+        { std::lock_guard<std::mutex> lk(failure_mu); if (w->seq < fail_seq.load()) { fail_seq = w->seq; failure = std::current_exception(); } }
+        w->failed = true;  // the writer stops printing in front of this block
+        stop.store(true);  // and the reader ends the stream at its next block
+        predicted_q.push(w);
+        continue;          // keep draining: blocks before this one may still be on their way through other GPUs
+      }
+      { std::lock_guard<std::mutex> lk(failure_mu); tm.predict += secs(t0, Clock::now()); tm.sets += S; tm.records += w->batch.n_records(); }
       predicted_q.push(w);
-      break;
     }
-    tm.predict += secs(t0, Clock::now());
-    tm.sets += S; tm.records += w->batch.n_records();
-    predicted_q.push(w);
-  }
+  };
+  std::vector<std::thread> gpu_threads;
+  for (size_t g = 1; g < n_gpu; ++g) gpu_threads.emplace_back(gpu_loop, g);
+  gpu_loop(0);
+  for (auto& t : gpu_threads) t.join();
   writer_thread.join();
   stop.store(true);
-  for (int k = 0; k < 3; ++k) free_q.push(nullptr);  // wake the reader if it waits for a Work object
+  for (size_t k = 0; k < works.size(); ++k) free_q.push(nullptr);  // wake the reader if it waits for a Work object
   reader_thread.join();
   fflush(stdout);
   if (failure) std::rethrow_exception(failure);
@@ -223,6 +262,14 @@ int main(int argc, char** argv) {
     else if (a == "-n" || a == "--nbest") o.nbest = (unsigned)atoi(val("--nbest").c_str());
     else if (a == "-u" || a == "--ignore-unclassified") o.ignore_unclassified = true;
     else if (a == "--device") o.device = atoi(val("--device").c_str());
+    else if (a == "--devices") {
+      std::stringstream ss(val("--devices"));
+      std::string item;
+      while (std::getline(ss, item, ',')) if (!item.empty()) o.devices.push_back(atoi(item.c_str()));
+    }
+    else if (a == "-w" || a == "--db-whitelist") (void)val("--db-whitelist");  // parsed and never used by the reference either (taxator.cpp:294, :220-254)
+    else if (a == "--advanced-options") { usage(std::cout); return EXIT_SUCCESS; }
+    else if (a == "--citation") { std::cout << "Droege J, Gregor I, McHardy AC. Taxator-tk: precise taxonomic assignment of metagenomes by fast approximation of evolutionary neighborhoods. Bioinformatics 2015." << std::endl; return EXIT_SUCCESS; }
     else if (a == "--timing") o.timing = true;
     else if (a == "--record-objects") o.record_objects = true;
     else if (a == "--block-mb") o.block_mb = atof(val("--block-mb").c_str());
@@ -249,19 +296,26 @@ int main(int argc, char** argv) {
   const Clock::time_point t_start = Clock::now();
   double t_parse = 0, t_predict = 0, t_write = 0;
   size_t n_sets = 0, n_records = 0;
-  std::unique_ptr<Taxonomy> tax(loadTaxonomyFromEnvironment(&o.ranks, o.delete_unmarked));
-  if (!tax) return EXIT_FAILURE;
+  if (o.devices.empty()) o.devices.push_back(o.device);
   try {
+    std::unique_ptr<Taxonomy> tax(loadTaxonomyFromEnvironment(&o.ranks, o.delete_unmarked));
+    if (!tax) return EXIT_FAILURE;
+    if (tax->getMaxDepth() > 15) {  // the placement kernels keep taxon paths of at most 15 levels (rpa_create)
+      std::cerr << "the taxonomy keeps " << (int)tax->getMaxDepth() << " levels below the root; this build supports 15: use -d 1 (delete-notranks) "
+                   "and at most 15 ranks with -r" << std::endl;
+      return EXIT_FAILURE;
+    }
     std::unique_ptr<StrIDConverter> seqid2taxid(loadStrIDConverterFromFile(o.mapping, 1000));
     std::ofstream logsink(o.logfile.c_str(), std::ios_base::app);
     if (alignment_free) {  // taxator.cpp:346-361; doPredictionsSerial (:50-77) in batches
       std::unique_ptr<TaxonPredictionModel> model;
-      if (o.algorithm == "dummy") model.reset(new DummyPredictionModel(tax.get(), o.device));
-      else if (o.algorithm == "simple-lca") model.reset(new LCASimplePredictionModel(tax.get(), o.device));
-      else if (o.algorithm == "n-best-lca") model.reset(new NBestLCAPredictionModel(tax.get(), (int)o.nbest, o.device));
-      else model.reset(new MeganLCAPredictionModel(tax.get(), o.ignore_unclassified, o.toppercent, o.minscore, (int)o.minsupport, o.maxevalue, o.device));
+      const int dev = o.devices[0];
+      if (o.algorithm == "dummy") model.reset(new DummyPredictionModel(tax.get(), dev));
+      else if (o.algorithm == "simple-lca") model.reset(new LCASimplePredictionModel(tax.get(), dev));
+      else if (o.algorithm == "n-best-lca") model.reset(new NBestLCAPredictionModel(tax.get(), (int)o.nbest, dev));
+      else model.reset(new MeganLCAPredictionModel(tax.get(), o.ignore_unclassified, o.toppercent, o.minscore, (int)o.minsupport, o.maxevalue, dev));
       AlignmentRecordFactory fac(*seqid2taxid, tax.get(), nullptr);
-      RecordSetGenerator recgen(std::cin, fac, o.split_alignments);
+      RecordSetGenerator recgen(std::cin, fac, o.split_alignments, o.alignments_sorted);
       std::vector<RecordSetType> sets;
       std::vector<PredictionRecord> precs;
       std::cout << GFF3Header();
@@ -277,29 +331,49 @@ int main(int argc, char** argv) {
       }
       return EXIT_SUCCESS;
     }
-    SequenceStore query_storage(o.query);
-    SequenceStore db_storage(o.db);
-    RPAPredictionModel rpa(tax.get(), query_storage, db_storage, o.filterout, o.toppercent, o.dataformat == "protein", o.device);
+    // in memory unless an index file is named (core/taxator.cpp:232-249); an indexed store loads nothing here
+    std::unique_ptr<SequenceStore> query_ptr(o.query_index.empty() ? new SequenceStore(o.query) : new SequenceStore(o.query, o.query_index));
+    std::unique_ptr<SequenceStore> db_ptr(o.db_index.empty() ? new SequenceStore(o.db) : new SequenceStore(o.db, o.db_index));
+    SequenceStore& query_storage = *query_ptr;
+    SequenceStore& db_storage = *db_ptr;
+    const unsigned host_threads = o.processors ? o.processors : std::max(1u, std::thread::hardware_concurrency());
+    std::vector<std::unique_ptr<RPAPredictionModel>> engines;
+    for (int dev : o.devices) {
+      engines.emplace_back(new RPAPredictionModel(tax.get(), query_storage, db_storage, o.filterout, o.toppercent, o.dataformat == "protein", dev));
+      engines.back()->setHostThreads(std::max(1u, host_threads / (unsigned)o.devices.size()));
+    }
+    RPAPredictionModel& rpa = *engines[0];
     const Clock::time_point t_loaded = Clock::now();
+    auto store_report = [&]() {  // what is resident in HBM (per engine; the engines hold the same sequences)
+      if (!o.timing) return;
+      for (int which = 0; which < 2; ++which) {
+        const rpa_store_info si = rpa.storeInfo(which == 0 ? RPA_STORE_QUERY : RPA_STORE_DB);
+        std::cerr << "STORE\t" << (which == 0 ? "query" : "ref") << "\t" << ((which == 0 ? query_storage : db_storage).indexed() ? "indexed" : "in-memory")
+                  << "\tsequences=" << si.n_seqs << "\tresident=" << si.n_resident << "\tresidues=" << si.residues << "\tdevice_bytes=" << si.device_bytes << std::endl;
+      }
+    };
     if (!o.record_objects) {
       std::cout << GFF3Header() << std::flush;
       ColumnarReader reader(stdin, *seqid2taxid, tax.get(), &db_storage, &query_storage, o.split_alignments, o.processors,
-                            (size_t)std::max(4096.0, o.block_mb * 1048576.0));
+                            (size_t)std::max(4096.0, o.block_mb * 1048576.0), o.alignments_sorted);
       Timing tm;
       const bool logging = o.logfile != "/dev/null";
-      try { run_columnar(reader, rpa, *tax, logging ? &logsink : nullptr, o.batch, o.processors ? o.processors : std::thread::hardware_concurrency(), tm); }
+      std::vector<RPAPredictionModel*> models;
+      for (auto& m : engines) models.push_back(m.get());
+      try { run_columnar(reader, models, *tax, logging ? &logsink : nullptr, o.batch, host_threads, tm); }
       catch (...) {
         if (o.timing) std::cerr << "TIMING\tincomplete" << std::endl;
         throw;
       }
+      store_report();
       if (o.timing)
         std::cerr << "TIMING\tload_s=" << secs(t_start, t_loaded) << "\tparse_s=" << tm.parse << "\tpredict_s=" << tm.predict << "\twrite_s="
                   << tm.write << "\twall_s=" << secs(t_loaded, Clock::now()) << "\trecord_sets=" << tm.sets << "\trecords=" << tm.records
-                  << "\t(columnar pipeline: the three stages overlap)" << std::endl;
+                  << "\tgpus=" << o.devices.size() << "\t(columnar pipeline: the three stages overlap)" << std::endl;
       return EXIT_SUCCESS;
     }
     AlignmentRecordFactory fac(*seqid2taxid, tax.get(), &db_storage);
-    RecordSetGenerator recgen(std::cin, fac, o.split_alignments);
+    RecordSetGenerator recgen(std::cin, fac, o.split_alignments, o.alignments_sorted);
     std::vector<RecordSetType> sets;
     std::vector<PredictionRecord> precs;
     std::cout << GFF3Header();
@@ -330,9 +404,13 @@ int main(int argc, char** argv) {
     if (o.timing)
       std::cerr << "TIMING\tload_s=" << secs(t_start, t_loaded) << "\tparse_s=" << t_parse << "\tpredict_s=" << t_predict << "\twrite_s="
                 << t_write << "\trecord_sets=" << n_sets << "\trecords=" << n_records << std::endl;
+    store_report();
     return EXIT_SUCCESS;
   } catch (Exception& e) {
     std::cerr << "An unrecoverable error occurred: " << e.what() << std::endl;  // taxator.cpp:381-386
+    return EXIT_FAILURE;
+  } catch (std::exception& e) {  // e.g. std::bad_alloc on a huge input: same way out
+    std::cerr << "An unrecoverable error occurred: " << e.what() << std::endl;
     return EXIT_FAILURE;
   }
 }

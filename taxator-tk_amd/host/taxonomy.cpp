@@ -6,6 +6,7 @@
 #include <iostream>
 #include <set>
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include "exception.hh"
 
@@ -15,6 +16,26 @@ const std::vector<std::string> default_ranks = {"superkingdom", "phylum", "class
 const char* const ENVVAR_TAXONOMY_NCBI = "TAXATORTK_TAXONOMY_NCBI";
 
 static bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+// Lines of a plain or gzip-compressed file (the reference opens the dump files through zstr, ncbidata.cpp:24-37, and
+// prefers nodes.dmp.gz / names.dmp.gz over the plain files, :184-196); gzopen reads both.
+class DumpFile {
+ public:
+  explicit DumpFile(const std::string& path) : f_(gzopen(path.c_str(), "rb")) { if (f_) gzbuffer(f_, 1 << 20); }
+  ~DumpFile() { if (f_) gzclose(f_); }
+  explicit operator bool() const { return f_ != nullptr; }
+  bool getline(std::string& line) {
+    line.clear();
+    char buf[4096];
+    for (;;) {
+      if (!gzgets(f_, buf, (int)sizeof(buf))) return !line.empty();
+      line.append(buf);
+      if (!line.empty() && line.back() == '\n') { line.pop_back(); return true; }
+    }
+  }
+ private:
+  gzFile f_;
+};
 
 // fields separated by "\t|\t" (ncbidata.cpp:42,59)
 static void split_dmp(const std::string& line, std::vector<std::string>& out, size_t max_fields) {
@@ -42,9 +63,9 @@ Taxonomy* parseNCBIFlatFiles(const std::string& nodes_filename, const std::strin
   std::vector<std::string> f;
   std::string line;
   {
-    std::ifstream nodes(nodes_filename);
+    DumpFile nodes(nodes_filename);
     if (!nodes) throw FileNotFound(nodes_filename);
-    while (std::getline(nodes, line)) {
+    while (nodes.getline(line)) {
       split_dmp(line, f, 4);
       if (f.size() < 3) continue;
       rank_of[f[0]] = f[2];
@@ -52,9 +73,9 @@ Taxonomy* parseNCBIFlatFiles(const std::string& nodes_filename, const std::strin
     }
   }
   {
-    std::ifstream names(names_filename);
+    DumpFile names(names_filename);
     if (names) {
-      while (std::getline(names, line)) {
+      while (names.getline(line)) {
         split_dmp(line, f, 5);
         if (f.size() >= 4 && f[3].compare(0, 15, "scientific name") == 0) name_of[f[0]] = f[1];  // :60
       }
@@ -89,6 +110,7 @@ Taxonomy* parseNCBIFlatFiles(const std::string& nodes_filename, const std::strin
       tax->right.push_back(0);
       stack.push_back({fr.id, fr.kept_parent, fr.depth, true, idx, fr.uncl});
       kp = (int32_t)idx;
+      if (fr.depth == 255) throw GeneralError("taxonomy deeper than 255 kept levels");  // root_pathlength is a uint8_t in the reference too (taxontree.hh:66)
       kd = (uint8_t)(fr.depth + 1);
     }
     auto it = children.find(fr.id);
@@ -111,9 +133,12 @@ Taxonomy* loadTaxonomyFromEnvironment(const std::vector<std::string>* ranks_to_m
     return nullptr;
   }
   const std::string folder = env;
-  const std::string nodes = folder + "/nodes.dmp", names = folder + "/names.dmp";
-  if (!file_exists(nodes)) { std::cerr << " \"" << nodes << "\" not found" << std::endl; return nullptr; }
-  if (!file_exists(names)) { std::cerr << " \"" << names << "\" not found" << std::endl; return nullptr; }
+  std::string nodes = folder + "/nodes.dmp", names = folder + "/names.dmp";
+  // the compressed dump wins when both exist (ncbidata.cpp:184-196)
+  if (file_exists(nodes + ".gz")) nodes += ".gz";
+  else if (!file_exists(nodes)) { std::cerr << " \"" << nodes << "\" not found" << std::endl; return nullptr; }
+  if (file_exists(names + ".gz")) names += ".gz";
+  else if (!file_exists(names)) { std::cerr << " \"" << names << "\" not found" << std::endl; return nullptr; }
   Taxonomy* tax = parseNCBIFlatFiles(nodes, names, ranks_to_mark, delete_unmarked);
   if (tax) {  // optional version file (ncbidata.cpp:201-207)
     std::ifstream versionfile(folder + "/version.txt");

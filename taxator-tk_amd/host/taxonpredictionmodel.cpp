@@ -1,6 +1,11 @@
 // taxator-tk_amd/host/taxonpredictionmodel.cpp -- see taxonpredictionmodel.hh.
 #include "taxonpredictionmodel.hh"
 
+#include <algorithm>
+#include <memory>
+#include <mutex>
+#include <thread>
+
 #include "columnar.hh"
 #include "exception.hh"
 
@@ -19,7 +24,7 @@ static void check(rpa_engine* e, int rc) {
 
 RPAPredictionModel::RPAPredictionModel(const Taxonomy* tax, const SequenceStore& q_storage, const SequenceStore& db_storage,
                                        float exclude_factor, float reeval_bandwidth, bool protein, int device)
-    : TaxonPredictionModel(tax), query_sequences_(q_storage) {
+    : TaxonPredictionModel(tax), query_sequences_(q_storage), db_sequences_(db_storage) {
   rpa_taxonomy t{(uint32_t)tax->size(), tax->parent.data(), tax->left.data(), tax->right.data(), tax->depth.data()};
   rpa_params p;
   rpa_default_params(&p);
@@ -27,10 +32,82 @@ RPAPredictionModel::RPAPredictionModel(const Taxonomy* tax, const SequenceStore&
   p.exclude_alignments_factor = exclude_factor;
   p.reeval_bandwidth = reeval_bandwidth;
   p.device = device;
-  int rc = rpa_create(&t, &p, &engine_);
+  rpa_engine* created = nullptr;
+  int rc = rpa_create(&t, &p, &created);
   if (rc != RPA_OK) throw DeviceError(rpa_last_error(nullptr));
-  check(engine_, rpa_store_load(engine_, RPA_STORE_QUERY, q_storage.size(), q_storage.letters().data(), q_storage.offsets().data(), RPA_MEM_HOST));
-  check(engine_, rpa_store_load(engine_, RPA_STORE_DB, db_storage.size(), db_storage.letters().data(), db_storage.offsets().data(), RPA_MEM_HOST));
+  std::unique_ptr<rpa_engine, void (*)(rpa_engine*)> guard(created, rpa_destroy);  // a store that fails to load must not leak the engine
+  const SequenceStore* stores[2] = {&q_storage, &db_storage};
+  const int which[2] = {RPA_STORE_QUERY, RPA_STORE_DB};
+  for (int k = 0; k < 2; ++k) {
+    const SequenceStore& st = *stores[k];
+    if (st.indexed()) {  // nothing resident yet: sequences come in as the alignment stream refers to them
+      check(created, rpa_store_reserve(created, which[k], st.size()));
+      resident_[which[k]].assign(st.size(), 0);
+    } else {
+      check(created, rpa_store_load(created, which[k], st.size(), st.letters().data(), st.offsets().data(), RPA_MEM_HOST));
+    }
+  }
+  engine_ = guard.release();
+}
+
+size_t RPAPredictionModel::makeResident(int which, const uint32_t* idx, size_t n) {
+  const SequenceStore& st = which == RPA_STORE_QUERY ? query_sequences_ : db_sequences_;
+  if (!st.indexed() || n == 0) return 0;
+  std::vector<uint8_t>& res = resident_[which];
+  // candidates: every host thread scans a slice of the indices against the (read-only) residency marks ...
+  const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, n / 65536 + 1));
+  std::vector<std::vector<uint32_t>> cand(T);
+  auto scan = [&](unsigned t) {
+    const size_t lo = n * t / T, hi = n * (t + 1) / T;
+    uint32_t last = 0xFFFFFFFFu;
+    for (size_t k = lo; k < hi; ++k) {
+      const uint32_t i = idx[k];
+      if (i == last) continue;
+      last = i;
+      if (i >= res.size()) throw SequenceNotFound("sequence index outside the store");
+      if (!res[i]) cand[t].push_back(i);
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(scan, t);
+    scan(0);
+    for (auto& x : th) x.join();
+  }
+  // ... then one pass marks them (a sequence several threads found is taken once)
+  std::vector<uint32_t> need;
+  for (auto& c : cand)
+    for (uint32_t i : c)
+      if (!res[i]) { res[i] = 1; need.push_back(i); }
+  if (need.empty()) return 0;
+  fetch_offsets_.assign(need.size() + 1, 0);
+  for (size_t k = 0; k < need.size(); ++k) fetch_offsets_[k + 1] = fetch_offsets_[k] + st.length(need[k]);
+  fetch_letters_.resize((size_t)fetch_offsets_.back() + 8);
+  const unsigned F = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, need.size()));
+  std::exception_ptr err;
+  std::mutex err_mu;
+  auto fetch = [&](unsigned t) {  // slices of equal residue count, not of equal sequence count
+    const uint64_t total = fetch_offsets_.back();
+    const size_t lo = std::lower_bound(fetch_offsets_.begin(), fetch_offsets_.end() - 1, total * t / F) - fetch_offsets_.begin();
+    const size_t hi = t + 1 == F ? need.size() : std::lower_bound(fetch_offsets_.begin(), fetch_offsets_.end() - 1, total * (t + 1) / F) - fetch_offsets_.begin();
+    try { for (size_t k = lo; k < hi; ++k) st.fetch(need[k], fetch_letters_.data() + fetch_offsets_[k]); }
+    catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < F; ++t) th.emplace_back(fetch, t);
+    fetch(0);
+    for (auto& x : th) x.join();
+  }
+  if (err) std::rethrow_exception(err);
+  check(engine_, rpa_store_append(engine_, which, (uint32_t)need.size(), need.data(), fetch_letters_.data(), fetch_offsets_.data()));
+  return need.size();
+}
+
+rpa_store_info RPAPredictionModel::storeInfo(int which) const {
+  rpa_store_info info{};
+  check(engine_, rpa_store_info_get(engine_, which, &info));
+  return info;
 }
 
 RPAPredictionModel::~RPAPredictionModel() { rpa_destroy(engine_); }
@@ -63,6 +140,8 @@ void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, s
   b.filtered = filtered_.data(); b.mem_kind = RPA_MEM_HOST;
   rows_.resize(S);
   stats_.resize(S);
+  makeResident(RPA_STORE_QUERY, query_seq_.data(), query_seq_.size());
+  makeResident(RPA_STORE_DB, ref_seq_.data(), ref_seq_.size());
   check(engine_, rpa_predict_batch(engine_, &b, rows_.data(), stats_.data(), RPA_MEM_HOST));
   for (size_t s = 0; s < S; ++s) {
     const rpa_prediction& r = rows_[s];
@@ -90,6 +169,8 @@ void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size
   b.rstop = cb.rec.rstop.data() + base; b.score = cb.rec.score.data() + base; b.identities = cb.rec.identities.data() + base;
   b.alnlen = cb.rec.alnlen.data() + base; b.ref_seq = cb.rec.ref_seq.data() + base; b.node = cb.rec.node.data() + base;
   b.filtered = cb.rec.filtered.data() + base; b.mem_kind = RPA_MEM_HOST;
+  makeResident(RPA_STORE_QUERY, b.query_seq, b.n_sets);
+  makeResident(RPA_STORE_DB, b.ref_seq, b.n_records);
   check(engine_, rpa_predict_batch(engine_, &b, rows, stats, RPA_MEM_HOST));
 }
 

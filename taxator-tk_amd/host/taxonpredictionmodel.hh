@@ -37,8 +37,20 @@ class RPAPredictionModel : public TaxonPredictionModel {
   // The same call for record sets that are already in columns (columnar.hh): sets [lo, hi) of `batch`, rows and STATS
   // counters written to rows[0 .. hi-lo) / stats[0 .. hi-lo).  No per-record objects on this path.
   void predictColumns(const struct ColumnarBatch& batch, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats);
+  // Indexed stores (taxator -i / -v): make the sequences idx[0..n) of store `which` (RPA_STORE_QUERY / RPA_STORE_DB)
+  // resident in this engine's HBM if they are not yet -- fetched through the .fai from the mapped FASTA by `threads`
+  // host threads, appended with rpa_store_append.  predict() / predictColumns() call it for what their batch refers to;
+  // a no-op for in-memory stores.  Returns the number of sequences that had to be loaded.
+  size_t makeResident(int which, const uint32_t* idx, size_t n);
+  void setHostThreads(unsigned t) { threads_ = t ? t : 1; }
+  rpa_store_info storeInfo(int which) const;
  private:
   const SequenceStore& query_sequences_;
+  const SequenceStore& db_sequences_;
+  std::vector<uint8_t> resident_[2];   // per store: sequence already appended to this engine
+  std::vector<uint8_t> fetch_letters_;
+  std::vector<uint64_t> fetch_offsets_;
+  unsigned threads_ = 1;
   rpa_engine* engine_ = nullptr;
   float stale_ival_ = -1.f;  // PredictionRecord is reused across calls in the reference (taxator.cpp:66): n==0 keeps the last ival
   std::vector<rpa_stats> stats_;

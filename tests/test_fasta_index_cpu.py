@@ -1,0 +1,98 @@
+"""The indexed sequence store of the host driver (taxator -i / -v: memory-mapped FASTA + .fai, host/sequencestorage.*)
+against the in-memory store: same identifiers, lengths and residues -- with a samtools-style .fai, with an index rebuilt
+by a scan (no .fai), with irregular lines, CRLF line ends, blanks inside lines, empty sequences and a last line without a
+line break; a .fai that does not fit the file is refused.  Also -o 1 (alignments-sorted): both readers cut the record
+sets in INPUT order (core/src/alignmentrecord.hh:569-631) and agree with each other.  No GPU involved."""
+import os
+import random
+import subprocess
+
+import pytest
+
+import __graft_entry__ as graft
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "taxator-tk_amd", "bin", "parsecheck")
+
+
+@pytest.fixture(scope="module")
+def parsecheck():
+    if not os.path.exists(BIN):
+        graft.build()
+    return BIN
+
+
+def _write_regular(path, seqs, width, eol=b"\n", last_eol=True):
+    """FASTA with fixed line width + the .fai samtools would write (core/src/faidx.h:438-476)."""
+    fai = []
+    with open(path, "wb") as f:
+        for k, (name, seq) in enumerate(seqs):
+            f.write(b">" + name + b" some description" + eol)
+            off = f.tell()
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width])
+                if i + width < len(seq) or last_eol or k + 1 < len(seqs):
+                    f.write(eol)
+            fai.append(b"%s\t%d\t%d\t%d\t%d\n" % (name, len(seq), off, width, width + len(eol)))
+    with open(path + ".fai", "wb") as f:
+        f.write(b"".join(fai))
+
+
+def _check(binary, fasta, fai):
+    r = subprocess.run([binary, "--fasta", fasta, fai], capture_output=True, text=True)
+    return r.returncode, r.stdout.strip()
+
+
+def test_indexed_store_equals_in_memory_store(parsecheck, tmp_path):
+    rng = random.Random(3)
+    seqs = [(b"s%d" % k, bytes(rng.choice(b"ACGTNacgtnRY") for _ in range(rng.choice([0, 1, 59, 60, 61, 120, 121, 1000, 7777]))))
+            for k in range(40)]
+    total = sum(len(s) for _, s in seqs)
+    for width, eol, last_eol in ((60, b"\n", True), (80, b"\r\n", True), (7, b"\n", False), (10000, b"\n", True)):
+        path = str(tmp_path / ("w%d_%d.fna" % (width, len(eol))))
+        _write_regular(path, seqs, width, eol, last_eol)
+        assert _check(parsecheck, path, path + ".fai") == (0, "OK 40 %d" % total), (width, eol)
+        assert _check(parsecheck, path, "-") == (0, "OK 40 %d" % total), (width, eol)          # index rebuilt by a scan
+        assert _check(parsecheck, path, str(tmp_path / "missing.fai")) == (0, "OK 40 %d" % total)
+    # irregular lines, blanks inside lines: only the scanned index can describe them
+    path = str(tmp_path / "irregular.fna")
+    with open(path, "wb") as f:
+        for name, seq in seqs:
+            f.write(b">" + name + b"\n")
+            i = 0
+            while i < len(seq):
+                n = rng.randint(1, 90)
+                chunk = seq[i:i + n]
+                if rng.random() < 0.2 and len(chunk) > 2:
+                    chunk = chunk[:1] + b" " + chunk[1:2] + b"\t" + chunk[2:]
+                f.write(chunk + rng.choice([b"\n", b"\r\n", b"\n\n"]))
+                i += n
+    assert _check(parsecheck, path, "-") == (0, "OK 40 %d" % total)
+    # a .fai that points beyond the file is refused, not followed
+    path = str(tmp_path / "w60_1.fna")
+    open(path + ".bad.fai", "w").write("s0\t100\t99999999\t60\t61\n")
+    rc, out = _check(parsecheck, path, path + ".bad.fai")
+    assert rc == 1 and out.startswith("ERROR") and "does not fit" in out
+
+
+def test_alignments_sorted_option(parsecheck, golden_dir):
+    """-o 1: no sort before the cut.  On input that IS sorted by (qstart, qstop) within each query the record sets equal the
+    default path's; on unsorted input they follow the input order, and the two readers still agree."""
+    folder = os.path.join(golden_dir, "survey_edge")
+    env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
+
+    def run(mode, data, sorted_flag):
+        e = dict(env, PARSECHECK_SORTED="1") if sorted_flag else env
+        cmd = [parsecheck, os.path.join(folder, "mapping.tax"), os.path.join(folder, "query_edge.fna"), os.path.join(folder, "ref.fna"), mode, "1", "2", "4096"]
+        r = subprocess.run(cmd, input=data, capture_output=True, env=e)
+        assert r.returncode == 0, r.stdout[-300:]
+        return r.stdout
+
+    rows = [(5, 40), (1, 30), (35, 60), (100, 140), (90, 99), (141, 150)]
+    unsorted = "".join("e0\t%d\t%d\t200\tref3\t%d\t%d\t%d\t0\t10\t10\n" % (a, b, a, b, 100 + a) for a, b in rows).encode()
+    srt = "".join("e0\t%d\t%d\t200\tref3\t%d\t%d\t%d\t0\t10\t10\n" % (a, b, a, b, 100 + a) for a, b in sorted(rows)).encode()
+    assert run("objects", srt, True) == run("objects", srt, False) == run("columnar", srt, True) == run("columnar", srt, False)
+    o, c = run("objects", unsorted, True), run("columnar", unsorted, True)
+    assert o == c and o != run("objects", unsorted, False)
+    # input order: (5,40) (1,30) (35,60) | (100,140) (90,99: 90 <= 140 joins) | (141,150)
+    assert [int(l.split(b"\t")[4]) for l in o.split(b"\n") if l.startswith(b"SET")] == [3, 2, 1]

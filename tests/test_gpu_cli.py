@@ -122,3 +122,74 @@ def test_cli_alignment_free_models(oracle, golden_dir, tmp_path, algo, extra, kw
     assert r.stdout == fds.gff3(rows, b["qids"], b["qlen"])
     if algo in ("megan-lca", "n-best-lca"):  # (the LCA over ALL hits of these sets is the superkingdom)
         assert len(set(rows["lower"])) > 3
+
+
+def test_cli_indexed_store_loads_only_what_the_stream_touches(oracle, tmp_path):
+    """with -i the reference reads only the regions it needs through the .fai.  Here: a reference FASTA with
+    100x more sequences than the alignments touch -- the GFF3 must equal the in-memory run's byte for byte, and the STORE
+    report must show that only the touched sequences went to HBM (--timing prints resident / known sequences)."""
+    graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    ds = synth.make_dataset(n_sets=60, n_hits=6, seg_len=150, branching=2, genome_len=1500, seed=4, variety=True)
+    folder = str(tmp_path / "sparse")
+    synth.write_files(ds, folder)
+    # pad the collection: 100x more sequences nobody refers to, spread between the real ones (.fai rewritten to match)
+    rng = np.random.default_rng(1)
+    real = {}
+    name = None
+    for line in open(os.path.join(folder, "ref.fna")):
+        if line.startswith(">"): name = line[1:].strip(); real[name] = []
+        else: real[name].append(line.strip())
+    names = list(real)
+    with open(os.path.join(folder, "ref.fna"), "w") as f, open(os.path.join(folder, "ref.fna.fai"), "w") as fai:
+        def put(nm, seq):
+            f.write(">%s\n" % nm)
+            off = f.tell()
+            for i in range(0, len(seq), 70): f.write(seq[i:i + 70] + "\n")
+            fai.write("%s\t%d\t%d\t70\t71\n" % (nm, len(seq), off))
+        filler = 0
+        for nm in names:
+            for _ in range(100):
+                put("filler%d" % filler, "".join(rng.choice(list("ACGT"), int(rng.integers(200, 900))))); filler += 1
+            put(nm, "".join(real[nm]))
+    with open(os.path.join(folder, "mapping.tax"), "a") as f:
+        for k in range(filler): f.write("filler%d\t%s\n" % (k, ds.tax.taxid[int(ds.tax.species[0])]))
+    env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
+    base = [BIN, "-g", os.path.join(folder, "mapping.tax"), "-q", os.path.join(folder, "query.fna"), "-f", os.path.join(folder, "ref.fna"), "--timing"]
+    mem = subprocess.run(base, stdin=open(os.path.join(folder, "aln.tsv")), capture_output=True, text=True, env=env)
+    idx = subprocess.run(base + ["-i", os.path.join(folder, "ref.fna.fai"), "-v", os.path.join(folder, "query.fna.fai"), "--block-mb", "0.01"],
+                         stdin=open(os.path.join(folder, "aln.tsv")), capture_output=True, text=True, env=env)  # no query .fai on disk: rebuilt by a scan
+    assert mem.returncode == 0 and idx.returncode == 0, (mem.stderr, idx.stderr)
+    assert idx.stdout == mem.stdout and idx.stdout.count("\n") == 61
+
+    def store(stderr, which):
+        line = [l for l in stderr.splitlines() if l.startswith("STORE\t" + which)][0].split("\t")
+        return line[2], {k: int(v) for k, v in (x.split("=") for x in line[3:])}
+    kind, ref_mem = store(mem.stderr, "ref")
+    assert kind == "in-memory" and ref_mem["resident"] == ref_mem["sequences"] == len(names) * 101
+    kind, ref_idx = store(idx.stderr, "ref")
+    touched = len(set(int(x) for x in ds.batch["ref_seq"]))
+    assert kind == "indexed" and ref_idx["sequences"] == len(names) * 101 and ref_idx["resident"] == touched
+    assert ref_idx["residues"] * 20 < ref_mem["residues"] and ref_idx["device_bytes"] * 10 < ref_mem["device_bytes"]
+    kind, q_idx = store(idx.stderr, "query")
+    assert kind == "indexed" and q_idx["resident"] <= q_idx["sequences"] == ds.n_sets
+
+
+@pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])
+def test_cli_several_engines_keep_input_order(golden_dir, tmp_path, name, ext, extra):
+    """--devices a,b: one engine + one host thread per listed GPU, blocks dealt to whichever is free, GFF3 in input order
+    (the replacement of doPredictionsParallel, core/taxator.cpp:181-210).  The test box has one GPU: two engines on device
+    0 exercise the same pipeline.  Tiny blocks -> dozens of batches in flight across the two engines."""
+    folder = _unpack(golden_dir, name, ext, tmp_path)
+    r = _run(folder, ext, extra + ["--devices", "0,0", "--block-mb", "0.004", "-p", "4"])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(os.path.join(folder, "out.gff3")).read()
+    # a failure in the middle of the stream: what precedes it is printed, the exit code and message are the serial loop's
+    lines = open(os.path.join(folder, "aln.tsv")).read().split("\n")
+    bad = lines[:len(lines) // 2] + ["q_unknown\t1\t50\t200\tnope\t1\t50\t10\t0\t50\t50"] + lines[len(lines) // 2:]
+    (tmp_path / name / "aln_bad.tsv").write_text("\n".join(bad))
+    r = _run(folder, ext, extra + ["--devices", "0,0", "--block-mb", "0.004"], aln="aln_bad.tsv")
+    assert r.returncode == 1 and "An unrecoverable error occurred" in r.stderr
+    good = open(os.path.join(folder, "out.gff3")).read()
+    assert good.startswith(r.stdout) and 0 < len(r.stdout) < len(good)
+
