@@ -180,6 +180,11 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 = the headline configuration (BASELINE config 2); c3 = config 3's per-GPU share (for --gpus 8), c4 protein, "
                          "c5 long contigs are extra measurements")
+    ap.add_argument("--store-replicas", type=int, default=1,
+                    help="lay the reference store out R times (R x 4096 sequences; every alignment row points at a random replica of its "
+                         "species): the same work against a store that is really spread over HBM instead of sitting in L2 / "
+                         "Infinity Cache -- 2000 replicas of config 2's 16 Mbase collection = 32 GB packed.  An extra measurement, "
+                         "never the headline")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl = RCCL) and run the gather path even with one rank (hardware rehearsal of the N > 1 code)")
     ap.add_argument("--sets", type=int, default=None, help="record sets per GPU (default: the configuration's)")
@@ -236,7 +241,28 @@ def main():
 
     model = pkg.RPAPredictionModel(ds.tax, alphabet=cfg["alphabet"], device=local_rank)
     model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
-    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    store_bytes = int(ds.ref_offsets[-1]) // (2 if cfg["alphabet"] == 0 else 1)
+    if args.store_replicas > 1:
+        # R copies of the collection back to back, built on the device (letters R x 16 MB, packed by the engine, then freed);
+        # replica k of species s is sequence s + k * n_species
+        R_, n_sp, total = args.store_replicas, len(ds.ref_offsets) - 1, int(ds.ref_offsets[-1])
+        pad = (-total) % 8                                            # keep every replica 8-byte aligned in the letter buffer
+        one = torch.from_numpy(np.concatenate([ds.ref_letters, np.full(pad, ord("A"), np.uint8)])).cuda()
+        letters = one.repeat(R_)
+        offs = (torch.from_numpy(ds.ref_offsets[:-1].astype(np.int64)).cuda()[None, :] + (torch.arange(R_, device="cuda", dtype=torch.int64) * (total + pad))[:, None]).reshape(-1)
+        # a replica's last sequence ends where its padding starts: lengths come from consecutive offsets, so give every replica's
+        # pad its own (never referenced) slot of length `pad` by ending the table per replica
+        ends = offs.reshape(R_, n_sp)[:, -1] + int(ds.ref_offsets[-1] - ds.ref_offsets[-2])
+        table = torch.cat([torch.cat([offs.reshape(R_, n_sp), ends[:, None]], dim=1).reshape(-1), torch.tensor([R_ * (total + pad)], device="cuda", dtype=torch.int64)])
+        # sequences per replica: n_sp real ones + 1 pad slot
+        model.load_store(pkg.STORE_DB, letters, table, mem_kind=pkg.MEM_DEVICE)
+        del letters, one
+        torch.cuda.empty_cache()
+        g = np.random.default_rng(12345)
+        ds.batch["ref_seq"] = (ds.batch["ref_seq"].astype(np.int64) + g.integers(0, R_, len(ds.batch["ref_seq"])) * (n_sp + 1)).astype(np.uint32)
+        store_bytes *= R_
+    else:
+        model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
     dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).cuda()
            for k, v in ds.batch.items()}
     rows = torch.zeros((ds.n_sets, 8), dtype=torch.int32, device="cuda")
@@ -336,6 +362,8 @@ def main():
             "device_ms_per_step": prof["total_ms"] / args.steps, "align_ms_per_step": prof["align_ms"] / args.steps,
             "computed_over_demanded": prof["pairs"] / max(prof["demanded"], 1), "rounds_per_step": prof["rounds"] / args.steps,
             "datagen_s": t_gen,
+            "reference_store": {"replicas": args.store_replicas, "packed_bytes": store_bytes,
+                                "note": "config 2's 4096-species collection is 8 MB packed (cache resident); --store-replicas spreads the same work over HBM"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, ds)
