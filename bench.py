@@ -275,13 +275,23 @@ def main():
     gather_out = ([torch.empty((max(gather_sizes), 8), dtype=torch.int32, device="cuda") for _ in range(world)]
                   if (use_dist and rank == 0) else None)
 
+    import collections
+    in_flight = collections.deque()
+
+    def finish_one():
+        r_host, s_host = in_flight.popleft().wait()
+        if not step.copied:
+            rows.copy_(torch.from_numpy(r_host.view(np.int32).reshape(-1, 8)))
+            stats.copy_(torch.from_numpy(s_host.view(np.int32).reshape(-1, 4)))
+            step.copied = True
+
     def step():
         if args.host_buffers:
-            r_host, s_host = model.predict(ds.batch)  # H2D of the batch columns and D2H of rows + counters inside the call
-            if not step.copied:
-                rows.copy_(torch.from_numpy(r_host.view(np.int32).reshape(-1, 8)))
-                stats.copy_(torch.from_numpy(s_host.view(np.int32).reshape(-1, 4)))
-                step.copied = True
+            # the asynchronous boundary (rpa_submit_batch / rpa_wait): H2D of the batch columns and D2H of rows + counters
+            # inside every job, two jobs in flight -- the copies of one under the kernels of the other
+            in_flight.append(model.submit(ds.batch))
+            if len(in_flight) == 2:
+                finish_one()
         else:
             model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
         if use_dist:
@@ -290,6 +300,8 @@ def main():
     step.copied = False
     for _ in range(args.warmup):
         step()
+    while in_flight:
+        finish_one()
     model.profile(enable=True, reset=True)
     torch.cuda.synchronize()
     if use_dist:
@@ -298,6 +310,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    while in_flight:
+        finish_one()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -344,7 +358,7 @@ def main():
             "dtype": "u32" if cfg["alphabet"] == 0 else "i32", "data": "synthetic",
             "config": {"workload": "%s: %d record sets x %d hits x %d %s RPA per GPU, mock NCBI taxonomy (b=4, 5462 nodes), batch resident in HBM"
                                    % (cfg["name"], args.sets, args.hits, args.seg_len, "bp nucleotide" if cfg["alphabet"] == 0 else "aa protein")
-                                   + (" -- HOST BUFFERS: batch copied to the device and rows back inside every step (PCIe-inclusive, not the headline)" if args.host_buffers else ""),
+                                   + (" -- HOST BUFFERS: batch copied to the device and rows back inside every step, two steps in flight through rpa_submit_batch / rpa_wait (PCIe-inclusive, not the headline)" if args.host_buffers else ""),
                        "record_sets_per_gpu": args.sets, "hits_per_set": args.hits, "segment_bp": args.seg_len,
                        "parallelism": ("record sets sharded over %d GPU(s)%s; RCCL gather of 32-byte rows to rank 0 every step"
                                        % (world, ", ONE workload cut by summed alignment cells" if cut_by_cost else "")) if use_dist else "single GPU",

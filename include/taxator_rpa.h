@@ -157,8 +157,21 @@ typedef struct {
 } rpa_stats;
 
 /* predict() for every set of the batch.  `out` (n_sets rows) and `stats` (n_sets rows or NULL) live where out_mem_kind
- * says.  Results are in input order.  Synchronous: returns when the rows are written. */
+ * says.  Results are in input order.  Synchronous: returns when the rows are written (asynchronous form: rpa_submit_batch). */
 int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind);
+
+/* Asynchronous form for host batches: the replacement of the reference's producer / consumer pool
+ * (core/taxator.cpp:80-124,159-176) at the boundary.  rpa_submit_batch hands the batch to one of the engine's
+ * RPA_JOBS_IN_FLIGHT job slots (each with its own HIP stream, working set, staging buffers and host thread) and returns;
+ * the host -> device copies of one job run under the kernels of the other.  It blocks only while the slot whose turn it
+ * is still works on its previous job.  The batch arrays, `out` and `stats` must stay valid until rpa_wait(job) returns,
+ * which also reports the job's status (rpa_last_error has the text) and releases the handle.  Jobs may be waited for in
+ * any order; rows are in input order within a job, as with rpa_predict_batch (same semantics:
+ * core/src/taxonpredictionmodel.hh:36-52).  Store loads / appends wait for the jobs in flight. */
+#define RPA_JOBS_IN_FLIGHT 2
+typedef struct rpa_job rpa_job;
+int rpa_submit_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, rpa_job** job);
+int rpa_wait(rpa_engine* e, rpa_job* job);
 
 /* The reference's alignment-free models behind the same seam (taxator -a dummy | simple-lca | megan-lca | n-best-lca,
  * core/taxator.cpp:346-361): DummyPredictionModel, LCASimplePredictionModel, MeganLCAPredictionModel,

@@ -114,6 +114,26 @@ struct rpa_engine {
   hipEvent_t ev_inputs = nullptr;       // owner: everything queued on the owner's stream before the parts start
   int parts_override = 0;               // RPA_PARTS=n: cut every batch into n parts (tests, A/B); 0 = by size
   bool part_mode = false;               // running as one of several parts: the call's device time is taken by the owner
+  // asynchronous jobs (rpa_submit_batch / rpa_wait): each slot is a worker engine (own stream, working set, staging) with
+  // a host thread of its own; two slots = two batches in flight, the copies of one under the kernels of the other
+  rpa_engine* owner = nullptr;          // slots: whose stores and taxonomy they read
+  std::vector<rpa_engine*> slots;       // owner only
+  std::thread job_thread;               // slot only
+  std::mutex job_mu;
+  std::condition_variable job_cv;
+  struct rpa_job* job_pending = nullptr;
+  bool job_busy = false, job_quit = false;
+  unsigned next_slot = 0;               // owner: jobs go to the slots in turn
+};
+
+struct rpa_job {
+  rpa_batch batch;
+  rpa_prediction* out = nullptr;
+  rpa_stats* stats = nullptr;
+  int status = RPA_OK;
+  bool done = false;
+  std::string err;
+  rpa_engine* slot = nullptr;
 };
 
 namespace {
@@ -737,6 +757,13 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
 
 void rpa_destroy(rpa_engine* e) {
   if (!e) return;
+  for (rpa_engine* s : e->slots) {
+    { std::lock_guard<std::mutex> lk(s->job_mu); s->job_quit = true; }
+    s->job_cv.notify_all();
+    if (s->job_thread.joinable()) s->job_thread.join();
+    rpa_destroy(s);
+  }
+  e->slots.clear();
   for (rpa_engine* w : e->workers) rpa_destroy(w);
   e->workers.clear();
   (void)hipSetDevice(e->device);
@@ -765,6 +792,8 @@ int rpa_set_stream(rpa_engine* e, void* hip_stream) {
   e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
   return RPA_OK;
 }
+
+static void quiesce_slots(rpa_engine* e);
 
 // Make room for `more` residues behind the ones in use (rounded up to whole words); the arena grows by doubling, its
 // contents move with a device-to-device copy.  Returns the residue index the new residues start at (a multiple of 8).
@@ -852,6 +881,7 @@ int rpa_store_load(rpa_engine* e, int which, uint32_t n_seqs, const uint8_t* let
   if (!offsets || (n_seqs && !letters)) return fail(e, RPA_ERR_INVALID, "rpa_store_load: null argument");
   if (mem_kind != RPA_MEM_HOST && mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_store_load: bad mem_kind");
   HIP_TRY(e, hipSetDevice(e->device));
+  quiesce_slots(e);
   int rc = pack_store(e, &e->stores[which], n_seqs, letters, offsets, mem_kind, &e->tmp_letters);
   e->tmp_letters.release();  // the raw letters are not kept: the packed store is the resident copy
   return rc;
@@ -862,6 +892,7 @@ int rpa_store_reserve(rpa_engine* e, int which, uint32_t n_seqs) {
   std::lock_guard<std::mutex> lk(e->mu);
   if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_reserve: bad store id");
   HIP_TRY(e, hipSetDevice(e->device));
+  quiesce_slots(e);
   Store* st = &e->stores[which];
   st->n_residues = 0; st->n_resident = 0; st->n_seqs = n_seqs;
   HIP_TRY(e, st->extent.ensure((size_t)(n_seqs ? n_seqs : 1) * sizeof(ulonglong2)));
@@ -885,6 +916,7 @@ int rpa_store_append(rpa_engine* e, int which, uint32_t n, const uint32_t* seq_i
   for (uint32_t k = 0; k < n; ++k)
     if (seq_index[k] >= st->n_seqs) return fail(e, RPA_ERR_INVALID, "rpa_store_append: sequence index %u outside the store (%u sequences)", seq_index[k], st->n_seqs);
   HIP_TRY(e, hipSetDevice(e->device));
+  quiesce_slots(e);  // the arena may move: no job may be reading it
   int rc = store_add(e, st, n, seq_index, letters, offsets, RPA_MEM_HOST, &e->tmp_letters);
   return rc;
 }
@@ -899,11 +931,10 @@ int rpa_store_info_get(rpa_engine* e, int which, rpa_store_info* out) {
   return RPA_OK;
 }
 
-int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind) {
-  if (!e) return RPA_ERR_INVALID;
-  std::lock_guard<std::mutex> lk(e->mu);
+// Everything rpa_predict_batch does, on the stream / buffers of `e` with the stores of `so` (e itself, or the owner of a job slot).
+static int predict_on(rpa_engine* e, rpa_engine* so, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind) {
   if (!batch || !out) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: null argument");
-  if (!e->stores[0].loaded || !e->stores[1].loaded) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: load both sequence stores first");
+  if (!so->stores[0].loaded || !so->stores[1].loaded) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: load both sequence stores first");
   const uint32_t S = batch->n_sets, H = batch->n_records;
   if (S == 0) return RPA_OK;
   if (!batch->set_offsets || !batch->query_seq || !batch->query_len ||
@@ -949,7 +980,12 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
     rows_dev = e->out_rows.p;
     if (stats) { HIP_TRY(e, e->out_stats.ensure((size_t)S * sizeof(rpa_stats))); stats_dev = e->out_stats.p; }
   } else if (out_mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_predict_batch: bad out_mem_kind");
-  int rc = run_parts(e, b, batch->mem_kind == RPA_MEM_HOST ? batch->set_offsets : nullptr, rows_dev, stats_dev);
+  int rc;
+  if (e == so) rc = run_parts(e, b, batch->mem_kind == RPA_MEM_HOST ? batch->set_offsets : nullptr, rows_dev, stats_dev);
+  else {  // a job slot: one part, the owner's stores
+    PartGate g;
+    rc = predict_part(e, b, so->stores[RPA_STORE_QUERY].view(), so->stores[RPA_STORE_DB].view(), rows_dev, stats_dev, g);
+  }
   if (rc) return rc;
   if (out_mem_kind == RPA_MEM_HOST) {
     HIP_TRY(e, hipMemcpyAsync(out, rows_dev, (size_t)S * sizeof(rpa_prediction), hipMemcpyDeviceToHost, e->stream));
@@ -957,6 +993,87 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
   return RPA_OK;
+}
+
+int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  return predict_on(e, e, batch, out, stats, out_mem_kind);
+}
+
+// ---- asynchronous jobs ----
+static void slot_main(rpa_engine* slot) {
+  for (;;) {
+    rpa_job* job = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(slot->job_mu);
+      slot->job_cv.wait(lk, [&] { return slot->job_pending || slot->job_quit; });
+      if (slot->job_quit && !slot->job_pending) return;
+      job = slot->job_pending;
+    }
+    slot->err.clear();
+    const int rc = predict_on(slot, slot->owner, &job->batch, job->out, job->stats, RPA_MEM_HOST);
+    {
+      std::lock_guard<std::mutex> lk(slot->job_mu);
+      job->status = rc;
+      if (rc) job->err = slot->err;
+      job->done = true;
+      slot->job_pending = nullptr;
+      slot->job_busy = false;
+    }
+    slot->job_cv.notify_all();
+  }
+}
+
+// every job slot idle (store loads and appends change what the slots read)
+static void quiesce_slots(rpa_engine* e) {
+  for (rpa_engine* s : e->slots) {
+    std::unique_lock<std::mutex> lk(s->job_mu);
+    s->job_cv.wait(lk, [&] { return !s->job_busy; });
+  }
+}
+
+int rpa_submit_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, rpa_job** job_out) {
+  if (!e || !job_out) return RPA_ERR_INVALID;
+  *job_out = nullptr;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!batch || !out) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch: null argument");
+  if (batch->mem_kind != RPA_MEM_HOST) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch takes host batches (device batches: rpa_predict_batch on a stream of your own)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  while (e->slots.size() < RPA_JOBS_IN_FLIGHT) {
+    rpa_engine* s = make_worker(e);
+    if (!s) return RPA_ERR_DEVICE;
+    s->owner = e;
+    s->profiling = false;
+    s->job_thread = std::thread(slot_main, s);
+    e->slots.push_back(s);
+  }
+  rpa_engine* slot = e->slots[e->next_slot++ % e->slots.size()];
+  rpa_job* job = new (std::nothrow) rpa_job();
+  if (!job) return fail(e, RPA_ERR_DEVICE, "out of host memory");
+  job->batch = *batch; job->out = out; job->stats = stats; job->slot = slot;
+  {
+    std::unique_lock<std::mutex> sl(slot->job_mu);
+    slot->job_cv.wait(sl, [&] { return !slot->job_busy; });  // the slot's previous job has written its rows
+    slot->job_busy = true;
+    slot->job_pending = job;
+  }
+  slot->job_cv.notify_all();
+  *job_out = job;
+  return RPA_OK;
+}
+
+int rpa_wait(rpa_engine* e, rpa_job* job) {
+  if (!e || !job) return RPA_ERR_INVALID;
+  rpa_engine* slot = job->slot;
+  {
+    std::unique_lock<std::mutex> sl(slot->job_mu);
+    slot->job_cv.wait(sl, [&] { return job->done; });
+  }
+  const int rc = job->status;
+  if (rc) { std::lock_guard<std::mutex> lk(e->mu); e->err = job->err; }
+  delete job;
+  return rc;
 }
 
 int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, uint32_t n_pairs,

@@ -105,7 +105,9 @@ double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::dura
 // blocks back into input order (what the reference's serial loop prints, :69-74).
 void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& models, const Taxonomy& tax, std::ostream* logsink, size_t max_sets,
                   unsigned threads, Timing& tm) {
-  const size_t n_gpu = models.size();
+  // two host threads per engine: each submits a block and waits for it (rpa_submit_batch / rpa_wait), so every engine has
+  // two batches in flight -- the host->device copies of one run under the kernels of the other
+  const size_t n_gpu = 2 * models.size();
   std::vector<Work> works(2 * n_gpu + 1);
   Channel<Work*> free_q, parsed_q, predicted_q;
   for (Work& w : works) free_q.push(&w);
@@ -186,7 +188,7 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
   std::mutex failure_mu;
   std::atomic<uint64_t> fail_seq(~0ull);  // the earliest block that failed: what the serial loop would have died on
   auto gpu_loop = [&](size_t g) {
-    RPAPredictionModel& rpa = *models[g];
+    RPAPredictionModel& rpa = *models[g / 2];
     for (;;) {
       Work* w = parsed_q.pop();
       if (!w) return;

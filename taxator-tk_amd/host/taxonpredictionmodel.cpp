@@ -53,6 +53,7 @@ RPAPredictionModel::RPAPredictionModel(const Taxonomy* tax, const SequenceStore&
 size_t RPAPredictionModel::makeResident(int which, const uint32_t* idx, size_t n) {
   const SequenceStore& st = which == RPA_STORE_QUERY ? query_sequences_ : db_sequences_;
   if (!st.indexed() || n == 0) return 0;
+  std::lock_guard<std::mutex> resident_lock(resident_mu_);
   std::vector<uint8_t>& res = resident_[which];
   // candidates: every host thread scans a slice of the indices against the (read-only) residency marks ...
   const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, n / 65536 + 1));
@@ -159,19 +160,28 @@ void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, s
 
 void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats) {
   if (hi <= lo) return;
+  // (re-entrant: the driver keeps two batches in flight per engine from two host threads)
   const uint32_t base = cb.set_offsets[lo];
-  set_offsets_.resize(hi - lo + 1);
-  for (size_t s = lo; s <= hi; ++s) set_offsets_[s - lo] = cb.set_offsets[s] - base;
+  std::vector<uint32_t> rebased;
+  const uint32_t* offsets = cb.set_offsets.data() + lo;
+  if (base != 0) {
+    rebased.resize(hi - lo + 1);
+    for (size_t s = lo; s <= hi; ++s) rebased[s - lo] = cb.set_offsets[s] - base;
+    offsets = rebased.data();
+  }
   rpa_batch b;
   b.n_sets = (uint32_t)(hi - lo); b.n_records = cb.set_offsets[hi] - base;
-  b.set_offsets = set_offsets_.data(); b.query_seq = cb.query_seq.data() + lo; b.query_len = cb.query_len.data() + lo;
+  b.set_offsets = offsets; b.query_seq = cb.query_seq.data() + lo; b.query_len = cb.query_len.data() + lo;
   b.qstart = cb.rec.qstart.data() + base; b.qstop = cb.rec.qstop.data() + base; b.rstart = cb.rec.rstart.data() + base;
   b.rstop = cb.rec.rstop.data() + base; b.score = cb.rec.score.data() + base; b.identities = cb.rec.identities.data() + base;
   b.alnlen = cb.rec.alnlen.data() + base; b.ref_seq = cb.rec.ref_seq.data() + base; b.node = cb.rec.node.data() + base;
   b.filtered = cb.rec.filtered.data() + base; b.mem_kind = RPA_MEM_HOST;
   makeResident(RPA_STORE_QUERY, b.query_seq, b.n_sets);
   makeResident(RPA_STORE_DB, b.ref_seq, b.n_records);
-  check(engine_, rpa_predict_batch(engine_, &b, rows, stats, RPA_MEM_HOST));
+  // asynchronous boundary: the engine runs two jobs at a time, the copies of one under the kernels of the other
+  rpa_job* job = nullptr;
+  check(engine_, rpa_submit_batch(engine_, &b, rows, stats, &job));
+  check(engine_, rpa_wait(engine_, job));
 }
 
 // ---- alignment-free models ----

@@ -5,6 +5,7 @@
 // and fills one PredictionRecord per set, in input order (what the reference's serial loop prints, taxator.cpp:69-74).
 // All computation happens behind the C ABI (include/taxator_rpa.h) in hand-written HIP; there is no CPU path.
 #pragma once
+#include <mutex>
 #include <ostream>
 #include <vector>
 
@@ -51,6 +52,7 @@ class RPAPredictionModel : public TaxonPredictionModel {
   std::vector<uint8_t> fetch_letters_;
   std::vector<uint64_t> fetch_offsets_;
   unsigned threads_ = 1;
+  std::mutex resident_mu_;
   rpa_engine* engine_ = nullptr;
   float stale_ival_ = -1.f;  // PredictionRecord is reused across calls in the reference (taxator.cpp:66): n==0 keeps the last ival
   std::vector<rpa_stats> stats_;

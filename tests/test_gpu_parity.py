@@ -642,3 +642,35 @@ def test_bad_batches_rejected(pkg, oracle, synth):
     rows2, _ = model.predict(ds.batch)                        # the engine is still usable
     assert rows2.tobytes() == rows.tobytes()
 
+
+def test_async_jobs_equal_synchronous_calls(pkg, oracle, synth):
+    """rpa_submit_batch / rpa_wait: two jobs in flight on two streams with their own working sets.  Different batches
+    (sizes, seeds, with and without masked records) submitted back to back, waited for out of order: every job's rows and
+    counters equal the synchronous call's; an invalid batch fails its own job only; a store append waits for the jobs."""
+    ds = synth.make_dataset(n_sets=3000, n_hits=12, seg_len=160, branching=2, genome_len=3000, seed=21, variety=True)
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    sharding = importlib.import_module("taxator_tk_amd.sharding")
+    cuts = [0, 1, 700, 701, 1500, 2999, 3000]
+    parts = [sharding.slice_batch(ds.batch, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    want = [model.predict(p) for p in parts]
+    jobs = [model.submit(p) for p in parts]
+    for k in (1, 0, 3, 2, 5, 4):
+        rows, st = jobs[k].wait()
+        assert rows.tobytes() == want[k][0].tobytes() and st.tobytes() == want[k][1].tobytes(), k
+    bad = {k: (v.copy() if v is not None else None) for k, v in parts[2].items()}
+    bad["node"][5] = 10 ** 7
+    j_ok, j_bad, j_ok2 = model.submit(parts[1]), model.submit(bad), model.submit(parts[3])
+    with pytest.raises(pkg.RpaError) as ei:
+        j_bad.wait()
+    assert ei.value.code == 1
+    assert j_ok.wait()[0].tobytes() == want[1][0].tobytes() and j_ok2.wait()[0].tobytes() == want[3][0].tobytes()
+    full = model.submit(ds.batch)
+    rows, _ = full.wait()
+    tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    q = oracle.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+    db = oracle.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+    rc, exp, _ = oracle.predict_batch(tax, q, db, 0, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"], synth.records_aos(ds.batch, oracle.RECORD_DTYPE))
+    assert rc == 0 and rows.tobytes() == exp.tobytes()
+
