@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 = the headline configuration (BASELINE config 2); c3 = config 3's per-GPU share (for --gpus 8), c4 protein, "
                          "c5 long contigs are extra measurements")
+    ap.add_argument("--in-flight", type=int, default=3, help="with --host-buffers: jobs submitted before the oldest is waited for (1..3)")
     ap.add_argument("--store-replicas", type=int, default=1,
                     help="lay the reference store out R times (R x 4096 sequences; every alignment row points at a random replica of its "
                          "species): the same work against a store that is really spread over HBM instead of sitting in L2 / "
@@ -277,6 +278,16 @@ def main():
 
     import collections
     in_flight = collections.deque()
+    host_out = []
+    if args.host_buffers:
+        # the caller's arrays are pinned once (a driver that reuses its batch buffers does the same): DMA at the PCIe rate
+        host_batch = {k: np.ascontiguousarray(v) for k, v in ds.batch.items()}
+        for v in host_batch.values():
+            model.pin(v)
+        for _ in range(4):  # rows / counters of the jobs in flight (+ one being read)
+            r_, s_ = np.zeros(ds.n_sets, pkg.PRED_DTYPE), np.zeros(ds.n_sets, pkg.STATS_DTYPE)
+            model.pin(r_); model.pin(s_)
+            host_out.append((r_, s_))
 
     def finish_one():
         r_host, s_host = in_flight.popleft().wait()
@@ -289,8 +300,10 @@ def main():
         if args.host_buffers:
             # the asynchronous boundary (rpa_submit_batch / rpa_wait): H2D of the batch columns and D2H of rows + counters
             # inside every job, two jobs in flight -- the copies of one under the kernels of the other
-            in_flight.append(model.submit(ds.batch))
-            if len(in_flight) == 2:
+            r_, s_ = host_out[step.n % 4]
+            step.n += 1
+            in_flight.append(model.submit(host_batch, out=r_, stats=s_))
+            if len(in_flight) == args.in_flight:
                 finish_one()
         else:
             model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
@@ -298,6 +311,7 @@ def main():
             sharding.gather_rows(rows, dst=0, sizes=gather_sizes, out=gather_out, force=True)
 
     step.copied = False
+    step.n = 0
     for _ in range(args.warmup):
         step()
     while in_flight:

@@ -168,7 +168,13 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
  * which also reports the job's status (rpa_last_error has the text) and releases the handle.  Jobs may be waited for in
  * any order; rows are in input order within a job, as with rpa_predict_batch (same semantics:
  * core/src/taxonpredictionmodel.hh:36-52).  Store loads / appends wait for the jobs in flight. */
-#define RPA_JOBS_IN_FLIGHT 2
+/* Host arrays handed to the engine are read with hipMemcpyAsync.  From pageable memory that copy is staged by the driver
+ * on the calling thread (~25 GB/s, and it does not overlap the other job's copies); from memory pinned with
+ * rpa_host_register it is a DMA at the PCIe rate that runs beside the kernels.  Register the batch arrays / output arrays
+ * you reuse from batch to batch once (page-pinning itself is slow: a few GB/s), unregister before freeing them. */
+int rpa_host_register(rpa_engine* e, void* ptr, size_t bytes);
+int rpa_host_unregister(rpa_engine* e, void* ptr);
+#define RPA_JOBS_IN_FLIGHT 3
 typedef struct rpa_job rpa_job;
 int rpa_submit_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, rpa_job** job);
 int rpa_wait(rpa_engine* e, rpa_job* job);

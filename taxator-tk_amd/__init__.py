@@ -33,7 +33,8 @@ ERROR_NAMES = {0: "OK", 1: "INVALID", 2: "DEVICE", 3: "RANGE", 4: "SEQ_ID", 5: "
 ABI_SYMBOLS = ["rpa_abi_version", "rpa_default_params", "rpa_create", "rpa_destroy", "rpa_last_error", "rpa_set_stream",
                "rpa_store_load", "rpa_predict_batch", "rpa_align_pairs", "rpa_profile_enable", "rpa_profile_get",
                "rpa_profile_reset", "rpa_lca_default_params", "rpa_lca_predict_batch", "rpa_store_reserve", "rpa_store_append",
-               "rpa_store_info_get", "rpa_submit_batch", "rpa_wait"]
+               "rpa_store_info_get", "rpa_submit_batch", "rpa_wait", "rpa_host_register",
+               "rpa_host_unregister"]
 
 LCA_DUMMY, LCA_SIMPLE, LCA_MEGAN, LCA_NBEST = 0, 1, 2, 3  # taxator -a dummy | simple-lca | megan-lca | n-best-lca
 
@@ -119,6 +120,10 @@ def load_library(path=None):
     L.rpa_submit_batch.restype = C.c_int
     L.rpa_wait.argtypes = [C.c_void_p, C.c_void_p]
     L.rpa_wait.restype = C.c_int
+    L.rpa_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rpa_host_register.restype = C.c_int
+    L.rpa_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
+    L.rpa_host_unregister.restype = C.c_int
     L.rpa_lca_default_params.argtypes = [C.POINTER(_LcaParams)]
     L.rpa_lca_default_params.restype = None
     L.rpa_lca_predict_batch.argtypes = [C.c_void_p, C.POINTER(_Batch), C.c_void_p, C.c_void_p, C.POINTER(_LcaParams), C.c_void_p, C.c_int]
@@ -203,15 +208,22 @@ class RPAPredictionModel:
         self._check(self._L.rpa_store_load(self._h, which, n, _ptr(letters), _ptr(offsets), mem_kind))
         self._keep = None
 
-    def submit(self, batch, want_stats=True):
-        """Asynchronous predict for a host batch: returns a job; job.wait() -> (rows, stats).  Two jobs run at a time."""
+    def pin(self, array):
+        """Page-lock a numpy array that is handed to predict()/submit() again and again (rpa_host_register)."""
+        self._check(self._L.rpa_host_register(self._h, array.ctypes.data, array.nbytes))
+
+    def unpin(self, array):
+        self._check(self._L.rpa_host_unregister(self._h, array.ctypes.data))
+
+    def submit(self, batch, want_stats=True, out=None, stats=None):
+        """Asynchronous predict for a host batch: returns a job; job.wait() -> (rows, stats).  RPA_JOBS_IN_FLIGHT (3) jobs run at a time."""
         arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in BATCH_FIELDS}
         filt = batch.get("filtered")
         filt = None if filt is None else np.ascontiguousarray(filt, np.uint8)
         n_sets, n_rec = len(arrs["set_offsets"]) - 1, len(arrs["qstart"])
         b = _Batch(n_sets, n_rec, *[_ptr(arrs[name]) for name, _ in BATCH_FIELDS], _ptr(filt), MEM_HOST)
-        rows = np.zeros(n_sets, PRED_DTYPE)
-        st = np.zeros(n_sets, STATS_DTYPE) if want_stats else None
+        rows = out if out is not None else np.zeros(n_sets, PRED_DTYPE)
+        st = stats if stats is not None else (np.zeros(n_sets, STATS_DTYPE) if want_stats else None)
         handle = C.c_void_p()
         self._check(self._L.rpa_submit_batch(self._h, C.byref(b), rows.ctypes.data, st.ctypes.data if want_stats else None, C.byref(handle)))
         model = self

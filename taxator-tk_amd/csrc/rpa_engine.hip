@@ -115,7 +115,7 @@ struct rpa_engine {
   int parts_override = 0;               // RPA_PARTS=n: cut every batch into n parts (tests, A/B); 0 = by size
   bool part_mode = false;               // running as one of several parts: the call's device time is taken by the owner
   // asynchronous jobs (rpa_submit_batch / rpa_wait): each slot is a worker engine (own stream, working set, staging) with
-  // a host thread of its own; two slots = two batches in flight, the copies of one under the kernels of the other
+  // a host thread of its own; RPA_JOBS_IN_FLIGHT slots = that many batches in flight, the copies of one under the kernels of the others
   rpa_engine* owner = nullptr;          // slots: whose stores and taxonomy they read
   std::vector<rpa_engine*> slots;       // owner only
   std::thread job_thread;               // slot only
@@ -999,6 +999,24 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
   if (!e) return RPA_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);
   return predict_on(e, e, batch, out, stats, out_mem_kind);
+}
+
+int rpa_host_register(rpa_engine* e, void* ptr, size_t bytes) {
+  if (!e) return RPA_ERR_INVALID;
+  if (!ptr || !bytes) return RPA_OK;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipHostRegister(ptr, bytes, hipHostRegisterPortable));  // every device of the process may DMA from it
+  return RPA_OK;
+}
+
+int rpa_host_unregister(rpa_engine* e, void* ptr) {
+  if (!e) return RPA_ERR_INVALID;
+  if (!ptr) return RPA_OK;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipHostUnregister(ptr));
+  return RPA_OK;
 }
 
 // ---- asynchronous jobs ----

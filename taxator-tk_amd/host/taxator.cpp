@@ -92,7 +92,30 @@ struct Work {
   bool failed = false;          // a GPU call failed on this block: nothing from here on is printed
   std::exception_ptr err;
   uint64_t seq = 0;             // position in the input: the writer prints in this order
+  std::vector<std::pair<void*, size_t>> pinned;  // the arrays below as they were page-locked last
 };
+
+// The columns of a Work object are reused from block to block: page-lock them (once per growth of a vector) so that the
+// engine's host<->device copies are DMA transfers that run beside the kernels of the other job in flight.
+template <class T> void add_range(std::vector<std::pair<void*, size_t>>& v, std::vector<T>& a) {
+  if (a.capacity()) v.emplace_back((void*)a.data(), a.capacity() * sizeof(T));
+}
+void pin_work(Work& w, const RPAPredictionModel& rpa) {
+  std::vector<std::pair<void*, size_t>> now;
+  ColumnarBatch& b = w.batch;
+  add_range(now, b.set_offsets); add_range(now, b.query_seq); add_range(now, b.query_len);
+  add_range(now, b.rec.qstart); add_range(now, b.rec.qstop); add_range(now, b.rec.rstart); add_range(now, b.rec.rstop);
+  add_range(now, b.rec.identities); add_range(now, b.rec.alnlen); add_range(now, b.rec.ref_seq); add_range(now, b.rec.node);
+  add_range(now, b.rec.score); add_range(now, b.rec.filtered); add_range(now, w.rows); add_range(now, w.stats);
+  if (now == w.pinned) return;
+  for (auto& r : w.pinned) rpa.unpinHost(r.first);
+  w.pinned.clear();
+  for (auto& r : now) { rpa.pinHost(r.first, r.second); w.pinned.push_back(r); }
+}
+void unpin_work(Work& w, const RPAPredictionModel& rpa) {
+  for (auto& r : w.pinned) { try { rpa.unpinHost(r.first); } catch (...) {} }
+  w.pinned.clear();
+}
 
 struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, records = 0; };
 
@@ -202,6 +225,7 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
       w->rows.resize(S);
       w->stats.resize(S);
       try {
+        if (S >= 4096) pin_work(*w, rpa);  // (not worth it for tiny blocks: page-locking costs more than their copies)
         const size_t step = max_sets ? max_sets : S;
         for (size_t lo = 0; lo < S; lo += step) {
           const size_t hi = std::min(S, lo + step);
@@ -226,6 +250,7 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
   stop.store(true);
   for (size_t k = 0; k < works.size(); ++k) free_q.push(nullptr);  // wake the reader if it waits for a Work object
   reader_thread.join();
+  for (Work& w : works) unpin_work(w, *models[0]);
   fflush(stdout);
   if (failure) std::rethrow_exception(failure);
 }

@@ -105,6 +105,9 @@ size_t RPAPredictionModel::makeResident(int which, const uint32_t* idx, size_t n
   return need.size();
 }
 
+void RPAPredictionModel::pinHost(void* p, size_t bytes) const { check(engine_, rpa_host_register(engine_, p, bytes)); }
+void RPAPredictionModel::unpinHost(void* p) const { check(engine_, rpa_host_unregister(engine_, p)); }
+
 rpa_store_info RPAPredictionModel::storeInfo(int which) const {
   rpa_store_info info{};
   check(engine_, rpa_store_info_get(engine_, which, &info));

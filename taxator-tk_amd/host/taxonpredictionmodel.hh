@@ -45,6 +45,9 @@ class RPAPredictionModel : public TaxonPredictionModel {
   size_t makeResident(int which, const uint32_t* idx, size_t n);
   void setHostThreads(unsigned t) { threads_ = t ? t : 1; }
   rpa_store_info storeInfo(int which) const;
+  // page-lock / release host arrays that are handed to predictColumns() again and again (rpa_host_register)
+  void pinHost(void* p, size_t bytes) const;
+  void unpinHost(void* p) const;
  private:
   const SequenceStore& query_sequences_;
   const SequenceStore& db_sequences_;
