@@ -9,63 +9,86 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as graft
 from helpers import oracle as O
 
-pkg = graft.load_package()
-synth = importlib.import_module("taxator_tk_amd.synth")
-n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(12345)
-t0 = time.time()
-total_sets = 0
-for k in range(n_seeds):
-    alphabet = int(rng.random() < 0.35)
-    n_hits = int(rng.integers(2, 41))
-    branching = int(rng.integers(2, 5))
-    if alphabet == 0:
-        seg = int(rng.choice([40, 90, 150, 200, 257, 320, 700, 1500]))
-        n_sets = int(rng.integers(50, 600)) if seg < 700 else int(rng.integers(10, 60))
-        kw = dict(level_rate=float(rng.choice([0.01, 0.03, 0.06])), query_rate=float(rng.choice([0.0, 0.05, 0.1])))
-    else:
-        seg = int(rng.choice([20, 67, 120, 253, 312, 400]))
-        n_sets = int(rng.integers(30, 300))
-        kw = dict(level_rate=float(rng.choice([0.03, 0.06, 0.12])), query_rate=float(rng.choice([0.0, 0.08, 0.15])))
-    n_species = branching ** 6
-    n_hits = min(n_hits, n_species)
-    ds = synth.make_dataset(n_sets=n_sets, n_hits=n_hits, seg_len=seg, branching=branching, genome_len=max(4 * seg, 1200),
-                            seed=1000 + k, alphabet=alphabet, variety=True, **kw)
-    env = {}
-    if rng.random() < 0.5:
-        env = {"RPA_SPEC1": str(int(rng.integers(0, 9))), "RPA_SPEC2": str(int(rng.integers(0, 9))),
-               "RPA_SPEC_GROW": str(int(rng.integers(0, 2))), "RPA_SPARSE_DECIDE": str(int(rng.choice([1, 3, 6, 24, 100000]))),
-               "RPA_SPARSE_EMIT": str(int(rng.choice([1, 6, 24, 100000])))}
-        if rng.random() < 0.3:
-            env["RPA_NO_COMBINED"] = "1"
-        if rng.random() < 0.3:
-            env["RPA_PARTS"] = str(int(rng.integers(2, 5)))
-    for kk in ("RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS"):
-        os.environ.pop(kk, None)
-    os.environ.update(env)
-    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
-    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
-    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
-    tax = O.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
-    q = O.StoreArrays(synth.encode(ds.query_letters, alphabet), ds.query_offsets)
-    db = O.StoreArrays(synth.encode(ds.ref_letters, alphabet), ds.ref_offsets)
-    rc, exp, est = O.predict_batch(tax, q, db, alphabet, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
-                                   synth.records_aos(ds.batch, O.RECORD_DTYPE))
-    try:
-        rows, stats = model.predict(ds.batch)
-        ok = rc == 0 and rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes()
-        what = "ok" if ok else "MISMATCH (oracle rc %d)" % rc
-    except pkg.RpaError as e:  # a batch the reference would abort on: both sides must say so (oracle 1/2/3 = engine 3/4/5)
-        ok = rc != 0 and e.code == rc + 2
-        rows = None
-        what = "both abort (oracle rc %d, engine %d)" % (rc, e.code) if ok else "MISMATCH: engine error %d %s, oracle rc %d" % (e.code, e, rc)
-    total_sets += n_sets
-    print("seed %d: %s sets=%d hits=%d seg=%d b=%d env=%s -> %s  (%.0f s)" % (1000 + k, "protein" if alphabet else "dna", n_sets, n_hits, seg,
-                                                                       branching, env, what, time.time() - t0), flush=True)
-    if not ok:
-        for f in (rows.dtype.names if rows is not None else ()):
-            bad = np.nonzero(rows[f] != exp[f])[0]
-            if len(bad):
-                print("  field", f, "sets", bad[:5], rows[f][bad[:5]], exp[f][bad[:5]])
-        sys.exit(1)
-print("soak ok: %d batches, %d record sets" % (n_seeds, total_sets))
+KNOBS = ("RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
+         "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL")
+
+
+def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
+  """Returns (batches, record sets, batches on which engine and oracle both abort); raises AssertionError at the first difference."""
+  pkg = graft.load_package()
+  synth = importlib.import_module("taxator_tk_amd.synth")
+  rng = np.random.default_rng(rng_seed)
+  t0 = time.time()
+  total_sets = 0
+  aborts = 0
+  for k in range(n_seeds):
+      alphabet = int(rng.random() < 0.35)
+      n_hits = int(rng.integers(2, 41))
+      branching = int(rng.integers(2, 5))
+      if alphabet == 0:
+          seg = int(rng.choice([40, 90, 150, 200, 257, 320, 700, 1500]))
+          n_sets = int(rng.integers(50, 600)) if seg < 700 else int(rng.integers(10, 60))
+          kw = dict(level_rate=float(rng.choice([0.01, 0.03, 0.06])), query_rate=float(rng.choice([0.0, 0.05, 0.1])))
+      else:
+          seg = int(rng.choice([20, 67, 120, 253, 312, 400]))
+          n_sets = int(rng.integers(30, 300))
+          kw = dict(level_rate=float(rng.choice([0.03, 0.06, 0.12])), query_rate=float(rng.choice([0.0, 0.08, 0.15])))
+      n_species = branching ** 6
+      n_hits = min(n_hits, n_species)
+      ds = synth.make_dataset(n_sets=n_sets, n_hits=n_hits, seg_len=seg, branching=branching, genome_len=max(4 * seg, 1200),
+                              seed=first_seed + k, alphabet=alphabet, variety=True, **kw)
+      env = {}
+      if rng.random() < 0.5:
+          env = {"RPA_SPEC1": str(int(rng.integers(0, 9))), "RPA_SPEC2": str(int(rng.integers(0, 9))),
+                 "RPA_SPEC_GROW": str(int(rng.integers(0, 2))), "RPA_SPARSE_DECIDE": str(int(rng.choice([1, 3, 6, 24, 100000]))),
+                 "RPA_SPARSE_EMIT": str(int(rng.choice([1, 6, 24, 100000])))}
+          if rng.random() < 0.3:
+              env["RPA_NO_COMBINED"] = "1"
+          if rng.random() < 0.3:
+              env["RPA_PARTS"] = str(int(rng.integers(2, 5)))
+      # the exact bands: forced onto launches of any size, margins from "every pair is retried" to generous, or switched off
+      if rng.random() < 0.6:
+          env["RPA_BAND_SHORT_MIN"] = "1"
+          env["RPA_BAND_MARGIN"] = str(int(rng.choice([1, 8, 16, 21, 40])))
+          if rng.random() < 0.15: env["RPA_BAND"] = "0"
+          if rng.random() < 0.15: env["RPA_BAND_SHORT"] = "0"
+          if alphabet == 0 and seg > 256 and rng.random() < 0.5: env["RPA_LONG_KERNEL"] = "lane"
+      for kk in KNOBS:
+          os.environ.pop(kk, None)
+      os.environ.update(env)
+      model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
+      model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+      model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+      tax = O.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+      q = O.StoreArrays(synth.encode(ds.query_letters, alphabet), ds.query_offsets)
+      db = O.StoreArrays(synth.encode(ds.ref_letters, alphabet), ds.ref_offsets)
+      rc, exp, est = O.predict_batch(tax, q, db, alphabet, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
+                                     synth.records_aos(ds.batch, O.RECORD_DTYPE))
+      try:
+          rows, stats = model.predict(ds.batch)
+          ok = rc == 0 and rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes()
+          what = "ok" if ok else "MISMATCH (oracle rc %d)" % rc
+      except pkg.RpaError as e:  # a batch the reference would abort on: both sides must say so (oracle 1/2/3 = engine 3/4/5)
+          ok = rc != 0 and e.code == rc + 2
+          aborts += ok
+          rows = None
+          what = "both abort (oracle rc %d, engine %d)" % (rc, e.code) if ok else "MISMATCH: engine error %d %s, oracle rc %d" % (e.code, e, rc)
+      total_sets += n_sets
+      if verbose or not ok:
+        print("seed %d: %s sets=%d hits=%d seg=%d b=%d env=%s -> %s  (%.0f s)" % (first_seed + k, "protein" if alphabet else "dna", n_sets, n_hits, seg,
+                                                                           branching, env, what, time.time() - t0), flush=True)
+      if not ok:
+          for f in (rows.dtype.names if rows is not None else ()):
+              bad = np.nonzero(rows[f] != exp[f])[0]
+              if len(bad):
+                  print("  field", f, "sets", bad[:5], rows[f][bad[:5]], exp[f][bad[:5]])
+          for kk in KNOBS: os.environ.pop(kk, None)
+          raise AssertionError("soak: seed %d differs from the oracle (%s)" % (first_seed + k, what))
+  for kk in KNOBS:
+      os.environ.pop(kk, None)
+  return n_seeds, total_sets, aborts
+
+
+if __name__ == "__main__":
+    n, sets, aborts = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40)
+    print("soak ok: %d batches, %d record sets (%d batches on which engine and oracle both abort)" % (n, sets, aborts))
