@@ -13,7 +13,10 @@
 #include <seqan/sequence.h>
 #include <seqan/modifier.h>
 #include <seqan/score.h>
+#include <chrono>
 #include <cstdint>
+#include <thread>
+#include <vector>
 
 using namespace seqan;
 
@@ -89,6 +92,74 @@ void ref_align_protein_batch(const uint8_t* letters, const uint64_t* offsets, co
   for (int k = 0; k < n; ++k)
     ref_align_protein(letters + offsets[pa[k]], (int)(offsets[pa[k] + 1] - offsets[pa[k]]), letters + offsets[pb[k]],
                       (int)(offsets[pb[k] + 1] - offsets[pb[k]]), out6 + 6 * (size_t)k, fout2 + 2 * (size_t)k);
+}
+
+// The timed form: every String is built BEFORE the clock starts (the reference builds them in getSequence, outside
+// getAlignment), then n_threads std::threads run `reps` passes over their slice of the pairs.  Returns the wall seconds
+// from the moment all threads are released to the moment the last one is done; *checksum (sum of the distances / mutual
+// scores) keeps the optimiser honest and lets the caller compare runs.
+double ref_time_dna_pairs(const uint8_t* letters, const uint64_t* offsets, const uint32_t* pa, const uint32_t* pb, int n, int n_threads,
+                          int reps, long long* checksum) {
+  std::vector<String<Dna5> > A(n), B(n);
+  for (int k = 0; k < n; ++k) {
+    fill_dna(A[k], letters + offsets[pa[k]], (int)(offsets[pa[k] + 1] - offsets[pa[k]]));
+    fill_dna(B[k], letters + offsets[pb[k]], (int)(offsets[pb[k] + 1] - offsets[pb[k]]));
+  }
+  if (n_threads < 1) n_threads = 1;
+  std::vector<long long> sums(n_threads, 0);
+  std::vector<std::thread> th;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([&, t] {
+      const int lo = (int)((long long)n * t / n_threads), hi = (int)((long long)n * (t + 1) / n_threads);
+      long long s = 0;
+      for (int r = 0; r < reps; ++r)
+        for (int k = lo; k < hi; ++k) {  // getAlignmentDNA's call (:144-150): shorter sequence first
+          const String<Dna5>& x = length(A[k]) < length(B[k]) ? A[k] : B[k];
+          const String<Dna5>& y = length(A[k]) < length(B[k]) ? B[k] : A[k];
+          s += -globalAlignmentScore(x, y, MyersBitVector());
+        }
+      sums[t] = s;
+    });
+  for (auto& x : th) x.join();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  long long total = 0;
+  for (long long v : sums) total += v;
+  if (checksum) *checksum = total;
+  return dt;
+}
+
+double ref_time_protein_pairs(const uint8_t* letters, const uint64_t* offsets, const uint32_t* pa, const uint32_t* pb, int n, int n_threads,
+                              int reps, long long* checksum) {
+  typedef String<AminoAcid> S; typedef Align<S, ArrayGaps> TAlign;
+  std::vector<S> A(n), B(n);
+  for (int k = 0; k < n; ++k) {
+    fill_aa(A[k], letters + offsets[pa[k]], (int)(offsets[pa[k] + 1] - offsets[pa[k]]));
+    fill_aa(B[k], letters + offsets[pb[k]], (int)(offsets[pb[k] + 1] - offsets[pb[k]]));
+  }
+  if (n_threads < 1) n_threads = 1;
+  std::vector<long long> sums(n_threads, 0);
+  std::vector<std::thread> th;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([&, t] {
+      const int lo = (int)((long long)n * t / n_threads), hi = (int)((long long)n * (t + 1) / n_threads);
+      long long s = 0;
+      auto algo = LinearGaps(); auto sc = Blosum62();
+      for (int r = 0; r < reps; ++r)
+        for (int k = lo; k < hi; ++k) {  // getAlignmentProtein's calls (:190-199): two self scores + the traced alignment
+          s += globalAlignmentScore(A[k], A[k], sc, algo) + globalAlignmentScore(B[k], B[k], sc, algo);
+          TAlign aln; resize(rows(aln), 2); assignSource(row(aln, 0), A[k]); assignSource(row(aln, 1), B[k]);
+          s += globalAlignment(aln, sc, algo);
+        }
+      sums[t] = s;
+    });
+  for (auto& x : th) x.join();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  long long total = 0;
+  for (long long v : sums) total += v;
+  if (checksum) *checksum = total;
+  return dt;
 }
 
 }  // extern "C"
