@@ -588,6 +588,228 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
   }
 }
 
+// K1s, two lanes per pair.  Lanes 2p and 2p+1 of a wavefront work on the same alignment: in round t the even lane ("A")
+// sweeps strip 2t, the odd lane ("B") strip 2t+1, ONE column group behind.  What A's strip hands down travels lane to
+// lane through the wavefront's crossbar (the planes of group g are produced in one iteration and consumed by B in the next);
+// only what B hands to the A lane of the next round goes through the HBM scratch -- half the boundary traffic of one
+// lane per pair -- and a launch has twice as many lanes, i.e. half the granularity of the last round of the chip.  B idles
+// while A sweeps the ~8 groups by which its window starts later, A while B finishes its window (~8 % of a round).
+// Band, probe, retry: as in k_myers_band; the two strips of a round share one half width h (refreshed after every round,
+// effective two rounds on), which the exactness argument covers (any h per strip that grows by at most HS from strip to strip).
+template <int NW>
+__global__ __launch_bounds__(kBlock, 4) void k_myers_band_duo(const uint2* __restrict__ list, uint32_t n_list,
+                                                            const uint32_t* __restrict__ n_list_dev, WorkDev w,
+                                                            uint32_t* __restrict__ scratch, uint32_t stride, uint32_t wide_open,
+                                                            uint32_t margin, uint2* __restrict__ retry, uint32_t* __restrict__ retry_n,
+                                                            unsigned long long* prof_acc) {
+  extern __shared__ uint32_t peq[];  // [5][NW][kBlock]: every lane the masks of its own strip
+  constexpr uint32_t HS = NW * 32u;
+  constexpr uint32_t kPairs = kBlock / 2;
+  const int tid = threadIdx.x;
+  const uint32_t lag = (uint32_t)tid & 1u;  // 0: lane A (upper strip of a round), 1: lane B (lower strip, one group behind)
+  const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
+  if (n_list_dev && blockIdx.x == 0 && tid == 0 && total) atomicAdd(&w.counters[kCtrRetryTotal], total);
+  uint32_t* __restrict__ sc = scratch + (blockIdx.x * kPairs + ((uint32_t)tid >> 1));  // per PAIR: group g, plane p at sc[(2g + p) * stride]
+  for (uint32_t base = blockIdx.x * kPairs; base < total; base += gridDim.x * kPairs) {
+    const uint32_t t = base + ((uint32_t)tid >> 1);
+    const bool active = t < total;
+    uint32_t m = 0, n = 0;
+    SegView pat{}, txt{};
+    if (active) {
+      uint32_t a, b, dst0;
+      resolve_pair(w, list[t], a, b, dst0);
+      pat = seg_view(w, a); txt = seg_view(w, b);  // B = the record set's anchor: the same text for ~50 consecutive pairs
+      n = txt.len; m = pat.len;
+    }
+    if (prof_acc) profile_add(prof_acc, active && lag == 0u, n, m);
+    if (!active) continue;  // both lanes of a pair leave together; no barrier below
+
+    const uint32_t words = (m + 31u) / 32u;
+    const uint32_t nstrips = (words + NW - 1u) / NW;
+    const uint32_t nrounds = (nstrips + 1u) / 2u;
+    const uint32_t n_groups = (n + 31u) >> 5;
+    // (32-bit arithmetic: segments are shorter than 2^29 residues, kLiteLenMask)
+    const int32_t delta = (int32_t)n - (int32_t)m, dlo = delta < 0 ? delta : 0, dhi = delta > 0 ? delta : 0;
+    const uint32_t h_open = n > m ? n : m;
+    uint32_t h_prev = h_open, h_cur = h_open, h_next = h_open, h_min = h_open;  // per ROUND (see k_myers_band)
+    int32_t bottom = 0, round_top = 0;  // round_top: what this round's A strip starts on top of (A lanes)
+    uint32_t VP[NW], VN[NW];
+    // first column group of strip `s` under half width h, and one past its last
+    auto win_lo = [&](uint32_t s, uint32_t h) -> uint32_t { const int32_t lo = (int32_t)(s * HS) + dlo - (int32_t)h; return lo > 0 ? (uint32_t)lo >> 5 : 0u; };
+    auto win_hi = [&](uint32_t s, uint32_t h) -> uint32_t {
+      const int32_t hi = (int32_t)(s * HS + HS) + dhi + (int32_t)h - 1;
+      return hi < 0 ? 0u : (((uint32_t)hi >> 5) + 1u < n_groups ? ((uint32_t)hi >> 5) + 1u : n_groups);
+    };
+    // rnd = -1: the probe (strip 0 by the A lane over the first columns, nothing stored); rnd >= 0: strips 2 rnd, 2 rnd + 1
+    for (int32_t rnd = wide_open ? 0 : -1; rnd < (int32_t)nrounds; ++rnd) {
+      const bool probe = rnd < 0;
+      const uint32_t s = probe ? 0u : 2u * (uint32_t)rnd + lag;  // my strip
+      const bool mine = probe ? lag == 0u : s < nstrips;         // (an odd number of strips: B rests in the last round)
+      const bool first = s == 0, last = !probe && s + 1u == nstrips;
+      const uint32_t wbase = s * NW, R = wbase * 32u;
+      if (mine) {
+        NtStream ps;
+        ps.init(pat, R);
+#pragma unroll
+        for (int wi = 0; wi < NW; ++wi) {
+          uint32_t mask[5];
+          peq_word(ps, wbase + wi, m, mask);
+#pragma unroll
+          for (int c = 0; c < 5; ++c) peq[(c * NW + wi) * kBlock + tid] = mask[c];
+        }
+      }
+#pragma unroll
+      for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
+      // windows: mine [g_lo, g_hi); the strip above me [ab_lo, ab_hi); the strip below me starts at g_next
+      uint32_t g_lo = 0u, g_hi = 0u, g_next = 0xFFFFFFFFu, ab_lo = 0u, ab_hi = 0u;
+      // the round's iterations `it`: A works on group it, B on group it - 1
+      uint32_t it_lo, it_hi;
+      if (probe) {
+        const uint32_t pg = (3u * NW) / 2u < n_groups ? (3u * NW) / 2u : n_groups;  // 1.5 x the strip's height in columns
+        g_hi = mine ? pg : 0u;
+        it_lo = 0u; it_hi = pg;
+      } else {
+        const uint32_t sa = 2u * (uint32_t)rnd;
+        g_lo = win_lo(s, h_cur); g_hi = mine ? win_hi(s, h_cur) : g_lo;
+        if (mine && !last) g_next = win_lo(s + 1u, lag ? h_next : h_cur);
+        if (!first) { ab_lo = win_lo(s - 1u, lag ? h_cur : h_prev); ab_hi = win_hi(s - 1u, lag ? h_cur : h_prev); }
+        const uint32_t a_lo = win_lo(sa, h_cur), a_hi = win_hi(sa, h_cur);
+        const uint32_t b_hi = sa + 1u < nstrips ? win_hi(sa + 1u, h_cur) + 1u : 0u;
+        it_lo = a_lo; it_hi = a_hi > b_hi ? a_hi : b_hi;
+        h_min = h_cur < h_min ? h_cur : h_min;
+      }
+      uint32_t probe_min = 0xFFFFFFFFu;
+      if (lag == 0u) bottom = (first ? 0 : round_top) + (int32_t)HS;  // A: on top of what B left (B: set when A reaches B's first group)
+      int32_t next_top = bottom;  // B: what the A lane of the next round starts on top of (g_next == g_lo: right here)
+      uint32_t Pout = 0, Nout = 0;
+      auto column = [&](uint32_t c, uint32_t hp_prev, uint32_t hn_prev) {
+        const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
+        uint32_t HP = 0, HN = 0;
+        uint32_t carry = hn_prev >> 31;
+#pragma unroll
+        for (int wi = 0; wi < NW; ++wi) {
+          const uint32_t vp = VP[wi], vn = VN[wi];
+          const uint32_t X = e[wi * kBlock] | vn;
+          uint32_t cout;
+          const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
+          carry = cout;
+          const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);
+          HN = vp & D0;
+          HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);
+          const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
+          const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+          hp_prev = HP;
+          hn_prev = HN;
+          VN[wi] = Xs & D0;
+          VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);
+        }
+        Pout = __builtin_amdgcn_alignbit(Pout, HP, 31);
+        Nout = __builtin_amdgcn_alignbit(Nout, HN, 31);
+      };
+      NtStream ts;
+      uint4 pending = make_uint4(0u, 0u, 0u, 0u);
+      if (g_lo < g_hi) { ts.init(txt, g_lo * 32u); pending = ts.load4(); }
+      // A lanes: the planes of the strip above come from the scratch, asked for a group ahead
+      uint32_t Pn = 0xFFFFFFFFu, Nn = 0u;
+      if (lag == 0u && g_lo < g_hi && g_lo >= ab_lo && g_lo < ab_hi) { Pn = sc[(size_t)(2u * g_lo) * stride]; Nn = sc[(size_t)(2u * g_lo + 1u) * stride]; }
+      uint32_t Pkeep = 0u, Nkeep = 0u;  // my planes of the group I finished in the previous iteration (A: what B takes next)
+      for (uint32_t it = it_lo; it < it_hi; ++it) {
+        // from the lane above (the A lane of my pair, for B): its planes of the group it just finished = the group I am about
+        // to work on, and its bottom score BEFORE this iteration's group (= at column 32 it)
+        const uint32_t upP = (uint32_t)__shfl_up((int)Pkeep, 1, 64), upN = (uint32_t)__shfl_up((int)Nkeep, 1, 64);
+        const int32_t up_bottom = __shfl_up(bottom, 1, 64);
+        if (lag == 1u && mine && it == g_lo) { bottom = up_bottom + (int32_t)HS; next_top = bottom; }  // B starts here next iteration
+        const uint32_t g = it - lag;  // wraps for B at it == 0: not inside any window
+        if (g >= g_lo && g < g_hi) {
+          const uint4 buf = ts.take32(pending);
+          if (g + 1u < g_hi) pending = ts.load4();
+          uint32_t Pin, Nin;
+          if (lag == 0u) {
+            Pin = Pn; Nin = Nn;
+            Pn = 0xFFFFFFFFu; Nn = 0u;
+            if (g + 1u < g_hi && g + 1u >= ab_lo && g + 1u < ab_hi) {
+              const uint32_t* __restrict__ nx = sc + (size_t)(2u * (g + 1u)) * stride;
+              Pn = nx[0]; Nn = nx[stride];
+            }
+          } else {
+            const bool have = g >= ab_lo && g < ab_hi;  // did the A lane sweep this group?
+            Pin = have ? upP : 0xFFFFFFFFu; Nin = have ? upN : 0u;
+          }
+          const uint32_t cols = n - g * 32u;
+          Pout = 0u; Nout = 0u;
+#pragma unroll 1
+          for (uint32_t q = 0; q < 4u && q * 8u < cols; ++q) {
+            const uint32_t d = q == 0u ? buf.x : q == 1u ? buf.y : q == 2u ? buf.z : buf.w;
+            const uint32_t left = cols - q * 8u;
+            if (left >= 8u) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) column((d >> (4 * k)) & 7u, Pin << k, Nin << k);
+              Pin <<= 8; Nin <<= 8;
+            } else {
+#pragma unroll 1
+              for (uint32_t k = 0; k < left; ++k) {
+                column((d >> (4u * k)) & 7u, Pin, Nin);
+                Pin <<= 1; Nin <<= 1;
+              }
+            }
+          }
+          bottom += (int32_t)__popc(Pout) - (int32_t)__popc(Nout);
+          if (g + 1u == g_next) next_top = bottom;
+          probe_min = (uint32_t)bottom < probe_min ? (uint32_t)bottom : probe_min;
+          if (cols < 32u) { const uint32_t sh = 32u - cols; Pout <<= sh; Nout <<= sh; }
+          Pkeep = Pout; Nkeep = Nout;
+          if (lag == 1u && !last && !probe && g >= g_next) {  // B -> the A lane of the next round: through the scratch
+            uint32_t* __restrict__ o = sc + (size_t)(2u * g) * stride;
+            o[0] = Pout; o[stride] = Nout;
+          }
+        }
+      }
+      // B's strip is the round's lower one: the next round's A strip starts on top of it.  (An A strip that is the last of
+      // an odd count has no successor.)
+      {
+        const int32_t from_b = __shfl_down(next_top, 1, 64);
+        if (lag == 0u) round_top = from_b;
+      }
+      if (!wide_open) {
+        // budget for all m rows from the cheapest way to have consumed the rows seen so far (the round's deepest strip);
+        // one half width for the whole wavefront, effective two rounds on (k_myers_band)
+        const uint32_t rows = R + HS;
+        const float f = 1.0f + (float)((int32_t)margin - (int32_t)kProbeMarginDen) * (1.0f / kProbeMarginDen) * __builtin_sqrtf((float)HS / (float)rows);
+        const float est = (float)probe_min * ((float)m / (float)rows) * f + (float)kProbeSlack;
+        uint32_t mine_h = est * 0.5f < (float)h_open ? (uint32_t)(est * 0.5f) : h_open;
+        if (!mine || probe_min == 0xFFFFFFFFu) mine_h = 0u;  // a resting lane has no say
+        // within a pair the deeper strip's estimate counts (more rows seen): take B's when B worked
+        const uint32_t other = (uint32_t)__shfl_xor((int)mine_h, 1, 64);
+        const bool b_worked = probe ? false : (2u * (uint32_t)rnd + 1u < nstrips);
+        const uint32_t pair_h = b_worked ? (lag ? mine_h : other) : (lag ? other : mine_h);
+        uint32_t hmax = 0u;
+        for (unsigned long long mk = __ballot(1); mk; mk &= mk - 1ull) {
+          const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)pair_h, __ffsll((long long)mk) - 1);
+          hmax = o > hmax ? o : hmax;
+        }
+        if (probe) { h_prev = hmax; h_cur = hmax; h_next = hmax; }
+        else { h_prev = h_cur; h_cur = h_next; h_next = hmax < h_cur + HS ? hmax : h_cur + HS; }
+      }
+    }
+    // the lane that swept the last strip holds the answer
+    if (((nstrips - 1u) & 1u) == lag) {
+      int32_t dist = bottom;
+#pragma unroll
+      for (int wi = 0; wi < NW; ++wi) {
+        const uint32_t pos = ((nstrips - 1u) * NW + wi) * 32u;
+        const uint32_t tail = pos >= m ? 0xFFFFFFFFu : (m - pos >= 32u ? 0u : ~((1u << (m - pos)) - 1u));
+        dist -= (int32_t)__popc(VP[wi] & tail) - (int32_t)__popc(VN[wi] & tail);
+      }
+      const uint64_t k = 2ull * h_min + (uint64_t)(delta < 0 ? -delta : delta);
+      uint32_t a, b, dst;
+      const uint2 entry = list[t];  // (read again: two registers less to carry through the sweep)
+      resolve_pair(w, entry, a, b, dst);
+      if ((uint64_t)(uint32_t)dist <= k) store_dna_result(w, dst, dist, n, m);
+      else retry[atomicAdd(retry_n, 1u)] = entry;
+    }
+  }
+}
+
 static size_t strip_words_per_thread(uint32_t max_len) { return 2 * (((size_t)max_len + 31) / 32) + 2; }  // two bit planes per 32 columns
 
 size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len) {
@@ -607,18 +829,23 @@ hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2*
                                    bool wide_open, uint32_t margin, uint2* retry, uint32_t* retry_n, unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
   if (!retry || !retry_n) wide_open = true;  // nowhere to put a pair that leaves its band
-  size_t threads = scratch_words / strip_words_per_thread(max_len) / kBlock * kBlock;
-  if (threads == 0) return hipErrorOutOfMemory;
+  static const bool duo = !(getenv("RPA_BAND_DUO") && atoi(getenv("RPA_BAND_DUO")) == 0);  // two lanes per pair (default) / one (A/B)
+  const uint32_t per_block = duo ? kBlock / 2 : kBlock;  // pairs a workgroup holds = scratch slots it needs
+  size_t slots = scratch_words / strip_words_per_thread(max_len) / per_block * per_block;
+  if (slots == 0) return hipErrorOutOfMemory;
   const size_t lds = (size_t)5 * strip_words * kBlock * sizeof(uint32_t);
   for (uint32_t done = 0; done < n;) {
-    uint32_t chunk = (uint32_t)((size_t)(n - done) < threads ? (n - done) : threads);
-    uint32_t blocks = (chunk + kBlock - 1) / kBlock;
+    uint32_t chunk = (uint32_t)((size_t)(n - done) < slots ? (n - done) : slots);
+    uint32_t blocks = (chunk + per_block - 1) / per_block;
     if (n_dev) {  // one launch that strides over whatever the device-side count turns out to be
       chunk = n;
       if (grid_blocks && blocks > grid_blocks) blocks = grid_blocks;
     }
 #define RPA_LAUNCH_STRIPS(NWV) \
-  case NWV: hipLaunchKernelGGL(k_myers_band<NWV>, dim3(blocks), dim3(kBlock), lds, st, list + done, chunk, n_dev, w, scratch, blocks * kBlock, wide_open ? 1u : 0u, margin, retry, retry_n, prof_acc); break;
+  case NWV: \
+    if (duo) hipLaunchKernelGGL(k_myers_band_duo<NWV>, dim3(blocks), dim3(kBlock), lds, st, list + done, chunk, n_dev, w, scratch, blocks * per_block, wide_open ? 1u : 0u, margin, retry, retry_n, prof_acc); \
+    else hipLaunchKernelGGL(k_myers_band<NWV>, dim3(blocks), dim3(kBlock), lds, st, list + done, chunk, n_dev, w, scratch, blocks * per_block, wide_open ? 1u : 0u, margin, retry, retry_n, prof_acc); \
+    break;
     switch (strip_words) {
       RPA_LAUNCH_STRIPS(5) RPA_LAUNCH_STRIPS(6) RPA_LAUNCH_STRIPS(7) RPA_LAUNCH_STRIPS(8)
       default: return hipErrorInvalidValue;
