@@ -200,6 +200,10 @@ def main():
                          "species): the same work against a store that is really spread over HBM instead of sitting in L2 / "
                          "Infinity Cache -- 2000 replicas of config 2's 16 Mbase collection = 32 GB packed.  An extra measurement, "
                          "never the headline")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL over xGMI, the real thing) or gloo: rows are gathered through host memory, which lets several "
+                         "ranks share ONE GPU -- a rehearsal of the N > 1 code (shards, cost cut, uneven gathers) on a 1-GPU box")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (with --dist-backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl = RCCL) and run the gather path even with one rank (hardware rehearsal of the N > 1 code)")
     ap.add_argument("--sets", type=int, default=None, help="record sets per GPU (default: the configuration's)")
@@ -226,12 +230,18 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the RPA engine has no CPU path")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    gloo = args.dist_backend == "gloo"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = graft.load_package()
     synth = importlib.import_module("taxator_tk_amd.synth")
@@ -287,7 +297,8 @@ def main():
 
     # X1: PredictionRecord rows of every rank to rank 0 over xGMI (RCCL gather); shard sizes are equal and known, the
     # receive buffers on rank 0 are allocated once
-    gather_out = ([torch.empty((max(gather_sizes), 8), dtype=torch.int32, device="cuda") for _ in range(world)]
+    cdev = "cpu" if gloo else "cuda"  # where the collectives' tensors live
+    gather_out = ([torch.empty((max(gather_sizes), 8), dtype=torch.int32, device=cdev) for _ in range(world)]
                   if (use_dist and rank == 0) else None)
 
     import collections
@@ -322,10 +333,13 @@ def main():
         else:
             model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
         if use_dist:
-            sharding.gather_rows(rows, dst=0, sizes=gather_sizes, out=gather_out, force=True)
+            if gloo:
+                torch.cuda.current_stream().synchronize()
+            step.gathered = sharding.gather_rows(rows.cpu() if gloo else rows, dst=0, sizes=gather_sizes, out=gather_out, force=True)
 
     step.copied = False
     step.n = 0
+    step.gathered = None
     for _ in range(args.warmup):
         step()
     while in_flight:
@@ -348,9 +362,9 @@ def main():
     prof = model.profile()
 
     demanded = int(stats[:, 1:].to(torch.int64).sum().item())  # per step, this rank
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    d = torch.tensor([demanded], dtype=torch.int64, device="cuda")
-    n_sets_all = torch.tensor([ds.n_sets], dtype=torch.int64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    d = torch.tensor([demanded], dtype=torch.int64, device=cdev)
+    n_sets_all = torch.tensor([ds.n_sets], dtype=torch.int64, device=cdev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(d, op=dist.ReduceOp.SUM)
@@ -364,7 +378,12 @@ def main():
         traffic, traffic_src = None, None
         if use_dist and rank == 0:  # the gathered rows of this rank's own shard must be the rows it computed
             own = gather_out[0][: gather_sizes[0]] if isinstance(gather_out, list) else None
-            assert own is None or torch.equal(own, rows), "gathered rows differ from the computed ones"
+            assert own is None or torch.equal(own, rows.cpu() if gloo else rows), "gathered rows differ from the computed ones"
+            g = step.gathered
+            n_gathered = sum(x.shape[0] for x in g) if isinstance(g, list) else g.shape[0]
+            if isinstance(g, list) and len(set(gather_sizes)) == 1:
+                n_gathered = sum(gather_sizes)
+            assert n_gathered == sum(gather_sizes), "the gather did not return every rank's rows"
         if args.sets == cfg["sets"] and args.hits == cfg["hits"] and args.seg_len == cfg["seg_len"]:
             import glob
             # profiles/<round>_traffic.json = config 2 (the headline), profiles/<round>_cN_traffic.json = config N
@@ -388,8 +407,10 @@ def main():
                                    % (cfg["name"], args.sets, args.hits, args.seg_len, "bp nucleotide" if cfg["alphabet"] == 0 else "aa protein")
                                    + (" -- HOST BUFFERS: batch copied to the device and rows back inside every step, two steps in flight through rpa_submit_batch / rpa_wait (PCIe-inclusive, not the headline)" if args.host_buffers else ""),
                        "record_sets_per_gpu": args.sets, "hits_per_set": args.hits, "segment_bp": args.seg_len,
-                       "parallelism": ("record sets sharded over %d GPU(s)%s; RCCL gather of 32-byte rows to rank 0 every step"
-                                       % (world, ", ONE workload cut by summed alignment cells" if cut_by_cost else "")) if use_dist else "single GPU",
+                       "parallelism": ("record sets sharded over %d rank(s)%s; %s gather of 32-byte rows to rank 0 every step"
+                                       % (world, ", ONE workload cut by summed alignment cells" if cut_by_cost else "",
+                                          "gloo (host memory; REHEARSAL, ranks may share a GPU)" if gloo else "RCCL")) if use_dist else "single GPU",
+                       "shard_sets": gather_sizes,
                        "unit_counted": "alignments demanded by the reference control flow (STATS gcounter), not speculative ones"},
             "record_sets_per_s": int(n_sets_all.item()) * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

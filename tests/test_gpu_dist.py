@@ -37,3 +37,24 @@ def test_bench_one_rank_over_rccl(config, extra):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
     assert "RCCL gather" in out["config"]["parallelism"]
     assert out["roofline"]["achieved"] > 0 and out["roofline"]["launches"] > 0
+
+
+@pytest.mark.parametrize("config,extra", [("c3", ["--sets", "20000"]), ("c5", ["--sets", "24", "--seg-len", "2500"])])
+def test_bench_two_ranks_share_the_gpu(config, extra):
+    """Two ranks, two processes, two engines on the one GPU of the test box (gloo gathers the rows through host memory:
+    RCCL refuses two ranks on one device).  What this executes that nothing else does before the driver's 8-GPU run:
+    per-rank seeds (c3), ONE workload cut by summed alignment cells into shards of different sizes and the uneven gather
+    (c5), barrier / all_reduce bracketing with world size 2, two engines sharing a device."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--dist-backend", "gloo", "--one-device"] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    shards = out["config"]["shard_sets"]
+    assert len(shards) == 2 and sum(shards) == 2 * int(extra[1])
+    if config == "c5":
+        assert "cut by summed alignment cells" in out["config"]["parallelism"]
+
