@@ -333,6 +333,108 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band(const uint2* __rest
   else retry[atomicAdd(retry_n, 1u)] = entry;
 }
 
+// The same with a window of FOUR words, half a group out of phase with the text groups: the first 16 columns of group g
+// update words g-2 .. g+1, the last 16 columns words g-1 .. g+2.  A window that slides one word per 32 columns guarantees a
+// band of 16 (words - 1) diagonals either side when it is centred like this: |j - i| <= 48, i.e. h = 48 - |delta|,
+// k = 96 - |delta| (five words, in phase: 64 and 128).  Config 2's pass-1 pairs (55-65 edits, |delta| < 20) still fit; a
+// column costs 3.6 word updates on average instead of 4.3 (of 7).  tools/band_model.py: banded_window_phase.
+template <int NW, int WLO, int WHI>
+__device__ __forceinline__ void band_sweep16(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ peq_lane, uint32_t d0,
+                                             uint32_t d1, uint32_t ncols) {
+#pragma unroll 1
+  for (uint32_t q = 0; q < 2u && q * 8u < ncols; ++q) {
+    const uint32_t d = q == 0u ? d0 : d1;
+    const uint32_t left = ncols - q * 8u;
+    if (left >= 8u) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) myers_column_window<NW, WLO, WHI>(VP, VN, peq_lane + ((d >> (4 * k)) & 7u) * (NW * kBlock));
+    } else {
+#pragma unroll 1
+      for (uint32_t k = 0; k < left; ++k) myers_column_window<NW, WLO, WHI>(VP, VN, peq_lane + ((d >> (4u * k)) & 7u) * (NW * kBlock));
+    }
+  }
+}
+
+template <int NW, int G>
+struct BandGroups4 {
+  static __device__ __forceinline__ void run(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ peq_lane,
+                                             NtStream& ts, uint4& pending, uint32_t n, uint32_t n_groups, int32_t& T, int32_t& top) {
+    if ((uint32_t)G >= n_groups) return;
+    constexpr int ALO = G - 2 > 0 ? G - 2 : 0, AHI = G + 1 < NW - 1 ? G + 1 : NW - 1;
+    constexpr int BLO = G - 1 > 0 ? G - 1 : 0, BHI = G + 2 < NW - 1 ? G + 2 : NW - 1;
+    const uint4 buf = ts.take32(pending);
+    if ((uint32_t)G + 1u < n_groups) pending = ts.load4();
+    const uint32_t cols = n - (uint32_t)G * 32u < 32u ? n - (uint32_t)G * 32u : 32u;
+    const uint32_t ca = cols < 16u ? cols : 16u;
+    band_sweep16<NW, ALO, AHI>(VP, VN, peq_lane, buf.x, buf.y, ca);
+    T += (int32_t)ca;
+    top = ALO;
+    if (cols > 16u) {  // columns follow: the window moves down a word
+      if constexpr (G - 2 >= 0 && G - 2 <= NW - 1) T += (int32_t)__popc(VP[G - 2]) - (int32_t)__popc(VN[G - 2]);
+      top = BLO;
+      band_sweep16<NW, BLO, BHI>(VP, VN, peq_lane, buf.z, buf.w, cols - 16u);
+      T += (int32_t)(cols - 16u);
+    }
+    if constexpr (G + 1 < NW + 2) BandGroups4<NW, G + 1>::run(VP, VN, peq_lane, ts, pending, n, n_groups, T, top);
+  }
+};
+
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __restrict__ list, uint32_t n_list,
+                                                               const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
+                                                               uint2* __restrict__ retry, uint32_t* __restrict__ retry_n,
+                                                               unsigned long long* prof_acc) {
+  extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
+  const int tid = threadIdx.x;
+  const uint32_t t = blockIdx.x * kBlock + tid;
+  const bool active = t < n_list + n_list2;
+  uint32_t dst = 0, m = 0, n = 0;
+  SegView pat{}, txt{};
+  uint2 entry = make_uint2(0u, 0u);
+  if (active) {
+    uint32_t a, b;
+    entry = t < n_list ? list[t] : list2[t - n_list];
+    resolve_pair(w, entry, a, b, dst);
+    SegView va = seg_view(w, a), vb = seg_view(w, b);
+    const bool a_pat = (va.len + 31u) / 32u == (vb.len + 31u) / 32u ? va.len >= vb.len : va.len < vb.len;  // as in k_myers_short
+    if (a_pat) { txt = vb; pat = va; } else { txt = va; pat = vb; }
+    n = txt.len; m = pat.len;
+  }
+  if (prof_acc) profile_add(prof_acc, active, n, m);
+  NtStream ps;
+  if (active) ps.init(pat, 0u);
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) {
+    uint32_t mask[5] = {0u, 0u, 0u, 0u, 0u};
+    if (active) peq_word(ps, (uint32_t)wi, m, mask);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) peq[(c * NW + wi) * kBlock + tid] = mask[c];
+  }
+  if (!active) return;
+  const uint32_t ad = n > m ? n - m : m - n;
+  if (ad >= 48u) { retry[atomicAdd(retry_n, 1u)] = entry; return; }  // no band of this shape holds the corridor
+  uint32_t VP[NW], VN[NW];
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
+  const uint32_t n_groups = (n + 31u) >> 5;  // <= NW + 2: n < m + 48 <= 32 NW + 48
+  int32_t T = 0, top = 0;
+  if (n_groups) {
+    NtStream ts;
+    ts.init(txt, 0u);
+    uint4 pending = ts.load4();
+    BandGroups4<NW, 0>::run(VP, VN, peq + tid, ts, pending, n, n_groups, T, top);
+  }
+  int32_t dist = T;
+#pragma unroll
+  for (int wi = 0; wi < NW; ++wi) {
+    const uint32_t pos = (uint32_t)wi * 32u;
+    const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
+    if (wi >= top) dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
+  }
+  if ((uint32_t)dist <= 96u - ad) store_dna_result(w, dst, dist, n, m);
+  else retry[atomicAdd(retry_n, 1u)] = entry;
+}
+
 hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint32_t* n_dev, uint32_t grid_blocks,
                                   const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc) {
   if ((uint64_t)n + n2 == 0) return hipSuccess;
@@ -361,8 +463,13 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
   if ((uint64_t)n + n2 > 0xFFFFFF00ull || !retry || !retry_n) return hipErrorInvalidValue;
   const uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
   const size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
+  const char* bw = getenv("RPA_BAND_WORDS");  // 5: the in-phase five-word window (A/B, tests)
+  const bool five = bw && atoi(bw) == 5;
 #define RPA_LAUNCH_MYERS_BAND(NWV) \
-  case NWV: hipLaunchKernelGGL((k_myers_short_band<NWV, 2>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); break;
+  case NWV: \
+    if (five) hipLaunchKernelGGL((k_myers_short_band<NWV, 2>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
+    else hipLaunchKernelGGL((k_myers_short_band4<NWV>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
+    break;
   switch (words) {
     RPA_LAUNCH_MYERS_BAND(5) RPA_LAUNCH_MYERS_BAND(6) RPA_LAUNCH_MYERS_BAND(7) RPA_LAUNCH_MYERS_BAND(8)
     default: return hipErrorInvalidValue;
@@ -829,7 +936,8 @@ hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2*
                                    bool wide_open, uint32_t margin, uint2* retry, uint32_t* retry_n, unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
   if (!retry || !retry_n) wide_open = true;  // nowhere to put a pair that leaves its band
-  static const bool duo = !(getenv("RPA_BAND_DUO") && atoi(getenv("RPA_BAND_DUO")) == 0);  // two lanes per pair (default) / one (A/B)
+  const char* bd = getenv("RPA_BAND_DUO");
+  const bool duo = !(bd && atoi(bd) == 0);  // two lanes per pair (default) / one (A/B, tests)
   const uint32_t per_block = duo ? kBlock / 2 : kBlock;  // pairs a workgroup holds = scratch slots it needs
   size_t slots = scratch_words / strip_words_per_thread(max_len) / per_block * per_block;
   if (slots == 0) return hipErrorOutOfMemory;

@@ -12,3 +12,5 @@ def test_band_model():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check(trials=800, seed=3) == 800
+    assert mod.check_window(trials=1500, seed=4) == 1500              # K1: five words, in phase with the text groups
+    assert mod.check_window_phase(trials=2000, seed=6) == 2000       # K1: four words, half a group out of phase

@@ -108,7 +108,7 @@ def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
     assert out.tobytes() == out2.tobytes()
 
 
-@pytest.mark.parametrize("band", ["forced", "off"])
+@pytest.mark.parametrize("band", ["forced", "five-words", "off"])
 def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     """Patterns of 5..8 words (129..256 nt) go through a one-strip kernel that only updates the pattern words within two
     words of the diagonal; pairs whose distance lies outside that band (or whose lengths differ by 64 and more) are
@@ -116,6 +116,7 @@ def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     equal to the oracle -- from identical pairs to unrelated ones, with N's, and every length difference class."""
     monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")
     if band == "off": monkeypatch.setenv("RPA_BAND_SHORT", "0")
+    if band == "five-words": monkeypatch.setenv("RPA_BAND_WORDS", "5")  # the in-phase window (k = 128 - |delta|); default: four words, out of phase (96)
     rng = np.random.default_rng(12)
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
     a_codes, b_codes = [], []
@@ -143,7 +144,7 @@ def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     _check_dna(oracle, out, a_codes, b_codes)
 
 
-@pytest.mark.parametrize("band", ["default", "tight", "off"])
+@pytest.mark.parametrize("band", ["default", "tight", "off", "one-lane"])
 def test_dna_long_pairs_band(pkg, oracle, band, monkeypatch):
     """The strip kernel only computes the cells inside Ukkonen's band around a probed distance estimate; a pair whose
     distance lies outside its band is re-run with the band wide open (one pair per wavefront up to 16384 nt, the strip
@@ -152,6 +153,7 @@ def test_dna_long_pairs_band(pkg, oracle, band, monkeypatch):
     monkeypatch.setenv("RPA_LONG_KERNEL", "lane")
     if band == "tight": monkeypatch.setenv("RPA_BAND_MARGIN", "1")
     if band == "off": monkeypatch.setenv("RPA_BAND", "0")
+    if band == "one-lane": monkeypatch.setenv("RPA_BAND_DUO", "0")  # the strip kernel with one lane per pair (default: two)
     rng = np.random.default_rng(11)
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
     a_codes, b_codes = [], []

@@ -238,3 +238,98 @@ def check_window(trials=3000, seed=2):
 
 if __name__ == "__main__":
     print("window ok", check_window())
+
+
+# ---- K1, four-word window phase-shifted by half a group (k_myers_short_band<NW, 4 words>) --------------------------------
+def banded_window_phase(pat, txt, NW, W=4):
+    """Window of FOUR words that slides down one word per W columns, half a group out of phase with the text groups: the
+    first W/2 columns of group g update words [g-2, g+1], the last W/2 columns words [g-1, g+2] (clipped).  Guaranteed
+    band: |j - i| <= 1.5 W - ... => h = 1.5 W - |delta|, k = 2 h + |delta| = 3 W - |delta|  (W = 32: k = 96 - |delta|).
+    Returns (D', applicable, ok)."""
+    m, n = len(pat), len(txt)
+    assert 1 <= m <= NW * W and W % 2 == 0
+    ad = abs(n - m)
+    if 2 * ad >= 3 * W:
+        return None, False, False
+    k = 3 * W - ad
+    mask = (1 << W) - 1
+    eq = {}
+    for c in set(txt):
+        eq[c] = [sum(1 << r for r in range(W) if wi * W + r < m and pat[wi * W + r] == c) for wi in range(NW)]
+    VP = [mask] * NW
+    VN = [0] * NW
+    T = 0
+    half = W // 2
+
+    def sweep(j0, j1, wlo, whi):
+        for j in range(j0, j1):
+            e = eq[txt[j]]
+            hp_in, hn_in = 1, 0
+            for wi in range(wlo, whi + 1):
+                vp, vn = VP[wi], VN[wi]
+                X = e[wi] | vn
+                sm = vp + (X & vp) + hn_in
+                D0 = ((sm ^ vp) | X) & mask
+                HN = vp & D0
+                HP = (vn | ~(vp | D0)) & mask
+                Xs = ((HP << 1) | hp_in) & mask
+                Hs = ((HN << 1) | hn_in) & mask
+                VN[wi] = Xs & D0
+                VP[wi] = (Hs | ~(Xs | D0)) & mask
+                hp_in, hn_in = (HP >> (W - 1)) & 1, (HN >> (W - 1)) & 1
+
+    n_groups = (n + W - 1) // W
+    top = 0  # first word of the window in effect
+    for g in range(n_groups):
+        c0 = g * W
+        ca = min(n, c0 + half)
+        top = max(0, g - 2)
+        sweep(c0, ca, top, min(NW - 1, g + 1))
+        T += ca - c0
+        if ca < n:  # columns follow: the window moves down a word (if its first word was a real one)
+            if g - 2 >= 0 and g - 2 <= NW - 1:
+                T += bin(VP[g - 2]).count("1") - bin(VN[g - 2]).count("1")
+            top = max(0, g - 1)
+            cb = min(n, c0 + W)
+            sweep(ca, cb, top, min(NW - 1, g + 2))
+            T += cb - ca
+    dist = T
+    for wi in range(min(top, NW), NW):
+        for r in range(W):
+            if wi * W + r < m:
+                dist += ((VP[wi] >> r) & 1) - ((VN[wi] >> r) & 1)
+    return dist, True, dist <= k
+
+
+def check_window_phase(trials=4000, seed=5):
+    rng = random.Random(seed)
+    for t in range(trials):
+        W = rng.choice([4, 8]); NW = rng.randint(1, 8)
+        m = rng.randint(1, NW * W)
+        a = [rng.randrange(3) for _ in range(m)]
+        b = []
+        rate = rng.choice([0.0, 0.05, 0.2, 0.5, 0.9])
+        for c in a:
+            r = rng.random()
+            if r < rate / 3: continue
+            if r < 2 * rate / 3: b.append(rng.randrange(3)); b.append(c); continue
+            if r < rate: b.append(rng.randrange(3)); continue
+            b.append(c)
+        if rng.random() < 0.3:
+            b += [rng.randrange(3) for _ in range(rng.randint(0, 6))]
+        if not b: b = [0]
+        d = levenshtein(a, b)
+        dp, applicable, ok = banded_window_phase(a, b, NW, W)
+        if not applicable:
+            continue
+        k = 3 * W - abs(len(b) - m)
+        assert dp >= d, (a, b, NW, W, dp, d)
+        if d <= k:
+            assert ok and dp == d, (a, b, NW, W, dp, d, k)
+        else:
+            assert not ok, (a, b, NW, W, dp, d, k)
+    return trials
+
+
+if __name__ == "__main__":
+    print("window phase ok", check_window_phase())
