@@ -338,6 +338,30 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band(const uint2* __rest
 // band of 16 (words - 1) diagonals either side when it is centred like this: |j - i| <= 48, i.e. h = 48 - |delta|,
 // k = 96 - |delta| (five words, in phase: 64 and 128).  Config 2's pass-1 pairs (55-65 edits, |delta| < 20) still fit; a
 // column costs 3.6 word updates on average instead of 4.3 (of 7).  tools/band_model.py: banded_window_phase.
+// The same column over a RING of four table slots: word w's masks sit in slot w & 3 of a [symbol][4][lane] table (the
+// four-word window never holds two words of the same slot), so the table is 20 KB per workgroup whatever NW is.
+template <int NW, int WLO, int WHI>
+__device__ __forceinline__ void myers_column_ring(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ e) {
+  uint32_t carry = 0, hp_prev = 0x80000000u, hn_prev = 0;
+#pragma unroll
+  for (int wi = WLO; wi <= WHI; ++wi) {
+    const uint32_t vp = VP[wi], vn = VN[wi];
+    const uint32_t X = e[(wi & 3) * kBlock] | vn;
+    uint32_t cout;
+    const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
+    carry = cout;
+    const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);
+    const uint32_t HN = vp & D0;
+    const uint32_t HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);
+    const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
+    const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
+    hp_prev = HP;
+    hn_prev = HN;
+    VN[wi] = Xs & D0;
+    VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);
+  }
+}
+
 template <int NW, int WLO, int WHI>
 __device__ __forceinline__ void band_sweep16(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ peq_lane, uint32_t d0,
                                              uint32_t d1, uint32_t ncols) {
@@ -347,24 +371,36 @@ __device__ __forceinline__ void band_sweep16(uint32_t (&VP)[NW], uint32_t (&VN)[
     const uint32_t left = ncols - q * 8u;
     if (left >= 8u) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) myers_column_window<NW, WLO, WHI>(VP, VN, peq_lane + ((d >> (4 * k)) & 7u) * (NW * kBlock));
+      for (int k = 0; k < 8; ++k) myers_column_ring<NW, WLO, WHI>(VP, VN, peq_lane + ((d >> (4 * k)) & 7u) * (4 * kBlock));
     } else {
 #pragma unroll 1
-      for (uint32_t k = 0; k < left; ++k) myers_column_window<NW, WLO, WHI>(VP, VN, peq_lane + ((d >> (4u * k)) & 7u) * (NW * kBlock));
+      for (uint32_t k = 0; k < left; ++k) myers_column_ring<NW, WLO, WHI>(VP, VN, peq_lane + ((d >> (4u * k)) & 7u) * (4 * kBlock));
     }
   }
 }
 
+// the five match masks of pattern word `wi` into its ring slot
+__device__ __forceinline__ void ring_store(uint32_t* __restrict__ peq_lane, int wi, const uint32_t (&mask)[5]) {
+#pragma unroll
+  for (int c = 0; c < 5; ++c) peq_lane[(c * 4 + (wi & 3)) * kBlock] = mask[c];
+}
+
 template <int NW, int G>
 struct BandGroups4 {
-  static __device__ __forceinline__ void run(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ peq_lane,
-                                             NtStream& ts, uint4& pending, uint32_t n, uint32_t n_groups, int32_t& T, int32_t& top) {
+  static __device__ __forceinline__ void run(uint32_t (&VP)[NW], uint32_t (&VN)[NW], uint32_t* __restrict__ peq_lane, NtStream& ts,
+                                             uint4& pending, NtStream& ps, uint32_t m, uint32_t n, uint32_t n_groups, int32_t& T,
+                                             int32_t& top) {
     if ((uint32_t)G >= n_groups) return;
     constexpr int ALO = G - 2 > 0 ? G - 2 : 0, AHI = G + 1 < NW - 1 ? G + 1 : NW - 1;
     constexpr int BLO = G - 1 > 0 ? G - 1 : 0, BHI = G + 2 < NW - 1 ? G + 2 : NW - 1;
     const uint4 buf = ts.take32(pending);
     if ((uint32_t)G + 1u < n_groups) pending = ts.load4();
     const uint32_t cols = n - (uint32_t)G * 32u < 32u ? n - (uint32_t)G * 32u : 32u;
+    // the pattern word the window takes in at this group's half-way point (word G + 2): asked for now, turned into masks then
+    constexpr bool takes_in = G + 2 <= NW - 1;
+    uint4 pat_pending = make_uint4(0u, 0u, 0u, 0u);
+    const bool has_word = takes_in && cols > 16u && (uint32_t)(G + 2) * 32u < m;
+    if (has_word) pat_pending = ps.load4();
     const uint32_t ca = cols < 16u ? cols : 16u;
     band_sweep16<NW, ALO, AHI>(VP, VN, peq_lane, buf.x, buf.y, ca);
     T += (int32_t)ca;
@@ -372,10 +408,22 @@ struct BandGroups4 {
     if (cols > 16u) {  // columns follow: the window moves down a word
       if constexpr (G - 2 >= 0 && G - 2 <= NW - 1) T += (int32_t)__popc(VP[G - 2]) - (int32_t)__popc(VN[G - 2]);
       top = BLO;
+      if constexpr (takes_in) {  // word G + 2 enters the ring in the slot word G - 2 has just left
+        uint32_t mask[5] = {0u, 0u, 0u, 0u, 0u};
+        if (has_word) {
+          const uint4 x = ps.take32(pat_pending);
+          uint32_t p0, p1, pn;
+          planes32(x, p0, p1, pn);
+          const uint32_t rem = m - (uint32_t)(G + 2) * 32u;
+          const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+          mask[4] = pn & vm; mask[3] = p1 & p0 & vm; mask[2] = p1 & ~p0 & vm; mask[1] = p0 & ~p1 & ~pn & vm; mask[0] = ~(p0 | p1 | pn) & vm;
+        }
+        ring_store(peq_lane, G + 2, mask);
+      }
       band_sweep16<NW, BLO, BHI>(VP, VN, peq_lane, buf.z, buf.w, cols - 16u);
       T += (int32_t)(cols - 16u);
     }
-    if constexpr (G + 1 < NW + 2) BandGroups4<NW, G + 1>::run(VP, VN, peq_lane, ts, pending, n, n_groups, T, top);
+    if constexpr (G + 1 < NW + 2) BandGroups4<NW, G + 1>::run(VP, VN, peq_lane, ts, pending, ps, m, n, n_groups, T, top);
   }
 };
 
@@ -384,7 +432,10 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
                                                                const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
                                                                uint2* __restrict__ retry, uint32_t* __restrict__ retry_n,
                                                                unsigned long long* prof_acc) {
-  extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
+  // match masks of the four pattern words in the window, [symbol][word & 3][lane]: 20 KB per workgroup whatever NW is
+  // (the flat table of the full kernel is 5 NW KB and holds the kernel at 4 waves per SIMD; this one leaves that to the
+  // registers).  A word's masks are made when the window takes the word in.
+  __shared__ uint32_t peq[5 * 4 * kBlock];
   const int tid = threadIdx.x;
   const uint32_t t = blockIdx.x * kBlock + tid;
   const bool active = t < n_list + n_list2;
@@ -401,18 +452,17 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
     n = txt.len; m = pat.len;
   }
   if (prof_acc) profile_add(prof_acc, active, n, m);
-  NtStream ps;
-  if (active) ps.init(pat, 0u);
-#pragma unroll
-  for (int wi = 0; wi < NW; ++wi) {
-    uint32_t mask[5] = {0u, 0u, 0u, 0u, 0u};
-    if (active) peq_word(ps, (uint32_t)wi, m, mask);
-#pragma unroll
-    for (int c = 0; c < 5; ++c) peq[(c * NW + wi) * kBlock + tid] = mask[c];
-  }
   if (!active) return;
   const uint32_t ad = n > m ? n - m : m - n;
   if (ad >= 48u) { retry[atomicAdd(retry_n, 1u)] = entry; return; }  // no band of this shape holds the corridor
+  NtStream ps;
+  ps.init(pat, 0u);
+#pragma unroll
+  for (int wi = 0; wi < 2 && wi < NW; ++wi) {  // the first window: words 0 and 1
+    uint32_t mask[5];
+    peq_word(ps, (uint32_t)wi, m, mask);
+    ring_store(peq + tid, wi, mask);
+  }
   uint32_t VP[NW], VN[NW];
 #pragma unroll
   for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
@@ -422,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
     NtStream ts;
     ts.init(txt, 0u);
     uint4 pending = ts.load4();
-    BandGroups4<NW, 0>::run(VP, VN, peq + tid, ts, pending, n, n_groups, T, top);
+    BandGroups4<NW, 0>::run(VP, VN, peq + tid, ts, pending, ps, m, n, n_groups, T, top);
   }
   int32_t dist = T;
 #pragma unroll
@@ -465,10 +515,12 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
   const size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
   const char* bw = getenv("RPA_BAND_WORDS");  // 5: the in-phase five-word window (A/B, tests)
   const bool five = bw && atoi(bw) == 5;
+  const char* padv = getenv("RPA_BAND4_LDS_PAD");  // occupancy experiments: extra dynamic LDS per workgroup of the ring kernel
+  const size_t pad4 = padv ? (size_t)atoi(padv) : 0;
 #define RPA_LAUNCH_MYERS_BAND(NWV) \
   case NWV: \
     if (five) hipLaunchKernelGGL((k_myers_short_band<NWV, 2>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
-    else hipLaunchKernelGGL((k_myers_short_band4<NWV>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
+    else hipLaunchKernelGGL((k_myers_short_band4<NWV>), dim3(blocks), dim3(kBlock), pad4, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
     break;
   switch (words) {
     RPA_LAUNCH_MYERS_BAND(5) RPA_LAUNCH_MYERS_BAND(6) RPA_LAUNCH_MYERS_BAND(7) RPA_LAUNCH_MYERS_BAND(8)

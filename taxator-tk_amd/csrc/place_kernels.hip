@@ -773,6 +773,34 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     // whose pass 0 and first pass-1 loop were requested together (mode 4) takes a second trip through the pass-1 branch
     // right away when the anchor it then selects is the predicted one (hit 0).
     const uint32_t combined_hi = st.chunk_hi;  // mode 4: the pass-1 chunk that was requested together with pass 0
+    // Pass 0 of a set whose pass 0 and first pass-1 loop were requested together (mode 4): hit 0 is the ONLY member of the
+    // query group, so index_best, rtax and the first anchor are hit 0 whatever its distance is, and every other hit leaves
+    // pass 0 with (FLT_MAX, identities) -- what k_rank_records wrote.  What is left of the pass-0 walk are two aggregates
+    // over all hits (anchors_support = max similarity, lca_allnodes, :547-548): the pass-1 loop below gathers them while
+    // it walks the same rows (and a short tail walk takes the rows that loop does not reach), instead of a first walk over
+    // every row for their sake.
+    bool acc_pending = false;   // the pass-1 walk of this call also gathers pass 0's aggregates
+    uint32_t acc_next = 1;      // first hit they have not seen yet
+    uint32_t acc_support = 0, acc_d_all = 0;
+    if (st.phase == kPass0Wait && st.combined) {
+      st.combined = 0;
+      const HitCore h0 = R.core(0u);
+      const float2 r2 = R.result(0);
+      if (!result_ok(w, s, meta_err(h0.meta), st.qsegerr, r2.x)) failed = true;
+      else {
+        ++st.cnt0;
+        const float idf = (float)h0.ident;
+        const float sim0 = r2.y < idf ? idf : r2.y;  // std::max(similarity, identities), :531
+        R.store_qdqs(0u, r2.x, sim0);
+        if (r2.x == 0.f) w.lite[lo] = h0.seglen | kLiteZeroQd;  // (:620-621)
+        for (uint32_t k = 0; k < nw; ++k) { fq[k] = 0u; fo[k] = 0u; }  // qgroup = {0}, taken by the anchor selection; outgroup empty
+        const uint32_t d0 = meta_depth(h0.meta);
+        st.best = 0; st.d_rtax = d0; st.ival_g = 0.f; st.d_lnode_g = st.d_unode_g = d0; st.bf_max = 1.f; st.lrd_min = 255;  // :553,569-579
+        st.anchor = 0; st.phase = kPass1Wait; st.loop_live = 0;  // :582-583
+        acc_pending = true; acc_support = (uint32_t)sim0; acc_d_all = d0;
+      }
+    }
+    if (!failed)
     for (int trip = 0; trip < 2; ++trip) {
     if (st.phase == kPass0Wait) {  // ---- pass 0, :497-566 ----
       uint32_t path0[4 * P4];
@@ -897,6 +925,14 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         if (i + 2 < n) { nx2 = R.load(i + 2); rn2 = R.result(i + 2); }
         const HitCore h = row_core<P4>(cur);
         if (!(h.score >= (float)scut)) break;
+        uint32_t pth[4 * P4];
+        row_path<P4>(cur, pth);
+        const uint32_t dh = meta_depth(h.meta);
+        if (acc_pending && i >= acc_next) {  // pass 0's aggregates for this hit (it is not hit 0: similarity = identities)
+          acc_support = max(acc_support, h.ident);
+          acc_d_all = min(acc_d_all, common<P4>(pb, db, pth, dh));  // best = hit 0: pb is its path
+          acc_next = i + 1;
+        }
         const double qsearchpid = (double)h.ident / L;
         const double qpid = (double)h.qs / L;
         const double qpid_thresh = cut_g < cut_h ? cut_h : cut_g;
@@ -910,9 +946,6 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           dist = r2.x;
           ++st.cnt1;
         }
-        uint32_t pth[4 * P4];
-        row_path<P4>(cur, pth);
-        const uint32_t dh = meta_depth(h.meta);
         band.add(dist, common<P4>(pa, da, pth, dh));  // :641
         if (dist == 0.f) bit_clear(fq, i);  // :644
         else if (dist <= qdist) {  // :646-650
@@ -930,6 +963,21 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           }
           ogi[nog] = i; ogd[nog] = (int)dist; ++nog;
         }
+      }
+      if (acc_pending && !failed) {  // the hits the loop above did not reach (early exit, pause): identities and path only
+        Row<P4> nx = ra;
+        if (acc_next < n) nx = R.load(acc_next);
+        for (uint32_t k = acc_next; k < n; ++k) {
+          const Row<P4> cur = nx;
+          if (k + 1 < n) nx = R.load(k + 1);
+          const HitCore h = row_core<P4>(cur);
+          uint32_t pth[4 * P4];
+          row_path<P4>(cur, pth);
+          acc_support = max(acc_support, h.ident);
+          acc_d_all = min(acc_d_all, common<P4>(pb, db, pth, meta_depth(h.meta)));
+        }
+        st.support = acc_support; st.d_lca_all = acc_d_all;
+        acc_pending = false;
       }
       if (paused) {  // ask for the next chunk of this anchor's loop and come back
         st.loop_live = 1; st.i_next = i; st.nog = nog; st.d_lnode = d_lnode; st.ldist = ldist; st.udist = udist;
