@@ -92,13 +92,16 @@ struct Work {
   bool failed = false;          // a GPU call failed on this block: nothing from here on is printed
   std::exception_ptr err;
   uint64_t seq = 0;             // position in the input: the writer prints in this order
-  std::vector<std::pair<void*, size_t>> pinned;  // the arrays below as they were page-locked last
+  std::vector<std::pair<void*, size_t>> pinned;       // the arrays below that are page-locked
+  std::vector<std::pair<void*, size_t>> pinned_want;  // ... and what was asked for last (some may have been refused)
 };
 
 // The columns of a Work object are reused from block to block: page-lock them (once per growth of a vector) so that the
 // engine's host<->device copies are DMA transfers that run beside the kernels of the other job in flight.
 template <class T> void add_range(std::vector<std::pair<void*, size_t>>& v, std::vector<T>& a) {
-  if (a.capacity()) v.emplace_back((void*)a.data(), a.capacity() * sizeof(T));
+  // only arrays big enough to have a mapping of their own (glibc: >= 128 KiB): small ones share heap pages with their
+  // neighbours, and a page cannot be locked twice
+  if (a.capacity() * sizeof(T) >= ((size_t)1 << 18)) v.emplace_back((void*)a.data(), a.capacity() * sizeof(T));
 }
 void pin_work(Work& w, const RPAPredictionModel& rpa) {
   std::vector<std::pair<void*, size_t>> now;
@@ -107,10 +110,13 @@ void pin_work(Work& w, const RPAPredictionModel& rpa) {
   add_range(now, b.rec.qstart); add_range(now, b.rec.qstop); add_range(now, b.rec.rstart); add_range(now, b.rec.rstop);
   add_range(now, b.rec.identities); add_range(now, b.rec.alnlen); add_range(now, b.rec.ref_seq); add_range(now, b.rec.node);
   add_range(now, b.rec.score); add_range(now, b.rec.filtered); add_range(now, w.rows); add_range(now, w.stats);
-  if (now == w.pinned) return;
-  for (auto& r : w.pinned) rpa.unpinHost(r.first);
+  if (now == w.pinned || (now.size() == w.pinned_want.size() && now == w.pinned_want)) return;
+  w.pinned_want = now;
+  for (auto& r : w.pinned) { try { rpa.unpinHost(r.first); } catch (...) {} }
   w.pinned.clear();
-  for (auto& r : now) { rpa.pinHost(r.first, r.second); w.pinned.push_back(r); }
+  for (auto& r : now) {  // page-locking is an optimisation: an array the driver refuses to lock is copied from pageable memory
+    try { rpa.pinHost(r.first, r.second); w.pinned.push_back(r); } catch (...) {}
+  }
 }
 void unpin_work(Work& w, const RPAPredictionModel& rpa) {
   for (auto& r : w.pinned) { try { rpa.unpinHost(r.first); } catch (...) {} }
