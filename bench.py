@@ -176,9 +176,9 @@ def cpu_reference_pairs(synth, ds, seconds_target=4.0, n_pairs=20000):
 # seed on every rank) and cut into N contiguous shards of equal summed alignment cells (sharding.shard_bounds_by_cost).
 CONFIGS = {
     "c2": dict(sets=1_000_000, hits=20, seg_len=200, alphabet=0, genome_len=4000, level_rate=0.03, query_rate=0.05, seed=2,
-               name="BASELINE config 2", kernel="k_myers_short_band / k_myers_short (batched bit-parallel edit distance, one alignment per lane, pattern words within two words of the diagonal)"),
+               name="BASELINE config 2", kernel="k_myers_short_band4 / k_myers_short (batched bit-parallel edit distance, one alignment per lane, a four-word window of the pattern around the diagonal: exact Ukkonen band with retries)"),
     "c3": dict(sets=1_250_000, hits=20, seg_len=200, alphabet=0, genome_len=4000, level_rate=0.03, query_rate=0.05, seed=3,
-               name="BASELINE config 3 (10 M record sets over 8 GPUs: 1.25 M per GPU)", kernel="k_myers_short_band / k_myers_short (batched bit-parallel edit distance, one alignment per lane, pattern words within two words of the diagonal)"),
+               name="BASELINE config 3 (10 M record sets over 8 GPUs: 1.25 M per GPU)", kernel="k_myers_short_band4 / k_myers_short (batched bit-parallel edit distance, one alignment per lane, a four-word window of the pattern around the diagonal: exact Ukkonen band with retries)"),
     "c4": dict(sets=500_000, hits=20, seg_len=67, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08, seed=2,
                name="BASELINE config 4 (protein, 67 aa)", kernel="k_nw_protein_packed (BLOSUM62 global DP, score + tie order + path counters in one 32-bit cell, one alignment per lane)"),
     "c5": dict(sets=12_500, hits=50, seg_len=10_000, alphabet=0, genome_len=40_000, level_rate=0.03, query_rate=0.05, seed=2, cut_by_cost=True,
