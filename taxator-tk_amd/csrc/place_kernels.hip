@@ -222,7 +222,13 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   }
   __syncthreads();
   const uint32_t r = r0 + threadIdx.x;
-  if (r >= b.n_records) return;
+  // what this thread's record turns into: its row (2 + P4 quads) at row slot `slot` (0xFFFFFFFF: none -- past the end of
+  // the batch, or a masked record); written out by the whole workgroup below
+  constexpr int Q = 2 + P4;
+  uint4 rowq[Q];
+  uint32_t slot = 0xFFFFFFFFu, my_set = 0, my_rank = 0;
+  bool staged_set = false;  // my set's offsets are in the LDS window
+  if (r < b.n_records) {
   uint32_t lo = 0, hi = kBlock + 1;  // largest j in [0, kBlock] with s_off[j] <= r  (s_off[0] <= r0 <= r)
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -249,21 +255,34 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   const uint32_t id = s_rec[me].y;
   uint32_t rank = 0, n = 0, qrstart = 0xFFFFFFFFu, qrstop = 0;
   float smax = 0.f;  // score of the set's best record (its first one in SortFilter order)
-  for (uint32_t j = beg; j < end; ++j) {
-    uint4 v;
-    bool filt;
-    const uint32_t jl = j - w0;  // wraps for j < w0
-    if (jl < kWin) { v = s_rec[jl]; filt = s_filt[jl] != 0; }
-    else { v = make_uint4(__float_as_uint(b.score[j]), b.identities[j], b.qstart[j], b.qstop[j]); filt = rec_filtered(b, j); }
-    if (filt) continue;
+  auto take = [&](uint32_t j, const uint4 v, bool filt) {  // one record of my set (branch-free: masked records change nothing)
     const float sj = __uint_as_float(v.x);
     const uint32_t ij = v.y;
-    smax = n == 0 ? sj : (sj > smax ? sj : smax);
-    ++n;
-    qrstart = min(qrstart, v.z);
-    qrstop = max(qrstop, v.w);
+    const bool act = !filt;
+    smax = act ? (n == 0 ? sj : (sj > smax ? sj : smax)) : smax;
+    n += act ? 1u : 0u;
+    qrstart = act ? min(qrstart, v.z) : qrstart;
+    qrstop = act ? max(qrstop, v.w) : qrstop;
     const bool before = (sj > sc) || (sj == sc && (ij > id || (ij == id && j < r)));
-    rank += before ? 1u : 0u;
+    rank += (act && before) ? 1u : 0u;
+  };
+  if (beg >= w0 && end <= w0 + kWin) {
+    // the whole set is staged (the usual case): a tight loop over LDS, four records in flight (the loop is bound by the
+    // LDS round trip of each record, not by the compares)
+    uint32_t j = beg;
+    for (; j + 4u <= end; j += 4u) {
+      const uint32_t jl = j - w0;
+      const uint4 v0 = s_rec[jl], v1 = s_rec[jl + 1], v2 = s_rec[jl + 2], v3 = s_rec[jl + 3];
+      const bool f0 = s_filt[jl] != 0, f1 = s_filt[jl + 1] != 0, f2 = s_filt[jl + 2] != 0, f3 = s_filt[jl + 3] != 0;
+      take(j, v0, f0); take(j + 1, v1, f1); take(j + 2, v2, f2); take(j + 3, v3, f3);
+    }
+    for (; j < end; ++j) take(j, s_rec[j - w0], s_filt[j - w0] != 0);
+  } else {
+    for (uint32_t j = beg; j < end; ++j) {
+      const uint32_t jl = j - w0;  // wraps for j < w0
+      if (jl < kWin) take(j, s_rec[jl], s_filt[jl] != 0);
+      else take(j, make_uint4(__float_as_uint(b.score[j]), b.identities[j], b.qstart[j], b.qstop[j]), rec_filtered(b, j));
+    }
   }
   if (r == beg) {
     uint2 qp = make_uint2(0u, 0u);
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     w.set_info[s] = make_uint4(n, qrstart, qrstop, 0u);
     w.set_qseg[s] = qp;
   }
-  if (me_filtered) return;
+  if (!me_filtered) {
   const uint32_t pos = beg + rank;  // row position = segment id = result slot of this hit
   uint2 sp = make_uint2(0u, 0u);
   if (n >= 2) {
@@ -299,11 +318,68 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   if (sp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); sp.x = 0; }
   // compact per-row word for k_emit: segment length + "pass 0 re-aligns this hit" (:511-518, threshold :499)
   w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u) | (perfect ? kLitePerfect : 0u);
-  R.store_quad(rank, 0, make_uint4(__float_as_uint(sc), id, node, r));
-  R.store_quad(rank, 1, make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta));
+  rowq[0] = make_uint4(__float_as_uint(sc), id, node, r);
+  rowq[1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta);
   const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
 #pragma unroll
-  for (int k = 0; k < P4; ++k) R.store_quad(rank, 2 + k, anc[k]);
+  for (int k = 0; k < P4; ++k) rowq[2 + k] = anc[k];
+  slot = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);  // row slot = result slot (tiled: tile_base + 64 rank + l; linear: beg + rank)
+  my_set = s; my_rank = rank; staged_set = in_window;
+  }  // !me_filtered
+  }  // r < n_records
+
+  // ---- write the rows out.  Tiled layout: quad q of the row at slot x lives at quad index (x & ~63) Q + 64 q + (x & 63), i.e.
+  // the same quad of the same rank of CONSECUTIVE record sets is contiguous.  A thread storing its own row's quads hits
+  // 64 different lines per wave-level store (and there are 2 + P4 of them per record: the kernel spent 0.5 of its 1.2 ms
+  // there on config 2); instead the workgroup stages its rows in LDS and walks (rank, quad, set) so that consecutive lanes
+  // write consecutive sets: runs of ~13 adjacent quads.  Batches whose workgroup windows do not fit (runs of empty sets,
+  // sets far longer than a workgroup) and the linear layout keep the direct stores.
+  __shared__ uint4 s_rows[kBlock * Q];
+  __shared__ uint32_t s_slot[kBlock];
+  __shared__ uint16_t s_who[kWin];      // (row position of the block's sets) - s_off[0]  ->  thread that holds the row
+  __shared__ uint32_t s_lim[3];         // highest set, highest rank + 1, "some row cannot be staged"
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t k = tid; k < kWin; k += kBlock) s_who[k] = 0xFFFFu;
+  if (tid < 3) s_lim[tid] = tid == 0 ? first : 0u;
+  __syncthreads();
+  const bool tiled = w.tile_base != nullptr;
+  if (slot != 0xFFFFFFFFu) {
+#pragma unroll
+    for (int k = 0; k < Q; ++k) s_rows[tid * Q + k] = rowq[k];
+    s_slot[tid] = slot;
+    atomicMax(&s_lim[0], my_set);
+    atomicMax(&s_lim[1], my_rank + 1u);
+    const uint32_t sl = my_set - first;
+    bool ok = staged_set && sl < (uint32_t)kBlock;
+    if (ok) {
+      const uint32_t widx = s_off[sl] - s_off[0] + my_rank;
+      ok = widx < kWin;
+      if (ok) s_who[widx] = (uint16_t)tid;
+    }
+    if (!ok) atomicOr(&s_lim[2], 1u);
+  }
+  __syncthreads();
+  const uint32_t ns = s_lim[0] - first + 1u, maxrank = s_lim[1];
+  const uint64_t total = (uint64_t)maxrank * Q * ns;
+  uint4* __restrict__ hits4 = reinterpret_cast<uint4*>(w.hits);
+  if (tiled && s_lim[2] == 0u && ns <= (uint32_t)kBlock && total <= 24ull * kBlock) {
+    for (uint32_t idx = tid; idx < (uint32_t)total; idx += kBlock) {
+      const uint32_t sl = idx % ns, t2 = idx / ns, q = t2 % (uint32_t)Q, i = t2 / (uint32_t)Q;
+      const uint32_t begs = s_off[sl];
+      if (i >= s_off[sl + 1] - begs) continue;          // the set has fewer records than that
+      const uint32_t widx = begs - s_off[0] + i;
+      if (widx >= kWin) continue;
+      const uint32_t src = s_who[widx];
+      if (src == 0xFFFFu) continue;                      // another workgroup's record, or fewer ACTIVE records than that
+      const uint32_t x = s_slot[src];
+      hits4[(size_t)(x & ~63u) * Q + 64u * q + (x & 63u)] = s_rows[src * Q + q];
+    }
+  } else if (slot != 0xFFFFFFFFu) {
+    const size_t base = tiled ? (size_t)(slot & ~63u) * Q + (slot & 63u) : (size_t)slot * Q;
+    const size_t sq = tiled ? 64 : 1;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) hits4[base + (size_t)k * sq] = rowq[k];
+  }
 }
 
 // Pair emission bookkeeping: a thread first counts what it will emit per bin, reserves list space with one atomic
