@@ -194,7 +194,11 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 = the headline configuration (BASELINE config 2); c3 = config 3's per-GPU share (for --gpus 8), c4 protein, "
                          "c5 long contigs are extra measurements")
-    ap.add_argument("--in-flight", type=int, default=3, help="with --host-buffers: jobs submitted before the oldest is waited for (1..3)")
+    ap.add_argument("--in-flight", type=int, default=3, help="with --host-buffers / --pipeline: jobs submitted before the oldest is waited for (1..3)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="device-resident batch, but the steps go through rpa_submit_batch with --in-flight of them running at a time: the "
+                         "placement rounds of one step under the alignment kernels of another.  A throughput figure for streams of "
+                         "batches; the per-launch durations behind `roofline` overlap and are inflated by it -- not the headline")
     ap.add_argument("--store-replicas", type=int, default=1,
                     help="lay the reference store out R times (R x 4096 sequences; every alignment row points at a random replica of its "
                          "species): the same work against a store that is really spread over HBM instead of sitting in L2 / "
@@ -314,7 +318,12 @@ def main():
             model.pin(r_); model.pin(s_)
             host_out.append((r_, s_))
 
+    pipe_out = [(rows, stats)] + [(torch.zeros_like(rows), torch.zeros_like(stats)) for _ in range(3)] if args.pipeline else []
+
     def finish_one():
+        if args.pipeline:
+            in_flight.popleft().wait()
+            return
         r_host, s_host = in_flight.popleft().wait()
         if not step.copied:
             rows.copy_(torch.from_numpy(r_host.view(np.int32).reshape(-1, 8)))
@@ -330,6 +339,12 @@ def main():
             in_flight.append(model.submit(host_batch, out=r_, stats=s_))
             if len(in_flight) == args.in_flight:
                 finish_one()
+        elif args.pipeline:
+            k = step.n % len(pipe_out)
+            step.n += 1
+            in_flight.append(model.submit(dev, out=pipe_out[k][0], stats=pipe_out[k][1], mem_kind=pkg.MEM_DEVICE))
+            if len(in_flight) == args.in_flight:
+                in_flight.popleft().wait()
         else:
             model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
         if use_dist:
@@ -405,7 +420,8 @@ def main():
             "dtype": "u32" if cfg["alphabet"] == 0 else "i32", "data": "synthetic",
             "config": {"workload": "%s: %d record sets x %d hits x %d %s RPA per GPU, mock NCBI taxonomy (b=4, 5462 nodes), batch resident in HBM"
                                    % (cfg["name"], args.sets, args.hits, args.seg_len, "bp nucleotide" if cfg["alphabet"] == 0 else "aa protein")
-                                   + (" -- HOST BUFFERS: batch copied to the device and rows back inside every step, two steps in flight through rpa_submit_batch / rpa_wait (PCIe-inclusive, not the headline)" if args.host_buffers else ""),
+                                   + (" -- HOST BUFFERS: batch copied to the device and rows back inside every step, several steps in flight through rpa_submit_batch / rpa_wait (PCIe-inclusive, not the headline)" if args.host_buffers else "")
+                                   + (" -- PIPELINED: %d steps in flight through rpa_submit_batch (not the headline)" % args.in_flight if args.pipeline else ""),
                        "record_sets_per_gpu": args.sets, "hits_per_set": args.hits, "segment_bp": args.seg_len,
                        "parallelism": ("record sets sharded over %d rank(s)%s; %s gather of 32-byte rows to rank 0 every step"
                                        % (world, ", ONE workload cut by summed alignment cells" if cut_by_cost else "",

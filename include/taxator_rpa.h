@@ -164,7 +164,8 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
  * (core/taxator.cpp:80-124,159-176) at the boundary.  rpa_submit_batch hands the batch to one of the engine's
  * RPA_JOBS_IN_FLIGHT job slots (each with its own HIP stream, working set, staging buffers and host thread) and returns;
  * the host -> device copies of one job run under the kernels of the other.  It blocks only while the slot whose turn it
- * is still works on its previous job.  The batch arrays, `out` and `stats` must stay valid until rpa_wait(job) returns,
+ * is still works on its previous job.  `out` / `stats` live where the batch lives (batch->mem_kind; a device batch must be
+ * complete when it is submitted: the job runs on a stream of the engine's own).  The batch arrays, `out` and `stats` must stay valid until rpa_wait(job) returns,
  * which also reports the job's status (rpa_last_error has the text) and releases the handle.  Jobs may be waited for in
  * any order; rows are in input order within a job, as with rpa_predict_batch (same semantics:
  * core/src/taxonpredictionmodel.hh:36-52).  Store loads / appends wait for the jobs in flight. */

@@ -215,8 +215,23 @@ class RPAPredictionModel:
     def unpin(self, array):
         self._check(self._L.rpa_host_unregister(self._h, array.ctypes.data))
 
-    def submit(self, batch, want_stats=True, out=None, stats=None):
-        """Asynchronous predict for a host batch: returns a job; job.wait() -> (rows, stats).  RPA_JOBS_IN_FLIGHT (3) jobs run at a time."""
+    def submit(self, batch, want_stats=True, out=None, stats=None, mem_kind=MEM_HOST):
+        """Asynchronous predict: returns a job; job.wait() -> (rows, stats).  RPA_JOBS_IN_FLIGHT (3) jobs run at a time.
+        mem_kind=MEM_DEVICE: batch / out / stats are torch cuda tensors that are complete (synchronise your stream first)."""
+        if mem_kind == MEM_DEVICE:
+            so, qs = batch["set_offsets"], batch["qstart"]
+            b = _Batch(so.numel() - 1, qs.numel(), *[_ptr(batch[name]) for name, _ in BATCH_FIELDS], _ptr(batch.get("filtered")), MEM_DEVICE)
+            handle = C.c_void_p()
+            self._check(self._L.rpa_submit_batch(self._h, C.byref(b), _ptr(out), _ptr(stats), C.byref(handle)))
+            model = self
+
+            class DevJob:
+                keep = (batch, b, out, stats)
+
+                def wait(self_job):
+                    model._check(model._L.rpa_wait(model._h, handle))
+                    return out, stats
+            return DevJob()
         arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in BATCH_FIELDS}
         filt = batch.get("filtered")
         filt = None if filt is None else np.ascontiguousarray(filt, np.uint8)

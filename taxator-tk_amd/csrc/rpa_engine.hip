@@ -1030,7 +1030,7 @@ static void slot_main(rpa_engine* slot) {
       job = slot->job_pending;
     }
     slot->err.clear();
-    const int rc = predict_on(slot, slot->owner, &job->batch, job->out, job->stats, RPA_MEM_HOST);
+    const int rc = predict_on(slot, slot->owner, &job->batch, job->out, job->stats, job->batch.mem_kind);  // rows go where the batch lives
     {
       std::lock_guard<std::mutex> lk(slot->job_mu);
       job->status = rc;
@@ -1056,7 +1056,7 @@ int rpa_submit_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out,
   *job_out = nullptr;
   std::lock_guard<std::mutex> lk(e->mu);
   if (!batch || !out) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch: null argument");
-  if (batch->mem_kind != RPA_MEM_HOST) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch takes host batches (device batches: rpa_predict_batch on a stream of your own)");
+  if (batch->mem_kind != RPA_MEM_HOST && batch->mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch: bad mem_kind");
   HIP_TRY(e, hipSetDevice(e->device));
   while (e->slots.size() < RPA_JOBS_IN_FLIGHT) {
     rpa_engine* s = make_worker(e);
