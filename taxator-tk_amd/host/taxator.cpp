@@ -76,7 +76,8 @@ static void usage(std::ostream& o) {
        "  -p [ --processors ] arg (=0)       host threads for parsing and output formatting, 0 = all\n"
        "  -l [ --logfile ] arg (=/dev/null)  per record set STATS lines are appended here\n"
        "  -b [ --dataformat ] arg (=nucleotide)  nucleotide | protein\n"
-       "  advanced: -r ranks..., -s split-alignments (=1), -o alignments-sorted (=0), -d delete-notranks (=1),\n"
+       "  advanced: -r ranks..., -s split-alignments (=1), -o alignments-sorted (=0), -d delete-notranks (=1; the engine keeps taxon\n"
+       "            paths of at most 15 levels below the root: -d 0 on the full NCBI tree, or more than 15 ranks, is refused),\n"
        "            -x heuristic-cutoff (=0.5), -t toppercent (=0.05), -e max-evalue (=1000), -c min-support (=1), -m minscore (=0),\n"
        "            -n nbest (=1), -u ignore-unclassified, --device N (=0), --devices a,b,... (several GPUs), --batch N (record sets per GPU call),\n"
        "            --block-mb N (=128, input block parsed at a time), --timing, --record-objects (per-record object loop)\n";
