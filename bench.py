@@ -304,6 +304,13 @@ def main():
     cdev = "cpu" if gloo else "cuda"  # where the collectives' tensors live
     gather_out = ([torch.empty((max(gather_sizes), 8), dtype=torch.int32, device=cdev) for _ in range(world)]
                   if (use_dist and rank == 0) else None)
+    # RCCL: the gather of step k runs beside the kernels of step k + 1 (rows double-buffered; every step's rows still reach
+    # rank 0 inside the timed region).  gloo rehearsals keep the plain blocking gather.
+    overlap_gather = use_dist and not gloo and not args.host_buffers and not args.pipeline
+    rows_buf = [rows, torch.zeros_like(rows)] if overlap_gather else [rows]
+    stats_buf = [stats, torch.zeros_like(stats)] if overlap_gather else [stats]
+    gather_buf = [gather_out, ([torch.empty_like(t) for t in gather_out] if gather_out is not None else None)] if overlap_gather else [gather_out]
+    pending_gather = [None, None]
 
     import collections
     in_flight = collections.deque()
@@ -345,6 +352,16 @@ def main():
             in_flight.append(model.submit(dev, out=pipe_out[k][0], stats=pipe_out[k][1], mem_kind=pkg.MEM_DEVICE))
             if len(in_flight) == args.in_flight:
                 in_flight.popleft().wait()
+        elif overlap_gather:
+            k = step.n % 2
+            step.n += 1
+            if pending_gather[k] is not None:   # the exchange that read this buffer two steps ago (stream-level wait, the host goes on)
+                pending_gather[k][0].wait()
+                pending_gather[k] = None
+            model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows_buf[k], stats=stats_buf[k])
+            pending_gather[k] = sharding.gather_rows(rows_buf[k], dst=0, sizes=gather_sizes, out=gather_buf[k], force=True, async_op=True)
+            step.last = k
+            return
         else:
             model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
         if use_dist:
@@ -355,10 +372,15 @@ def main():
     step.copied = False
     step.n = 0
     step.gathered = None
+    step.last = 0
     for _ in range(args.warmup):
         step()
     while in_flight:
         finish_one()
+    for k_ in range(len(pending_gather)):
+        if pending_gather[k_] is not None:
+            pending_gather[k_][0].wait()
+            pending_gather[k_] = None
     model.profile(enable=True, reset=True)
     torch.cuda.synchronize()
     if use_dist:
@@ -369,6 +391,9 @@ def main():
         step()
     while in_flight:
         finish_one()
+    for pg in pending_gather:
+        if pg is not None:
+            pg[0].wait()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -392,6 +417,9 @@ def main():
         # rocprofv3 PMC passes of this same command (profiles/*traffic.json, see profiles/README.md)
         traffic, traffic_src = None, None
         if use_dist and rank == 0:  # the gathered rows of this rank's own shard must be the rows it computed
+            if overlap_gather:
+                gather_out, rows = gather_buf[step.last], rows_buf[step.last]
+                step.gathered = gather_out if len(set(gather_sizes)) == 1 else torch.cat([b_[:n_] for b_, n_ in zip(gather_out, gather_sizes)], dim=0)
             own = gather_out[0][: gather_sizes[0]] if isinstance(gather_out, list) else None
             assert own is None or torch.equal(own, rows.cpu() if gloo else rows), "gathered rows differ from the computed ones"
             g = step.gathered

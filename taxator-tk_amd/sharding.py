@@ -58,7 +58,7 @@ def slice_batch(batch, lo, hi):
     return out
 
 
-def gather_rows(rows, dst=0, group=None, sizes=None, out=None, force=False):
+def gather_rows(rows, dst=0, group=None, sizes=None, out=None, force=False, async_op=False):
     """rows: (n_local, 8) int32 tensor (any device).  Returns the rows of all ranks concatenated in rank order on `dst`
     (None elsewhere).  Shards may differ in size: sizes are exchanged first, rows are padded to the largest shard.
     Shards need not be equal (config 5 is cut by cost).  A caller that gathers the same shapes every step passes `sizes` (rows per rank, known up front) to skip the size
@@ -80,6 +80,12 @@ def gather_rows(rows, dst=0, group=None, sizes=None, out=None, force=False):
     bufs = None
     if rank == dst:
         bufs = out if out is not None else [torch.empty_like(padded) for _ in range(world)]
+    if async_op:
+        # the caller overlaps the exchange with its next step: it gets (work, what to keep alive until work.wait()) and reads
+        # `out` (its own preallocated receive buffers, required here) afterwards
+        assert rank != dst or out is not None
+        send = padded.contiguous()
+        return dist.gather(send, bufs, dst=dst, group=group, async_op=True), send
     dist.gather(padded.contiguous(), bufs, dst=dst, group=group)
     if rank != dst:
         return None
