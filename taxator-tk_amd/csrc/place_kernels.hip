@@ -582,44 +582,111 @@ __device__ __forceinline__ int sparse_bin(const Params& p, int bin) {
 // Sparse rounds: when only a small fraction of the record sets is still running, scanning every row of the batch
 // would cost more than the work left.  One wavefront per live set; lane j looks at hits j, j+64, ...; lane 0 also
 // emits the anchor <-> query alignment.  Same predicate and same list format as k_emit.
+constexpr int kSparseBlock = 1024;  // 16 live sets per workgroup: one list reservation per bin per workgroup
 template <int P4>
-__global__ __launch_bounds__(kBlock) void k_emit_sparse(BatchDev b, WorkDev w, Params p) {
-  const uint32_t wave_id = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (wave_id >= w.counters[kCtrActive]) return;  // exact list length (the grid is sized by an upper bound); whole wave
-  const uint32_t s = w.live_in[wave_id];
+__global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDev w, Params p) {
+  // The sparse rounds put nearly everything into ONE list (sparse_bin), and a reservation per wavefront means thousands of
+  // atomics on one counter at ~11 ns each (6 k live sets: 92 of the kernel's 140 us).  The first 64 hits of every set
+  // (all of them, for sets of up to 63 hits: the anchor <-> query pair rides in the lane behind the last hit) are
+  // therefore reserved per WORKGROUP: ballots -> LDS -> one atomic per bin; longer sets finish with per-wave reservations.
+  __shared__ uint32_t s_cnt[kNumBins][kSparseBlock / 64];
+  const uint32_t wave_id = (blockIdx.x * kSparseBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool have = wave_id < w.counters[kCtrActive];  // exact list length (the grid is sized by an upper bound)
   const uint32_t H = b.n_records;
-  const EmitInfo info = w.emit[s];
-  if (info.mode == 0) return;
-  const uint32_t lo = b.set_offsets[s];
+  uint32_t s = 0, lo = 0, i_hi = 0, i_lo = 0;
+  EmitInfo info{};
+  info.mode = 0;
+  if (have) {
+    s = w.live_in[wave_id];
+    info = w.emit[s];
+    lo = b.set_offsets[s];
+    i_hi = min(info.i_hi, info.n);
+    i_lo = info.i_lo;
+  }
+  const bool work = have && info.mode != 0;
   uint32_t maxlen = 0;
-  const uint32_t i_hi = min(info.i_hi, info.n);
-  for (uint32_t i0 = info.i_lo; i0 < i_hi; i0 += 64) {
-    const uint32_t i = i0 + (uint32_t)lane;
-    int bin = -1;
-    uint2 entry = make_uint2(0u, 0u);
+  // ---- first chunk: hits i_lo .. i_lo + 63, workgroup-level reservation ----
+  int bin = -1;
+  uint2 entry = make_uint2(0u, 0u);
+  bool extra_done = false;
+  if (work) {
+    const uint32_t i = i_lo + (uint32_t)lane;
     if (i < i_hi && (info.mode == 1 || info.mode == 4 || i != info.anchor)) {
       uint32_t ml = 0;
       bin = sparse_bin(p, emit_predicate<P4>(b, w, p, info, s, lo, lo + i, w.lite[lo + i], entry, ml));
       maxlen = max(maxlen, ml);
     }
-#pragma unroll
-    for (int k = 0; k < kNumBins; ++k) {
-      const unsigned long long mask = __ballot(bin == k);
-      if (mask == 0ull) continue;
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&w.counters[k], (uint32_t)__popcll(mask));
-      base = __shfl(base, 0, 64);
-      if (bin == k) w.bin_list[(size_t)k * w.T2 + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
+    const uint32_t span = i_hi > i_lo ? i_hi - i_lo : 0u;
+    if (info.mode == 3 && info.emit_query && span < 64u) {  // anchor <-> query range (:792-797) in the first free lane
+      extra_done = true;
+      if ((uint32_t)lane == span) {
+        int xb = pair_bin(p, info.anchor_len, info.qseglen);
+        if (xb >= kNumBins) raise_error(w, kErrUnsupported, s);
+        else {
+          bin = sparse_bin(p, xb);
+          maxlen = max(maxlen, p.alphabet == 0 ? max(info.anchor_len, info.qseglen) : info.anchor_len);
+          entry = make_uint2(lo + info.anchor, (H + s) | kDstIsB);
+        }
+      }
     }
   }
-  if (info.mode == 3 && info.emit_query && lane == 0) {  // anchor <-> query range (:792-797)
-    int bin = pair_bin(p, info.anchor_len, info.qseglen);
-    if (bin >= kNumBins) raise_error(w, kErrUnsupported, s);
-    else {
-      bin = sparse_bin(p, bin);
-      maxlen = max(maxlen, p.alphabet == 0 ? max(info.anchor_len, info.qseglen) : info.anchor_len);
-      w.bin_list[(size_t)bin * w.T2 + atomicAdd(&w.counters[bin], 1u)] = make_uint2(lo + info.anchor, (H + s) | kDstIsB);
+  unsigned long long my_mask = 0ull;
+#pragma unroll
+  for (int k = 0; k < kNumBins; ++k) {
+    const unsigned long long mask = __ballot(bin == k);
+    if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(mask);
+    if (bin == k) my_mask = mask;
+  }
+  __syncthreads();
+  if (wave == 0) {  // lane l < 16 = wave l of the workgroup: exclusive prefix per bin, one reservation per non-empty bin
+#pragma unroll
+    for (int k = 0; k < kNumBins; ++k) {
+      const uint32_t c = lane < kSparseBlock / 64 ? s_cnt[k][lane] : 0u;
+      if (!__any(c != 0u)) continue;
+      uint32_t inc = c;
+#pragma unroll
+      for (int d = 1; d < kSparseBlock / 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      uint32_t base = 0;
+      if (lane == kSparseBlock / 64 - 1) base = atomicAdd(&w.counters[k], inc);
+      base = __shfl(base, kSparseBlock / 64 - 1, 64);
+      if (lane < kSparseBlock / 64) s_cnt[k][lane] = base + inc - c;
+    }
+  }
+  __syncthreads();
+  if (bin >= 0) w.bin_list[(size_t)bin * w.T2 + s_cnt[bin][wave] + (uint32_t)__popcll(my_mask & ((1ull << lane) - 1ull))] = entry;
+  // ---- sets with more than 64 hits in their range: the rest, one reservation per wavefront and bin ----
+  if (work) {
+    for (uint32_t i0 = i_lo + 64u; i0 < i_hi; i0 += 64) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      int bn = -1;
+      uint2 en = make_uint2(0u, 0u);
+      if (i < i_hi && (info.mode == 1 || info.mode == 4 || i != info.anchor)) {
+        uint32_t ml = 0;
+        bn = sparse_bin(p, emit_predicate<P4>(b, w, p, info, s, lo, lo + i, w.lite[lo + i], en, ml));
+        maxlen = max(maxlen, ml);
+      }
+#pragma unroll
+      for (int k = 0; k < kNumBins; ++k) {
+        const unsigned long long mask = __ballot(bn == k);
+        if (mask == 0ull) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&w.counters[k], (uint32_t)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (bn == k) w.bin_list[(size_t)k * w.T2 + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = en;
+      }
+    }
+    if (info.mode == 3 && info.emit_query && !extra_done && lane == 0) {  // anchor <-> query range (:792-797)
+      int xb = pair_bin(p, info.anchor_len, info.qseglen);
+      if (xb >= kNumBins) raise_error(w, kErrUnsupported, s);
+      else {
+        xb = sparse_bin(p, xb);
+        maxlen = max(maxlen, p.alphabet == 0 ? max(info.anchor_len, info.qseglen) : info.anchor_len);
+        w.bin_list[(size_t)xb * w.T2 + atomicAdd(&w.counters[xb], 1u)] = make_uint2(lo + info.anchor, (H + s) | kDstIsB);
+      }
     }
   }
   wave_max_to(&w.counters[kCtrMaxLen], maxlen);
@@ -1349,8 +1416,8 @@ hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w,
 hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p) {
   if (w.live_in) {  // sparse round: one wave per live set
     if (w.n_live_in == 0) return hipSuccess;
-    const dim3 grid(((size_t)w.n_live_in * 64 + kBlock - 1) / kBlock);
-    RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_emit_sparse<P4>, grid, dim3(kBlock), 0, st, b, w, p));
+    const dim3 grid(((size_t)w.n_live_in * 64 + kSparseBlock - 1) / kSparseBlock);
+    RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_emit_sparse<P4>, grid, dim3(kSparseBlock), 0, st, b, w, p));
     return hipGetLastError();
   }
   const uint32_t total = b.n_records + b.n_sets;
