@@ -78,7 +78,7 @@ struct rpa_engine {
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
   DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
-      tmp_words, tmp_offsets, protein_ws, retry_list, retry_short;
+      protein_ws, retry_list, retry_short;
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
   bool profiling = false;
@@ -772,7 +772,7 @@ void rpa_destroy(rpa_engine* e) {
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
-                    &e->tmp_words, &e->tmp_offsets, &e->protein_ws, &e->retry_list, &e->retry_short, &e->prof_acc, &e->part_offsets};
+                    &e->protein_ws, &e->retry_list, &e->retry_short, &e->prof_acc, &e->part_offsets};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
   for (auto& s : e->stores) s.release();
