@@ -317,12 +317,22 @@ def main():
     host_out = []
     if args.host_buffers:
         # the caller's arrays are pinned once (a driver that reuses its batch buffers does the same): DMA at the PCIe rate
-        host_batch = {k: np.ascontiguousarray(v) for k, v in ds.batch.items()}
-        for v in host_batch.values():
-            model.pin(v)
+        def pinned_copy(a):  # page-locked memory from the runtime's own allocator (torch pin_memory = hipHostMalloc)
+            a = np.ascontiguousarray(a)
+            t_ = torch.empty(a.nbytes, dtype=torch.uint8, pin_memory=True)
+            out_ = t_.numpy().view(a.dtype).reshape(a.shape)
+            out_[...] = a
+            pinned_keep.append(t_)
+            return out_
+        pinned_keep = []
+        if os.environ.get("RPA_BENCH_REGISTER"):  # A/B: register the numpy arrays instead (rpa_host_register)
+            host_batch = {k: np.ascontiguousarray(v) for k, v in ds.batch.items()}
+            for v in host_batch.values():
+                model.pin(v)
+        else:
+            host_batch = {k: pinned_copy(v) for k, v in ds.batch.items()}
         for _ in range(4):  # rows / counters of the jobs in flight (+ one being read)
-            r_, s_ = np.zeros(ds.n_sets, pkg.PRED_DTYPE), np.zeros(ds.n_sets, pkg.STATS_DTYPE)
-            model.pin(r_); model.pin(s_)
+            r_, s_ = pinned_copy(np.zeros(ds.n_sets, pkg.PRED_DTYPE)), pinned_copy(np.zeros(ds.n_sets, pkg.STATS_DTYPE))
             host_out.append((r_, s_))
 
     pipe_out = [(rows, stats)] + [(torch.zeros_like(rows), torch.zeros_like(stats)) for _ in range(3)] if args.pipeline else []

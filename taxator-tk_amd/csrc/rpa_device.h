@@ -211,6 +211,8 @@ struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells
 
 // ---- launchers (each enqueues on `st`, returns the hipError of the launch) ----
 hipError_t launch_pack_letters(hipStream_t st, int alphabet, const uint8_t* letters, uint64_t n_residues, uint32_t* words);
+// n <= 64 words from device memory into host-mapped pinned memory, by a kernel (not the copy engine); read them after a stream sync
+hipError_t launch_publish_words(hipStream_t st, const uint32_t* src, uint32_t* dst_host_mapped, uint32_t n);
 // extent table of a store: from an offsets table (n_seqs + 1 entries, sequence i at base + offsets[i]) for all sequences,
 // or scattered for the sequences `index[k]` (k < n) of an append
 hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const uint32_t* index, uint32_t n, uint64_t base, ulonglong2* extent);

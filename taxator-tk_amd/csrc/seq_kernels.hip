@@ -89,4 +89,16 @@ hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const u
   return hipGetLastError();
 }
 
+// A few words from device memory into host-mapped (pinned) memory by a kernel instead of a copy command: the per-round
+// counter read-back of the placement loop must not queue behind another job's 80 MB host->device transfers on the
+// copy engine (it did: seven read-backs per batch each waited ~1.4 ms for the transfer in flight).
+__global__ void k_publish_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst_host, uint32_t n) {
+  if (threadIdx.x < n) dst_host[threadIdx.x] = src[threadIdx.x];
+}
+hipError_t launch_publish_words(hipStream_t st, const uint32_t* src, uint32_t* dst_host_mapped, uint32_t n) {
+  if (n == 0 || n > 64) return n ? hipErrorInvalidValue : hipSuccess;
+  hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, src, dst_host_mapped, n);
+  return hipGetLastError();
+}
+
 }  // namespace rpa
