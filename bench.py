@@ -180,7 +180,7 @@ CONFIGS = {
     "c3": dict(sets=1_250_000, hits=20, seg_len=200, alphabet=0, genome_len=4000, level_rate=0.03, query_rate=0.05, seed=3,
                name="BASELINE config 3 (10 M record sets over 8 GPUs: 1.25 M per GPU)", kernel="k_myers_short_band4 / k_myers_short (batched bit-parallel edit distance, one alignment per lane, a four-word window of the pattern around the diagonal: exact Ukkonen band with retries)"),
     "c4": dict(sets=500_000, hits=20, seg_len=67, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08, seed=2,
-               name="BASELINE config 4 (protein, 67 aa)", kernel="k_nw_protein_packed (BLOSUM62 global DP, score + tie order + path counters in one 32-bit cell, one alignment per lane)"),
+               name="BASELINE config 4 (protein, 67 aa)", kernel="k_nw_protein_lanes / k_nw_protein_packed (BLOSUM62 global DP, score + tie order + path counters in one 32-bit cell; the 24-row strips of a pair in adjacent lanes, strip boundaries over DPP)"),
     "c5": dict(sets=12_500, hits=50, seg_len=10_000, alphabet=0, genome_len=40_000, level_rate=0.03, query_rate=0.05, seed=2, cut_by_cost=True,
                name="BASELINE config 5 (10 kbp contigs, per-GPU share of 100 k)", kernel="k_myers_band (bit-parallel edit distance inside Ukkonen's band, one alignment per lane, pattern in register strips of 5-8 words)"),
 }

@@ -380,6 +380,189 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2*
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K3l: K3p's cell with the strips of ONE pair in ADJACENT LANES (G lanes per pair, G = number of R-row strips the
+// vertical sequence needs, 64 / G pairs per wavefront).  Lane s of a pair owns rows sR+1 .. sR+R and runs s columns
+// behind lane s-1, so the cell above its strip for the column it is about to compute is the bottom cell its neighbour
+// produced one step earlier: it comes over the DPP network (v_mov_b32 wave_shr:1, no LDS, no memory).  Nothing of the DP
+// touches HBM: a launch reads the residues and writes one result per pair (K3p hands every strip boundary through a
+// scratch row in memory: 13x the algorithmic bytes at 67 aa).  The price is the s idle steps per lane at either end of
+// a pair (G - 1 of la + G - 1 steps), the lanes of strips a shorter pair of the same class does not have, and lane 63 when
+// G = 3.  Same table, same packed cell, same results as K3p bit for bit.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v) {  // lane i receives lane i-1's value (lane 0: 0)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// One run of 64 / G pairs of a G-lanes-per-pair list, starting at pair `run` (the whole wavefront calls it together).
+template <int R, int G>
+__device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list, uint32_t n_list, uint32_t run, const WorkDev& w,
+                                                  const uint8_t* __restrict__ tabb, const int32_t* __restrict__ selfdiag,
+                                                  uint32_t c_horiz, uint32_t c_keep, uint32_t c_one, unsigned long long* prof_acc) {
+  constexpr uint32_t kPairs = 64u / G;  // pairs per wavefront
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t sub = lane % G, slot = lane / G;  // my strip, my pair of the run (slot == kPairs: the spare lane of G = 3)
+  const uint32_t bank4 = (threadIdx.x & 31u) * 4u;
+  {
+    const uint32_t t = run + slot;
+    const bool have = slot < kPairs && t < n_list;
+    uint32_t dst = 0, la = 0, lb = 0;
+    const uint8_t* __restrict__ pa = nullptr;
+    const uint8_t* __restrict__ pb = nullptr;
+    if (have) {
+      uint32_t sa, sb;
+      resolve_pair(w, list[t], sa, sb, dst);
+      const SegView va = seg_view(w, sa), vb = seg_view(w, sb);
+      la = va.len; lb = vb.len;
+      pa = reinterpret_cast<const uint8_t*>(va.words) + va.src;
+      pb = reinterpret_cast<const uint8_t*>(vb.words) + vb.src;
+    }
+    if (prof_acc) {  // pairs, len_a+len_b+8, cells: counted by the first lane of a pair
+      const bool cnt = have && sub == 0u;
+      unsigned long long v0 = cnt ? 1ull : 0ull, v1 = cnt ? (unsigned long long)la + lb + 8ull : 0ull,
+                         v2 = cnt ? (unsigned long long)la * lb : 0ull;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); v2 += __shfl_down(v2, d, 64); }
+      if (lane == 0) {
+        unsigned long long* acc = prof_acc + ((run / kPairs) & (kProfParts - 1)) * 4;
+        atomicAdd(&acc[0], v0); atomicAdd(&acc[1], v1); atomicAdd(&acc[2], v2);
+      }
+    }
+    const uint32_t nstrips = (lb + R - 1) / R;  // <= G by the bin
+    const bool mine = have && sub < nstrips;
+    const uint32_t bias = la + 32u;
+    int32_t selfscore = 0;  // my share of NW(A,A) + NW(B,B): my rows of B; the first lane of the pair adds A's residues
+    uint32_t rowoff[R];
+    if (mine) {
+      uint32_t bw[(R + 3) / 4];  // unaligned dword loads; reads run at most R + 2 bytes past the segment (store slack)
+#pragma unroll
+      for (int q = 0; q < (R + 3) / 4; ++q) __builtin_memcpy(&bw[q], pb + (size_t)sub * R + 4 * q, 4);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t bres = (bw[r >> 2] >> (8 * (r & 3))) & 0xFFu;  // rows past lb are never used
+        rowoff[r] = (sub * R + r < lb ? bres : 0u) * (kAA * 128u) + bank4;
+        if (sub * R + r < lb) selfscore += selfdiag[bres];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) rowoff[r] = bank4;
+    }
+    if (have && sub == 0u && nstrips == 0u)  // no rows: K3p's answer (score 0, no steps), A's residues still count
+      for (uint32_t j = 0; j < la; ++j) selfscore += selfdiag[pa[j]];
+    uint32_t L[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) L[r] = (bias << kPkScore) | c_one;  // column 0: M[i][0] + i = 0
+    uint32_t dtop = (bias << kPkScore) | c_one;                      // (row sub*R, column 0)
+    auto column = [&](uint32_t a, uint32_t top) -> uint32_t {
+      const uint32_t colterm = a * 128u;
+      uint32_t up = top, dg = dtop;
+      dtop = top;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t tv = *reinterpret_cast<const uint32_t*>(tabb + rowoff[r] + colterm);
+        const uint32_t left = L[r];
+        const uint32_t raw = max(max(dg + tv, up), left + c_horiz);
+        const uint32_t cell = __builtin_amdgcn_bitop3_b32(raw, c_keep, c_one, 0xEA);
+        dg = left;
+        L[r] = cell;
+        up = cell;
+      }
+      return up;
+    };
+    // Steps: at step u my column is u - sub (0-based).  The loop bound is the wavefront's largest la + sub.
+    uint32_t n_steps = mine ? la + sub : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_steps = max(n_steps, (uint32_t)__shfl_xor((int)n_steps, d, 64));
+    n_steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_steps);
+    // The residues of A for my columns u-sub .. u-sub+3 as one unaligned dword, asked for one group of steps ahead.
+    auto residues = [&](uint32_t u) -> uint32_t {
+      uint32_t v = 0u;
+      if (mine) {
+        if (u >= sub) { if (u - sub < la) __builtin_memcpy(&v, pa + (u - sub), 4); }
+        else if (la) { __builtin_memcpy(&v, pa, 4); v <<= 8u * (sub - u); }  // (sub - u <= 3: u is a multiple of 4, sub < 4)
+      }
+      return v;
+    };
+    uint32_t ad_cur = residues(0u);
+    uint32_t bottom = 0u;
+    for (uint32_t u4 = 0; u4 < n_steps; u4 += 4u) {
+      const uint32_t ad_nxt = residues(u4 + 4u);
+#pragma unroll
+      for (uint32_t q = 0; q < 4u; ++q) {
+        const uint32_t above = from_lane_below(bottom);  // (every lane, before any lane diverges)
+        const uint32_t c = u4 + q - sub;                 // wraps for the steps before my first column
+        if (mine && c < la) {
+          const uint32_t a = (ad_cur >> (8u * q)) & 0xFFu;
+          uint32_t top = above;
+          if (sub == 0u) { top = ((bias - (c + 1u)) << kPkScore) | c_one; selfscore += selfdiag[a]; }  // row 0: M[0][j] = -j
+          bottom = column(a, top);
+        }
+      }
+      ad_cur = ad_nxt;
+    }
+    // the corner cell sits in the pair's last strip; the self scores are summed over the pair's lanes
+    int32_t self_all = 0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) self_all += __shfl(selfscore, (int)(lane - sub) + k, 64);
+    uint32_t res = (bias << kPkScore);
+    if (mine && sub + 1u == nstrips) {
+      const uint32_t rr = lb - sub * R - 1u;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if ((uint32_t)r == rr) res = L[r];
+    }
+    if (have && (nstrips ? sub + 1u == nstrips : sub == 0u)) {
+      const int32_t selfscore_all = self_all;
+      const int32_t mutual = (int32_t)(res >> kPkScore) - (int32_t)(bias + lb);
+      const uint32_t ndiag = res & 0x1FFu, nmatch = (res >> kPkMatch) & 0x1FFu;
+      const uint32_t gap = (la - ndiag) + (lb - ndiag);
+      const uint32_t mismatch = ndiag - nmatch;
+      const uint32_t len = gap + nmatch + mismatch;                           // :227
+      const float normfactor = (float)len / (float)selfscore_all;             // :228
+      float distance = (float)(selfscore_all - 2 * mutual) * normfactor;      // :232
+      const float similarity = (float)(2 * mutual) * normfactor;              // :233
+      if (!(selfscore_all >= mutual) || !(distance >= 0.f)) distance = __builtin_nanf("");
+      w.pair_res[res_index(w, dst)] = make_float2(distance, similarity);
+      if (w.pair_ext) w.pair_ext[dst] = make_uint4(nmatch, mismatch, gap, len);
+    }
+  }
+}
+
+// One kernel per class (one launch that dispatched on the class of each run was tried: the four inlined bodies cost the
+// dominant class 15 % -- config 4: 4.1 -> 4.8 ms of alignment per step).
+template <int R, int G>
+__global__ __launch_bounds__(kPackedBlock) void k_nw_protein_lanes(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
+                                                                   uint32_t* __restrict__ work_counter, unsigned long long* prof_acc) {
+  __shared__ uint32_t tab[kAA * kAA * 32];  // [b][a][bank] -> T(a,b), as in K3p
+  __shared__ int32_t selfdiag[32];
+  __shared__ int8_t blosum[kAA * kAA];
+  if (threadIdx.x < kAA * kAA) blosum[threadIdx.x] = c_blosum62[threadIdx.x];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < kAA * kAA * 32; idx += kPackedBlock) {
+    const int bres = idx / (kAA * 32), a = (idx / 32) % kAA;
+    const int sc = blosum[a * kAA + bres];
+    tab[idx] = ((uint32_t)(sc + 1) << kPkScore) + (1u << kPkMove) + (a == bres ? 1u << kPkMatch : 0u) + 1u;
+  }
+  if (threadIdx.x < 32) selfdiag[threadIdx.x] = threadIdx.x < kAA ? blosum[threadIdx.x * kAA + threadIdx.x] : 0;
+  __syncthreads();
+  const uint8_t* __restrict__ tabb = reinterpret_cast<const uint8_t*>(tab);
+  uint32_t c_horiz = 0u - (1u << kPkScore) - (1u << kPkMove);  // score - 1, move 1 -> 0
+  uint32_t c_keep = ~kPkMoveMask, c_one = 1u << kPkMove;
+  asm volatile("" : "+v"(c_horiz), "+v"(c_keep), "+v"(c_one));
+  // Runs of 64 / G pairs: the first one of a wavefront is fixed (one run per CU before any CU gets a second), the
+  // following ones come from the counter, which starts behind the fixed runs and only grows -- every wavefront leaves
+  // through the break.
+  constexpr uint32_t kPairs = 64u / G;
+  uint32_t base = ((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * kPairs;
+  for (;;) {
+    if (base >= n_list) break;
+    const uint32_t run = base;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(work_counter, kPairs);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    protein_lanes_run<R, G>(list, n_list, run, w, tabb, selfdiag, c_horiz, c_keep, c_one, prof_acc);
+  }
+}
+
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len) {
   size_t threads = ((size_t)n_pairs + kPackedBlock - 1) / kPackedBlock * kPackedBlock;
   const size_t cap = (size_t)1 << 20;  // at most 1 Mi alignments in flight per launch
@@ -445,5 +628,38 @@ hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32
   hipLaunchKernelGGL(k_nw_protein_packed<kPackedRows>, dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
   return hipGetLastError();
 }
+
+// K3l over the list of a lanes-per-pair class (protein_bin(): the vertical sequence needs `lanes` strips of
+// kProteinLaneRows).  Persistent workgroups as in K3p; `work_counter` is one word of device memory.
+hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* work_counter,
+                                      unsigned long long* prof_acc) {
+  if (n == 0) return hipSuccess;
+  hipError_t e = upload_blosum();
+  if (e != hipSuccess) return e;
+  if (lanes < 1 || lanes > kProteinMaxLanes) return hipErrorInvalidValue;
+  static int cus[64] = {0};
+  int dev = 0;
+  e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  int n_cu = dev < 64 ? cus[dev] : 0;
+  if (!n_cu) {
+    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64) cus[dev] = n_cu;
+  }
+  const uint32_t per_wave = 64u / (uint32_t)lanes;
+  uint32_t blocks = (n + per_wave - 1u) / per_wave;
+  if (blocks > (uint32_t)n_cu) blocks = (uint32_t)n_cu;
+  e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(work_counter), (int)(blocks * (kPackedBlock / 64) * per_wave), 1, st);  // behind the fixed first runs
+  if (e != hipSuccess) return e;
+  switch (lanes) {
+    case 1: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, 1>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
+    case 2: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, 2>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
+    case 3: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, 3>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
+    default: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, 4>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
+  }
+  return hipGetLastError();
+}
+static_assert(kProteinMaxLanes == 4, "launch_align_protein_lanes dispatches classes 1..4");
 
 }  // namespace rpa

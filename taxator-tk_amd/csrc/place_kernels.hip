@@ -411,7 +411,7 @@ __device__ __forceinline__ int pair_bin(const Params& p, uint32_t la, uint32_t l
   if (p.alphabet == 0) return dna_bin(la < lb ? la : lb);
   (void)la;
   if (p.force_bin >= 0) return p.force_bin;
-  return protein_bin(la, lb);  // protein: B (second segment) is the vertical sequence cut into register strips
+  return protein_bin(la, lb, p.protein_lanes != 0);  // protein: B (second segment) is the vertical sequence cut into register strips
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -200,6 +200,7 @@ struct Params {
   float reeval_factor;    // reeval_bandwidth_factor_ = (float)(1. - reeval_bandwidth)
   uint32_t spec1, spec2;  // speculation chunk (hits per round) of the pass-1 / pass-2 loops; 0 = the whole set at once
   int force_bin;          // >= 0: put every pair into this bin (experiments: RPA_FORCE_BIN); -1 normally
+  int protein_lanes;      // 0: packed protein pairs all go to K3p (one lane per pair), none to K3l (A/B: RPA_PROTEIN_LANES=0)
   int no_combined;        // 1: never ask for pass 0 and the first pass-1 loop in one round (A/B: RPA_NO_COMBINED)
   int grow;               // 1: a loop that pauses asks for as many hits again as it has already walked (chunks 2,2,4,8,...):
                           //    a loop that has not stopped early so far probably will not; log2(n) rounds instead of n/chunk
@@ -271,6 +272,8 @@ hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* lis
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                        size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
+hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* work_counter,
+                                      unsigned long long* prof_acc);
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
 
 // Work-list entry -> (segment A, segment B, result index).  Order matters for protein (A is the horizontal sequence):
@@ -300,13 +303,25 @@ __device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
 // Bin 4: the pair fits the packed-cell kernel (K3p, align_protein_kernels.hip): its two 9-bit path counters hold up to
 // 511 steps and its 12-bit score field holds la + lb + 11 * min(la, lb) + 32 (row-relative score + bias, BLOSUM62's
 // largest entry is 11) -- 312 x 312 residues, or e.g. 511 x 100.
+// Bins 5..8: a packed pair whose vertical sequence needs 1..4 strips of kProteinLaneRows rows (lb <= 96; every pair of
+// the 67 aa workload: three) goes to K3l, the same cell with the strips of a pair in adjacent lanes: bin = 4 + strips.
 constexpr uint32_t kPackedMaxLen = 511;
-constexpr int kProteinBins = 5;
+constexpr int kProteinBins = 9;
 constexpr int kProteinPackedBin = 4;
+#ifndef RPA_LANE_ROWS
+#define RPA_LANE_ROWS 24
+#endif
+constexpr int kProteinLaneRows = RPA_LANE_ROWS;
+constexpr int kProteinMaxLanes = 4;
 __host__ __device__ __forceinline__ bool protein_fits_packed(uint32_t la, uint32_t lb) {
   return la <= kPackedMaxLen && lb <= kPackedMaxLen && la + lb + 11u * (la < lb ? la : lb) + 32u <= 4095u;
 }
-__host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb) { return protein_fits_packed(la, lb) ? kProteinPackedBin : 2; }
+__host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb, bool lanes = true) {
+  if (!protein_fits_packed(la, lb)) return 2;
+  const uint32_t strips = (lb + kProteinLaneRows - 1u) / kProteinLaneRows;
+  if (lanes && strips <= (uint32_t)kProteinMaxLanes) return kProteinPackedBin + (strips ? (int)strips : 1);
+  return kProteinPackedBin;
+}
 
 // ---- reading a segment out of the packed store --------------------------------------------------------------
 __device__ __forceinline__ uint32_t revcomp8(uint32_t x) {  // 8 packed nt: reverse the nibble order, A<->T, C<->G, N stays

@@ -78,7 +78,7 @@ struct rpa_engine {
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
   DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
-      protein_ws, retry_list, retry_short;
+      protein_ws, lanes_counter, retry_list, retry_short;
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
   bool profiling = false;
@@ -274,6 +274,13 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
       }
     } else {
       const uint32_t max_len = counts[kCtrMaxLen];
+      if (bin > kProteinPackedBin) {  // K3l: the strips of a pair in adjacent lanes, nothing but the work counter in memory
+        HIP_TRY(e, e->lanes_counter.ensure(256));
+        HIP_TRY(e, launch_align_protein_lanes(e->stream, bin - kProteinPackedBin, list, n, w, e->lanes_counter.as<uint32_t>(), acc));
+        trc = timer.end();
+        if (trc) return trc;
+        continue;
+      }
       HIP_TRY(e, e->protein_ws.ensure(protein_scratch_words(n, max_len) * 4));
       if (bin == kProteinPackedBin)  // every pair of this list passed protein_fits_packed(): no sequence above kPackedMaxLen
         HIP_TRY(e, launch_align_protein_packed(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4,
@@ -709,6 +716,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_PARTS")) e->parts_override = atoi(v);
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
+  e->params.protein_lanes = 1;
+  if (const char* v = getenv("RPA_PROTEIN_LANES")) e->params.protein_lanes = atoi(v) != 0;
   e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
   e->params.grow = 0;
   if (const char* v = getenv("RPA_SPEC_GROW")) e->params.grow = atoi(v);

@@ -211,7 +211,12 @@ def test_dna_pairs_many_200bp(pkg, oracle):
     _check_dna(oracle, out[idx], [base[k] for k in idx], [mut[k, :cut[k]] for k in idx])
 
 
-def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir):
+@pytest.mark.parametrize("lanes", ["lanes-per-pair", "one-lane"])
+def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir, lanes, monkeypatch):
+    # default: packed pairs whose vertical sequence has <= 96 residues run with their strips in adjacent lanes (K3l);
+    # RPA_PROTEIN_LANES=0 sends them all to the one-lane-per-pair kernel (K3p)
+    if lanes == "one-lane":
+        monkeypatch.setenv("RPA_PROTEIN_LANES", "0")
     vec = json.load(open(os.path.join(golden_dir, "pairs_protein.json")))
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.PROTEIN)
     seqs = []
@@ -261,6 +266,15 @@ def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir):
         mm = rng.random(lb) < 0.15
         b[mm] = rng.integers(0, 20, int(mm.sum()))
         a_codes.append(a); b_codes.append(b)
+    # every strip count of the lanes-per-pair kernel and its edges (24-row strips; columns go in groups of four; lanes of
+    # one wavefront with different column counts), more pairs than one run of a wavefront holds
+    for lb in [1, 2, 23, 24, 25, 47, 48, 49, 71, 72, 73, 95, 96, 97]:
+        for la in [1, 2, 3, 4, 5, 7, 8, 9, lb, lb + 1, 2 * lb + 3, 150]:
+            a = rng.integers(0, 20, la).astype(np.uint8)
+            b = np.resize(a, lb).copy()
+            mm = rng.random(lb) < 0.25
+            b[mm] = rng.integers(0, 20, int(mm.sum()))
+            a_codes.append(a); b_codes.append(b)
     seqs = [LETTERS_AA[x] for pair in zip(a_codes, b_codes) for x in pair]
     letters, offsets = _pack(seqs)
     n = len(a_codes)
@@ -347,7 +361,10 @@ def test_predict_dna_ragged_sets_and_lengths(pkg, oracle, synth):
         _engine_vs_oracle(pkg, oracle, synth, ds, 0)
 
 
-def test_predict_protein(pkg, oracle, synth):
+@pytest.mark.parametrize("lanes", ["lanes-per-pair", "one-lane"])
+def test_predict_protein(pkg, oracle, synth, lanes, monkeypatch):
+    if lanes == "one-lane":
+        monkeypatch.setenv("RPA_PROTEIN_LANES", "0")
     ds = synth.make_dataset(n_sets=400, n_hits=20, seg_len=67, branching=3, genome_len=1500, seed=4, alphabet=1,
                             level_rate=0.06, query_rate=0.08, variety=True)
     _engine_vs_oracle(pkg, oracle, synth, ds, 1)
