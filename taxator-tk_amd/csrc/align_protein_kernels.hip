@@ -30,6 +30,7 @@ namespace rpa {
 
 constexpr int kAA = 27;
 constexpr int kAAGroups = 7;  // ceil(27/4)
+constexpr int kAX = kAA + 1;   // K3l: the residues and one more code (null column / padding row)
 
 __device__ __constant__ int8_t c_blosum62[kAA * kAA];
 static bool g_blosum_uploaded[64] = {false};
@@ -388,7 +389,12 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2*
 // touches HBM: a launch reads the residues and writes one result per pair (K3p hands every strip boundary through a
 // scratch row in memory: 13x the algorithmic bytes at 67 aa).  The price is the s idle steps per lane at either end of
 // a pair (G - 1 of la + G - 1 steps), the lanes of strips a shorter pair of the same class does not have, and lane 63 when
-// G = 3.  Same table, same packed cell, same results as K3p bit for bit.
+// G = 3.  Same packed cell, same results as K3p bit for bit.
+// No lane is ever masked inside the column loop (a branch around the column made the compiler copy all R cells at its
+// end, +20 % VALU): a lane without a column at some step computes one for the NULL residue, a 28th table column of
+// zeros.  In front of a pair that leaves the strip in its column-0 state K = (bias, move 1, no steps) -- diagonal K + 0,
+// vertical K, horizontal K - 1 -> K again, and the cell handed down is K, which is what the neighbour's idle steps need --
+// and behind a pair the strip's content no longer matters: the corner cell is picked up at the step that computes it.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t from_lane_below(uint32_t v) {  // lane i receives lane i-1's value (lane 0: 0)
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -430,18 +436,26 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
     }
     const uint32_t nstrips = (lb + R - 1) / R;  // <= G by the bin
     const bool mine = have && sub < nstrips;
+    const uint32_t cols = mine ? la : 0u;  // the columns this lane really computes
     const uint32_t bias = la + 32u;
     int32_t selfscore = 0;  // my share of NW(A,A) + NW(B,B): my rows of B; the first lane of the pair adds A's residues
     uint32_t rowoff[R];
+    // Strips are aligned to the END of B: strip s > 0 owns rows p + (s-1)R + 1 .. p + sR, strip 0 the first p = lb - (nstrips-1)R
+    // rows in its LAST p registers; the R - p registers above them are padding rows (residue code kAA: every table entry is
+    // "score - 1, move 0", so the cell of a padding row is the cell above it: row 0 passes through them unchanged).  The
+    // corner cell is then always the bottom cell of the pair's last lane.
+    const uint32_t pad = mine && sub == 0u ? nstrips * R - lb : 0u;  // padding rows in front of my rows (strip 0 only)
     if (mine) {
-      uint32_t bw[(R + 3) / 4];  // unaligned dword loads; reads run at most R + 2 bytes past the segment (store slack)
+      // my first register's row (0-based, may be "negative" for strip 0) relative to pb
+      const uint8_t* __restrict__ rows = pb + (size_t)sub * R - (size_t)(nstrips * R - lb);
+      uint32_t bw[(R + 3) / 4];  // unaligned dword loads; they start at most R - 1 bytes in front of the segment and end at most 3 bytes behind it (store slack)
 #pragma unroll
-      for (int q = 0; q < (R + 3) / 4; ++q) __builtin_memcpy(&bw[q], pb + (size_t)sub * R + 4 * q, 4);
+      for (int q = 0; q < (R + 3) / 4; ++q) __builtin_memcpy(&bw[q], rows + 4 * q, 4);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const uint32_t bres = (bw[r >> 2] >> (8 * (r & 3))) & 0xFFu;  // rows past lb are never used
-        rowoff[r] = (sub * R + r < lb ? bres : 0u) * (kAA * 128u) + bank4;
-        if (sub * R + r < lb) selfscore += selfdiag[bres];
+        const uint32_t bres = (uint32_t)r < pad ? (uint32_t)kAA : (bw[r >> 2] >> (8 * (r & 3))) & 0xFFu;
+        rowoff[r] = bres * (kAX * 128u) + bank4;
+        selfscore += selfdiag[bres];  // (padding rows: 0)
       }
     } else {
 #pragma unroll
@@ -449,10 +463,11 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
     }
     if (have && sub == 0u && nstrips == 0u)  // no rows: K3p's answer (score 0, no steps), A's residues still count
       for (uint32_t j = 0; j < la; ++j) selfscore += selfdiag[pa[j]];
+    const uint32_t K = (bias << kPkScore) | c_one;  // column 0: M[i][0] + i = 0
     uint32_t L[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) L[r] = (bias << kPkScore) | c_one;  // column 0: M[i][0] + i = 0
-    uint32_t dtop = (bias << kPkScore) | c_one;                      // (row sub*R, column 0)
+    for (int r = 0; r < R; ++r) L[r] = K;
+    uint32_t dtop = K;                              // (row sub*R, column 0)
     auto column = [&](uint32_t a, uint32_t top) -> uint32_t {
       const uint32_t colterm = a * 128u;
       uint32_t up = top, dg = dtop;
@@ -483,20 +498,24 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
       }
       return v;
     };
+    // the first lane of a pair: row 0 above its strip, and A's self scores (the other lanes add from a table of zeros)
+    const bool first = sub == 0u;
+    const int32_t* __restrict__ sd = selfdiag + (first ? 0 : 32);
+    const bool corner_mine = mine && sub + 1u == nstrips;  // the pair's last strip: its bottom cell of column la is the corner
+    uint32_t res = K;                                      // no columns or no rows: score 0, no steps
     uint32_t ad_cur = residues(0u);
-    uint32_t bottom = 0u;
+    uint32_t bottom = K;
     for (uint32_t u4 = 0; u4 < n_steps; u4 += 4u) {
       const uint32_t ad_nxt = residues(u4 + 4u);
 #pragma unroll
       for (uint32_t q = 0; q < 4u; ++q) {
-        const uint32_t above = from_lane_below(bottom);  // (every lane, before any lane diverges)
-        const uint32_t c = u4 + q - sub;                 // wraps for the steps before my first column
-        if (mine && c < la) {
-          const uint32_t a = (ad_cur >> (8u * q)) & 0xFFu;
-          uint32_t top = above;
-          if (sub == 0u) { top = ((bias - (c + 1u)) << kPkScore) | c_one; selfscore += selfdiag[a]; }  // row 0: M[0][j] = -j
-          bottom = column(a, top);
-        }
+        const uint32_t above = from_lane_below(bottom);
+        const uint32_t c = u4 + q - sub;  // wraps for the steps in front of my first column
+        const uint32_t a = c < cols ? (ad_cur >> (8u * q)) & 0xFFu : (uint32_t)kAA;  // (kAA: the null residue)
+        const uint32_t top = first ? ((bias - (c + 1u)) << kPkScore) | c_one : above;   // row 0: M[0][j] = -j
+        selfscore += sd[a];
+        bottom = column(a, top);
+        res = corner_mine && c + 1u == la ? bottom : res;
       }
       ad_cur = ad_nxt;
     }
@@ -504,13 +523,6 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
     int32_t self_all = 0;
 #pragma unroll
     for (int k = 0; k < G; ++k) self_all += __shfl(selfscore, (int)(lane - sub) + k, 64);
-    uint32_t res = (bias << kPkScore);
-    if (mine && sub + 1u == nstrips) {
-      const uint32_t rr = lb - sub * R - 1u;
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if ((uint32_t)r == rr) res = L[r];
-    }
     if (have && (nstrips ? sub + 1u == nstrips : sub == 0u)) {
       const int32_t selfscore_all = self_all;
       const int32_t mutual = (int32_t)(res >> kPkScore) - (int32_t)(bias + lb);
@@ -533,17 +545,18 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
 template <int R, int G>
 __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_lanes(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
                                                                    uint32_t* __restrict__ work_counter, unsigned long long* prof_acc) {
-  __shared__ uint32_t tab[kAA * kAA * 32];  // [b][a][bank] -> T(a,b), as in K3p
-  __shared__ int32_t selfdiag[32];
+  __shared__ uint32_t tab[kAX * kAX * 32];  // [b][a][bank] -> T(a,b) as in K3p; T(null,b) = 0; T(a,padding) = "score - 1, move 0"
+  __shared__ int32_t selfdiag[64];          // s(x,x); [27..31] = 0 (null residue), [32..63] = 0 (lanes that do not count A)
   __shared__ int8_t blosum[kAA * kAA];
   if (threadIdx.x < kAA * kAA) blosum[threadIdx.x] = c_blosum62[threadIdx.x];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < kAA * kAA * 32; idx += kPackedBlock) {
-    const int bres = idx / (kAA * 32), a = (idx / 32) % kAA;
-    const int sc = blosum[a * kAA + bres];
-    tab[idx] = ((uint32_t)(sc + 1) << kPkScore) + (1u << kPkMove) + (a == bres ? 1u << kPkMatch : 0u) + 1u;
+  for (int idx = threadIdx.x; idx < kAX * kAX * 32; idx += kPackedBlock) {
+    const int bres = idx / (kAX * 32), a = (idx / 32) % kAX;
+    const int sc = a < kAA && bres < kAA ? blosum[a * kAA + bres] : 0;
+    tab[idx] = bres == kAA ? 0u - (1u << kPkScore) - (1u << kPkMove)
+               : a < kAA ? ((uint32_t)(sc + 1) << kPkScore) + (1u << kPkMove) + (a == bres ? 1u << kPkMatch : 0u) + 1u : 0u;
   }
-  if (threadIdx.x < 32) selfdiag[threadIdx.x] = threadIdx.x < kAA ? blosum[threadIdx.x * kAA + threadIdx.x] : 0;
+  if (threadIdx.x < 64) selfdiag[threadIdx.x] = threadIdx.x < kAA ? blosum[threadIdx.x * kAA + threadIdx.x] : 0;
   __syncthreads();
   const uint8_t* __restrict__ tabb = reinterpret_cast<const uint8_t*>(tab);
   uint32_t c_horiz = 0u - (1u << kPkScore) - (1u << kPkMove);  // score - 1, move 1 -> 0
