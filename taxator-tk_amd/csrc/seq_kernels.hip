@@ -90,8 +90,10 @@ hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const u
 }
 
 // A few words from device memory into host-mapped (pinned) memory by a kernel instead of a copy command: the per-round
-// counter read-back of the placement loop must not queue behind another job's 80 MB host->device transfers on the
-// copy engine (it did: seven read-backs per batch each waited ~1.4 ms for the transfer in flight).
+// counter read-back of the placement loop then never meets another job's 80 MB host->device transfers on a copy queue.
+// (Measured: no change by itself -- what stalled jobs in flight were pooled hardware queues, see make_stream in
+// rpa_engine.hip -- and polling a sequence number written behind the words instead of hipStreamSynchronize gains
+// nothing either, 11.9 ms per step both ways: the runtime's wait already spins.)
 __global__ void k_publish_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst_host, uint32_t n) {
   if (threadIdx.x < n) dst_host[threadIdx.x] = src[threadIdx.x];
 }
