@@ -196,9 +196,13 @@ def main():
                          "c5 long contigs are extra measurements")
     ap.add_argument("--in-flight", type=int, default=3, help="with --host-buffers / --pipeline: jobs submitted before the oldest is waited for (1..3)")
     ap.add_argument("--pipeline", action="store_true",
-                    help="device-resident batch, but the steps go through rpa_submit_batch with --in-flight of them running at a time: the "
-                         "placement rounds of one step under the alignment kernels of another.  A throughput figure for streams of "
-                         "batches; the per-launch durations behind `roofline` overlap and are inflated by it -- not the headline")
+                    help="(the default, kept for old command lines) the steps go through rpa_submit_batch with --in-flight of them "
+                         "running at a time on the engine's job slots: the placement rounds of one step under the alignment kernels of "
+                         "another")
+    ap.add_argument("--sync", action="store_true",
+                    help="one synchronous rpa_predict_batch per step instead (round 1's timed region).  The default run times the "
+                         "steps through the asynchronous boundary and then repeats them this way, untimed for `value`, for the "
+                         "per-launch durations behind `roofline` (overlapping jobs inflate those)")
     ap.add_argument("--store-replicas", type=int, default=1,
                     help="lay the reference store out R times (R x 4096 sequences; every alignment row points at a random replica of its "
                          "species): the same work against a store that is really spread over HBM instead of sitting in L2 / "
@@ -306,7 +310,9 @@ def main():
                   if (use_dist and rank == 0) else None)
     # RCCL: the gather of step k runs beside the kernels of step k + 1 (rows double-buffered; every step's rows still reach
     # rank 0 inside the timed region).  gloo rehearsals keep the plain blocking gather.
-    overlap_gather = use_dist and not gloo and not args.host_buffers and not args.pipeline
+    pipelined = not args.sync and not args.host_buffers
+    args.in_flight = max(1, min(3, args.in_flight))
+    overlap_gather = use_dist and not gloo and not args.host_buffers and not pipelined
     rows_buf = [rows, torch.zeros_like(rows)] if overlap_gather else [rows]
     stats_buf = [stats, torch.zeros_like(stats)] if overlap_gather else [stats]
     gather_buf = [gather_out, ([torch.empty_like(t) for t in gather_out] if gather_out is not None else None)] if overlap_gather else [gather_out]
@@ -335,11 +341,23 @@ def main():
             r_, s_ = pinned_copy(np.zeros(ds.n_sets, pkg.PRED_DTYPE)), pinned_copy(np.zeros(ds.n_sets, pkg.STATS_DTYPE))
             host_out.append((r_, s_))
 
-    pipe_out = [(rows, stats)] + [(torch.zeros_like(rows), torch.zeros_like(stats)) for _ in range(3)] if args.pipeline else []
+    # pipelined: a buffer set per job in flight + two whose rows may still be on their way to rank 0
+    n_pipe = args.in_flight + 2
+    pipe_out = [(rows, stats)] + [(torch.zeros_like(rows), torch.zeros_like(stats)) for _ in range(n_pipe - 1)] if pipelined else []
+    if pipelined and use_dist:
+        pending_gather = [None] * n_pipe
+        gather_buf = [gather_out] + [([torch.empty_like(t) for t in gather_out] if gather_out is not None else None) for _ in range(n_pipe - 1)]
 
     def finish_one():
-        if args.pipeline:
-            in_flight.popleft().wait()
+        if pipelined:
+            k, job = in_flight.popleft()
+            job.wait()  # the job's rows are complete in pipe_out[k]
+            if use_dist:
+                if gloo:
+                    step.gathered = sharding.gather_rows(pipe_out[k][0].cpu(), dst=0, sizes=gather_sizes, out=gather_buf[k], force=True)
+                else:   # RCCL: the exchange runs beside the jobs still in flight; its buffers are not reused before it is done
+                    pending_gather[k] = sharding.gather_rows(pipe_out[k][0], dst=0, sizes=gather_sizes, out=gather_buf[k], force=True, async_op=True)
+                step.last = k
             return
         r_host, s_host = in_flight.popleft().wait()
         if not step.copied:
@@ -356,12 +374,15 @@ def main():
             in_flight.append(model.submit(host_batch, out=r_, stats=s_))
             if len(in_flight) == args.in_flight:
                 finish_one()
-        elif args.pipeline:
-            k = step.n % len(pipe_out)
+        elif pipelined:
+            k = step.n % n_pipe
             step.n += 1
-            in_flight.append(model.submit(dev, out=pipe_out[k][0], stats=pipe_out[k][1], mem_kind=pkg.MEM_DEVICE))
+            if use_dist and pending_gather[k] is not None:  # the exchange that read this buffer set n_pipe steps ago
+                pending_gather[k][0].wait()
+                pending_gather[k] = None
+            in_flight.append((k, model.submit(dev, out=pipe_out[k][0], stats=pipe_out[k][1], mem_kind=pkg.MEM_DEVICE)))
             if len(in_flight) == args.in_flight:
-                in_flight.popleft().wait()
+                finish_one()
         elif overlap_gather:
             k = step.n % 2
             step.n += 1
@@ -410,6 +431,20 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = model.profile()
+    prof_steps = args.steps
+    sync_ms = None
+    if pipelined:
+        # The same steps once more as synchronous calls, for the profile only (launch durations by HIP events on the
+        # engine's stream, cells, demanded / computed alignments, rounds): jobs that overlap inflate each other's launches.
+        prof_steps = max(1, min(args.steps, 10))
+        model.profile(enable=True, reset=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
+        torch.cuda.synchronize()
+        sync_ms = (time.perf_counter() - t1) / prof_steps * 1e3
+        prof = model.profile()
 
     demanded = int(stats[:, 1:].to(torch.int64).sum().item())  # per step, this rank
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -426,7 +461,14 @@ def main():
         # HBM traffic of the alignment kernels cannot be read from inside the process: it comes from the committed
         # rocprofv3 PMC passes of this same command (profiles/*traffic.json, see profiles/README.md)
         traffic, traffic_src = None, None
+        valu_per_launch, valu_src = None, None
         if use_dist and rank == 0:  # the gathered rows of this rank's own shard must be the rows it computed
+            if pipelined and not gloo:
+                gather_out = gather_buf[step.last]
+                step.gathered = gather_out if len(set(gather_sizes)) == 1 else torch.cat([b_[:n_] for b_, n_ in zip(gather_out, gather_sizes)], dim=0)
+                rows = pipe_out[step.last][0]
+            elif pipelined:
+                gather_out, rows = gather_buf[step.last], pipe_out[step.last][0]
             if overlap_gather:
                 gather_out, rows = gather_buf[step.last], rows_buf[step.last]
                 step.gathered = gather_out if len(set(gather_sizes)) == 1 else torch.cat([b_[:n_] for b_, n_ in zip(gather_out, gather_sizes)], dim=0)
@@ -447,6 +489,21 @@ def main():
             if cands:
                 tj = json.load(open(cands[-1]))
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
+                # the SQ pass of the same profile: vector instructions the alignment kernels issued, per launch
+                sq = cands[-1].replace("_traffic.json", "_pmc_sq.txt")
+                if os.path.exists(sq):
+                    import re
+                    cur, instr, disp = None, 0.0, 0
+                    for line in open(sq):
+                        m = re.match(r"(?:void )?(rpa::.+?)\s+dispatches=(\d+)", line)
+                        if m:
+                            cur = m.group(1) if ("k_myers" in m.group(1) or "k_nw_protein" in m.group(1)) else None
+                            disp += int(m.group(2)) if cur else 0
+                        m = re.search(r"SQ_INSTS_VALU\s+sum=(\S+)", line)
+                        if m and cur:
+                            instr += float(m.group(1))
+                    if disp:
+                        valu_per_launch, valu_src = instr / disp, os.path.relpath(sq, ROOT)
         value = demanded_all * args.steps / elapsed
         n_launch = max(prof["launches"], 1)
         align_s = prof["align_ms"] / 1e3
@@ -459,7 +516,7 @@ def main():
             "config": {"workload": "%s: %d record sets x %d hits x %d %s RPA per GPU, mock NCBI taxonomy (b=4, 5462 nodes), batch resident in HBM"
                                    % (cfg["name"], args.sets, args.hits, args.seg_len, "bp nucleotide" if cfg["alphabet"] == 0 else "aa protein")
                                    + (" -- HOST BUFFERS: batch copied to the device and rows back inside every step, several steps in flight through rpa_submit_batch / rpa_wait (PCIe-inclusive, not the headline)" if args.host_buffers else "")
-                                   + (" -- PIPELINED: %d steps in flight through rpa_submit_batch (not the headline)" % args.in_flight if args.pipeline else ""),
+                                   + (" -- one synchronous rpa_predict_batch per step" if args.sync else ""),
                        "record_sets_per_gpu": args.sets, "hits_per_set": args.hits, "segment_bp": args.seg_len,
                        "parallelism": ("record sets sharded over %d rank(s)%s; %s gather of 32-byte rows to rank 0 every step"
                                        % (world, ", ONE workload cut by summed alignment cells" if cut_by_cost else "",
@@ -475,9 +532,20 @@ def main():
                          "avg_launch_ms": prof["align_ms"] / n_launch, "launches": prof["launches"],
                          "computed_alignments_per_s_in_kernel": prof["pairs"] / max(align_s, 1e-12),
                          "cell_updates_per_s_in_kernel": prof["cells"] / max(align_s, 1e-12),
-                         "note": "integer-VALU bound bit-parallel DP: HBM fraction is reported per contract; cell updates/s is the honest bound"},
-            "device_ms_per_step": prof["total_ms"] / args.steps, "align_ms_per_step": prof["align_ms"] / args.steps,
-            "computed_over_demanded": prof["pairs"] / max(prof["demanded"], 1), "rounds_per_step": prof["rounds"] / args.steps,
+                         "note": "integer-VALU bound bit-parallel DP: HBM fraction is reported per contract; cell updates/s and valu_issue are the honest bounds",
+                         # vector-instruction issue: wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of the committed profile)
+                         # over the live launch duration, per SIMD (1024 of them); a wave64 instruction takes a SIMD-32 two cycles
+                         # (MI355X_MICROARCH.md) = 1.2 per ns at 2.4 GHz; plain and/or/add measured ~1.0, shifts and carry ops ~0.57
+                         "valu_issue": None if valu_per_launch is None or prof["align_ms"] <= 0 else {
+                             "achieved": valu_per_launch / (prof["align_ms"] / n_launch * 1e6) / 1024.0, "peak": 1.2,
+                             "unit": "wave-instr/ns/SIMD", "frac": valu_per_launch / (prof["align_ms"] / n_launch * 1e6) / 1024.0 / 1.2,
+                             "wave_instr_per_launch": valu_per_launch, "source": valu_src}},
+            "device_ms_per_step": prof["total_ms"] / prof_steps, "align_ms_per_step": prof["align_ms"] / prof_steps,
+            "computed_over_demanded": prof["pairs"] / max(prof["demanded"], 1), "rounds_per_step": prof["rounds"] / prof_steps,
+            "submission": ("rpa_submit_batch / rpa_wait, %d steps in flight on the engine's job slots (the timed region); `roofline`, device_ms_per_step, "
+                           "align_ms_per_step and rounds_per_step come from %d synchronous rpa_predict_batch calls on the same batch after it"
+                           % (args.in_flight, prof_steps)) if pipelined else "one synchronous call per step",
+            "sync_ms_per_step": sync_ms,
             "datagen_s": t_gen,
             "reference_store": {"replicas": args.store_replicas, "packed_bytes": store_bytes,
                                 "note": "config 2's 4096-species collection is 8 MB packed (cache resident); --store-replicas spreads the same work over HBM"},

@@ -9,7 +9,7 @@ for REP in 1 $N; do
   for P in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     NAME=$(echo $P | cut -d' ' -f1 | tr A-Z a-z | cut -d_ -f1)
     rm -rf /tmp/pmc_${TAG}_${NAME}_$REP
-    rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "rpa::" --output-format csv -d /tmp/pmc_${TAG}_${NAME}_$REP -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --store-replicas $REP > /dev/null 2> $R/gpurun_out/${TAG}_bigstore_pmc_${NAME}_r$REP.err
+    rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "rpa::" --output-format csv -d /tmp/pmc_${TAG}_${NAME}_$REP -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sync --store-replicas $REP > /dev/null 2> $R/gpurun_out/${TAG}_bigstore_pmc_${NAME}_r$REP.err
     python3 $R/tools/pmc_summary.py /tmp/pmc_${TAG}_${NAME}_$REP/pmc_counter_collection.csv > $R/gpurun_out/${TAG}_bigstore_pmc_${NAME}_r$REP.txt
   done
   echo "replicas $REP done" >> $R/gpurun_out/${TAG}_bigstore_progress.txt
