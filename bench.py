@@ -311,7 +311,7 @@ def main():
     # RCCL: the gather of step k runs beside the kernels of step k + 1 (rows double-buffered; every step's rows still reach
     # rank 0 inside the timed region).  gloo rehearsals keep the plain blocking gather.
     pipelined = not args.sync and not args.host_buffers
-    args.in_flight = max(1, min(3, args.in_flight))
+    args.in_flight = max(1, min(int(os.environ.get("RPA_JOB_SLOTS", "3")), args.in_flight))
     overlap_gather = use_dist and not gloo and not args.host_buffers and not pipelined
     rows_buf = [rows, torch.zeros_like(rows)] if overlap_gather else [rows]
     stats_buf = [stats, torch.zeros_like(stats)] if overlap_gather else [stats]

@@ -494,7 +494,7 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
       uint32_t v = 0u;
       if (mine) {
         if (u >= sub) { if (u - sub < la) __builtin_memcpy(&v, pa + (u - sub), 4); }
-        else if (la) { __builtin_memcpy(&v, pa, 4); v <<= 8u * (sub - u); }  // (sub - u <= 3: u is a multiple of 4, sub < 4)
+        else if (la && sub - u <= 3u) { __builtin_memcpy(&v, pa, 4); v <<= 8u * (sub - u); }  // my first column falls into this group
       }
       return v;
     };
@@ -665,14 +665,15 @@ hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* li
   if (blocks > (uint32_t)n_cu) blocks = (uint32_t)n_cu;
   e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(work_counter), (int)(blocks * (kPackedBlock / 64) * per_wave), 1, st);  // behind the fixed first runs
   if (e != hipSuccess) return e;
+#define RPA_LAUNCH_LANES(GV) \
+  case GV: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, GV>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
   switch (lanes) {
-    case 1: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, 1>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
-    case 2: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, 2>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
-    case 3: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, 3>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
-    default: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, 4>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
+    RPA_LAUNCH_LANES(1) RPA_LAUNCH_LANES(2) RPA_LAUNCH_LANES(3) RPA_LAUNCH_LANES(4) RPA_LAUNCH_LANES(6) RPA_LAUNCH_LANES(8) RPA_LAUNCH_LANES(13)
+    default: return hipErrorInvalidValue;
   }
+#undef RPA_LAUNCH_LANES
   return hipGetLastError();
 }
-static_assert(kProteinMaxLanes == 4, "launch_align_protein_lanes dispatches classes 1..4");
+static_assert(kProteinMaxLanes == 13 && kProteinLaneClasses == 7, "launch_align_protein_lanes dispatches the classes of protein_class_lanes()");
 
 }  // namespace rpa

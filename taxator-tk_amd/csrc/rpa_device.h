@@ -303,25 +303,34 @@ __device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
 // Bin 4: the pair fits the packed-cell kernel (K3p, align_protein_kernels.hip): its two 9-bit path counters hold up to
 // 511 steps and its 12-bit score field holds la + lb + 11 * min(la, lb) + 32 (row-relative score + bias, BLOSUM62's
 // largest entry is 11) -- 312 x 312 residues, or e.g. 511 x 100.
-// Bins 5..8: a packed pair whose vertical sequence needs 1..4 strips of kProteinLaneRows rows (lb <= 96; every pair of
-// the 67 aa workload: three) goes to K3l, the same cell with the strips of a pair in adjacent lanes: bin = 4 + strips.
+// Bins 5..11: a packed pair whose vertical sequence needs up to 13 strips of kProteinLaneRows rows (lb <= 312; every pair
+// of the 67 aa workload: three) goes to K3l, the same cell with the strips of a pair in adjacent lanes.  Seven classes of
+// lanes per pair -- 1, 2, 3, 4, 6, 8, 13 -- a pair takes the narrowest one that holds its strips (bin = 5 + class).
 constexpr uint32_t kPackedMaxLen = 511;
-constexpr int kProteinBins = 9;
+constexpr int kProteinBins = 12;
 constexpr int kProteinPackedBin = 4;
 #ifndef RPA_LANE_ROWS
 #define RPA_LANE_ROWS 24
 #endif
 constexpr int kProteinLaneRows = RPA_LANE_ROWS;
-constexpr int kProteinMaxLanes = 4;
+constexpr int kProteinLaneClasses = 7;
+constexpr int kProteinMaxLanes = 13;
+__host__ __device__ __forceinline__ int protein_class_lanes(int cls) {  // lanes per pair of a class
+  return cls < 4 ? cls + 1 : cls == 4 ? 6 : cls == 5 ? 8 : 13;
+}
 __host__ __device__ __forceinline__ bool protein_fits_packed(uint32_t la, uint32_t lb) {
   return la <= kPackedMaxLen && lb <= kPackedMaxLen && la + lb + 11u * (la < lb ? la : lb) + 32u <= 4095u;
 }
 __host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb, bool lanes = true) {
   if (!protein_fits_packed(la, lb)) return 2;
   const uint32_t strips = (lb + kProteinLaneRows - 1u) / kProteinLaneRows;
-  if (lanes && strips <= (uint32_t)kProteinMaxLanes) return kProteinPackedBin + (strips ? (int)strips : 1);
+  if (lanes && strips <= (uint32_t)kProteinMaxLanes) {
+    const int cls = strips <= 4u ? (strips ? (int)strips - 1 : 0) : strips <= 6u ? 4 : strips <= 8u ? 5 : 6;
+    return kProteinPackedBin + 1 + cls;
+  }
   return kProteinPackedBin;
 }
+static_assert(kProteinPackedBin + 1 + kProteinLaneClasses <= kProteinBins && kProteinBins <= kNumBins, "protein bins");
 
 // ---- reading a segment out of the packed store --------------------------------------------------------------
 __device__ __forceinline__ uint32_t revcomp8(uint32_t x) {  // 8 packed nt: reverse the nibble order, A<->T, C<->G, N stays

@@ -276,7 +276,7 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
       const uint32_t max_len = counts[kCtrMaxLen];
       if (bin > kProteinPackedBin) {  // K3l: the strips of a pair in adjacent lanes, nothing but the work counter in memory
         HIP_TRY(e, e->lanes_counter.ensure(256));
-        HIP_TRY(e, launch_align_protein_lanes(e->stream, bin - kProteinPackedBin, list, n, w, e->lanes_counter.as<uint32_t>(), acc));
+        HIP_TRY(e, launch_align_protein_lanes(e->stream, protein_class_lanes(bin - kProteinPackedBin - 1), list, n, w, e->lanes_counter.as<uint32_t>(), acc));
         trc = timer.end();
         if (trc) return trc;
         continue;
@@ -1094,7 +1094,8 @@ int rpa_submit_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out,
   if (!batch || !out) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch: null argument");
   if (batch->mem_kind != RPA_MEM_HOST && batch->mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch: bad mem_kind");
   HIP_TRY(e, hipSetDevice(e->device));
-  while (e->slots.size() < RPA_JOBS_IN_FLIGHT) {
+  static const size_t n_slots = [] { const char* v = getenv("RPA_JOB_SLOTS"); const long n = v ? atol(v) : 0; return (size_t)(n >= 1 && n <= 8 ? n : RPA_JOBS_IN_FLIGHT); }();  // (experiments)
+  while (e->slots.size() < n_slots) {
     rpa_engine* s = make_worker(e);
     if (!s) return RPA_ERR_DEVICE;
     s->owner = e;
