@@ -508,15 +508,19 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
 bool dna_short_band_available(int words) { return words >= 5 && words <= kShortWords; }
 
 hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
-                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, unsigned long long* prof_acc) {
+                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, unsigned long long* prof_acc) {
   if ((uint64_t)n + n2 == 0) return hipSuccess;
   if ((uint64_t)n + n2 > 0xFFFFFF00ull || !retry || !retry_n) return hipErrorInvalidValue;
   const uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
   const size_t lds = (size_t)5 * words * kBlock * sizeof(uint32_t);
   const char* bw = getenv("RPA_BAND_WORDS");  // 5: the in-phase five-word window (A/B, tests)
   const bool five = bw && atoi(bw) == 5;
-  const char* padv = getenv("RPA_BAND4_LDS_PAD");  // occupancy experiments: extra dynamic LDS per workgroup of the ring kernel
-  const size_t pad4 = padv ? (size_t)atoi(padv) : 0;
+  // Occupancy of the ring kernel: 20 KB of LDS and 73-79 VGPRs per wavefront give six wavefronts per SIMD, which is worth
+  // 2 % to a batch that has the GPU to itself and leaves no registers for anybody else.  A job slot (several batches in
+  // flight) asks for 20 KB more: four wavefronts per SIMD, and the memory-bound placement kernels of the other jobs find
+  // room beside them (config 2, three steps in flight: 10.17 -> 9.76 ms per step; one synchronous batch: 11.5 -> 11.7).
+  const char* padv = getenv("RPA_BAND4_LDS_PAD");  // (experiments: extra dynamic LDS per workgroup in bytes, whoever launches)
+  const size_t pad4 = padv ? (size_t)atoi(padv) : (shared_gpu ? 20000u : 0u);
 #define RPA_LAUNCH_MYERS_BAND(NWV) \
   case NWV: \
     if (five) hipLaunchKernelGGL((k_myers_short_band<NWV, 2>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \

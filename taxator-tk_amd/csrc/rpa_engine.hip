@@ -241,7 +241,7 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
         // onto a retry list).  A launch of the dense rounds only: the sparse rounds put every class into one list.
         if (use_band_short && dna_short_band_available(bin + 1) && (uint64_t)n + n2 >= e->band_short_min) {
           HIP_TRY(e, launch_align_dna_short_band(e->stream, bin + 1, list, n, list2, n2, w, e->retry_short.as<uint2>(),
-                                                 w.counters + kCtrRetryShort, acc));
+                                                 w.counters + kCtrRetryShort, e->owner != nullptr /* a job slot: other batches are in flight */, acc));
           banded_short += (uint64_t)n + n2;
           widest_short = bin + 1;
         } else HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, nullptr, 0, list2, n2, w, acc));
