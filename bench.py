@@ -300,7 +300,13 @@ def main():
            for k, v in ds.batch.items()}
     rows = torch.zeros((ds.n_sets, 8), dtype=torch.int32, device="cuda")
     stats = torch.zeros((ds.n_sets, 4), dtype=torch.int32, device="cuda")
-    stream = torch.cuda.current_stream()
+    # Everything from here on runs on a NON-BLOCKING side stream, never on the legacy null stream: the engine's own streams
+    # are blocking ones (they were created with a CU mask to get hardware queues of their own), and any null-stream
+    # operation -- e.g. the event a collective records on the current stream before it starts -- is a barrier across all
+    # of them, i.e. across the jobs in flight.
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream() if os.environ.get("RPA_BENCH_NULL_STREAM") else torch.cuda.Stream()  # (A/B)
+    torch.cuda.set_stream(stream)
     model.set_stream(stream.cuda_stream)
 
     # X1: PredictionRecord rows of every rank to rank 0 over xGMI (RCCL gather); shard sizes are equal and known, the
@@ -377,8 +383,9 @@ def main():
         elif pipelined:
             k = step.n % n_pipe
             step.n += 1
-            if use_dist and pending_gather[k] is not None:  # the exchange that read this buffer set n_pipe steps ago
-                pending_gather[k][0].wait()
+            if use_dist and pending_gather[k] is not None:  # the exchange that read this buffer set n_pipe steps ago: done long
+                pending_gather[k][0].wait()                 # since, but the job about to overwrite the rows runs on a stream of
+                torch.cuda.current_stream().synchronize()   # its own, so the host makes sure
                 pending_gather[k] = None
             in_flight.append((k, model.submit(dev, out=pipe_out[k][0], stats=pipe_out[k][1], mem_kind=pkg.MEM_DEVICE)))
             if len(in_flight) == args.in_flight:
