@@ -28,6 +28,7 @@
 #include <float.h>
 #include <limits.h>
 
+#include <type_traits>
 #include "rpa_device.h"
 
 namespace rpa {
@@ -1056,11 +1057,21 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         nog = st.nog; d_lnode = st.d_lnode; ldist = st.ldist; udist = st.udist;
         qpid_upper = st.qpid_upper; cut_g = st.cut_g; cut_h = st.cut_h; scut = st.scut; i = st.i_next;
       }
+      // Sets of up to 64 hits keep outgroup_tmp as a BIT SET (hit i is a member; its distance is re-read from its result
+      // slot, which nothing overwrites while this anchor's loop lasts) and the query-group bits to clear as another, both in
+      // registers: the walk then contains no store at all.  On gfx9 loads and stores share one counter (vmcnt) and may
+      // complete out of order with each other, so a single store that may be pending makes every wait for a prefetched row
+      // a wait for ALL outstanding memory operations -- the two rows in flight were worth nothing.
+      const bool small = n <= 64u;
+      unsigned long long ogmask = (small && st.loop_live) ? ((unsigned long long)st.pad_ << 32) | st.nog : 0ull;
+      unsigned long long fqclr = 0ull;
       bool paused = false;
       Row<P4> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
       float2 rn = make_float2(0.f, 0.f), rn2 = rn;
       if (i < n) { nxt = R.load(i); rn = R.result(i); }
       if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
+      auto walk = [&](auto small_tag) {
+      constexpr bool kSmall = decltype(small_tag)::value;
       for (; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
@@ -1090,8 +1101,9 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           ++st.cnt1;
         }
         band.add(dist, common<P4>(pa, da, pth, dh));  // :641
-        if (dist == 0.f) bit_clear(fq, i);  // :644
-        else if (dist <= qdist) {  // :646-650
+        if (dist == 0.f) {  // :644
+          if constexpr (kSmall) fqclr |= 1ull << i; else bit_clear(fq, i);
+        } else if (dist <= qdist) {  // :646-650
           d_lnode = min(d_lnode, common<P4>(pb, db, pth, dh));
           if (dist > ldist) ldist = dist;
         } else {  // :651-662
@@ -1104,7 +1116,16 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
             }
             if (!scut) scut = (int)(h.score * X);
           }
-          ogi[nog] = i; ogd[nog] = (int)dist; ++nog;
+          if constexpr (kSmall) ogmask |= 1ull << i;
+          else { ogi[nog] = i; ogd[nog] = (int)dist; ++nog; }
+        }
+      }
+      };
+      if (small) walk(std::true_type{}); else walk(std::false_type{});
+      if (small && fqclr) {
+        for (uint32_t k = 0; k < nw; ++k) {
+          const uint32_t clr = (uint32_t)(fqclr >> (32u * k));
+          if (clr) fq[k] &= ~clr;
         }
       }
       if (acc_pending && !failed) {  // the hits the loop above did not reach (early exit, pause): identities and path only
@@ -1123,7 +1144,8 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         acc_pending = false;
       }
       if (paused) {  // ask for the next chunk of this anchor's loop and come back
-        st.loop_live = 1; st.i_next = i; st.nog = nog; st.d_lnode = d_lnode; st.ldist = ldist; st.udist = udist;
+        st.loop_live = 1; st.i_next = i; st.d_lnode = d_lnode; st.ldist = ldist; st.udist = udist;
+        if (small) { st.nog = (uint32_t)ogmask; st.pad_ = (uint32_t)(ogmask >> 32); } else st.nog = nog;
         st.qpid_upper = qpid_upper; st.cut_g = cut_g; st.cut_h = cut_h; st.scut = scut;
         band.save(w.band_save + (size_t)s * 2 * (kMaxDepth + 1));
         st.chunk_hi = p.spec1 ? min(n, i + (p.grow ? max(p.spec1, i) : p.spec1)) : n;
@@ -1137,20 +1159,42 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         // :673-687.  The reference also erases entries here (distance beyond both the band and the current minimum);
         // an erased entry stays above the final min_upper_dist (that value only rises while it is <= qdist_ex), so the
         // walk below skips it by its own test and the erase needs no copy.
-        for (uint32_t k = 0; k < nog; ++k) {
-          const float dist = (float)ogd[k];
+        auto upper = [&](float dist) {
           if (dist > qdist_ex) {
             if (dist < min_upper_dist) min_upper_dist = dist;
           } else {
             if (min_upper_dist > qdist_ex) min_upper_dist = dist;
             else min_upper_dist = min_upper_dist < dist ? dist : min_upper_dist;
           }
+        };
+        if (small) {  // members in index order, four result loads in flight; (float)(int): outgroup_tmp holds int distances
+          unsigned long long m = ogmask;
+          while (m) {
+            uint32_t io[4];
+            float dd[4];
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              io[q] = 0u;
+              if (m) { io[q] = (uint32_t)__ffsll((long long)m) - 1u; m &= m - 1ull; cnt = q + 1; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dd[q] = q < cnt ? R.result(io[q]).x : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (q < cnt) upper((float)(int)dd[q]);
+          }
+        } else {
+          for (uint32_t k = 0; k < nog; ++k) upper((float)ogd[k]);
         }
         uint32_t d_unode = d_lnode;  // unode = lnode, :690 -- (float)INT_MAX != FLT_MAX, so always taken
-        for (uint32_t k = 0; k < nog; ++k) {  // :691-711
-          const float dist = (float)ogd[k];
+        unsigned long long mleft = ogmask;
+        for (uint32_t k = 0; small ? mleft != 0ull : k < nog; ++k) {  // :691-711
+          uint32_t io;
+          float dist;
+          if (small) { io = (uint32_t)__ffsll((long long)mleft) - 1u; mleft &= mleft - 1ull; dist = (float)(int)R.result(io).x; }
+          else { io = ogi[k]; dist = (float)ogd[k]; }
           if (dist > min_upper_dist) continue;
-          const uint32_t io = ogi[k];
           const Row<P4> ri = R.load(io);
           uint32_t pth[4 * P4];
           row_path<P4>(ri, pth);
@@ -1192,6 +1236,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       float2 rn = make_float2(0.f, 0.f), rn2 = rn;
       if (i < n) { nxt = R.load(i); rn = R.result(i); }
       if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
+      // (sets of up to 64 hits: the stores of the walk -- querydistance[i], the anchor's pair, outgroup bits to clear -- are
+      // noted in registers and done behind it, for the same reason as in pass 1)
+      const bool small = n <= 64u;
+      unsigned long long qdmask = 0ull, foclr = 0ull;
+      bool anchor_pair = false;
+      auto walk = [&](auto small_tag) {
+      constexpr bool kSmall = decltype(small_tag)::value;
       for (; i < n; ++i) {  // :757
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
@@ -1212,10 +1263,11 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
           ++st.cnt2;
-          R.store_qd(i, dist);  // querydistance[i] = dist, :785
+          if constexpr (kSmall) qdmask |= 1ull << i; else R.store_qd(i, dist);  // querydistance[i] = dist, :785
         }
-        if (dist == 0.f) bit_clear(fo, i);  // :789
-        else {
+        if (dist == 0.f) {  // :789
+          if constexpr (kSmall) foclr |= 1ull << i; else bit_clear(fo, i);
+        } else {
           float qdist_ex;
           if (qd_a == FLT_MAX) {  // :792-808
             const float2 q2 = *qres_p;
@@ -1223,11 +1275,24 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
             const float d2 = q2.x;
             const float s2 = q2.y < qs_a ? qs_a : q2.y;
             qd_a = d2; qs_a = s2;
-            R.store_qdqs(a, d2, s2);
+            if constexpr (kSmall) anchor_pair = true; else R.store_qdqs(a, d2, s2);
             qdist_ex = d2 * st.bf_max;
             ++st.cnt2;
           } else qdist_ex = qd_a * st.bf_max;  // :809
           if (dist <= qdist_ex) st.d_unode_g = min(st.d_unode_g, cb);  // unode_global = LCA(unode_global, cnode), :811-813
+        }
+      }
+      };
+      if (small) walk(std::true_type{}); else walk(std::false_type{});
+      if (small && !failed) {
+        if (anchor_pair) R.store_qdqs(a, qd_a, qs_a);
+        for (unsigned long long m = qdmask; m; m &= m - 1ull) {
+          const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
+          R.store_qd(k, R.result(k).x);
+        }
+        for (uint32_t k = 0; k < nw && foclr; ++k) {
+          const uint32_t clr = (uint32_t)(foclr >> (32u * k));
+          if (clr) fo[k] &= ~clr;
         }
       }
       if (paused) {
