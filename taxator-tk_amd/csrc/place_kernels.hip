@@ -958,6 +958,12 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       Row<P4> nxt = R.load(0u), nx2 = nxt;  // rows i+1 and i+2 are in flight while row i is worked on
       float2 rn = R.result(0), rn2 = rn;
       if (n > 1) { nx2 = R.load(1); rn2 = R.result(1); }
+      // (sets of up to 64 hits: members and zero-distance hits are noted as register bit sets and their stores -- the
+      // (distance, similarity) pairs, the lite words, the query-group words -- done behind the walk, see pass 1)
+      const bool small0 = n <= 64u;
+      unsigned long long members0 = 0ull, zero0 = 0ull;
+      auto walk0 = [&](auto small_tag) {
+      constexpr bool kSmall = decltype(small_tag)::value;
       for (uint32_t i = 0; i < n; ++i) {
         const Row<P4> cur = nxt;
         const float2 r2 = rn;
@@ -986,10 +992,15 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         } else {
           dist = FLT_MAX; sim = (float)h.ident;
         }
-        if (member) R.store_qdqs(i, dist, sim);  // the others keep what k_rank_records wrote: (FLT_MAX, identities)
-        if (dist == 0.f) w.lite[lo + i] = h.seglen | kLiteZeroQd;  // pass 1 will not align this hit (:620-621)
-        if (member) qword |= 1u << (i & 31u);
-        if ((i & 31u) == 31u || i + 1 == n) { fq[i >> 5] = qword; qword = 0; }
+        if constexpr (kSmall) {
+          if (member) members0 |= 1ull << i;
+          if (dist == 0.f) zero0 |= 1ull << i;
+        } else {
+          if (member) R.store_qdqs(i, dist, sim);  // the others keep what k_rank_records wrote: (FLT_MAX, identities)
+          if (dist == 0.f) w.lite[lo + i] = h.seglen | kLiteZeroQd;  // pass 1 will not align this hit (:620-621)
+          if (member) qword |= 1u << (i & 31u);
+          if ((i & 31u) == 31u || i + 1 == n) { fq[i >> 5] = qword; qword = 0; }
+        }
         if (i == 0) { best_d = dist; best_s = sim; best_sc = h.score; }  // index_best starts at 0 (:500)
         else if (dist < best_d) { index_best = i; best_d = dist; best_s = sim; best_sc = h.score; }  // :542-546
         else if (dist == best_d) {
@@ -998,6 +1009,19 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         }
         support = max(support, (uint32_t)sim);  // :547
         d_all = min(d_all, common<P4>(path0, d0, pth, meta_depth(h.meta)));  // :548
+      }
+      };
+      if (small0) walk0(std::true_type{}); else walk0(std::false_type{});
+      if (small0 && !failed) {
+        for (unsigned long long m = members0; m; m &= m - 1ull) {  // same values as in the walk, from the same row and result
+          const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
+          const HitCore h = R.core(k);
+          const float idf = (float)h.ident;
+          if (h.meta & kMetaPerfect) R.store_qdqs(k, 0.f, idf);
+          else { const float2 r2 = R.result(k); R.store_qdqs(k, r2.x, r2.y < idf ? idf : r2.y); }
+          if ((zero0 >> k) & 1ull) w.lite[lo + k] = h.seglen | kLiteZeroQd;
+        }
+        for (uint32_t k = 0; k < nw; ++k) fq[k] = (uint32_t)(members0 >> (32u * k));
       }
       if (!failed) {
         for (uint32_t k = 0; k < nw; ++k) fo[k] = 0u;  // outgroup starts empty (:578)
