@@ -157,8 +157,8 @@ __device__ __forceinline__ uint32_t node_at(const uint32_t (&path)[4 * P4], uint
 // with the start floored at 1; reverse (rstart > rstop) [rstop-right_ext, rstart+left_ext] reverse-complemented.
 // Protein with reverse coordinates trips a live assert in the reference (:864).  Returns (length, error code).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, const StoreDev& store, bool from_query,
-                                              uint32_t seq, uint32_t start, uint32_t stop, bool rc) {
+__device__ __forceinline__ SegDesc plan_segment_desc(const StoreDev& store, bool from_query, uint32_t seq, uint32_t start, uint32_t stop,
+                                                     bool rc, uint2& len_err) {
   uint32_t err = 0, len = 0;
   uint64_t src = 0;
   if (seq >= store.n_seqs) err = kErrSeqId;
@@ -172,8 +172,14 @@ __device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, co
       else { len = stop - start + 1; src = off + (start - 1); }
     }
   }
-  w.seg[seg] = SegDesc{(uint32_t)src, (uint32_t)(src >> 32), len, (rc ? 1u : 0u) | (from_query ? 2u : 0u) | (err << 4)};
-  return make_uint2(len, err);
+  len_err = make_uint2(len, err);
+  return SegDesc{(uint32_t)src, (uint32_t)(src >> 32), len, (rc ? 1u : 0u) | (from_query ? 2u : 0u) | (err << 4)};
+}
+__device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, const StoreDev& store, bool from_query,
+                                              uint32_t seq, uint32_t start, uint32_t stop, bool rc) {
+  uint2 le;
+  w.seg[seg] = plan_segment_desc(store, from_query, seq, start, stop, rc, le);
+  return le;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -246,7 +252,6 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     s = glo;
   }
   if (s >= b.n_sets) { s = b.n_sets - 1; in_window = false; }  // clamped window entries (cannot be selected: set_offsets[n_sets] > r)
-  w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
   uint32_t beg, end;
   if (in_window) { beg = s_off[lo]; end = s_off[lo + 1]; }  // staged above: no second trip to memory
   else { beg = b.set_offsets[s]; end = b.set_offsets[s + 1]; }
@@ -285,25 +290,26 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
       else take(j, make_uint4(__float_as_uint(b.score[j]), b.identities[j], b.qstart[j], b.qstop[j]), rec_filtered(b, j));
     }
   }
-  if (r == beg) {
-    uint2 qp = make_uint2(0u, 0u);
-    if (n >= 2) qp = plan_segment(w, b.n_records + s, qstore, true, b.query_seq[s], qrstart, qrstop, false);  // :415
-    w.set_info[s] = make_uint4(n, qrstart, qrstop, 0u);
-    w.set_qseg[s] = qp;
-  }
+  // Every load of this thread comes before its first store: loads and stores share one counter on gfx9 and may complete
+  // out of order with each other, so a load behind a store waits for the store as well.
+  const bool set_head = r == beg;
+  uint2 qp = make_uint2(0u, 0u);
+  SegDesc qdesc{0u, 0u, 0u, 0u};
+  if (set_head && n >= 2) qdesc = plan_segment_desc(qstore, true, b.query_seq[s], qrstart, qrstop, false, qp);  // :415
   if (!me_filtered) {
   const uint32_t pos = beg + rank;  // row position = segment id = result slot of this hit
   uint2 sp = make_uint2(0u, 0u);
+  SegDesc sdesc{0u, 0u, 0u, 0u};
   if (n >= 2) {
     const uint32_t left_ext = b.qstart[r] - qrstart, right_ext = qrstop - b.qstop[r];  // :523
     const uint32_t start = b.rstart[r], stop = b.rstop[r];
     if (start <= stop) {
-      sp = plan_segment(w, pos, dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false);
+      sdesc = plan_segment_desc(dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false, sp);
     } else if (p.alphabet != 0) {
-      w.seg[pos] = SegDesc{0u, 0u, 0u, (uint32_t)kErrAssert << 4};
+      sdesc = SegDesc{0u, 0u, 0u, (uint32_t)kErrAssert << 4};
       sp = make_uint2(0u, (uint32_t)kErrAssert);
     } else {
-      sp = plan_segment(w, pos, dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true);
+      sdesc = plan_segment_desc(dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true, sp);
     }
   }
   const uint32_t node = b.node[r];
@@ -315,18 +321,26 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   float qd = FLT_MAX, qs = (float)id;
   if (n == 1) { qd = __uint_as_float(b.qstart[r]); qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
   const SetRows<P4> R = set_rows<P4>(w, s, beg);
-  w.res_slot[pos] = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);  // where the alignment kernels put this hit's result
+  const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
+#pragma unroll
+  for (int k = 0; k < P4; ++k) rowq[2 + k] = anc[k];
+  slot = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);  // row slot = result slot (tiled: tile_base + 64 rank + l; linear: beg + rank)
+  // ---- stores ----
+  w.seg[pos] = sdesc;  // (all zero for a set of one record: never aligned)
+  w.res_slot[pos] = slot;  // where the alignment kernels put this hit's result
   if (sp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); sp.x = 0; }
   // compact per-row word for k_emit: segment length + "pass 0 re-aligns this hit" (:511-518, threshold :499)
   w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u) | (perfect ? kLitePerfect : 0u);
   rowq[0] = make_uint4(__float_as_uint(sc), id, node, r);
   rowq[1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta);
-  const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
-#pragma unroll
-  for (int k = 0; k < P4; ++k) rowq[2 + k] = anc[k];
-  slot = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);  // row slot = result slot (tiled: tile_base + 64 rank + l; linear: beg + rank)
   my_set = s; my_rank = rank; staged_set = in_window;
   }  // !me_filtered
+  if (set_head) {
+    w.seg[b.n_records + s] = qdesc;
+    w.set_info[s] = make_uint4(n, qrstart, qrstop, 0u);
+    w.set_qseg[s] = qp;
+  }
+  w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
   }  // r < n_records
 
   // ---- write the rows out.  Tiled layout: quad q of the row at slot x lives at quad index (x & ~63) Q + 64 q + (x & 63), i.e.

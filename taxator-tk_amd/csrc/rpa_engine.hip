@@ -454,7 +454,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   rc = profile_begin(e);
   if (rc) return rc;
   HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * (kNumCounters + 1), e->stream));
-  HIP_TRY(e, hipMemsetAsync(w.seg, 0, (size_t)T * sizeof(SegDesc), e->stream));
+  // (w.seg needs no clearing: k_rank_records writes the descriptor of every row position and query range a list entry can name)
   w.set_offsets = b.set_offsets;
   w.store_q = q.words; w.store_db = db.words;
   HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
