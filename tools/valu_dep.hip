@@ -7,7 +7,7 @@
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters) {
-  uint32_t a = seed * (threadIdx.x + 1), b = seed ^ 0x9e3779b9u, c = seed * 31u + threadIdx.x;
+  uint32_t a = seed * (threadIdx.x + 1), b = seed ^ 0x9e3779b9u, c = seed * 31u + threadIdx.x, a2 = a ^ 0x5bd1e995u;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -21,10 +21,16 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters
       if (OP == 3) asm volatile("v_or_b32_e32 %0, %1, %0\n v_bitop3_b32 %0, %0, %1, %2 bitop3:0xc8\n v_addc_co_u32_e32 %0, vcc, %1, %0, vcc\n v_bitop3_b32 %0, %0, %1, %2 bitop3:0xbe\n"
                                 "v_and_b32_e32 %0, %1, %0\n v_bitop3_b32 %0, %0, %1, %2 bitop3:0xf1\n v_alignbit_b32 %0, %0, %1, 31\n v_alignbit_b32 %0, %0, %2, 31\n"
                                 "v_and_b32_e32 %0, %1, %0\n v_bitop3_b32 %0, %0, %1, %2 bitop3:0xf1\n" : "+v"(a) : "v"(b), "v"(c) : "vcc");
+      // the same mix as TWO independent chains interleaved instruction by instruction (count 20)
+      if (OP == 4) asm volatile("v_or_b32_e32 %0, %2, %0\n v_or_b32_e32 %1, %3, %1\n v_bitop3_b32 %0, %0, %2, %3 bitop3:0xc8\n v_bitop3_b32 %1, %1, %3, %2 bitop3:0xc8\n"
+                                "v_addc_co_u32_e32 %0, vcc, %2, %0, vcc\n v_addc_co_u32_e32 %1, vcc, %3, %1, vcc\n v_bitop3_b32 %0, %0, %2, %3 bitop3:0xbe\n v_bitop3_b32 %1, %1, %3, %2 bitop3:0xbe\n"
+                                "v_and_b32_e32 %0, %2, %0\n v_and_b32_e32 %1, %3, %1\n v_bitop3_b32 %0, %0, %2, %3 bitop3:0xf1\n v_bitop3_b32 %1, %1, %3, %2 bitop3:0xf1\n"
+                                "v_alignbit_b32 %0, %0, %2, 31\n v_alignbit_b32 %1, %1, %3, 31\n v_alignbit_b32 %0, %0, %3, 31\n v_alignbit_b32 %1, %1, %2, 31\n"
+                                "v_and_b32_e32 %0, %2, %0\n v_and_b32_e32 %1, %3, %1\n v_bitop3_b32 %0, %0, %2, %3 bitop3:0xf1\n v_bitop3_b32 %1, %1, %3, %2 bitop3:0xf1\n" : "+v"(a), "+v"(a2) : "v"(b), "v"(c) : "vcc");
     }
     b += 0x01010101u; c ^= b;
   }
-  out[blockIdx.x * 256 + threadIdx.x] = a;
+  out[blockIdx.x * 256 + threadIdx.x] = a ^ a2;
 }
 
 template <int OP>
@@ -50,5 +56,6 @@ int main() {
   for (int w : {1, 2, 4, 8}) run<1>("dependent v_alignbit", d_out, w, 20000, 8);
   for (int w : {1, 2, 4, 8}) run<2>("dependent v_addc_co (vcc)", d_out, w, 20000, 8);
   for (int w : {1, 2, 3, 4, 5, 6, 8}) run<3>("Myers word mix, one chain", d_out, w, 20000, 10);
+  for (int w : {1, 2, 3, 4, 6, 8}) run<4>("Myers word mix, two chains", d_out, w, 20000, 20);
   return 0;
 }
