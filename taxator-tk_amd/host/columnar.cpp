@@ -1,14 +1,37 @@
 // taxator-tk_amd/host/columnar.cpp -- see columnar.hh.
 #include "columnar.hh"
+#include "hostcpus.hh"
 
 #include <algorithm>
 #include <chrono>
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 
+#include <emmintrin.h>  // SSE2: part of the x86-64 baseline
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace taxator {
+
+void* raw_column_alloc(size_t bytes) {
+  if (bytes >= ((size_t)4 << 20)) {
+    void* p = nullptr;
+    const size_t rounded = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (posix_memalign(&p, (size_t)2 << 20, rounded) == 0) {
+      static const bool no_thp = getenv("TAXATOR_NO_THP") != nullptr;  // (A/B)
+      if (!no_thp) (void)madvise(p, rounded, MADV_HUGEPAGE);
+      return p;
+    }
+  }
+  void* p = malloc(bytes ? bytes : 1);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void raw_column_free(void* p) noexcept { free(p); }
 
 void RecordColumns::resize(size_t n) {
   qstart.resize(n); qstop.resize(n); qlen.resize(n); rstart.resize(n); rstop.resize(n); identities.resize(n); alnlen.resize(n);
@@ -133,7 +156,7 @@ static bool field_f64_valid(const char* p, const char* e) {
 ColumnarReader::ColumnarReader(FILE* in, const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db,
                                const SequenceStore* query, bool split_alignments, unsigned threads, size_t block_bytes, bool alignments_sorted)
     : in_(in), legacy_(acc2taxid, tax, db), query_(query), split_(split_alignments), sorted_(alignments_sorted), threads_(threads), block_bytes_(block_bytes) {
-  if (threads_ == 0) threads_ = std::max(1u, std::thread::hardware_concurrency());
+  if (threads_ == 0) threads_ = usable_cpus();
   if (block_bytes_ < 4096) block_bytes_ = 4096;
   // reference identifier -> (taxonomy node, index in the reference store); identifiers with a broken link are left out
   // of the table, so that their lines fall through to the strict parser, which raises the matching exception
@@ -163,11 +186,67 @@ struct ColumnarReader::Chunk {
   const char* bad_begin = nullptr;
   const char* bad_end = nullptr;
   size_t bad_record = 0;             // records before that line
+  std::vector<size_t> new_group;     // pass 2: records of this chunk (but its first) whose query identifier differs from the record before
 };
 
 static inline const char* line_end(const char* p, const char* end) {
   const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
   return nl ? nl : end;
+}
+
+// One sweep over a line, 16 bytes at a time: its end (the next '\n', or `limit`) and the positions of its first 11 tabs.
+// (A memchr call per field costs more than the conversion of the field: lines are ~50 bytes, fields ~4.)
+static inline const char* scan_line(const char* s, const char* limit, const char** tab, int& ntab) {
+  const __m128i vt = _mm_set1_epi8('\t'), vn = _mm_set1_epi8('\n');
+  ntab = 0;
+  const char* p = s;
+  while (p + 16 <= limit) {
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p));
+    unsigned mt = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, vt));
+    const unsigned mn = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, vn));
+    if (mn) {
+      const unsigned first = (unsigned)__builtin_ctz(mn);
+      mt &= (1u << first) - 1u;
+      while (mt && ntab < 11) { tab[ntab++] = p + __builtin_ctz(mt); mt &= mt - 1u; }
+      return p + first;
+    }
+    while (mt && ntab < 11) { tab[ntab++] = p + __builtin_ctz(mt); mt &= mt - 1u; }
+    p += 16;
+  }
+  for (; p < limit; ++p) {
+    if (*p == '\n') return p;
+    if (*p == '\t' && ntab < 11) tab[ntab++] = p;
+  }
+  return limit;
+}
+
+// Lines of [begin, end) and how many of them do not start with '#' (an empty line is a data line, fileparser.hh:61-67).
+// A line starts at `begin` and behind every '\n' that is not the last byte.
+static inline void count_lines(const char* begin, const char* end, size_t& lines, size_t& data_lines) {
+  lines = 0; data_lines = 0;
+  if (begin >= end) return;
+  size_t nl = *begin == '\n' ? 1 : 0, comment = *begin == '#' ? 1 : 0;
+  const __m128i vn = _mm_set1_epi8('\n'), vh = _mm_set1_epi8('#'), zero = _mm_setzero_si128();
+  const char* p = begin + 1;  // every byte from here on has a byte in front of it
+  while (p + 16 <= end) {
+    __m128i acc_n = zero, acc_c = zero;  // per byte lane: matches so far (at most 255 before they are summed)
+    int it = 0;
+    for (; it < 255 && p + 16 <= end; ++it, p += 16) {
+      const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p));
+      const __m128i before = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p - 1));
+      acc_n = _mm_sub_epi8(acc_n, _mm_cmpeq_epi8(v, vn));
+      acc_c = _mm_sub_epi8(acc_c, _mm_and_si128(_mm_cmpeq_epi8(before, vn), _mm_cmpeq_epi8(v, vh)));
+    }
+    const __m128i sn = _mm_sad_epu8(acc_n, zero), sc = _mm_sad_epu8(acc_c, zero);
+    nl += (size_t)_mm_cvtsi128_si64(sn) + (size_t)_mm_cvtsi128_si64(_mm_srli_si128(sn, 8));
+    comment += (size_t)_mm_cvtsi128_si64(sc) + (size_t)_mm_cvtsi128_si64(_mm_srli_si128(sc, 8));
+  }
+  for (; p < end; ++p) {
+    if (*p == '\n') ++nl;
+    else if (*p == '#' && p[-1] == '\n') ++comment;
+  }
+  lines = 1 + nl - (end[-1] == '\n' ? 1 : 0);
+  data_lines = lines - comment;
 }
 
 void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, ColumnarBatch& out) {
@@ -195,14 +274,7 @@ void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, C
     for (auto& x : th) x.join();
   };
   // ---- pass 1: count lines and data lines ----
-  for_chunks([](Chunk& c) {
-    for (const char* s = c.begin; s < c.end;) {
-      const char* e = line_end(s, c.end);
-      ++c.lines;
-      if (*s != '#' || s == e) ++c.data_lines;  // an empty line is a (bad) data line, fileparser.hh:61-67
-      s = e + 1;
-    }
-  });
+  for_chunks([](Chunk& c) { count_lines(c.begin, c.end, c.lines, c.data_lines); });
   const Clock::time_point t1 = Clock::now();
   size_t nrec = carry_;
   uint64_t line_no = line_base_;
@@ -215,8 +287,12 @@ void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, C
   for_chunks([this](Chunk& c) {
     size_t r = c.first_record;
     uint64_t ln = c.first_line;
+    const char* prev_qid = nullptr;  // query identifier of the record before (this chunk's records only)
+    uint32_t prev_len = 0;
     for (const char* s = c.begin; s < c.end;) {
-      const char* e = line_end(s, c.end);
+      const char* tab[11];
+      int ntab;
+      const char* e = scan_line(s, c.end, tab, ntab);
       ++ln;
       const char* next = e + 1;
       if (*s == '#' && s != e) { s = next; continue; }
@@ -227,17 +303,11 @@ void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, C
       const char* fb[11];
       const char* fe[11];
       if (ok) {
-        int k = 0;
-        const char* q = f;
-        for (; k < 10; ++k) {
-          const char* tab = (const char*)memchr(q, '\t', (size_t)(e - q));
-          if (!tab) break;
-          fb[k] = q; fe[k] = tab; q = tab + 1;
-        }
-        if (k < 10) ok = false;
+        if (ntab < 10) ok = false;
         else {
-          const char* tab = (const char*)memchr(q, '\t', (size_t)(e - q));
-          fb[10] = q; fe[10] = tab ? tab : e;
+          fb[0] = f; fe[0] = tab[0];
+          for (int k = 1; k < 10; ++k) { fb[k] = tab[k - 1] + 1; fe[k] = tab[k]; }
+          fb[10] = tab[9] + 1; fe[10] = ntab > 10 ? tab[10] : e;
         }
       }
       uint32_t refv = FlatStringMap::npos;
@@ -255,6 +325,8 @@ void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, C
       cols_.ref_seq[r] = ref_seqidx_[refv];
       qid_ptr_[r] = fb[0];
       qid_len_[r] = (uint32_t)(fe[0] - fb[0]);
+      if (prev_qid && (qid_len_[r] != prev_len || memcmp(fb[0], prev_qid, prev_len))) c.new_group.push_back(r);
+      prev_qid = fb[0]; prev_len = qid_len_[r];
       ++r;
       s = next;
     }
@@ -276,17 +348,26 @@ void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, C
   gstart_.clear();
   size_t i = 0;
   const bool closed = eof && !failed_;
-  while (i < usable) {
-    size_t j = i + 1;
-    const char* q = qid_ptr_[i];
-    const uint32_t ql = qid_len_[i];
-    while (j < usable && qid_len_[j] == ql && (qid_ptr_[j] == q || !memcmp(qid_ptr_[j], q, ql))) ++j;
-    if (j == usable && !closed) break;  // open group: more of it may follow (or, after a bad line, it is lost as in the
-                                        // reference, whose generator throws while still reading this group)
-    gstart_.push_back(i);
-    i = j;
+  // (the chunks noted where the identifier changes inside them; what is left are the seams: the carried records against
+  // the first parsed one, and the last record of a chunk against the first of the next)
+  auto same_qid = [&](size_t a, size_t b) {
+    return qid_len_[a] == qid_len_[b] && (qid_ptr_[a] == qid_ptr_[b] || !memcmp(qid_ptr_[a], qid_ptr_[b], qid_len_[a]));
+  };
+  if (usable) gstart_.push_back(0);
+  size_t seam = carry_;  // first record behind a seam (0: no record in front of it)
+  for (const Chunk& c : chunks) {
+    if (c.first_record >= usable) break;
+    const size_t first = c.first_record, stop = std::min(usable, first + c.data_lines);
+    if (first < stop && seam == first && first > 0 && !same_qid(first - 1, first)) gstart_.push_back(first);
+    for (size_t r : c.new_group) {
+      if (r >= stop) break;
+      gstart_.push_back(r);
+    }
+    seam = stop;
   }
-  gstart_.push_back(i);  // records [0, i) belong to complete groups
+  if (!closed && !gstart_.empty()) { i = gstart_.back(); gstart_.pop_back(); }  // open group: more of it may follow (or, after a bad
+  else i = usable;                                                              // line, it is lost as in the reference, whose
+  gstart_.push_back(i);  // records [0, i) belong to complete groups            // generator throws while still reading this group)
   const Clock::time_point t4 = Clock::now();
   emit_groups(out);
   if (!fail_query_.empty()) { carry_ = 0; return; }  // unknown query identifier: everything after it is dropped
@@ -327,45 +408,66 @@ void ColumnarReader::emit_groups(ColumnarBatch& out) {
       if (cols_.qstart[a] != cols_.qstart[b]) return cols_.qstart[a] < cols_.qstart[b];
       return cols_.qstop[a] < cols_.qstop[b];
     };
+    // Records of groups that keep their input order are copied column by column in one piece per run of such groups;
+    // a group that changes order is gathered column by column through its permutation.
+    size_t run_lo = gstart_[G * t / T];  // first record of the current run of groups in input order
+    auto flush_run = [&](size_t hi) {
+      if (hi <= run_lo) return;
+      const size_t n = hi - run_lo;
+      auto cp = [&](auto& dst, const auto& src) { memcpy(dst.data() + run_lo, src.data() + run_lo, n * sizeof(dst[0])); };
+      cp(o.qstart, cols_.qstart); cp(o.qstop, cols_.qstop); cp(o.qlen, cols_.qlen); cp(o.rstart, cols_.rstart); cp(o.rstop, cols_.rstop);
+      cp(o.identities, cols_.identities); cp(o.alnlen, cols_.alnlen); cp(o.ref_seq, cols_.ref_seq); cp(o.node, cols_.node);
+      cp(o.score, cols_.score); cp(o.filtered, cols_.filtered);
+    };
     for (size_t g = G * t / T; g < G * (t + 1) / T; ++g) {
       const size_t lo = gstart_[g], n = gstart_[g + 1] - lo;
       const uint32_t qseq = query_map_.find(qid_ptr_[lo], qid_len_[lo]);
-      if (qseq == FlatStringMap::npos) { part.unknown = g; return; }  // SequenceStore::getIndex in RPAPredictionModel::predict's staging
-      order.resize(n);
-      for (size_t k = 0; k < n; ++k) order[k] = (uint32_t)(lo + k);
+      if (qseq == FlatStringMap::npos) { flush_run(lo); part.unknown = g; return; }  // SequenceStore::getIndex in RPAPredictionModel::predict's staging
+      bool reorder = false;
       if (split_ && !sorted_) {  // stable by (qstart, qstop), ties keep input order (alignmentrecord.hh:476-481); -o 1: the input is
                                  // taken as sorted and cut in input order (RecordSetGeneratorSorted, :569-631)
-        if (n <= 64) {  // groups are short and mostly sorted already
-          for (size_t k = 1; k < n; ++k) {
-            const uint32_t x = order[k];
-            size_t m = k;
-            while (m > 0 && before(x, order[m - 1])) { order[m] = order[m - 1]; --m; }
-            order[m] = x;
-          }
-        } else std::stable_sort(order.begin(), order.end(), before);
+        for (size_t k = 1; k < n && !reorder; ++k) reorder = before((uint32_t)(lo + k), (uint32_t)(lo + k - 1));
+        if (reorder) {
+          order.resize(n);
+          for (size_t k = 0; k < n; ++k) order[k] = (uint32_t)(lo + k);
+          if (n <= 64) {  // groups are short
+            for (size_t k = 1; k < n; ++k) {
+              const uint32_t x = order[k];
+              size_t m = k;
+              while (m > 0 && before(x, order[m - 1])) { order[m] = order[m - 1]; --m; }
+              order[m] = x;
+            }
+          } else std::stable_sort(order.begin(), order.end(), before);
+        }
       }
-      for (size_t m = 0; m < n; ++m) {
-        const uint32_t s = order[m];
-        const size_t d = lo + m;
-        o.qstart[d] = cols_.qstart[s]; o.qstop[d] = cols_.qstop[s]; o.qlen[d] = cols_.qlen[s]; o.rstart[d] = cols_.rstart[s];
-        o.rstop[d] = cols_.rstop[s]; o.identities[d] = cols_.identities[s]; o.alnlen[d] = cols_.alnlen[s]; o.ref_seq[d] = cols_.ref_seq[s];
-        o.node[d] = cols_.node[s]; o.score[d] = cols_.score[s]; o.filtered[d] = cols_.filtered[s];
+      if (reorder) {
+        flush_run(lo);
+        run_lo = lo + n;
+        auto gather = [&](auto& dst, const auto& src) {
+          for (size_t m = 0; m < n; ++m) dst[lo + m] = src[order[m]];
+        };
+        gather(o.qstart, cols_.qstart); gather(o.qstop, cols_.qstop); gather(o.qlen, cols_.qlen); gather(o.rstart, cols_.rstart);
+        gather(o.rstop, cols_.rstop); gather(o.identities, cols_.identities); gather(o.alnlen, cols_.alnlen); gather(o.ref_seq, cols_.ref_seq);
+        gather(o.node, cols_.node); gather(o.score, cols_.score); gather(o.filtered, cols_.filtered);
       }
+      // (a group in input order has not been copied yet: its records are read where they were parsed)
+      const RecordColumns& c = reorder ? o : cols_;
       uint32_t n_sets = 0;
       for (size_t k = 0; k < n;) {  // one record set: [k, e)
         size_t e = k + 1;
         if (split_) {
-          uint32_t rstop = o.qstop[lo + k];
-          while (e < n && o.qstart[lo + e] <= rstop) { rstop = std::max(rstop, o.qstop[lo + e]); ++e; }  // :485-504
+          uint32_t rstop = c.qstop[lo + k];
+          while (e < n && c.qstart[lo + e] <= rstop) { rstop = std::max(rstop, c.qstop[lo + e]); ++e; }  // :485-504
         } else e = n;  // :543-566
         part.set_len.push_back((uint32_t)(e - k));
-        part.set_qlen.push_back(o.qlen[lo + k]);  // getQueryLength() of the set's first record
+        part.set_qlen.push_back(c.qlen[lo + k]);  // getQueryLength() of the set's first record
         ++n_sets;
         k = e;
       }
       part.group_sets.push_back(n_sets);
       part.group_qseq.push_back(qseq);
     }
+    flush_run(gstart_[G * (t + 1) / T]);
   };
   if (T == 1) work(0);
   else {
@@ -398,6 +500,7 @@ void ColumnarReader::emit_groups(ColumnarBatch& out) {
 }
 
 ColumnarReader::~ColumnarReader() {
+  if (map_) munmap(const_cast<char*>(map_), map_size_);
   if (!io_thread_.joinable()) return;
   if (eof_) { io_thread_.join(); return; }
   // abandoned mid-stream (a failure upstream of the end): the thread may sit in a blocking read; let it go
@@ -408,6 +511,49 @@ ColumnarReader::~ColumnarReader() {
 
 bool ColumnarReader::next(ColumnarBatch& out) {
   out.clear();
+  if (!map_tried_) {  // first call: a regular file with nothing buffered yet can be mapped from the current offset on
+    map_tried_ = true;
+    struct stat st;
+    const int fd = fileno(in_);
+    const off_t at = fd >= 0 ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
+    if (!getenv("TAXATOR_NO_MMAP") && fd >= 0 && at >= 0 && ftell(in_) == (long)at && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > at) {
+      void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m != MAP_FAILED) {
+        map_ = static_cast<const char*>(m);
+        map_size_ = (size_t)st.st_size;
+        map_pos_ = (size_t)at;
+        (void)madvise(m, map_size_, MADV_SEQUENTIAL);
+      }
+    }
+  }
+  if (map_) {
+    for (;;) {
+      if (failed_) {
+        if (!fail_query_.empty()) throw SequenceNotFound("seqid " + fail_query_);
+        AlignmentRecordTaxonomy rec;
+        try { legacy_.parse(fail_line_, rec); }
+        catch (Exception& e) { throw ParsingError(std::string(e.what()) + " [line " + std::to_string(fail_line_no_) + "]"); }
+        throw GeneralError("alignment line rejected by the columnar reader but accepted by the record parser [line " +
+                           std::to_string(fail_line_no_) + "]");
+      }
+      if (eof_) return false;
+      const char* begin = map_ + map_pos_;
+      const char* file_end = map_ + map_size_;
+      size_t want = block_bytes_;
+      const char* usable;
+      for (;;) {  // up to the last line break inside the block; a line longer than the block extends it
+        const char* end = (size_t)(file_end - begin) > want ? begin + want : file_end;
+        eof_ = end == file_end;
+        usable = end;
+        if (!eof_) while (usable > begin && usable[-1] != '\n') --usable;
+        if (usable > begin || eof_) break;
+        want += block_bytes_;
+      }
+      parse_block(begin, usable, eof_, out);
+      map_pos_ = (size_t)(usable - map_);
+      if (out.n_sets() > 0) return true;
+    }
+  }
   if (!io_) {  // first call: start reading ahead
     io_ = std::make_shared<Io>();
     io_->in = in_;

@@ -26,10 +26,29 @@
 
 namespace taxator {
 
+// std::vector whose resize() leaves new elements uninitialised: the record columns are tens of MB per block and every
+// element is written by the parser / the group emitter before anything reads it.
+// Big columns come 2 MiB-aligned and are offered to transparent huge pages (madvise mode): a fresh 11-column batch is
+// ~120 MB, i.e. 30 k first-touch faults of 4 KiB pages inside the parse of the first block that uses it.
+void* raw_column_alloc(size_t bytes);
+void raw_column_free(void* p) noexcept;
+template <class T, class A = std::allocator<T>>
+struct DefaultInitAllocator : A {
+  using A::A;
+  template <class U> struct rebind { using other = DefaultInitAllocator<U, typename std::allocator_traits<A>::template rebind_alloc<U>>; };
+  T* allocate(size_t n) { return static_cast<T*>(raw_column_alloc(n * sizeof(T))); }
+  void deallocate(T* p, size_t) noexcept { raw_column_free(p); }
+  template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... Args> void construct(U* p, Args&&... args) {
+    std::allocator_traits<A>::construct(static_cast<A&>(*this), p, std::forward<Args>(args)...);
+  }
+};
+template <class T> using RawVector = std::vector<T, DefaultInitAllocator<T>>;
+
 struct RecordColumns {
-  std::vector<uint32_t> qstart, qstop, qlen, rstart, rstop, identities, alnlen, ref_seq, node;
-  std::vector<float> score;
-  std::vector<uint8_t> filtered;
+  RawVector<uint32_t> qstart, qstop, qlen, rstart, rstop, identities, alnlen, ref_seq, node;
+  RawVector<float> score;
+  RawVector<uint8_t> filtered;
   void resize(size_t n);
   void move_range(size_t dst, size_t src, size_t n);  // overlapping-safe copy inside the columns
   size_t size() const { return qstart.size(); }
@@ -88,6 +107,11 @@ class ColumnarReader {
   };
   std::shared_ptr<Io> io_;      // shared with the (possibly detached) I/O thread
   std::thread io_thread_;
+  // A regular file on the stream (taxator < aln.tsv) is mapped instead of read: blocks are slices of the mapping, nothing
+  // is copied, and the page faults of a block are taken by the threads that count its lines.
+  const char* map_ = nullptr;
+  size_t map_size_ = 0, map_pos_ = 0;
+  bool map_tried_ = false;
   std::string tail_;            // bytes after the last line break of the previous block
   std::vector<char> joined_;    // only when tail_ does not fit the headroom (a line longer than 1 MiB)
   bool eof_ = false;

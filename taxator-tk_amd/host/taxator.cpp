@@ -35,6 +35,7 @@
 #include "alignmentrecord.hh"
 #include "channel.hh"
 #include "columnar.hh"
+#include "hostcpus.hh"
 #include "gff3writer.hh"
 #include "exception.hh"
 #include "predictionrecord.hh"
@@ -99,7 +100,7 @@ struct Work {
 
 // The columns of a Work object are reused from block to block: page-lock them (once per growth of a vector) so that the
 // engine's host<->device copies are DMA transfers that run beside the kernels of the other job in flight.
-template <class T> void add_range(std::vector<std::pair<void*, size_t>>& v, std::vector<T>& a) {
+template <class T, class A> void add_range(std::vector<std::pair<void*, size_t>>& v, std::vector<T, A>& a) {
   // only arrays big enough to have a mapping of their own (glibc: >= 128 KiB): small ones share heap pages with their
   // neighbours, and a page cannot be locked twice
   if (a.capacity() * sizeof(T) >= ((size_t)1 << 18)) v.emplace_back((void*)a.data(), a.capacity() * sizeof(T));
@@ -370,7 +371,7 @@ int main(int argc, char** argv) {
     std::unique_ptr<SequenceStore> db_ptr(o.db_index.empty() ? new SequenceStore(o.db) : new SequenceStore(o.db, o.db_index));
     SequenceStore& query_storage = *query_ptr;
     SequenceStore& db_storage = *db_ptr;
-    const unsigned host_threads = o.processors ? o.processors : std::max(1u, std::thread::hardware_concurrency());
+    const unsigned host_threads = o.processors ? o.processors : usable_cpus();
     std::vector<std::unique_ptr<RPAPredictionModel>> engines;
     for (int dev : o.devices) {
       engines.emplace_back(new RPAPredictionModel(tax.get(), query_storage, db_storage, o.filterout, o.toppercent, o.dataformat == "protein", dev));

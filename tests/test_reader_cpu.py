@@ -5,6 +5,7 @@ several parser threads and with blocks so small that every group straddles a blo
 import os
 import random
 import subprocess
+import tempfile
 
 import pytest
 
@@ -21,20 +22,28 @@ def parsecheck():
     return BIN
 
 
-def _run(binary, folder, mode, split, data, threads=0, block=1 << 26, query="query_edge.fna"):
+def _run(binary, folder, mode, split, data, threads=0, block=1 << 26, query="query_edge.fna", as_file=False):
     env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
     cmd = [binary, os.path.join(folder, "mapping.tax"), os.path.join(folder, query), os.path.join(folder, "ref.fna"), mode, str(split),
            str(threads), str(block)]
-    r = subprocess.run(cmd, input=data, capture_output=True, env=env)
+    if as_file:  # a regular file on stdin: the columnar reader maps it instead of reading it
+        with tempfile.NamedTemporaryFile() as f:
+            f.write(data)
+            f.flush()
+            with open(f.name, "rb") as g:
+                r = subprocess.run(cmd, stdin=g, capture_output=True, env=env)
+    else:        # a pipe: the read-ahead thread
+        r = subprocess.run(cmd, input=data, capture_output=True, env=env)
     assert r.returncode in (0, 1), r.stderr
     return r.returncode, r.stdout
 
 
 def _both(binary, folder, data, split=1, **kw):
     want = _run(binary, folder, "objects", split, data, **kw)
-    for threads, block in ((1, 1 << 26), (4, 1 << 26), (3, 4096), (1, 4096)):
-        got = _run(binary, folder, "columnar", split, data, threads=threads, block=block, **kw)
-        assert got == want, (threads, block, want[1][-300:], got[1][-300:])
+    for threads, block, as_file in ((1, 1 << 26, False), (4, 1 << 26, False), (3, 4096, False), (1, 4096, False),
+                                    (4, 1 << 26, True), (2, 4096, True), (1, 100, True)):
+        got = _run(binary, folder, "columnar", split, data, threads=threads, block=block, as_file=as_file, **kw)
+        assert got == want, (threads, block, as_file, want[1][-300:], got[1][-300:])
     return want
 
 
