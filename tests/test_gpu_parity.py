@@ -361,6 +361,16 @@ def test_predict_dna_ragged_sets_and_lengths(pkg, oracle, synth):
         _engine_vs_oracle(pkg, oracle, synth, ds, 0)
 
 
+@pytest.mark.parametrize("n_hits", [33, 64, 65])
+def test_predict_dna_group_bit_sets(pkg, oracle, synth, n_hits):
+    """k_decide keeps the query group / outgroup of a record set of up to 64 hits as register bit sets (one or two words)
+    and walks without stores; larger sets take the lists in memory.  Both sides of the switch, with loops that pause
+    (small speculation chunks: the bit sets travel through SetState) and without."""
+    ds = synth.make_dataset(n_sets=250, n_hits=n_hits, seg_len=120, branching=3, genome_len=2000, seed=60 + n_hits, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(5, 3))
+
+
 @pytest.mark.parametrize("lanes", ["lanes-per-pair", "one-lane"])
 def test_predict_protein(pkg, oracle, synth, lanes, monkeypatch):
     if lanes == "one-lane":
