@@ -10,7 +10,8 @@ import __graft_entry__ as graft
 from helpers import oracle as O
 
 KNOBS = ("RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
-         "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL")
+         "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL",
+         "RPA_PROTEIN_LANES")
 
 
 def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
@@ -33,6 +34,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           seg = int(rng.choice([20, 67, 120, 253, 312, 400]))
           n_sets = int(rng.integers(30, 300))
           kw = dict(level_rate=float(rng.choice([0.03, 0.06, 0.12])), query_rate=float(rng.choice([0.0, 0.08, 0.15])))
+      if rng.random() < 0.15: n_hits = int(rng.integers(41, 90))  # beyond k_decide's 64-hit bit sets
       n_species = branching ** 6
       n_hits = min(n_hits, n_species)
       ds = synth.make_dataset(n_sets=n_sets, n_hits=n_hits, seg_len=seg, branching=branching, genome_len=max(4 * seg, 1200),
@@ -55,6 +57,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           if rng.random() < 0.15: env["RPA_BAND"] = "0"
           if rng.random() < 0.15: env["RPA_BAND_SHORT"] = "0"
           if alphabet == 0 and seg > 256 and rng.random() < 0.5: env["RPA_LONG_KERNEL"] = "lane"
+      if alphabet == 1 and rng.random() < 0.3: env["RPA_PROTEIN_LANES"] = "0"
       for kk in KNOBS:
           os.environ.pop(kk, None)
       os.environ.update(env)
