@@ -564,6 +564,7 @@ def main():
                            % (args.in_flight, prof_steps)) if pipelined else "one synchronous call per step",
             "sync_ms_per_step": sync_ms,
             "datagen_s": t_gen,
+            "hbm_in_use_gb": (lambda fr_to: round((fr_to[1] - fr_to[0]) / 1e9, 2))(torch.cuda.mem_get_info()),  # this rank's device, everything resident
             "reference_store": {"replicas": args.store_replicas, "packed_bytes": store_bytes,
                                 "note": "config 2's 4096-species collection is 8 MB packed (cache resident); --store-replicas spreads the same work over HBM"},
         }
