@@ -488,6 +488,8 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(BatchDev b, WorkDev w, P
   __shared__ uint32_t s_maxlen[kVW];
   const uint32_t H = b.n_records, total = H + b.n_sets;
   const uint32_t pos0 = blockIdx.x * kEmitSpan + threadIdx.x;
+  for (int i = threadIdx.x; i < kNumBins * kVW; i += kEmitBlock) (&s_cnt[0][0])[i] = 0u;  // only bins that occur get a count below
+  __syncthreads();
   uint32_t set_of[kEmitRows], lo[kEmitRows], lite[kEmitRows];
   uint4 desc[kEmitRows];
 #pragma unroll
@@ -541,17 +543,22 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(BatchDev b, WorkDev w, P
     maxlen = max(maxlen, ml);
   }
   // block-level compaction: wave ballots -> LDS -> one atomic per non-empty bin per block
+  // (per row position of a thread: one ballot per bin PRESENT in the wavefront -- usually one or none -- instead of one
+  // per bin: twelve ballots per row were two thirds of the kernel's vector instructions)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long my_mask[kEmitRows];
 #pragma unroll
   for (int k = 0; k < kEmitRows; ++k) {
     my_mask[k] = 0ull;
     const int vw = k * (kEmitBlock / 64) + wave;
-#pragma unroll
-    for (int kk = 0; kk < kNumBins; ++kk) {
+    unsigned long long todo = __ballot(bin[k] >= 0);
+    while (todo) {
+      const int leader = (int)__ffsll((long long)todo) - 1;
+      const int kk = __builtin_amdgcn_readlane(bin[k], leader);
       const unsigned long long mask = __ballot(bin[k] == kk);
-      if (lane == 0) s_cnt[kk][vw] = (uint32_t)__popcll(mask);
+      if (lane == leader) s_cnt[kk][vw] = (uint32_t)__popcll(mask);
       if (bin[k] == kk) my_mask[k] = mask;
+      todo &= ~mask;
     }
   }
 #pragma unroll
