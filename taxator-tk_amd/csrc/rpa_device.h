@@ -78,13 +78,14 @@ struct SetState {
   uint32_t loop_live;  // 0: the loop of `anchor` has not started, 1: paused at i_next
   uint32_t i_next;     // first hit the paused loop has not processed
   uint32_t chunk_hi;   // hits below this index had their alignment emitted
-  uint32_t nog;        // pass 1: entries of outgroup_tmp so far
+  uint32_t nog;        // pass 1: entries of outgroup_tmp so far (sets of more than 64 hits: a list in og_idx / og_dist);
+                       // sets of up to 64 hits: the low word of outgroup_tmp as a bit set over the hits (k_decide)
   uint32_t d_lnode;    // pass 1: lnode (depth on the best hit's path)
   float ldist, udist;
   int32_t scut;        // qsearchscore_thresh_heuristic (:602)
   double qpid_upper, cut_g, cut_h;
   uint32_t combined;   // pass 0 and the pass-1 loop of hit 0 were requested together (EmitInfo mode 4)
-  uint32_t pad_;
+  uint32_t pad_;       // sets of up to 64 hits: the high word of that bit set
 };
 
 // One hit of a record set at its SortFilter position: 32 bytes of fields + the taxon path (4*path_quads words),
