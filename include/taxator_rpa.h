@@ -76,6 +76,10 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
 void rpa_destroy(rpa_engine* e);
 /* Text of the last error on this engine (or of the last failed rpa_create when e == NULL). */
 const char* rpa_last_error(const rpa_engine* e);
+/* Diagnostics for a caller's watchdog: a static string naming the blocking runtime call any engine of this process
+ * entered last ("predict_part: sync after emit (round)", "rpa_destroy: hipStreamDestroy", ...).  No reference counterpart
+ * (the reference has no device to wait for); the `taxator` driver prints it when it is told to report where it is. */
+const char* rpa_debug_where(void);
 
 /* Run on a caller-provided hipStream_t (e.g. the current stream of the framework that owns the device buffers).
  * NULL restores the engine's own stream.  The engine's own stream is independent (non-blocking): device-resident

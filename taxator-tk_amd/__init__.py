@@ -34,7 +34,7 @@ ABI_SYMBOLS = ["rpa_abi_version", "rpa_default_params", "rpa_create", "rpa_destr
                "rpa_store_load", "rpa_predict_batch", "rpa_align_pairs", "rpa_profile_enable", "rpa_profile_get",
                "rpa_profile_reset", "rpa_lca_default_params", "rpa_lca_predict_batch", "rpa_store_reserve", "rpa_store_append",
                "rpa_store_info_get", "rpa_submit_batch", "rpa_wait", "rpa_host_register",
-               "rpa_host_unregister"]
+               "rpa_host_unregister", "rpa_debug_where"]
 
 LCA_DUMMY, LCA_SIMPLE, LCA_MEGAN, LCA_NBEST = 0, 1, 2, 3  # taxator -a dummy | simple-lca | megan-lca | n-best-lca
 
@@ -101,6 +101,8 @@ def load_library(path=None):
     L.rpa_destroy.restype = None
     L.rpa_last_error.argtypes = [C.c_void_p]
     L.rpa_last_error.restype = C.c_char_p
+    L.rpa_debug_where.argtypes = []
+    L.rpa_debug_where.restype = C.c_char_p
     L.rpa_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.rpa_set_stream.restype = C.c_int
     L.rpa_store_load.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]

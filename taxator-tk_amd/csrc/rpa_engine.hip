@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -33,6 +34,11 @@ using namespace rpa;
 namespace {
 
 thread_local std::string g_create_error;
+
+// Diagnostics for watchdogs (rpa_debug_where): the engine-side blocking call entered last, process-wide.  A relaxed
+// store of a string literal's address per synchronisation point; never read by the engine itself.
+std::atomic<const char*> g_where{"idle"};
+#define RPA_WHERE(text) g_where.store(text, std::memory_order_relaxed)
 
 struct DevBuf {
   void* p = nullptr;
@@ -85,6 +91,8 @@ struct rpa_engine {
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
+  bool poison = false;        // RPA_POISON=1: every working buffer is filled with 0xA5 before each batch (tests: a kernel that
+                              // reads a slot nobody wrote this batch then reads garbage every time, not whatever the last batch left)
   // what the bands cost: pairs sent through the banded kernels / re-run wide open, per batch.  A band that sends more
   // than a quarter of its pairs to the retry list (unrelated sequences) is switched off for the next 16 batches.
   uint64_t banded_short_batch = 0, banded_long_batch = 0;
@@ -342,6 +350,7 @@ int profile_begin(rpa_engine* e) {
 int profile_end(rpa_engine* e) {
   if (!e->profiling) return RPA_OK;
   HIP_TRY(e, hipEventRecord(e->ev_total1, e->stream));
+  RPA_WHERE("profile_end: event sync");
   HIP_TRY(e, hipEventSynchronize(e->ev_total1));
   float ms = 0.f;
   HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_total0, e->ev_total1));
@@ -387,6 +396,13 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->band_save.ensure((size_t)(S ? S : 1) * 2 * (kMaxDepth + 1) * 4));
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
+  if (e->poison) {
+    DevBuf* bufs[] = {&e->state, &e->hits, &e->res_slot, &e->set_info, &e->set_qseg, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first,
+                      &e->flags, &e->lite, &e->seg, &e->pair_a, &e->pair_b, &e->pair_res, &e->pair_ext, &e->bin_list, &e->live_a, &e->live_b,
+                      &e->band_save, &e->og_idx, &e->og_dist, &e->retry_list, &e->retry_short, &e->protein_ws, &e->out_rows, &e->out_stats};
+    for (DevBuf* b : bufs)
+      if (b->p) HIP_TRY(e, hipMemsetAsync(b->p, 0xA5, b->cap, e->stream));
+  }
   w->state = e->state.as<SetState>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
   w->set_qseg = e->set_qseg.as<uint2>(); w->emit = e->emit.as<EmitInfo>(); w->emit_lite = e->emit_lite.as<uint4>(); w->hit_set = e->hit_set.as<uint32_t>(); w->block_first = e->block_first.as<uint32_t>();
   w->flags = e->flags.as<uint32_t>();
@@ -442,6 +458,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, tail + 1));
     if (!e->linear_rows) HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>()));
     HIP_TRY(e, launch_publish_words(e->stream, tail, e->h_counters, 3));
+    RPA_WHERE("predict_part: sync after validate/tile plan");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (e->h_counters[1]) return fail(e, RPA_ERR_INVALID, "batch rejected: set_offsets must run from 0 to n_records without decreasing and every node index must lie inside the taxonomy (set / record %u)", e->h_counters[2]);
     const uint64_t slots = e->h_counters[0];
@@ -472,6 +489,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     w.n_live_in = prev_live;  // grid bound only: the kernel reads the exact length from counters[kCtrActive]
     HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, e->params));
     HIP_TRY(e, launch_publish_words(e->stream, w.counters, e->h_counters, kNumCounters));  // (a kernel, not a copy: see k_publish_words)
+    RPA_WHERE("predict_part: sync after emit (round)");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     rc = check_device_error(e, e->h_counters);
     if (rc) return rc;
@@ -534,6 +552,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     ++rounds;
     if (rounds > (uint64_t)H + S + 8) return fail(e, RPA_ERR_INVALID, "placement state machine did not terminate");
   }
+  RPA_WHERE("predict_part: final sync");
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->prof.rounds += rounds;
   return profile_end(e);
@@ -567,7 +586,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows;
+  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison;
   w->fixed_speculation = e->fixed_speculation;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = make_stream(w->device, &w->own_stream);
@@ -682,6 +701,8 @@ void rpa_default_params(rpa_params* p) {
   p->speculation_pass2 = RPA_SPECULATION_DEFAULT;
 }
 
+const char* rpa_debug_where(void) { return g_where.load(std::memory_order_relaxed); }
+
 const char* rpa_last_error(const rpa_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
 int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** out) {
@@ -713,6 +734,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 10u) : params->speculation_pass2;  // tools/spec_sweep.sh, tools/spec_sweep4.sh
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
   if (const char* v = getenv("RPA_ROW_LAYOUT")) e->linear_rows = !strcmp(v, "linear");
+  if (const char* v = getenv("RPA_POISON")) e->poison = atoi(v) != 0;
   if (const char* v = getenv("RPA_PARTS")) e->parts_override = atoi(v);
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
@@ -741,6 +763,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
     hipError_t _err = (call);                                                                             \
     if (_err != hipSuccess) { fail(e, RPA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(_err)); return bail(RPA_ERR_DEVICE); } \
   } while (0)
+  RPA_WHERE("rpa_create: hipSetDevice (runtime initialisation)");
   CREATE_TRY(hipSetDevice(e->device));
   hipDeviceProp_t prop;
   CREATE_TRY(hipGetDeviceProperties(&prop, e->device));
@@ -748,8 +771,10 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
     fail(e, RPA_ERR_DEVICE, "rpa_create: device %d is %s; this library carries gfx950 code only", e->device, prop.gcnArchName);
     return bail(RPA_ERR_DEVICE);
   }
+  RPA_WHERE("rpa_create: stream");
   CREATE_TRY(make_stream(e->device, &e->own_stream));
   e->stream = e->own_stream;
+  RPA_WHERE("rpa_create: taxonomy copies");
   CREATE_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault));
   const size_t n = tax->n_nodes;
   CREATE_TRY(e->tax_parent.ensure(n * 4)); CREATE_TRY(e->tax_left.ensure(n * 4)); CREATE_TRY(e->tax_right.ensure(n * 4));
@@ -782,6 +807,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   CREATE_TRY(e->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long)));
   CREATE_TRY(hipMemset(e->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
 #undef CREATE_TRY
+  RPA_WHERE("rpa_create: done");
   *out = e;
   return RPA_OK;
 }
@@ -789,6 +815,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
 void rpa_destroy(rpa_engine* e) {
   if (!e) return;
   for (rpa_engine* s : e->slots) {
+    RPA_WHERE("rpa_destroy: joining a job slot thread");
     { std::lock_guard<std::mutex> lk(s->job_mu); s->job_quit = true; }
     s->job_cv.notify_all();
     if (s->job_thread.joinable()) s->job_thread.join();
@@ -798,22 +825,28 @@ void rpa_destroy(rpa_engine* e) {
   for (rpa_engine* w : e->workers) rpa_destroy(w);
   e->workers.clear();
   (void)hipSetDevice(e->device);
+  RPA_WHERE("rpa_destroy: sync own stream");
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
                     &e->protein_ws, &e->retry_list, &e->retry_short, &e->prof_acc, &e->part_offsets};
+  RPA_WHERE("rpa_destroy: hipFree of the buffers");
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
   for (auto& s : e->stores) s.release();
   e->pair_store.release();
+  RPA_WHERE("rpa_destroy: events");
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_total0) (void)hipEventDestroy(e->ev_total0);
   if (e->ev_total1) (void)hipEventDestroy(e->ev_total1);
   if (e->ev_inputs) (void)hipEventDestroy(e->ev_inputs);
+  RPA_WHERE("rpa_destroy: hipHostFree");
   if (e->h_counters) (void)hipHostFree(e->h_counters);
+  RPA_WHERE("rpa_destroy: hipStreamDestroy");
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  RPA_WHERE("rpa_destroy: done");
   delete e;
 }
 
@@ -843,6 +876,7 @@ static int store_grow(rpa_engine* e, Store* st, uint64_t more, uint64_t* first_r
     if (used_words) HIP_TRY(e, hipMemcpyAsync(bigger.as<uint32_t>() + kLeadWords, st->words.as<uint32_t>() + kLeadWords, (size_t)used_words * 4, hipMemcpyDeviceToDevice, e->stream));
     // everything behind the words in use reads as zero (slack for 16-byte text loads and funnel shifts)
     HIP_TRY(e, hipMemsetAsync(bigger.as<uint32_t>() + kLeadWords + used_words, 0, (size_t)(cap - used_words + kTailWords) * 4, e->stream));
+    RPA_WHERE("store_grow: sync after move");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     st->words.release();
     st->words = bigger;
@@ -867,6 +901,7 @@ static int store_add(rpa_engine* e, Store* st, uint32_t n, const uint32_t* index
   } else {
     HIP_TRY(e, hipMemcpyAsync(st->tmp_offsets.p, offsets, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(e, hipMemcpyAsync(&total, offsets + n, 8, hipMemcpyDeviceToHost, e->stream));
+    RPA_WHERE("store_add: sync after offsets");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
   const uint32_t* dev_index = nullptr;
@@ -889,6 +924,7 @@ static int store_add(rpa_engine* e, Store* st, uint32_t n, const uint32_t* index
   }
   HIP_TRY(e, launch_pack_letters(e->stream, e->params.alphabet, dev_letters, total, st->words.as<uint32_t>() + kLeadWords + first * bits / 32));
   HIP_TRY(e, launch_store_extents(e->stream, st->tmp_offsets.as<const uint64_t>(), dev_index, n, first, st->extent.as<ulonglong2>()));
+  RPA_WHERE("store_add: sync after pack");
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   st->n_residues = first + total;
   st->n_resident += n;
@@ -931,6 +967,7 @@ int rpa_store_reserve(rpa_engine* e, int which, uint32_t n_seqs) {
   uint64_t first = 0;
   int rc = store_grow(e, st, 0, &first);  // an (empty) arena with its slack words, so that a view exists
   if (rc) return rc;
+  RPA_WHERE("rpa_store_reserve: sync");
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   st->loaded = true;
   return RPA_OK;
@@ -994,6 +1031,7 @@ static int predict_on(rpa_engine* e, rpa_engine* so, const rpa_batch* batch, rpa
         if (cnt[k]) HIP_TRY(e, hipMemcpyAsync(e->in_u32[k].p, src_u32[k], cnt[k] * 4, hipMemcpyHostToDevice, e->stream));
       if (H) HIP_TRY(e, hipMemcpyAsync(e->in_f32.p, batch->score, (size_t)H * 4, hipMemcpyHostToDevice, e->stream));
       if (batch->filtered && H) HIP_TRY(e, hipMemcpyAsync(e->in_u8.p, batch->filtered, H, hipMemcpyHostToDevice, e->stream));
+      RPA_WHERE("predict_on: sync after host->device copies (job slot)");
       if (e != so) HIP_TRY(e, hipStreamSynchronize(e->stream));  // the link is free again when the data has arrived
     }
     b.set_offsets = e->in_u32[0].as<uint32_t>(); b.query_seq = e->in_u32[1].as<uint32_t>(); b.query_len = e->in_u32[2].as<uint32_t>();
@@ -1026,6 +1064,7 @@ static int predict_on(rpa_engine* e, rpa_engine* so, const rpa_batch* batch, rpa
   if (out_mem_kind == RPA_MEM_HOST) {
     HIP_TRY(e, hipMemcpyAsync(out, rows_dev, (size_t)S * sizeof(rpa_prediction), hipMemcpyDeviceToHost, e->stream));
     if (stats) HIP_TRY(e, hipMemcpyAsync(stats, stats_dev, (size_t)S * sizeof(rpa_stats), hipMemcpyDeviceToHost, e->stream));
+    RPA_WHERE("predict_on: sync after copying the rows back");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
   return RPA_OK;
@@ -1123,7 +1162,7 @@ int rpa_wait(rpa_engine* e, rpa_job* job) {
   rpa_engine* slot = job->slot;
   {
     std::unique_lock<std::mutex> sl(slot->job_mu);
-    slot->job_cv.wait(sl, [&] { return job->done; });
+    slot->job_cv.wait(sl, [&] { return job->done; });  // (no marker here: the slot thread's markers say where the job is)
   }
   const int rc = job->status;
   if (rc) { std::lock_guard<std::mutex> lk(e->mu); e->err = job->err; }
@@ -1156,6 +1195,7 @@ int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, cons
   HIP_TRY(e, launch_plan_plain_segments(e->stream, e->params.alphabet, w, sv));
   HIP_TRY(e, launch_bin_pairs(e->stream, e->params.alphabet, w, n_pairs));
   HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
+  RPA_WHERE("rpa_align_pairs: sync after bin_pairs");
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   rc = check_device_error(e, e->h_counters);
   if (rc) return rc;
@@ -1167,6 +1207,7 @@ int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, cons
   if (mem_kind == RPA_MEM_HOST) { HIP_TRY(e, e->out_rows.ensure((size_t)n_pairs * sizeof(rpa_alignment))); out_dev = e->out_rows.p; }
   HIP_TRY(e, launch_export_alignments(e->stream, w, n_pairs, out_dev));
   if (mem_kind == RPA_MEM_HOST) HIP_TRY(e, hipMemcpyAsync(out, out_dev, (size_t)n_pairs * sizeof(rpa_alignment), hipMemcpyDeviceToHost, e->stream));
+  RPA_WHERE("rpa_align_pairs: final sync");
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return profile_end(e);
 }
@@ -1241,6 +1282,7 @@ int rpa_lca_predict_batch(rpa_engine* e, const rpa_batch* batch, const double* e
     HIP_TRY(e, hipMemsetAsync(e->tile_base.p, 0, 8, e->stream));
     HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, e->tile_base.as<uint32_t>()));
     HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->tile_base.p, 8, hipMemcpyDeviceToHost, e->stream));
+    RPA_WHERE("rpa_lca_predict_batch: sync after validate");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (e->h_counters[0]) return fail(e, RPA_ERR_INVALID, "batch rejected: set_offsets must run from 0 to n_records without decreasing and every node index must lie inside the taxonomy (set / record %u)", e->h_counters[1]);
   }
@@ -1248,6 +1290,7 @@ int rpa_lca_predict_batch(rpa_engine* e, const rpa_batch* batch, const double* e
                        params->ignore_unclassified};
   HIP_TRY(e, launch_lca_models(e->stream, b, e->tax, p, ev, uncl, rows_dev));
   if (out_mem_kind == RPA_MEM_HOST) HIP_TRY(e, hipMemcpyAsync(out, rows_dev, (size_t)S * sizeof(rpa_prediction), hipMemcpyDeviceToHost, e->stream));
+  RPA_WHERE("rpa_lca_predict_batch: final sync");
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return RPA_OK;
 }

@@ -44,6 +44,19 @@ void RecordColumns::move_range(size_t dst, size_t src, size_t n) {
   mv(qstart); mv(qstop); mv(qlen); mv(rstart); mv(rstop); mv(identities); mv(alnlen); mv(ref_seq); mv(node); mv(score); mv(filtered);
 }
 
+void ColumnarBatch::make_room(size_t n_records, size_t n_sets) {
+  const bool grow = n_records > rec.qstart.capacity() || n_records > rec.filtered.capacity() || n_records > rec.score.capacity() ||
+                    n_sets + 1 > set_offsets.capacity() || n_sets > query_seq.capacity() || n_sets > query_len.capacity();
+  if (!grow) return;
+  if (before_regrow) before_regrow();
+  // a quarter more than asked for: blocks of one stream differ by a few per cent, and every growth is a re-registration
+  const size_t nr = n_records + n_records / 4, ns = n_sets + n_sets / 4;
+  rec.qstart.reserve(nr); rec.qstop.reserve(nr); rec.qlen.reserve(nr); rec.rstart.reserve(nr); rec.rstop.reserve(nr);
+  rec.identities.reserve(nr); rec.alnlen.reserve(nr); rec.ref_seq.reserve(nr); rec.node.reserve(nr); rec.score.reserve(nr);
+  rec.filtered.reserve(nr);
+  set_offsets.reserve(ns + 1); query_seq.reserve(ns); query_len.reserve(ns); qid_off.reserve(ns); qid_len.reserve(ns);
+}
+
 void ColumnarBatch::clear() {
   set_offsets.assign(1, 0);
   query_seq.clear(); query_len.clear(); qid_off.clear(); qid_len.clear(); qid_arena.clear();
@@ -394,6 +407,7 @@ void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, C
 void ColumnarReader::emit_groups(ColumnarBatch& out) {
   const size_t G = gstart_.size() - 1;
   RecordColumns& o = out.rec;
+  out.make_room(gstart_[G], out.n_sets());  // (the per-set arrays get their room below, once the sets are counted)
   o.resize(gstart_[G]);
   struct Part {
     std::vector<uint32_t> set_len, set_qlen, group_sets, group_qseq;
@@ -475,6 +489,11 @@ void ColumnarReader::emit_groups(ColumnarBatch& out) {
     for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
+  }
+  {
+    size_t total_sets = 0;
+    for (const Part& part : parts) total_sets += part.set_len.size();
+    out.make_room(o.size(), out.n_sets() + total_sets);
   }
   for (unsigned t = 0; t < T; ++t) {
     const Part& part = parts[t];

@@ -12,6 +12,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include <string>
 #include <thread>
@@ -64,6 +65,11 @@ struct ColumnarBatch {
   size_t n_sets() const { return query_seq.size(); }
   size_t n_records() const { return rec.size(); }
   void clear();
+  // Called (when set) right before any of the arrays rpa_batch points at -- set_offsets, query_seq, query_len, rec.* -- is
+  // about to be reallocated: whoever page-locked them (rpa_host_register) unregisters them first, as include/taxator_rpa.h
+  // asks ("unregister before freeing them").  Growth happens only inside ColumnarReader::next, through make_room().
+  std::function<void()> before_regrow;
+  void make_room(size_t n_records, size_t n_sets);
 };
 
 class ColumnarReader {

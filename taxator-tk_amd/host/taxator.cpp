@@ -40,6 +40,7 @@
 #include "exception.hh"
 #include "predictionrecord.hh"
 #include "sequencestorage.hh"
+#include "stage.hh"
 #include "taxonomy.hh"
 #include "taxonpredictionmodel.hh"
 
@@ -105,6 +106,17 @@ template <class T, class A> void add_range(std::vector<std::pair<void*, size_t>>
   // neighbours, and a page cannot be locked twice
   if (a.capacity() * sizeof(T) >= ((size_t)1 << 18)) v.emplace_back((void*)a.data(), a.capacity() * sizeof(T));
 }
+void unpin_work(Work& w, const RPAPredictionModel& rpa);
+// Registration never outlives an allocation: the reader unpins through ColumnarBatch::before_regrow before a column
+// grows, the GPU thread through room_for_rows before rows / stats grow; a range is registered again once it has settled.
+void room_for_rows(Work& w, size_t S, const RPAPredictionModel& rpa) {
+  if (S > w.rows.capacity() || S > w.stats.capacity()) {
+    unpin_work(w, rpa);
+    w.rows.reserve(S + S / 4); w.stats.reserve(S + S / 4);
+  }
+  w.rows.resize(S);
+  w.stats.resize(S);
+}
 void pin_work(Work& w, const RPAPredictionModel& rpa) {
   std::vector<std::pair<void*, size_t>> now;
   ColumnarBatch& b = w.batch;
@@ -123,6 +135,7 @@ void pin_work(Work& w, const RPAPredictionModel& rpa) {
 void unpin_work(Work& w, const RPAPredictionModel& rpa) {
   for (auto& r : w.pinned) { try { rpa.unpinHost(r.first); } catch (...) {} }
   w.pinned.clear();
+  w.pinned_want.clear();  // (an address that comes back after a reallocation is a new mapping: nothing may match it)
 }
 
 struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, records = 0; };
@@ -151,6 +164,7 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
       w->last = false; w->failed = false; w->err = nullptr; w->seq = seq++;
       if (stop.load()) { w->last = true; parsed_q.push(w); break; }  // a GPU call failed: end the stream here
       const Clock::time_point t0 = Clock::now();
+      if (!w->batch.before_regrow) w->batch.before_regrow = [w, &models] { unpin_work(*w, *models[0]); };
       try { if (!reader.next(w->batch)) w->last = true; }
       catch (...) { w->err = std::current_exception(); w->last = true; }
       tm.parse += secs(t0, Clock::now());
@@ -230,8 +244,7 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
       }
       const Clock::time_point t0 = Clock::now();
       const size_t S = w->batch.n_sets();
-      w->rows.resize(S);
-      w->stats.resize(S);
+      room_for_rows(*w, S, rpa);
       try {
         if (S >= 4096) pin_work(*w, rpa);  // (not worth it for tiny blocks: page-locking costs more than their copies)
         const size_t step = max_sets ? max_sets : S;
@@ -268,6 +281,9 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
 static bool parse_bool(const std::string& v) { return !(v == "0" || v == "false" || v == "no" || v == "off"); }
 
 int main(int argc, char** argv) {
+  install_stage_reporter();  // SIGUSR1 / SIGTERM / TAXATOR_WATCHDOG_S: say where the process is (stage.hh)
+  atexit([] { stage("exit handlers (runtime teardown)"); });
+  stage("options");
   Options o;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -333,6 +349,7 @@ int main(int argc, char** argv) {
   size_t n_sets = 0, n_records = 0;
   if (o.devices.empty()) o.devices.push_back(o.device);
   try {
+    stage("taxonomy");
     std::unique_ptr<Taxonomy> tax(loadTaxonomyFromEnvironment(&o.ranks, o.delete_unmarked));
     if (!tax) return EXIT_FAILURE;
     if (tax->getMaxDepth() > 15) {  // the placement kernels keep taxon paths of at most 15 levels (rpa_create)
@@ -340,11 +357,13 @@ int main(int argc, char** argv) {
                    "and at most 15 ranks with -r" << std::endl;
       return EXIT_FAILURE;
     }
+    stage("seqid->taxid mapping");
     std::unique_ptr<StrIDConverter> seqid2taxid(loadStrIDConverterFromFile(o.mapping, 1000));
     std::ofstream logsink(o.logfile.c_str(), std::ios_base::app);
     if (alignment_free) {  // taxator.cpp:346-361; doPredictionsSerial (:50-77) in batches
       std::unique_ptr<TaxonPredictionModel> model;
       const int dev = o.devices[0];
+      stage("alignment-free model: engine");
       if (o.algorithm == "dummy") model.reset(new DummyPredictionModel(tax.get(), dev));
       else if (o.algorithm == "simple-lca") model.reset(new LCASimplePredictionModel(tax.get(), dev));
       else if (o.algorithm == "n-best-lca") model.reset(new NBestLCAPredictionModel(tax.get(), (int)o.nbest, dev));
@@ -357,9 +376,12 @@ int main(int argc, char** argv) {
       std::ostringstream outbuf;
       const size_t batch_sets = o.batch ? o.batch : (size_t)1 << 16;
       while (recgen.notEmpty()) {
+        stage("alignment-free model: reading record sets");
         sets.clear();
         while (recgen.notEmpty() && sets.size() < batch_sets) { sets.emplace_back(); recgen.getNext(sets.back()); }
+        stage("alignment-free model: predict");
         model->predict(sets, precs, logsink);
+        stage("alignment-free model: output");
         outbuf.str("");
         for (size_t s = 0; s < sets.size(); ++s) outbuf << precs[s];
         std::cout << outbuf.str();
@@ -367,12 +389,14 @@ int main(int argc, char** argv) {
       return EXIT_SUCCESS;
     }
     // in memory unless an index file is named (core/taxator.cpp:232-249); an indexed store loads nothing here
+    stage("sequence stores (host)");
     std::unique_ptr<SequenceStore> query_ptr(o.query_index.empty() ? new SequenceStore(o.query) : new SequenceStore(o.query, o.query_index));
     std::unique_ptr<SequenceStore> db_ptr(o.db_index.empty() ? new SequenceStore(o.db) : new SequenceStore(o.db, o.db_index));
     SequenceStore& query_storage = *query_ptr;
     SequenceStore& db_storage = *db_ptr;
     const unsigned host_threads = o.processors ? o.processors : usable_cpus();
     std::vector<std::unique_ptr<RPAPredictionModel>> engines;
+    stage("engines (rpa_create + stores to HBM)");
     for (int dev : o.devices) {
       engines.emplace_back(new RPAPredictionModel(tax.get(), query_storage, db_storage, o.filterout, o.toppercent, o.dataformat == "protein", dev));
       engines.back()->setHostThreads(std::max(1u, host_threads / (unsigned)o.devices.size()));
@@ -395,11 +419,14 @@ int main(int argc, char** argv) {
       const bool logging = o.logfile != "/dev/null";
       std::vector<RPAPredictionModel*> models;
       for (auto& m : engines) models.push_back(m.get());
+      stage("columnar pipeline (reader / GPU / writer threads)");
       try { run_columnar(reader, models, *tax, logging ? &logsink : nullptr, o.batch, host_threads, tm); }
       catch (...) {
+        stage("columnar pipeline failed: unwinding (engines are destroyed)");
         if (o.timing) std::cerr << "TIMING\tincomplete" << std::endl;
         throw;
       }
+      stage("columnar pipeline done: reports, then engines are destroyed");
       store_report();
       if (o.timing)
         std::cerr << "TIMING\tload_s=" << secs(t_start, t_loaded) << "\tparse_s=" << tm.parse << "\tpredict_s=" << tm.predict << "\twrite_s="
@@ -407,6 +434,7 @@ int main(int argc, char** argv) {
                   << "\tgpus=" << o.devices.size() << "\t(columnar pipeline: the three stages overlap)" << std::endl;
       return EXIT_SUCCESS;
     }
+    stage("record-object loop: first record");
     AlignmentRecordFactory fac(*seqid2taxid, tax.get(), &db_storage);
     RecordSetGenerator recgen(std::cin, fac, o.split_alignments, o.alignments_sorted);
     std::vector<RecordSetType> sets;
@@ -415,6 +443,7 @@ int main(int argc, char** argv) {
     std::ostringstream outbuf;
     const size_t batch_sets = o.batch ? o.batch : (size_t)1 << 16;
     while (recgen.notEmpty()) {
+      stage("record-object loop: reading record sets");
       const Clock::time_point t0 = Clock::now();
       sets.clear();
       while (recgen.notEmpty() && sets.size() < batch_sets) {
@@ -424,7 +453,9 @@ int main(int argc, char** argv) {
       }
       n_sets += sets.size();
       const Clock::time_point t1 = Clock::now();
+      stage("record-object loop: predict");
       rpa.predict(sets, precs, logsink);
+      stage("record-object loop: output");
       const Clock::time_point t2 = Clock::now();
       outbuf.str("");
       for (size_t s = 0; s < sets.size(); ++s) outbuf << precs[s];
@@ -440,11 +471,14 @@ int main(int argc, char** argv) {
       std::cerr << "TIMING\tload_s=" << secs(t_start, t_loaded) << "\tparse_s=" << t_parse << "\tpredict_s=" << t_predict << "\twrite_s="
                 << t_write << "\trecord_sets=" << n_sets << "\trecords=" << n_records << std::endl;
     store_report();
+    stage("record-object loop done: engines are destroyed");
     return EXIT_SUCCESS;
   } catch (Exception& e) {
+    stage("error reported: leaving main");
     std::cerr << "An unrecoverable error occurred: " << e.what() << std::endl;  // taxator.cpp:381-386
     return EXIT_FAILURE;
   } catch (std::exception& e) {  // e.g. std::bad_alloc on a huge input: same way out
+    stage("error reported: leaving main");
     std::cerr << "An unrecoverable error occurred: " << e.what() << std::endl;
     return EXIT_FAILURE;
   }

@@ -3,17 +3,18 @@ import gzip
 import importlib
 import os
 import shutil
-import subprocess
 
 import numpy as np
 import pytest
 
 import __graft_entry__ as graft
 from helpers import refio as R
+from helpers.proc import run_child
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "taxator-tk_amd", "bin", "taxator")
+CHILD_LIMIT_S = 120  # a taxator run of these tests takes about a second (a cold GPU box: up to a minute for the first one)
 
 
 def _run(folder, ext, extra=(), aln="aln.tsv", query=None, log=None):
@@ -22,7 +23,7 @@ def _run(folder, ext, extra=(), aln="aln.tsv", query=None, log=None):
            os.path.join(folder, "ref" + ext), "-i", os.path.join(folder, "ref" + ext + ".fai"), "-p", "0"] + list(extra)
     if log:
         cmd += ["-l", log]
-    return subprocess.run(cmd, stdin=open(os.path.join(folder, aln)), capture_output=True, text=True, env=env)
+    return run_child(cmd, timeout=CHILD_LIMIT_S, stdin_path=os.path.join(folder, aln), env=env)
 
 
 def _unpack(golden_dir, name, ext, tmp_path):
@@ -107,7 +108,7 @@ def test_cli_alignment_free_models(oracle, golden_dir, tmp_path, algo, extra, kw
     open(names, "w").write("\n".join(lines))
     env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
     cmd = [BIN, "-a", algo, "-g", os.path.join(folder, "mapping.tax"), "--batch", "61"] + extra
-    r = subprocess.run(cmd, stdin=open(os.path.join(folder, "aln.tsv")), capture_output=True, text=True, env=env)
+    r = run_child(cmd, timeout=CHILD_LIMIT_S, stdin_path=os.path.join(folder, "aln.tsv"), env=env)
     assert r.returncode == 0, r.stderr
     fds = R.Dataset(folder, 0)
     b = fds.batch()
@@ -156,9 +157,9 @@ def test_cli_indexed_store_loads_only_what_the_stream_touches(oracle, tmp_path):
         for k in range(filler): f.write("filler%d\t%s\n" % (k, ds.tax.taxid[int(ds.tax.species[0])]))
     env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
     base = [BIN, "-g", os.path.join(folder, "mapping.tax"), "-q", os.path.join(folder, "query.fna"), "-f", os.path.join(folder, "ref.fna"), "--timing"]
-    mem = subprocess.run(base, stdin=open(os.path.join(folder, "aln.tsv")), capture_output=True, text=True, env=env)
-    idx = subprocess.run(base + ["-i", os.path.join(folder, "ref.fna.fai"), "-v", os.path.join(folder, "query.fna.fai"), "--block-mb", "0.01"],
-                         stdin=open(os.path.join(folder, "aln.tsv")), capture_output=True, text=True, env=env)  # no query .fai on disk: rebuilt by a scan
+    mem = run_child(base, timeout=CHILD_LIMIT_S, stdin_path=os.path.join(folder, "aln.tsv"), env=env)
+    idx = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "-v", os.path.join(folder, "query.fna.fai"), "--block-mb", "0.01"],
+                    timeout=CHILD_LIMIT_S, stdin_path=os.path.join(folder, "aln.tsv"), env=env)  # no query .fai on disk: rebuilt by a scan
     assert mem.returncode == 0 and idx.returncode == 0, (mem.stderr, idx.stderr)
     assert idx.stdout == mem.stdout and idx.stdout.count("\n") == 61
 

@@ -6,10 +6,11 @@ tests/test_distributed_cpu.py; the 8-GPU curve is the driver's to measure."""
 import json
 import os
 import socket
-import subprocess
 import sys
 
 import pytest
+
+from helpers.proc import run_child
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +31,7 @@ def test_bench_one_rank_over_rccl(config, extra):
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", config, "--steps", "2",
            "--warmup", "1", "--no-cpu-baseline", "--force-dist"] + extra
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    p = run_child(cmd, timeout=240, env=env, cwd=ROOT, what="bench.py, one rank over RCCL")
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
@@ -49,7 +50,7 @@ def test_bench_two_ranks_share_the_gpu(config, extra):
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--steps", "2",
            "--warmup", "1", "--no-cpu-baseline", "--dist-backend", "gloo", "--one-device"] + extra
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    p = run_child(cmd, timeout=240, env=env, cwd=ROOT, what="bench.py, two ranks on one GPU")
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0
