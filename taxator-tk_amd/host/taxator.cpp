@@ -280,9 +280,7 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
 
 static bool parse_bool(const std::string& v) { return !(v == "0" || v == "false" || v == "no" || v == "off"); }
 
-int main(int argc, char** argv) {
-  install_stage_reporter();  // SIGUSR1 / SIGTERM / TAXATOR_WATCHDOG_S: say where the process is (stage.hh)
-  atexit([] { stage("exit handlers (runtime teardown)"); });
+static int run(int argc, char** argv) {
   stage("options");
   Options o;
   for (int i = 1; i < argc; ++i) {
@@ -482,4 +480,26 @@ int main(int argc, char** argv) {
     std::cerr << "An unrecoverable error occurred: " << e.what() << std::endl;
     return EXIT_FAILURE;
   }
+}
+
+// Leaving.  When run() returns, every engine has been destroyed (rpa_destroy: streams synchronised and destroyed, device
+// and pinned memory freed), stdout / the log file are complete, and nothing of this process is left on the GPU that the
+// kernel driver does not reclaim by itself.  What a plain `return` from main would still do is run the exit handlers of the
+// HIP / HSA runtime -- and those can spin for ever when the process leaves within a few milliseconds of creating its
+// first stream: tools/hang_hunt.py caught it twice in 676 runs of `taxator --record-objects` on an input whose first line
+// does not parse (stage "exit handlers", engine "rpa_destroy: done", main thread running inside the runtime's teardown,
+// its helper threads asleep in kfd_wait_on_events; DESIGN.md section 5 has the stacks).  It is what hung round 2's GPU
+// test run.  So the driver flushes its streams and leaves with _exit: no handler of anybody's runs, the exit code is the
+// same.  TAXATOR_RUN_EXIT_HANDLERS=1 restores the plain return (the hunt's control arm).
+int main(int argc, char** argv) {
+  install_stage_reporter();  // SIGUSR1 / SIGTERM / TAXATOR_WATCHDOG_S: say where the process is (stage.hh)
+  atexit([] { stage("exit handlers (runtime teardown)"); });
+  const int rc = run(argc, argv);
+  stage("run() returned");
+  std::cout.flush();
+  std::cerr.flush();
+  fflush(nullptr);
+  const char* keep = getenv("TAXATOR_RUN_EXIT_HANDLERS");
+  if (!(keep && atoi(keep) != 0)) _exit(rc);
+  return rc;
 }

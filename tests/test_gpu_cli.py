@@ -88,6 +88,24 @@ def test_cli_errors_like_the_reference(golden_dir, tmp_path, path):
     assert r.returncode == 1 and "SequenceRangeError" in r.stderr
 
 
+def test_cli_leaves_at_once_when_the_first_line_does_not_parse(golden_dir, tmp_path):
+    """Regression for the run that never ended: `taxator --record-objects` on an input whose first line is
+    refused creates its engine, destroys it and leaves within milliseconds -- and the exit handlers of the HIP / HSA runtime
+    then span for ever in 2 of 676 and 15 of 850 such runs (tools/hang_hunt.py on the MI355X box: main thread running inside
+    libhsa-runtime64 under libamdhip64's static destructor, only when the engine's stream had been made with a CU mask).
+    The driver now flushes and leaves with _exit once every engine is destroyed (0 of 2200).  Thirty quick runs under the
+    child watchdog keep an eye on it; each must report the reference's error and exit code."""
+    work = tmp_path / "w"
+    shutil.copytree(os.path.join(golden_dir, "survey_edge"), work)
+    (work / "aln_bad.tsv").write_text("e0\t200\t1\t200\tref3\t101\t300\t400\t0\t200\t200\n")
+    slowest = 0.0
+    for k in range(30):
+        r = _run(str(work), ".fna", extra=["--record-objects"] if k % 3 else [], aln="aln_bad.tsv", query="query_edge.fna")
+        assert r.returncode == 1 and "reverse query positions not allowed" in r.stderr, (k, r.returncode, r.stderr[-500:])
+        slowest = max(slowest, r.seconds)
+    assert slowest < 60, slowest
+
+
 @pytest.mark.parametrize("algo,extra,kw", [
     ("dummy", [], {}), ("simple-lca", [], {}), ("megan-lca", [], {}),
     ("megan-lca", ["-t", "0.3", "-m", "150", "-e", "1e-5", "-c", "2"], dict(toppercent=0.3, minscore=150.0, maxevalue=1e-5, minsupport=2)),

@@ -106,12 +106,15 @@ def main():
     ap.add_argument("--dirty-sets", type=int, default=200000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hang_hunt.json"))
     ap.add_argument("--budget-s", type=float, default=900.0, help="stop starting children after this many seconds")
+    ap.add_argument("--only", default="", help="comma-separated variant names (e.g. mapping/objects,reverse/objects); default: all")
     a = ap.parse_args()
     a.parallel = max(1, min(4, a.parallel))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     sys.path.insert(0, ROOT)
     work = tempfile.mkdtemp(prefix="hang_hunt_")
     edge, vs = variants(work)
+    if a.only:
+        vs = [v for v in vs if v[0] in a.only.split(",")]
     env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(edge, "tax"))
     jobs = [v for _ in range(a.iters) for v in vs]
     t_start = time.time()
@@ -143,6 +146,7 @@ def main():
                     with open(progress, "a") as f:
                         f.write("dirty_device failed: %r\n" % (e,))
     summary = dict(children=done, seconds=time.time() - t_start, parallel=a.parallel, limit_s=a.limit, poison=os.environ.get("RPA_POISON", ""),
+                   env={k: v for k, v in os.environ.items() if k.startswith(("RPA_", "TAXATOR_"))},
                    hung=hung, wrong=wrong[:20], n_wrong=len(wrong), slow=slow[:20],
                    per_variant={k: dict(runs=v[0], mean_s=v[1] / max(1, v[0]), max_s=v[2]) for k, v in per_variant.items()})
     json.dump(summary, open(a.out, "w"), indent=1)
