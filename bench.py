@@ -186,6 +186,69 @@ CONFIGS = {
 }
 
 
+def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_flight, device):
+    """One of the other BASELINE configurations on this GPU, after the headline has been measured: `steps` steps through
+    rpa_submit_batch with `in_flight` of them running (the same timed region as the headline), then `steps` synchronous
+    calls for the per-launch profile.  No CPU leg.  Returns a small dict for the line's `secondary` object."""
+    import collections
+    t_gen = time.perf_counter()
+    ds = synth.make_dataset(n_sets=sets, n_hits=hits, seg_len=seg_len, branching=4, genome_len=cfg["genome_len"], seed=cfg["seed"],
+                            device="cuda", alphabet=cfg["alphabet"], level_rate=cfg["level_rate"], query_rate=cfg["query_rate"])
+    t_gen = time.perf_counter() - t_gen
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=cfg["alphabet"], device=device)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).cuda()
+           for k, v in ds.batch.items()}
+    outs = [(torch.zeros((ds.n_sets, 8), dtype=torch.int32, device="cuda"), torch.zeros((ds.n_sets, 4), dtype=torch.int32, device="cuda"))
+            for _ in range(in_flight + 1)]
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        model.set_stream(stream.cuda_stream)
+        model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=outs[0][0], stats=outs[0][1])  # allocation pass: the engine's own working set
+        jobs = collections.deque()
+
+        def run(n):
+            for k in range(n):
+                r_, s_ = outs[k % len(outs)]
+                jobs.append(model.submit(dev, out=r_, stats=s_, mem_kind=pkg.MEM_DEVICE))
+                if len(jobs) == in_flight:
+                    jobs.popleft().wait()
+            while jobs:
+                jobs.popleft().wait()
+
+        run(in_flight + 1)  # every job slot sizes its working set, + one warm step
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        model.profile(enable=True, reset=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=outs[0][0], stats=outs[0][1])
+        torch.cuda.synchronize()
+        sync_ms = (time.perf_counter() - t1) / steps * 1e3
+        prof = model.profile()
+    demanded = int(outs[0][1][:, 1:].to(torch.int64).sum().item())
+    align_s = max(prof["align_ms"] / 1e3, 1e-12)
+    res = {"workload": "%s: %d record sets x %d hits x %d %s" % (cfg["name"], sets, hits, seg_len, "bp" if cfg["alphabet"] == 0 else "aa"),
+           "value": demanded * steps / elapsed, "unit": "realignments/s", "steps": steps, "in_flight": in_flight,
+           "ms_per_step": elapsed / steps * 1e3, "sync_ms_per_step": sync_ms, "demanded_per_step": demanded,
+           "computed_over_demanded": prof["pairs"] / max(prof["demanded"], 1), "rounds_per_step": prof["rounds"] / steps,
+           "align_ms_per_step": prof["align_ms"] / steps,
+           "roofline": {"bound": "hbm", "achieved": prof["residue_bytes"] / align_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": prof["residue_bytes"] / align_s / 1e9 / 8000.0, "kernel": cfg["kernel"],
+                        "cell_updates_per_s_in_kernel": prof["cells"] / align_s, "launches": prof["launches"]},
+           "datagen_s": t_gen}
+    model.close()
+    del dev, outs, ds
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +281,10 @@ def main():
     ap.add_argument("--hits", type=int, default=None)
     ap.add_argument("--seg-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="the default command (one GPU, config 2 at its full size, CPU legs on) also runs configs 4 and 5 and a 200 aa "
+                         "protein workload for 3 steps each AFTER the headline has been measured and reports them under `secondary`; "
+                         "this switches that off (--no-cpu-baseline does too)")
     ap.add_argument("--host-buffers", action="store_true",
                     help="hand the batch over in host memory and take the rows back to the host every step (the PCIe-inclusive "
                          "rate noted in DESIGN.md; never the headline value, whose batch is resident in HBM)")
@@ -350,19 +417,16 @@ def main():
     # pipelined: a buffer set per job in flight + two whose rows may still be on their way to rank 0
     n_pipe = args.in_flight + 2
     pipe_out = [(rows, stats)] + [(torch.zeros_like(rows), torch.zeros_like(stats)) for _ in range(n_pipe - 1)] if pipelined else []
-    if pipelined and use_dist:
-        pending_gather = [None] * n_pipe
-        gather_buf = [gather_out] + [([torch.empty_like(t) for t in gather_out] if gather_out is not None else None) for _ in range(n_pipe - 1)]
+    ring = sharding.RowGatherRing(gather_sizes, n_pipe, cdev) if (pipelined and use_dist) else None
 
     def finish_one():
         if pipelined:
             k, job = in_flight.popleft()
             job.wait()  # the job's rows are complete in pipe_out[k]
             if use_dist:
-                if gloo:
-                    step.gathered = sharding.gather_rows(pipe_out[k][0].cpu(), dst=0, sizes=gather_sizes, out=gather_buf[k], force=True)
-                else:   # RCCL: the exchange runs beside the jobs still in flight; its buffers are not reused before it is done
-                    pending_gather[k] = sharding.gather_rows(pipe_out[k][0], dst=0, sizes=gather_sizes, out=gather_buf[k], force=True, async_op=True)
+                # the exchange runs beside the jobs still in flight; a buffer set is not reused before its gather is done
+                # (RCCL: device rows over xGMI; gloo rehearsal: the same calls on a host copy of the rows)
+                ring.post(k, pipe_out[k][0].cpu() if gloo else pipe_out[k][0])
                 step.last = k
             return
         r_host, s_host = in_flight.popleft().wait()
@@ -383,10 +447,9 @@ def main():
         elif pipelined:
             k = step.n % n_pipe
             step.n += 1
-            if use_dist and pending_gather[k] is not None:  # the exchange that read this buffer set n_pipe steps ago: done long
-                pending_gather[k][0].wait()                 # since, but the job about to overwrite the rows runs on a stream of
+            if use_dist and ring.pending[k] is not None:    # the exchange that read this buffer set n_pipe steps ago: done long
+                ring.reuse(k)                               # since, but the job about to overwrite the rows runs on a stream of
                 torch.cuda.current_stream().synchronize()   # its own, so the host makes sure
-                pending_gather[k] = None
             in_flight.append((k, model.submit(dev, out=pipe_out[k][0], stats=pipe_out[k][1], mem_kind=pkg.MEM_DEVICE)))
             if len(in_flight) == args.in_flight:
                 finish_one()
@@ -429,6 +492,8 @@ def main():
         if pending_gather[k_] is not None:
             pending_gather[k_][0].wait()
             pending_gather[k_] = None
+    if ring is not None:
+        ring.drain()
     model.profile(enable=True, reset=True)
     torch.cuda.synchronize()
     if use_dist:
@@ -442,6 +507,8 @@ def main():
     for pg in pending_gather:
         if pg is not None:
             pg[0].wait()
+    if ring is not None:
+        ring.drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -480,12 +547,10 @@ def main():
         traffic, traffic_src = None, None
         valu_per_launch, valu_src = None, None
         if use_dist and rank == 0:  # the gathered rows of this rank's own shard must be the rows it computed
-            if pipelined and not gloo:
-                gather_out = gather_buf[step.last]
-                step.gathered = gather_out if len(set(gather_sizes)) == 1 else torch.cat([b_[:n_] for b_, n_ in zip(gather_out, gather_sizes)], dim=0)
-                rows = pipe_out[step.last][0]
-            elif pipelined:
-                gather_out, rows = gather_buf[step.last], pipe_out[step.last][0]
+            if pipelined:
+                gather_out, rows = ring.recv[step.last], pipe_out[step.last][0]
+                step.gathered = ring.result(step.last)
+                assert ring.posted == args.in_flight + args.warmup + args.steps, "a step's rows were not sent to rank 0"
             if overlap_gather:
                 gather_out, rows = gather_buf[step.last], rows_buf[step.last]
                 step.gathered = gather_out if len(set(gather_sizes)) == 1 else torch.cat([b_[:n_] for b_, n_ in zip(gather_out, gather_sizes)], dim=0)
@@ -568,11 +633,33 @@ def main():
             "reference_store": {"replicas": args.store_replicas, "packed_bytes": store_bytes,
                                 "note": "config 2's 4096-species collection is 8 MB packed (cache resident); --store-replicas spreads the same work over HBM"},
         }
+        if use_dist:  # what the collective layer saw: an 8-GPU line must show eight ranks on RCCL
+            out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if not gloo else None),
+                           "gather": "asynchronous, ring of %d receive-buffer sets (sharding.RowGatherRing)" % n_pipe if ring is not None else "blocking"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, ds)
             ref = cpu_reference_pairs(synth, ds)
             if ref is not None:
                 out["cpu_reference"] = ref
+        default_sizes = args.sets == cfg["sets"] and args.hits == cfg["hits"] and args.seg_len == cfg["seg_len"]
+        if (world == 1 and args.config == "c2" and default_sizes and pipelined and not use_dist and not args.no_cpu_baseline
+                and not args.no_secondary and args.store_replicas == 1):
+            # the other single-GPU configurations of BASELINE.json, outside the headline's timed region and after it
+            model.set_stream(None)
+            model.close()
+            del dev, rows, stats, pipe_out
+            torch.cuda.empty_cache()
+            sec = {}
+            c4, c5 = CONFIGS["c4"], CONFIGS["c5"]
+            for key, c_, sets_, hits_, len_ in (("c4", c4, c4["sets"], c4["hits"], c4["seg_len"]),
+                                                ("c4_200aa", c4, c4["sets"], c4["hits"], 200),
+                                                ("c5", c5, c5["sets"], c5["hits"], c5["seg_len"])):
+                try:
+                    sec[key] = measure_secondary(pkg, synth, torch, c_, sets_, hits_, len_, 3, args.in_flight, local_rank)
+                except Exception as e:  # the headline stands whatever happens here
+                    sec[key] = {"error": repr(e)}
+            out["secondary"] = sec
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -157,6 +157,31 @@ BATCH_FIELDS = (("set_offsets", np.uint32), ("query_seq", np.uint32), ("query_le
                 ("identities", np.uint32), ("alnlen", np.uint32), ("ref_seq", np.uint32), ("node", np.uint32))
 
 
+class _Job:
+    """A batch in flight (rpa_submit_batch): holds the batch arrays and the output arrays until rpa_wait has returned."""
+
+    def __init__(self, model, handle, rows, stats, keep):
+        self._model, self._handle, self._rows, self._stats, self._keep = model, handle, rows, stats, keep
+        self._done = False
+
+    def wait(self):
+        if not self._done:
+            self._done = True  # the handle is released by rpa_wait whatever the status: never wait for it twice
+            m, self._model = self._model, None
+            try:
+                m._check(m._L.rpa_wait(m._h, self._handle))
+            finally:
+                self._keep = None
+        return self._rows, self._stats
+
+    def __del__(self):
+        try:
+            if not self._done and self._model is not None and self._model._h and self._model._h.value:
+                self.wait()
+        except Exception:
+            pass
+
+
 class RPAPredictionModel:
     """One engine on one GPU.
 
@@ -219,21 +244,15 @@ class RPAPredictionModel:
 
     def submit(self, batch, want_stats=True, out=None, stats=None, mem_kind=MEM_HOST):
         """Asynchronous predict: returns a job; job.wait() -> (rows, stats).  RPA_JOBS_IN_FLIGHT (3) jobs run at a time.
-        mem_kind=MEM_DEVICE: batch / out / stats are torch cuda tensors that are complete (synchronise your stream first)."""
+        mem_kind=MEM_DEVICE: batch / out / stats are torch cuda tensors that are complete (synchronise your stream first).
+        The job object owns every buffer the engine reads or writes until wait() has returned; a job that is dropped without
+        wait() (an exception between submit and wait) waits in its finaliser, so the buffers never go away under the engine."""
         if mem_kind == MEM_DEVICE:
             so, qs = batch["set_offsets"], batch["qstart"]
             b = _Batch(so.numel() - 1, qs.numel(), *[_ptr(batch[name]) for name, _ in BATCH_FIELDS], _ptr(batch.get("filtered")), MEM_DEVICE)
             handle = C.c_void_p()
             self._check(self._L.rpa_submit_batch(self._h, C.byref(b), _ptr(out), _ptr(stats), C.byref(handle)))
-            model = self
-
-            class DevJob:
-                keep = (batch, b, out, stats)
-
-                def wait(self_job):
-                    model._check(model._L.rpa_wait(model._h, handle))
-                    return out, stats
-            return DevJob()
+            return _Job(self, handle, out, stats, keep=(batch, b))
         arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in BATCH_FIELDS}
         filt = batch.get("filtered")
         filt = None if filt is None else np.ascontiguousarray(filt, np.uint8)
@@ -242,16 +261,8 @@ class RPAPredictionModel:
         rows = out if out is not None else np.zeros(n_sets, PRED_DTYPE)
         st = stats if stats is not None else (np.zeros(n_sets, STATS_DTYPE) if want_stats else None)
         handle = C.c_void_p()
-        self._check(self._L.rpa_submit_batch(self._h, C.byref(b), rows.ctypes.data, st.ctypes.data if want_stats else None, C.byref(handle)))
-        model = self
-
-        class Job:
-            keep = (arrs, filt, b)  # the engine reads these until wait() returns
-
-            def wait(self_job):
-                model._check(model._L.rpa_wait(model._h, handle))
-                return rows, st
-        return Job()
+        self._check(self._L.rpa_submit_batch(self._h, C.byref(b), rows.ctypes.data, None if st is None else st.ctypes.data, C.byref(handle)))
+        return _Job(self, handle, rows, st, keep=(arrs, filt, b))
 
     def reserve_store(self, which, n_seqs):
         """An indexed store (sequencestorage.hh:318-406): n_seqs sequences known, none resident yet."""

@@ -92,3 +92,48 @@ def gather_rows(rows, dst=0, group=None, sizes=None, out=None, force=False, asyn
     if all(n == n_max for n in sizes) and out is not None:
         return bufs  # equal shards, caller-owned buffers: no concatenation copy
     return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+
+
+class RowGatherRing:
+    """The exchange of a stream of steps: every step's rows go to `dst` with an asynchronous gather that runs beside the
+    steps that follow, through a ring of `n_buf` receive-buffer sets so that a set is not reused before the gather that
+    reads or fills it is done.  bench.py posts the rows of step k into buffer set k % n_buf; on RCCL the tensors are device
+    tensors and the gather runs on RCCL's stream over xGMI, in the gloo rehearsals they are host tensors -- same calls.
+
+        ring = RowGatherRing(sizes, n_buf, device)      # sizes: rows per rank (may differ: config 5 is cut by cost)
+        ring.reuse(k)                                   # before buffer set k is written again: its gather has finished
+        ring.post(k, rows)                              # start the gather of this step's rows
+        ring.drain()                                    # every gather posted so far has finished
+        ring.result(k)                                  # on dst: the rows of all ranks in rank order (a tensor)
+    """
+
+    def __init__(self, sizes, n_buf, device, dst=0, group=None, width=8, dtype=torch.int32):
+        self.sizes, self.n_buf, self.dst, self.group = [int(s) for s in sizes], int(n_buf), dst, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        assert len(self.sizes) == self.world
+        n_max = max(self.sizes) if self.sizes else 0
+        self.recv = [([torch.empty((n_max, width), dtype=dtype, device=device) for _ in range(self.world)] if self.rank == dst else None)
+                     for _ in range(self.n_buf)]
+        self.pending = [None] * self.n_buf
+        self.posted = 0
+
+    def reuse(self, k):
+        if self.pending[k] is not None:
+            self.pending[k][0].wait()
+            self.pending[k] = None
+
+    def post(self, k, rows):
+        self.reuse(k)
+        assert rows.shape[0] == self.sizes[self.rank], (rows.shape, self.sizes, self.rank)
+        self.pending[k] = gather_rows(rows, dst=self.dst, group=self.group, sizes=self.sizes, out=self.recv[k], force=True, async_op=True)
+        self.posted += 1
+
+    def drain(self):
+        for k in range(self.n_buf):
+            self.reuse(k)
+
+    def result(self, k):
+        self.reuse(k)
+        if self.rank != self.dst:
+            return None
+        return torch.cat([b[:n] for b, n in zip(self.recv[k], self.sizes)], dim=0)

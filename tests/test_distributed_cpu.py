@@ -73,6 +73,64 @@ def test_shard_and_gather_world2(tmp_path, uneven):
     assert open(out).read() == "ok"
 
 
+def _ring_worker(rank, world, port, out_path):
+    """Eight ranks, shards of different sizes, a stream of steps through the ring of receive buffers exactly as bench.py's
+    default N > 1 path drives it: at most IN_FLIGHT steps started and not yet posted, a buffer set reused every N_BUF steps."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    graft.load_package()
+    sharding = importlib.import_module("taxator_tk_amd.sharding")
+    costs = (np.arange(1, 1001, dtype=np.float64) % 37 + 1) ** 2          # one workload, cut where the summed cost is equal
+    bounds = sharding.shard_bounds_by_cost(costs, world)
+    sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
+    assert len(set(sizes)) > 1 and sum(sizes) == 1000
+    IN_FLIGHT, STEPS = 3, 23
+    n_buf = IN_FLIGHT + 2
+    ring = sharding.RowGatherRing(sizes, n_buf, "cpu")
+
+    def rows_of(r, step):  # what rank r computes in step `step`: a function of (global set index, step)
+        idx = torch.arange(bounds[r], bounds[r + 1], dtype=torch.int32)
+        return torch.stack([idx * 7 + step + c for c in range(8)], dim=1).contiguous()
+
+    import collections
+    started = collections.deque()
+    ok = True
+    last = None
+    for step in range(STEPS):
+        k = step % n_buf
+        ring.reuse(k)                      # the buffer set this step will post into
+        started.append((k, step))
+        if len(started) == IN_FLIGHT:
+            kk, st = started.popleft()
+            ring.post(kk, rows_of(rank, st)); last = (kk, st)
+    while started:
+        kk, st = started.popleft()
+        ring.post(kk, rows_of(rank, st)); last = (kk, st)
+    ring.drain()
+    if rank == 0:
+        # the last n_buf steps are still in their buffer sets: every one must hold every rank's rows of its own step
+        for step in range(STEPS - n_buf, STEPS):
+            got = ring.result(step % n_buf)
+            want = torch.cat([rows_of(r, step) for r in range(world)], dim=0)
+            ok = ok and got.shape == want.shape and bool(torch.equal(got, want))
+        ok = ok and ring.posted == STEPS and last == ((STEPS - 1) % n_buf, STEPS - 1)
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    else:
+        assert ring.result(0) is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_gather_ring_world8(tmp_path):
+    """The exchange of bench.py's default multi-GPU path (asynchronous gathers through a ring of receive buffers) with the
+    eight ranks the driver launches, on gloo: uneven shards (a workload cut by cost), 23 steps, three in flight."""
+    out = str(tmp_path / "ring.txt")
+    mp.spawn(_ring_worker, args=(8, _free_port(), out), nprocs=8, join=True)
+    assert open(out).read() == "ok"
+
+
 def test_shard_bounds_and_slices():
     graft.load_package()
     sharding = importlib.import_module("taxator_tk_amd.sharding")

@@ -37,25 +37,33 @@ def test_bench_one_rank_over_rccl(config, extra):
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
     assert "RCCL gather" in out["config"]["parallelism"]
+    assert out["dist"]["backend"] == "nccl" and out["dist"]["world_size"] == 1 and out["dist"]["rccl_version"]
     assert out["roofline"]["achieved"] > 0 and out["roofline"]["launches"] > 0
 
 
-@pytest.mark.parametrize("config,extra", [("c3", ["--sets", "20000"]), ("c5", ["--sets", "24", "--seg-len", "2500"])])
-def test_bench_two_ranks_share_the_gpu(config, extra):
-    """Two ranks, two processes, two engines on the one GPU of the test box (gloo gathers the rows through host memory:
-    RCCL refuses two ranks on one device).  What this executes that nothing else does before the driver's 8-GPU run:
-    per-rank seeds (c3), ONE workload cut by summed alignment cells into shards of different sizes and the uneven gather
-    (c5), barrier / all_reduce bracketing with world size 2, two engines sharing a device."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--steps", "2",
+RANKS = 4  # the GPU box allows six processes on its card: the test runner + four ranks (eight ranks: tests/test_distributed_cpu.py)
+
+
+@pytest.mark.parametrize("config,extra", [("c3", ["--sets", "8000"]), ("c5", ["--sets", "16", "--seg-len", "2000"])])
+def test_bench_four_ranks_share_the_gpu(config, extra):
+    """Four ranks, four processes, four engines on the one GPU of the test box (gloo gathers the rows through host memory:
+    RCCL refuses several ranks on one device), through bench.py's DEFAULT multi-GPU step function: steps submitted to the
+    engines' job slots, three in flight, every step's rows sent to rank 0 by an asynchronous gather through the ring of
+    receive buffers.  What this executes that nothing else does before the driver's 8-GPU run: per-rank seeds (c3), ONE
+    workload cut by summed alignment cells into shards of different sizes and the uneven gather (c5), barrier / all_reduce
+    bracketing with several ranks, several engines sharing a device."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(RANKS), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(RANKS), "--config", config, "--steps", "4",
            "--warmup", "1", "--no-cpu-baseline", "--dist-backend", "gloo", "--one-device"] + extra
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = run_child(cmd, timeout=240, env=env, cwd=ROOT, what="bench.py, two ranks on one GPU")
+    p = run_child(cmd, timeout=240, env=env, cwd=ROOT, what="bench.py, four ranks on one GPU")
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["n_gpus"] == RANKS and out["value"] > 0
+    assert out["dist"]["world_size"] == RANKS and out["dist"]["backend"] == "gloo" and out["dist"]["gather"].startswith("asynchronous")
+    assert "steps in flight" in out["submission"]
     shards = out["config"]["shard_sets"]
-    assert len(shards) == 2 and sum(shards) == 2 * int(extra[1])
+    assert len(shards) == RANKS and sum(shards) == RANKS * int(extra[1])
     if config == "c5":
         assert "cut by summed alignment cells" in out["config"]["parallelism"]
 
