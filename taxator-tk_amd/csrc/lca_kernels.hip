@@ -7,7 +7,7 @@
 // One thread per record set; the set's records are read straight from the batch columns.  The filters of the
 // reference mark records ("filterOut"); here a record's mask is a pure function of the set-level quantities the
 // filters compute (running maximum, n-th best distinct score), so no per-record scratch is written.  The LCA of a set
-// of taxa is the common prefix of their root paths (per-node ancestor table, see place_kernels.hip).
+// of taxa is found by climbing from the running LCA until its preorder interval holds the next taxon (any depth).
 // None of these models sets the interpolation value: rows carry ival = -1 and RPA_FLAG_IVAL_UNTOUCHED.
 #include "rpa_device.h"
 
@@ -19,29 +19,14 @@ struct LcaRow {  // = rpa_prediction
   uint32_t flags;
 };
 
-template <int P4>
-__device__ __forceinline__ void node_path(const TaxDev& tax, uint32_t node, uint32_t (&path)[4 * P4]) {
-  const uint4* a = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
-#pragma unroll
-  for (int k = 0; k < P4; ++k) { const uint4 v = a[k]; path[4 * k] = v.x; path[4 * k + 1] = v.y; path[4 * k + 2] = v.z; path[4 * k + 3] = v.w; }
-}
-template <int P4>
-__device__ __forceinline__ uint32_t common_prefix(const uint32_t (&a)[4 * P4], uint32_t da, const uint32_t (&b)[4 * P4], uint32_t db) {
-  uint32_t c = 0;
-  bool run = true;
-#pragma unroll
-  for (int d = 0; d < 4 * P4; ++d) { run = run && (a[d] == b[d]); c += run ? 1u : 0u; }
-  return min(c, min(da, db));
-}
-template <int P4>
-__device__ __forceinline__ uint32_t path_node(const uint32_t (&path)[4 * P4], uint32_t depth) {
-  uint32_t v = kRoot;
-#pragma unroll
-  for (int d = 0; d < 4 * P4; ++d) if ((uint32_t)d + 1 == depth) v = path[d];
-  return v;
+// LCA of a running node `lca` and node x: climb from `lca` until its subtree holds x (the reference's getLCA walks the
+// same way, core/src/taxonomyinterface.cpp:67-77).  Preorder intervals made at rpa_create; any depth.
+__device__ __forceinline__ uint32_t lca_with(const TaxDev& tax, uint32_t lca, uint32_t x) {
+  const uint32_t px = tax.pre[x];
+  while (!(tax.pre[lca] <= px && px <= tax.last[lca])) lca = tax.parent[lca];  // the root's interval holds every node
+  return lca;
 }
 
-template <int P4>
 __global__ __launch_bounds__(kBlock) void k_lca_models(BatchDev b, TaxDev tax, LcaParamsDev p, const double* __restrict__ evalue,
                                                         const uint8_t* __restrict__ unclassified, LcaRow* __restrict__ rows) {
   const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
@@ -110,11 +95,7 @@ __global__ __launch_bounds__(kBlock) void k_lca_models(BatchDev b, TaxDev tax, L
       uint32_t qrstart = b.qstart[r], qrstop = b.qstop[r];
       float maxscore = b.score[r];
       if (qrstart > qrstop) { const uint32_t t = qrstart; qrstart = qrstop; qrstop = t; }
-      uint32_t ref_path[4 * P4], pth[4 * P4];
-      const uint32_t n0 = b.node[r];
-      node_path<P4>(tax, n0, ref_path);
-      const uint32_t d0 = tax.depth[n0];
-      uint32_t d_all = d0;  // LCA of all unmasked nodes as a point on the first node's path
+      uint32_t lca_all = b.node[r];  // LCA of all unmasked nodes (:95-111)
       for (uint32_t k = r + 1; k < hi; ++k) {
         const float sc = b.score[k];
         if (masked(k, sc)) continue;
@@ -122,26 +103,23 @@ __global__ __launch_bounds__(kBlock) void k_lca_models(BatchDev b, TaxDev tax, L
         if (qs <= qe) { qrstart = min(qs, qrstart); qrstop = max(qe, qrstop); }
         else { qrstart = min(qe, qrstart); qrstop = max(qs, qrstop); }
         if (sc > maxscore) maxscore = sc;
-        const uint32_t nk = b.node[k];
-        node_path<P4>(tax, nk, pth);
-        d_all = min(d_all, common_prefix<P4>(ref_path, d0, pth, tax.depth[nk]));
+        lca_all = lca_with(tax, lca_all, b.node[k]);
       }
       // best reference taxon: LCA of the nodes of the records that reach the maximum score (:113-126)
       bool have = false;
-      uint32_t best_path[4 * P4];
-      uint32_t d_best = 0, db0 = 0;
+      uint32_t lca_best = kRoot;
       for (uint32_t k = r; k < hi; ++k) {
         const float sc = b.score[k];
         if (masked(k, sc) || !(sc == maxscore)) continue;
         const uint32_t nk = b.node[k];
-        if (!have) { node_path<P4>(tax, nk, best_path); db0 = tax.depth[nk]; d_best = db0; have = true; }
-        else { node_path<P4>(tax, nk, pth); d_best = min(d_best, common_prefix<P4>(best_path, db0, pth, tax.depth[nk])); }
+        if (!have) { lca_best = nk; have = true; }
+        else lca_best = lca_with(tax, lca_best, nk);
       }
-      const uint32_t node = path_node<P4>(ref_path, d_all);
+      const uint32_t node = lca_all;
       row.begin = qrstart; row.end = qrstop;
       row.lower = row.upper = node;
       row.support = qrstop - qrstart + 1;  // setNodePoint(node): getQueryFeatureWidth(), predictionrecord.hh:68,178-181
-      row.rtax = have ? path_node<P4>(best_path, d_best) : node;
+      row.rtax = have ? lca_best : node;
     }
   }
   rows[s] = row;
@@ -151,13 +129,7 @@ hipError_t launch_lca_models(hipStream_t st, const BatchDev& b, const TaxDev& ta
                              const uint8_t* unclassified, void* rows) {
   if (b.n_sets == 0) return hipSuccess;
   const dim3 grid((b.n_sets + kBlock - 1) / kBlock);
-  switch (tax.path_quads) {
-    case 1: hipLaunchKernelGGL(k_lca_models<1>, grid, dim3(kBlock), 0, st, b, tax, p, evalue, unclassified, (LcaRow*)rows); break;
-    case 2: hipLaunchKernelGGL(k_lca_models<2>, grid, dim3(kBlock), 0, st, b, tax, p, evalue, unclassified, (LcaRow*)rows); break;
-    case 3: hipLaunchKernelGGL(k_lca_models<3>, grid, dim3(kBlock), 0, st, b, tax, p, evalue, unclassified, (LcaRow*)rows); break;
-    case 4: hipLaunchKernelGGL(k_lca_models<4>, grid, dim3(kBlock), 0, st, b, tax, p, evalue, unclassified, (LcaRow*)rows); break;
-    default: return hipErrorInvalidValue;
-  }
+  hipLaunchKernelGGL(k_lca_models, grid, dim3(kBlock), 0, st, b, tax, p, evalue, unclassified, (LcaRow*)rows);
   return hipGetLastError();
 }
 

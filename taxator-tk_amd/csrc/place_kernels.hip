@@ -15,13 +15,21 @@
 //
 // Memory shape (this is what makes a thread-per-set kernel viable on a GPU): a set's hits are ONE contiguous array of
 // fixed-size rows in SortFilter order; a row carries everything the loops read per hit, including the hit's taxon
-// PATH (its ancestors at depth 1..P from the flattened parent-pointer taxonomy, copied once per hit from a
-// per-node table).  Every node predict() ever forms -- rtax, lnode, unode, lca_allnodes and their global versions -- is
+// PATH.  Every node predict() ever forms -- rtax, lnode, unode, lca_allnodes and their global versions -- is
 // an LCA that includes the best reference's taxon, i.e. a point on the best hit's root path, so the state machine
 // keeps DEPTHS on that path instead of nodes, and every getLCA / isParentOf of the reference becomes
 //     common(x, i) = length of the common prefix of two paths,   LCA(point d on x's path, node_i) = min(d, common(x, i)),
-// pure register arithmetic with no dependent walks over the taxonomy arrays.  Alignment results come back in a per-hit
-// array parallel to the rows, so a round reads ~72 contiguous bytes per hit.
+// pure register arithmetic with no dependent walks over the taxonomy arrays.
+// A path is not stored as node ids (4 bytes per level, and a row then weighs 64 bytes at 8 levels) but as per-set LABELS:
+//     label_d(i) = the smallest index (input order inside the record set) of a record whose ancestor at depth d is hit i's.
+// Two hits of a set share their ancestor at depth d exactly when their labels at level d are equal, so the common prefix
+// of two label strings is the depth of the LCA, as with ids -- but a label needs 8 bits (sets of up to 256 records; 16 /
+// 32 bits beyond), not 32: 8 levels fit 8 bytes and a row is 32 bytes, a 40-level tree costs 40 bytes.  k_rank_records
+// makes them without touching another record's path: record j shares hit i's ancestor at depth d iff j's node lies in
+// that ancestor's subtree, i.e. iff pre[node_j] falls into the ancestor's preorder interval (TaxDev::anc_iv), so a thread
+// holds its own node's intervals and scans the preorder numbers of the records in front of it (staged in LDS).
+// The node at a depth of the best hit's path, needed only when a set's result is written, comes from TaxDev::anc.
+// Alignment results come back in a per-hit array parallel to the rows, so a round reads ~40 contiguous bytes per hit.
 //
 // Float discipline (bit-exact decisions): f32 distances/similarities/scores, f64 percent identities, int truncations
 // exactly where the reference has them (:592,602,659,661); compiled with -ffp-contract=off and IEEE divide/sqrt.
@@ -55,39 +63,42 @@ __device__ __forceinline__ void raise_error(const WorkDev& w, uint32_t code, uin
 // lanes of a wave (= 64 consecutive sets) read "quad q of my row i" they read 1 KB of contiguous memory, and the
 // alignment result of row i at slot tile_base + 64 i + l likewise.  Linear layout (fallback for batches whose sets
 // differ wildly in size, where padding every tile to its largest set would waste memory): rows of a set contiguous.
-template <int P4>
-struct Row { uint4 q[2 + P4]; };  // a whole row in registers
+template <int Q>
+struct Row { uint4 q[Q]; };  // a whole row in registers
+template <int Q> constexpr int path_words() { return 4 * Q - 6; }
 
-template <int P4>
+template <int Q>
 struct SetRows {
   uint4* p;         // quad 0 of row 0
   size_t si, sq;    // quads from a row to the next / from a quad of a row to the next
   float2* res;      // result slot of row 0
   size_t sr;        // slots from a row to the next
-  __device__ __forceinline__ Row<P4> load(uint32_t i) const {
+  __device__ __forceinline__ Row<Q> load(uint32_t i) const {
     const uint4* r = p + (size_t)i * si;
-    Row<P4> o;
+    Row<Q> o;
 #pragma unroll
-    for (int k = 0; k < 2 + P4; ++k) o.q[k] = r[(size_t)k * sq];
+    for (int k = 0; k < Q; ++k) o.q[k] = r[(size_t)k * sq];
     return o;
   }
-  __device__ __forceinline__ HitCore core(uint32_t i) const {
+  __device__ __forceinline__ HitCore core(uint32_t i) const {  // 24 bytes: quad 0 + the first half of quad 1
     const uint4* r = p + (size_t)i * si;
-    const uint4 a = r[0], b = r[sq];
+    const uint4 a = r[0];
+    const float2 b = reinterpret_cast<const float2*>(r + sq)[0];
     HitCore c;
-    c.score = __uint_as_float(a.x); c.ident = a.y; c.node = a.z; c.rec = a.w;
-    c.qd = __uint_as_float(b.x); c.qs = __uint_as_float(b.y); c.seglen = b.z; c.meta = b.w;
+    c.score = __uint_as_float(a.x); c.ident = a.y; c.node = a.z; c.meta = a.w;
+    c.qd = b.x; c.qs = b.y;
     return c;
   }
-  __device__ __forceinline__ void path(uint32_t i, uint32_t (&path)[4 * P4]) const {
+  __device__ __forceinline__ void path(uint32_t i, uint32_t (&path)[4 * Q - 6]) const {
     const uint4* r = p + (size_t)i * si;
+    const uint2 h = reinterpret_cast<const uint2*>(r + sq)[1];
+    path[0] = h.x; path[1] = h.y;
 #pragma unroll
-    for (int k = 0; k < P4; ++k) {
-      const uint4 v = r[(size_t)(2 + k) * sq];
-      path[4 * k] = v.x; path[4 * k + 1] = v.y; path[4 * k + 2] = v.z; path[4 * k + 3] = v.w;
+    for (int k = 2; k < Q; ++k) {
+      const uint4 v = r[(size_t)k * sq];
+      path[4 * k - 6] = v.x; path[4 * k - 5] = v.y; path[4 * k - 4] = v.z; path[4 * k - 3] = v.w;
     }
   }
-  __device__ __forceinline__ void store_quad(uint32_t i, int k, uint4 v) const { p[(size_t)i * si + (size_t)k * sq] = v; }
   // the only mutable fields of a row: querydistance / querysimilarity (first 8 bytes of its second quad)
   __device__ __forceinline__ void store_qdqs(uint32_t i, float qd, float qs) const {
     reinterpret_cast<float2*>(p + (size_t)i * si + sq)[0] = make_float2(qd, qs);
@@ -95,10 +106,9 @@ struct SetRows {
   __device__ __forceinline__ void store_qd(uint32_t i, float qd) const { reinterpret_cast<float*>(p + (size_t)i * si + sq)[0] = qd; }
   __device__ __forceinline__ float2 result(uint32_t i) const { return res[(size_t)i * sr]; }
 };
-template <int P4>
-__device__ __forceinline__ SetRows<P4> set_rows(const WorkDev& w, uint32_t s, uint32_t lo) {
-  constexpr size_t Q = 2 + P4;
-  SetRows<P4> r;
+template <int Q>
+__device__ __forceinline__ SetRows<Q> set_rows(const WorkDev& w, uint32_t s, uint32_t lo) {
+  SetRows<Q> r;
   uint4* base = reinterpret_cast<uint4*>(w.hits);
   if (w.tile_base) {
     const size_t t0 = w.tile_base[s >> 6], l = s & 63u;
@@ -110,18 +120,19 @@ __device__ __forceinline__ SetRows<P4> set_rows(const WorkDev& w, uint32_t s, ui
   }
   return r;
 }
-template <int P4>
-__device__ __forceinline__ HitCore row_core(const Row<P4>& r) {
+template <int Q>
+__device__ __forceinline__ HitCore row_core(const Row<Q>& r) {
   HitCore c;
-  c.score = __uint_as_float(r.q[0].x); c.ident = r.q[0].y; c.node = r.q[0].z; c.rec = r.q[0].w;
-  c.qd = __uint_as_float(r.q[1].x); c.qs = __uint_as_float(r.q[1].y); c.seglen = r.q[1].z; c.meta = r.q[1].w;
+  c.score = __uint_as_float(r.q[0].x); c.ident = r.q[0].y; c.node = r.q[0].z; c.meta = r.q[0].w;
+  c.qd = __uint_as_float(r.q[1].x); c.qs = __uint_as_float(r.q[1].y);
   return c;
 }
-template <int P4>
-__device__ __forceinline__ void row_path(const Row<P4>& r, uint32_t (&path)[4 * P4]) {
+template <int Q>
+__device__ __forceinline__ void row_path(const Row<Q>& r, uint32_t (&path)[4 * Q - 6]) {
+  path[0] = r.q[1].z; path[1] = r.q[1].w;
 #pragma unroll
-  for (int k = 0; k < P4; ++k) {
-    path[4 * k] = r.q[2 + k].x; path[4 * k + 1] = r.q[2 + k].y; path[4 * k + 2] = r.q[2 + k].z; path[4 * k + 3] = r.q[2 + k].w;
+  for (int k = 2; k < Q; ++k) {
+    path[4 * k - 6] = r.q[k].x; path[4 * k - 5] = r.q[k].y; path[4 * k - 4] = r.q[k].z; path[4 * k - 3] = r.q[k].w;
   }
 }
 __device__ __forceinline__ uint32_t meta_depth(uint32_t meta) { return (meta >> kMetaDepthShift) & 0xFFu; }
@@ -130,25 +141,21 @@ __device__ __forceinline__ uint32_t meta_err(uint32_t meta) { return (meta >> kM
 __device__ __forceinline__ void bit_clear(uint32_t* words, uint32_t i) { words[i >> 5] &= ~(1u << (i & 31u)); }
 __device__ __forceinline__ void bit_set(uint32_t* words, uint32_t i) { words[i >> 5] |= 1u << (i & 31u); }
 
-// length of the common prefix of two root paths = depth of the LCA of the two nodes
-template <int P4>
-__device__ __forceinline__ uint32_t common(const uint32_t (&a)[4 * P4], uint32_t da, const uint32_t (&b)[4 * P4], uint32_t db) {
-  uint32_t c = 0;
-  bool run = true;
+// length of the common prefix of two label paths = depth of the LCA of the two nodes: the first bit in which the strings
+// differ, in labels (lb_shift = log2 of the label width), never more than either node's own depth
+template <int PW>
+__device__ __forceinline__ uint32_t common(const uint32_t (&a)[PW], uint32_t da, const uint32_t (&b)[PW], uint32_t db, uint32_t lb_shift) {
+  uint32_t bit = 32u * PW;
 #pragma unroll
-  for (int d = 0; d < 4 * P4; ++d) {
-    run = run && (a[d] == b[d]);
-    c += run ? 1u : 0u;
+  for (int k = PW - 1; k >= 0; --k) {
+    const uint32_t x = a[k] ^ b[k];
+    if (x) bit = 32u * (uint32_t)k + (uint32_t)__builtin_ctz(x);
   }
-  return min(c, min(da, db));
+  return min(bit >> lb_shift, min(da, db));
 }
-template <int P4>
-__device__ __forceinline__ uint32_t node_at(const uint32_t (&path)[4 * P4], uint32_t depth) {  // point `depth` on a path
-  uint32_t v = kRoot;
-#pragma unroll
-  for (int d = 0; d < 4 * P4; ++d)
-    if ((uint32_t)d + 1 == depth) v = path[d];
-  return v;
+// point `depth` on the root path of `node` (depth <= depth of node; 0 = the root)
+__device__ __forceinline__ uint32_t anc_node(const TaxDev& tax, uint32_t node, uint32_t depth) {
+  return depth == 0u ? kRoot : tax.anc[(size_t)node * tax.max_depth + (depth - 1u)];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -186,11 +193,11 @@ __device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, co
 // Rank + gather: one thread per record.  It scans the records of its own set once (neighbouring lanes read the same
 // few cache lines) to get (a) its position in SortFilter order (score desc, identities desc, input order on full ties
 // = what a stable list::sort gives) among the unmasked records, and (b) the set's n / query range (:391-404).  It
-// plans its own reference segment, then writes its row -- core fields plus the taxon path copied from the per-node
-// ancestor table -- at the sorted position.  The thread of a set's first record also plans the query-range segment
-// and writes the set header.
+// plans its own reference segment, makes its taxon path labels (file header) from its node's ancestor intervals and the
+// preorder numbers of the records in front of it in its set, then writes its row at the sorted position.  The thread of a
+// set's first record also plans the query-range segment and writes the set header.
 // ------------------------------------------------------------------------------------------------------------
-template <int P4>
+template <int Q>
 __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, TaxDev tax, StoreDev qstore, StoreDev dbstore, Params p) {
   // Record -> record set.  The records of a workgroup are consecutive, so their sets are consecutive too: the set of
   // the block's first record comes from k_block_first (one binary search per workgroup, all of them in one small launch
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   // up to a whole set's worth of iterations -- 45 vector loads per wave on config 2 instead of 15)
   constexpr uint32_t kHalo = 64, kWin = kBlock + 2 * kHalo;
   __shared__ uint4 s_rec[kWin];      // score bits, identities, qstart, qstop
+  __shared__ uint32_t s_pre[kWin];   // preorder number of the record's taxon
   __shared__ uint8_t s_filt[kWin];
   // Rows are written in the tiled layout: the 64-byte row of a record lands 16 bytes at a time in lines it shares with
   // the same row of the 63 neighbouring record sets, i.e. with records handled by this and the next few workgroups.
@@ -219,6 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     const uint32_t rr = w0 + k;
     if (rr < b.n_records) {
       s_rec[k] = make_uint4(__float_as_uint(b.score[rr]), b.identities[rr], b.qstart[rr], b.qstop[rr]);
+      s_pre[k] = tax.pre[b.node[rr]];  // (node indices were checked by k_validate_batch)
       s_filt[k] = rec_filtered(b, rr) ? 1 : 0;
     }
   }
@@ -229,10 +238,11 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   }
   __syncthreads();
   const uint32_t r = r0 + threadIdx.x;
-  // what this thread's record turns into: its row (2 + P4 quads) at row slot `slot` (0xFFFFFFFF: none -- past the end of
-  // the batch, or a masked record); written out by the whole workgroup below
-  constexpr int Q = 2 + P4;
-  uint4 rowq[Q];
+  // what this thread's record turns into: its row (Q quads, staged in LDS) at row slot `slot` (0xFFFFFFFF: none -- past
+  // the end of the batch, or a masked record); written out by the whole workgroup below
+  constexpr int PW = 4 * Q - 6;
+  __shared__ uint4 s_rows[kBlock * Q];
+  uint32_t* const my_row = reinterpret_cast<uint32_t*>(&s_rows[threadIdx.x * Q]);
   uint32_t slot = 0xFFFFFFFFu, my_set = 0, my_rank = 0;
   bool staged_set = false;  // my set's offsets are in the LDS window
   if (r < b.n_records) {
@@ -320,19 +330,49 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   // reads the pair (:535-537) -- written here so that k_decide only stores the pairs of the hits pass 0 does align
   float qd = FLT_MAX, qs = (float)id;
   if (n == 1) { qd = __uint_as_float(b.qstart[r]); qs = __uint_as_float(b.qstop[r]); }  // n==1 needs them (:373-374)
-  const SetRows<P4> R = set_rows<P4>(w, s, beg);
-  const uint4* anc = reinterpret_cast<const uint4*>(tax.anc) + (size_t)node * P4;
-#pragma unroll
-  for (int k = 0; k < P4; ++k) rowq[2 + k] = anc[k];
+  const SetRows<Q> R = set_rows<Q>(w, s, beg);
   slot = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);  // row slot = result slot (tiled: tile_base + 64 rank + l; linear: beg + rank)
+  // ---- taxon path labels: label_d = index (input order in the set) of the first record under my ancestor at depth d.
+  // Eight levels at a time: my node's eight ancestor intervals in registers, one pass over the records in front of me.
+  // Levels below my own depth keep my own index (nobody shares them; common() never looks past a node's depth).
+#pragma unroll
+  for (int k = 0; k < PW; ++k) my_row[6 + k] = 0xFFFFFFFFu;
+  if (n >= 2) {
+    const uint32_t D = tax.max_depth, my = r - beg;
+    const uint2* __restrict__ iv = tax.anc_iv + (size_t)node * D;
+    const bool staged = beg >= w0;  // the records in front of me are all in the LDS window (r itself always is)
+    for (uint32_t c = 0; c < D; c += 8u) {
+      uint2 v[8];
+      uint32_t lab[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) { v[d] = c + d < D ? iv[c + d] : make_uint2(1u, 0u); lab[d] = my; }
+      for (uint32_t j = beg; j < r; ++j) {
+        const uint32_t pj = staged ? s_pre[j - w0] : tax.pre[b.node[j]];
+        const uint32_t idx = j - beg;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) lab[d] = (pj >= v[d].x && pj <= v[d].y && idx < lab[d]) ? idx : lab[d];
+      }
+      // pack the chunk's eight labels behind the chunks before it (levels past D are never compared: left as they are)
+      if (w.lb_shift == 3u) {
+        my_row[6 + c / 4u] = (lab[0] & 255u) | ((lab[1] & 255u) << 8) | ((lab[2] & 255u) << 16) | (lab[3] << 24);
+        my_row[6 + c / 4u + 1u] = (lab[4] & 255u) | ((lab[5] & 255u) << 8) | ((lab[6] & 255u) << 16) | (lab[7] << 24);
+      } else if (w.lb_shift == 4u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) my_row[6 + c / 2u + k] = (lab[2 * k] & 0xFFFFu) | (lab[2 * k + 1] << 16);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) my_row[6 + c + k] = lab[k];
+      }
+    }
+  }
   // ---- stores ----
   w.seg[pos] = sdesc;  // (all zero for a set of one record: never aligned)
   w.res_slot[pos] = slot;  // where the alignment kernels put this hit's result
   if (sp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); sp.x = 0; }
   // compact per-row word for k_emit: segment length + "pass 0 re-aligns this hit" (:511-518, threshold :499)
   w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u) | (perfect ? kLitePerfect : 0u);
-  rowq[0] = make_uint4(__float_as_uint(sc), id, node, r);
-  rowq[1] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), sp.x, meta);
+  my_row[0] = __float_as_uint(sc); my_row[1] = id; my_row[2] = node; my_row[3] = meta;
+  my_row[4] = __float_as_uint(qd); my_row[5] = __float_as_uint(qs);
   my_set = s; my_rank = rank; staged_set = in_window;
   }  // !me_filtered
   if (set_head) {
@@ -345,11 +385,10 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
 
   // ---- write the rows out.  Tiled layout: quad q of the row at slot x lives at quad index (x & ~63) Q + 64 q + (x & 63), i.e.
   // the same quad of the same rank of CONSECUTIVE record sets is contiguous.  A thread storing its own row's quads hits
-  // 64 different lines per wave-level store (and there are 2 + P4 of them per record: the kernel spent 0.5 of its 1.2 ms
+  // 64 different lines per wave-level store (and there are Q of them per record: the kernel spent 0.5 of its 1.2 ms
   // there on config 2); instead the workgroup stages its rows in LDS and walks (rank, quad, set) so that consecutive lanes
   // write consecutive sets: runs of ~13 adjacent quads.  Batches whose workgroup windows do not fit (runs of empty sets,
   // sets far longer than a workgroup) and the linear layout keep the direct stores.
-  __shared__ uint4 s_rows[kBlock * Q];
   __shared__ uint32_t s_slot[kBlock];
   __shared__ uint16_t s_who[kWin];      // (row position of the block's sets) - s_off[0]  ->  thread that holds the row
   __shared__ uint32_t s_lim[3];         // highest set, highest rank + 1, "some row cannot be staged"
@@ -359,8 +398,6 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   __syncthreads();
   const bool tiled = w.tile_base != nullptr;
   if (slot != 0xFFFFFFFFu) {
-#pragma unroll
-    for (int k = 0; k < Q; ++k) s_rows[tid * Q + k] = rowq[k];
     s_slot[tid] = slot;
     atomicMax(&s_lim[0], my_set);
     atomicMax(&s_lim[1], my_rank + 1u);
@@ -393,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     const size_t base = tiled ? (size_t)(slot & ~63u) * Q + (slot & 63u) : (size_t)slot * Q;
     const size_t sq = tiled ? 64 : 1;
 #pragma unroll
-    for (int k = 0; k < Q; ++k) hits4[base + (size_t)k * sq] = rowq[k];
+    for (int k = 0; k < Q; ++k) hits4[base + (size_t)k * sq] = s_rows[tid * Q + k];
   }
 }
 
@@ -449,7 +486,7 @@ constexpr int kEmitSpan = kEmitBlock * kEmitRows;
 
 // "can the loop the set is about to run reach the alignment of the hit at row `pos`?"  Passes 0 and 1 decide from the
 // row's 4-byte lite word alone; pass 2 (few sets, late rounds) reads the row.  Returns the bin (or -1), fills entry / maxlen.
-template <int P4>
+template <int Q>
 __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& w, const Params& p, const EmitInfo& info, uint32_t s,
                                               uint32_t lo, uint32_t pos, const uint32_t lite, uint2& entry, uint32_t& maxlen) {
   const uint32_t H = b.n_records;
@@ -460,14 +497,14 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
   else if (info.mode == 4) want = vs_query ? (lite & kLiteWant0) != 0u : !(lite & kLiteZeroQd);
   else if (info.mode == 2) want = !(lite & kLiteZeroQd);
   else {
-    const SetRows<P4> R = set_rows<P4>(w, s, lo);
+    const SetRows<Q> R = set_rows<Q>(w, s, lo);
     const uint32_t i = pos - lo;
     const HitCore h = R.core(i);
     if (h.score >= info.fcut && (double)h.qs / info.L >= info.qpid_thresh) {
-      uint32_t pb[4 * P4], pth[4 * P4];
+      uint32_t pb[4 * Q - 6], pth[4 * Q - 6];
       R.path(info.best, pb);
       R.path(i, pth);
-      want = !(common<P4>(pb, meta_depth(R.core(info.best).meta), pth, meta_depth(h.meta)) >= info.d_unode_g);
+      want = !(common<4 * Q - 6>(pb, meta_depth(R.core(info.best).meta), pth, meta_depth(h.meta), w.lb_shift) >= info.d_unode_g);
     }
   }
   if (!want) return -1;
@@ -480,7 +517,7 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
   return bin;
 }
 
-template <int P4>
+template <int Q>
 __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(BatchDev b, WorkDev w, Params p) {  // two resident blocks per CU: one computes while the other waits on its loads
   constexpr int kVW = kEmitSpan / 64;  // "virtual waves": runs of 64 consecutive row positions
   static_assert(kVW == 64, "the prefix over virtual waves is done by one wavefront");
@@ -528,7 +565,7 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_emit(BatchDev b, WorkDev w, P
           }
         } else {
           const EmitInfo info = w.emit[set_of[k]];
-          bin[k] = emit_predicate<P4>(b, w, p, info, set_of[k], lo[k], pos, lite[k], entry[k], ml);
+          bin[k] = emit_predicate<Q>(b, w, p, info, set_of[k], lo[k], pos, lite[k], entry[k], ml);
         }
       }
     } else if (pos < total && mode == 3u) {  // anchor <-> query range (:792-797)
@@ -605,7 +642,7 @@ __device__ __forceinline__ int sparse_bin(const Params& p, int bin) {
 // would cost more than the work left.  One wavefront per live set; lane j looks at hits j, j+64, ...; lane 0 also
 // emits the anchor <-> query alignment.  Same predicate and same list format as k_emit.
 constexpr int kSparseBlock = 1024;  // 16 live sets per workgroup: one list reservation per bin per workgroup
-template <int P4>
+template <int Q>
 __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDev w, Params p) {
   // The sparse rounds put nearly everything into ONE list (sparse_bin), and a reservation per wavefront means thousands of
   // atomics on one counter at ~11 ns each (6 k live sets: 92 of the kernel's 140 us).  The first 64 hits of every set
@@ -636,7 +673,7 @@ __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDe
     const uint32_t i = i_lo + (uint32_t)lane;
     if (i < i_hi && (info.mode == 1 || info.mode == 4 || i != info.anchor)) {
       uint32_t ml = 0;
-      bin = sparse_bin(p, emit_predicate<P4>(b, w, p, info, s, lo, lo + i, w.lite[lo + i], entry, ml));
+      bin = sparse_bin(p, emit_predicate<Q>(b, w, p, info, s, lo, lo + i, w.lite[lo + i], entry, ml));
       maxlen = max(maxlen, ml);
     }
     const uint32_t span = i_hi > i_lo ? i_hi - i_lo : 0u;
@@ -688,7 +725,7 @@ __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDe
       uint2 en = make_uint2(0u, 0u);
       if (i < i_hi && (info.mode == 1 || info.mode == 4 || i != info.anchor)) {
         uint32_t ml = 0;
-        bn = sparse_bin(p, emit_predicate<P4>(b, w, p, info, s, lo, lo + i, w.lite[lo + i], en, ml));
+        bn = sparse_bin(p, emit_predicate<Q>(b, w, p, info, s, lo, lo + i, w.lite[lo + i], en, ml));
         maxlen = max(maxlen, ml);
       }
 #pragma unroll
@@ -739,9 +776,10 @@ __device__ __forceinline__ void append_live(const WorkDev& w, bool running, uint
 // n == 1, perfect-best-hit shortcut; otherwise emits pass 0.  (Masking, query range, sorting and segment plans were
 // done per record by k_rank_records.)
 // ------------------------------------------------------------------------------------------------------------
-template <int P4>
-__global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Params p, OutRow* __restrict__ rows,
+template <int Q>
+__global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
                                                        OutStats* __restrict__ stats) {
+  constexpr int PW = 4 * Q - 6;
   const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
   const bool live = s < b.n_sets;
   SetState st;
@@ -766,18 +804,18 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
     if (n == 0) {  // :359-368
       row.flags = kFlagIvalUntouched;
     } else if (n == 1) {  // :371-388
-      const HitCore h = set_rows<P4>(w, s, lo).core(0u);
+      const HitCore h = set_rows<Q>(w, s, lo).core(0u);
       row.begin = __float_as_uint(h.qd); row.end = __float_as_uint(h.qs); row.ival = 1.f;
       row.lower = h.node; row.upper = kRoot; row.support = h.ident; row.rtax = h.node;
       row.flags = kFlagSingle;
     } else {
-      const SetRows<P4> R = set_rows<P4>(w, s, lo);
+      const SetRows<Q> R = set_rows<Q>(w, s, lo);
       const HitCore h0 = R.core(0u);
       // the reference fetches the query range (:415) BEFORE it looks at the best hit: an unreadable range aborts the run
       // even where the shortcut below would not have needed the sequence
       if (st.qsegerr) raise_error(w, st.qsegerr, s);
       if (h0.meta & kMetaPerfect) {  // :431-472: lnode / unode are points on hit 0's path
-        uint32_t path0[4 * P4];
+        uint32_t path0[PW];
         R.path(0u, path0);
         const uint32_t d0 = meta_depth(h0.meta);
         const float best = h0.score;
@@ -786,14 +824,14 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
         for (;;) {
           if (i == n) { d_u = 0; break; }  // unode = root
           HitCore hi2 = R.core(i);
-          uint32_t pth[4 * P4];
+          uint32_t pth[PW];
           R.path(i, pth);
-          if (hi2.score == best) d_l = min(d_l, common<P4>(path0, d0, pth, meta_depth(hi2.meta)));
+          if (hi2.score == best) d_l = min(d_l, common<PW>(path0, d0, pth, meta_depth(hi2.meta), w.lb_shift));
           else {
             const float sc = hi2.score;
             d_u = d_l;
             for (;;) {
-              d_u = min(d_u, common<P4>(path0, d0, pth, meta_depth(hi2.meta)));
+              d_u = min(d_u, common<PW>(path0, d0, pth, meta_depth(hi2.meta), w.lb_shift));
               if (++i >= n) break;
               hi2 = R.core(i);
               if (!(hi2.score == sc)) break;
@@ -804,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
           ++i;
         }
         row.begin = qrstart; row.end = qrstop; row.ival = 0.f;
-        row.lower = node_at<P4>(path0, d_l); row.upper = node_at<P4>(path0, d_u); row.support = st.L; row.rtax = row.lower;
+        row.lower = anc_node(tax, h0.node, d_l); row.upper = anc_node(tax, h0.node, d_u); row.support = st.L; row.rtax = row.lower;
         row.flags = kFlagShortcut;
       } else {
         done = false;
@@ -821,7 +859,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Par
         uint32_t members = 0;
         for (uint32_t i = 0; i < n; ++i) members += (w.lite[lo + i] & (kLiteWant0 | kLitePerfect)) ? 1u : 0u;
         if (members == 1 && (w.lite[lo] & kLiteWant0) && !p.no_combined) {
-          em.mode = 4; em.anchor = 0; em.anchor_len = h0.seglen;
+          em.mode = 4; em.anchor = 0; em.anchor_len = w.lite[lo] & kLiteLenMask;
           em.i_hi = p.spec1 ? min(n, p.spec1) : n;  // the first speculation chunk of the pass-1 loop (hit 0 is part of it)
           st.chunk_hi = em.i_hi;                    // remembered: k_decide may run with another chunk size by then
           st.combined = 1;
@@ -873,16 +911,16 @@ struct BandAcc {
   }
   __device__ float factor() const {  // getFactor (:271-277)
     float bandfactor = 1.f;
-    uint32_t remembered = 0;
+    unsigned long long remembered = 0ull;  // (ranks 0 .. kMaxDepth = 63)
     float lowmin = FLT_MAX;
     for (uint32_t r = 0; r < anchor_rank; ++r) {
       const float f = fmin[r * kBlock];
-      if (f < lowmin) { remembered |= 1u << r; lowmin = f; }
+      if (f < lowmin) { remembered |= 1ull << r; lowmin = f; }
     }
     float dsuf = dmax[anchor_rank * kBlock];
     for (int r = (int)anchor_rank - 1; r >= 0; --r) {
       const float f = fmin[r * kBlock];
-      if ((remembered >> r) & 1u) {
+      if ((remembered >> r) & 1ull) {
         if (f != 0.f && dsuf >= 0.f) { const float q = dsuf / f; bandfactor = bandfactor < q ? q : bandfactor; }
       }
       const float d = dmax[r * kBlock];
@@ -905,9 +943,11 @@ __device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t
 // its alignment result in flight while it works on the current one; qgroup / outgroup are bit sets in WorkDev::flags,
 // so "first member", "any member left" and "clear" never touch the rows.
 // ------------------------------------------------------------------------------------------------------------
-template <int P4>
-__global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params p, OutRow* __restrict__ rows,
+template <int Q>
+__global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
                                                     OutStats* __restrict__ stats, unsigned long long* prof_acc) {
+  constexpr int PW = 4 * Q - 6;
+  const uint32_t lbs = w.lb_shift;
   // BandFactor accumulators: (deepest taxonomy level + 1) ranks x 256 threads x {fmin, dmax}; sized at launch so that a
   // pruned NCBI tree (8 levels) needs 18 KB and the kernel can share a CU with the alignment kernel of another stream
   extern __shared__ float s_band[];
@@ -927,7 +967,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     const uint32_t lo = b.set_offsets[s];
     const uint32_t n = st.n, L = st.L;
     const float X = p.exclude_factor;
-    const SetRows<P4> R = set_rows<P4>(w, s, lo);              // rows and alignment results of this set
+    const SetRows<Q> R = set_rows<Q>(w, s, lo);              // rows and alignment results of this set
     const float2* __restrict__ qres_p = w.pair_res + w.P + s;  // result of the anchor <-> query alignment
     const uint32_t nw = (n + 31u) >> 5;
     uint32_t* fq = w.flags + lo;   // qgroup bits
@@ -957,7 +997,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         const float idf = (float)h0.ident;
         const float sim0 = r2.y < idf ? idf : r2.y;  // std::max(similarity, identities), :531
         R.store_qdqs(0u, r2.x, sim0);
-        if (r2.x == 0.f) w.lite[lo] = h0.seglen | kLiteZeroQd;  // (:620-621)
+        if (r2.x == 0.f) w.lite[lo] = (w.lite[lo] & kLiteLenMask) | kLiteZeroQd;  // (:620-621)
         for (uint32_t k = 0; k < nw; ++k) { fq[k] = 0u; fo[k] = 0u; }  // qgroup = {0}, taken by the anchor selection; outgroup empty
         const uint32_t d0 = meta_depth(h0.meta);
         st.best = 0; st.d_rtax = d0; st.ival_g = 0.f; st.d_lnode_g = st.d_unode_g = d0; st.bf_max = 1.f; st.lrd_min = 255;  // :553,569-579
@@ -968,7 +1008,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
     if (!failed)
     for (int trip = 0; trip < 2; ++trip) {
     if (st.phase == kPass0Wait) {  // ---- pass 0, :497-566 ----
-      uint32_t path0[4 * P4];
+      uint32_t path0[PW];
       uint32_t d0 = 0;
       float thr = 0.f;
       uint32_t index_best = 0;
@@ -976,7 +1016,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       uint32_t support = 0;
       uint32_t d_all = 0;  // lca_allnodes as a point on hit 0's path (:495)
       uint32_t qword = 0;
-      Row<P4> nxt = R.load(0u), nx2 = nxt;  // rows i+1 and i+2 are in flight while row i is worked on
+      Row<Q> nxt = R.load(0u), nx2 = nxt;  // rows i+1 and i+2 are in flight while row i is worked on
       float2 rn = R.result(0), rn2 = rn;
       if (n > 1) { nx2 = R.load(1); rn2 = R.result(1); }
       // (sets of up to 64 hits: members and zero-distance hits are noted as register bit sets and their stores -- the
@@ -986,16 +1026,16 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       auto walk0 = [&](auto small_tag) {
       constexpr bool kSmall = decltype(small_tag)::value;
       for (uint32_t i = 0; i < n; ++i) {
-        const Row<P4> cur = nxt;
+        const Row<Q> cur = nxt;
         const float2 r2 = rn;
         nxt = nx2; rn = rn2;
         if (i + 2 < n) { nx2 = R.load(i + 2); rn2 = R.result(i + 2); }
-        const HitCore h = row_core<P4>(cur);
-        uint32_t pth[4 * P4];
-        row_path<P4>(cur, pth);
+        const HitCore h = row_core<Q>(cur);
+        uint32_t pth[PW];
+        row_path<Q>(cur, pth);
         if (i == 0) {
 #pragma unroll
-          for (int d = 0; d < 4 * P4; ++d) path0[d] = pth[d];
+          for (int d = 0; d < PW; ++d) path0[d] = pth[d];
           d0 = meta_depth(h.meta); d_all = d0;
           thr = p.reeval_factor * h.score;  // :499
         }
@@ -1018,7 +1058,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           if (dist == 0.f) zero0 |= 1ull << i;
         } else {
           if (member) R.store_qdqs(i, dist, sim);  // the others keep what k_rank_records wrote: (FLT_MAX, identities)
-          if (dist == 0.f) w.lite[lo + i] = h.seglen | kLiteZeroQd;  // pass 1 will not align this hit (:620-621)
+          if (dist == 0.f) w.lite[lo + i] = (w.lite[lo + i] & kLiteLenMask) | kLiteZeroQd;  // pass 1 will not align this hit (:620-621)
           if (member) qword |= 1u << (i & 31u);
           if ((i & 31u) == 31u || i + 1 == n) { fq[i >> 5] = qword; qword = 0; }
         }
@@ -1029,7 +1069,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           else if (sim == best_s && h.score > best_sc) { index_best = i; best_sc = h.score; }
         }
         support = max(support, (uint32_t)sim);  // :547
-        d_all = min(d_all, common<P4>(path0, d0, pth, meta_depth(h.meta)));  // :548
+        d_all = min(d_all, common<PW>(path0, d0, pth, meta_depth(h.meta), lbs));  // :548
       }
       };
       if (small0) walk0(std::true_type{}); else walk0(std::false_type{});
@@ -1040,16 +1080,16 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           const float idf = (float)h.ident;
           if (h.meta & kMetaPerfect) R.store_qdqs(k, 0.f, idf);
           else { const float2 r2 = R.result(k); R.store_qdqs(k, r2.x, r2.y < idf ? idf : r2.y); }
-          if ((zero0 >> k) & 1ull) w.lite[lo + k] = h.seglen | kLiteZeroQd;
+          if ((zero0 >> k) & 1ull) w.lite[lo + k] = (w.lite[lo + k] & kLiteLenMask) | kLiteZeroQd;
         }
         for (uint32_t k = 0; k < nw; ++k) fq[k] = (uint32_t)(members0 >> (32u * k));
       }
       if (!failed) {
         for (uint32_t k = 0; k < nw; ++k) fo[k] = 0u;  // outgroup starts empty (:578)
-        const Row<P4> rb = R.load(index_best);
-        uint32_t pb[4 * P4];
-        row_path<P4>(rb, pb);
-        const uint32_t db = meta_depth(row_core<P4>(rb).meta);
+        const Row<Q> rb = R.load(index_best);
+        uint32_t pb[PW];
+        row_path<Q>(rb, pb);
+        const uint32_t db = meta_depth(row_core<Q>(rb).meta);
         uint32_t d_rtax = db;  // rtax = node[index_best] (:553), then LCA with every member that stays in qgroup
         bool any = false;
         for (uint32_t k = 0; k < nw; ++k) {  // :554-562, members only
@@ -1057,13 +1097,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           while (word) {
             const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
             word &= word - 1u;
-            const Row<P4> ri = R.load(k * 32u + bit);
-            const HitCore h = row_core<P4>(ri);
+            const Row<Q> ri = R.load(k * 32u + bit);
+            const HitCore h = row_core<Q>(ri);
             if (h.qd != best_d || h.qs != best_s || h.score != best_sc) keep &= ~(1u << bit);
             else {
-              uint32_t pth[4 * P4];
-              row_path<P4>(ri, pth);
-              d_rtax = min(d_rtax, common<P4>(pb, db, pth, meta_depth(h.meta)));
+              uint32_t pth[PW];
+              row_path<Q>(ri, pth);
+              d_rtax = min(d_rtax, common<PW>(pb, db, pth, meta_depth(h.meta), lbs));
               any = true;
             }
           }
@@ -1076,14 +1116,14 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       }
     } else if (st.phase == kPass1Wait) {  // ---- pass 1 for one anchor, :580-728 ----
       const uint32_t a = st.anchor;
-      uint32_t pa[4 * P4], pb[4 * P4];
-      const Row<P4> ra = R.load(a);
-      const Row<P4> rb = R.load(st.best);
-      const HitCore ha = row_core<P4>(ra);
-      row_path<P4>(ra, pa);
+      uint32_t pa[PW], pb[PW];
+      const Row<Q> ra = R.load(a);
+      const Row<Q> rb = R.load(st.best);
+      const HitCore ha = row_core<Q>(ra);
+      row_path<Q>(ra, pa);
       const uint32_t da = meta_depth(ha.meta);
-      row_path<P4>(rb, pb);
-      const uint32_t db = meta_depth(row_core<P4>(rb).meta);
+      row_path<Q>(rb, pb);
+      const uint32_t db = meta_depth(row_core<Q>(rb).meta);
       const float qdist = ha.qd;
       uint32_t* __restrict__ ogi = w.og_idx + lo;
       int32_t* __restrict__ ogd = w.og_dist + lo;
@@ -1098,7 +1138,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         nog = 0; d_lnode = st.d_rtax /* lnode = rtax, :587 */; ldist = 0.f; udist = FLT_MAX;
         qpid_upper = cut_g = cut_h = 0.; scut = 0; i = 0;
       } else {
-        band.restore(da, w.band_save + (size_t)s * 2 * (kMaxDepth + 1));
+        band.restore(da, w.band_save + (size_t)s * 2 * w.band_ranks);
         nog = st.nog; d_lnode = st.d_lnode; ldist = st.ldist; udist = st.udist;
         qpid_upper = st.qpid_upper; cut_g = st.cut_g; cut_h = st.cut_h; scut = st.scut; i = st.i_next;
       }
@@ -1111,25 +1151,25 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       unsigned long long ogmask = (small && st.loop_live) ? ((unsigned long long)st.pad_ << 32) | st.nog : 0ull;
       unsigned long long fqclr = 0ull;
       bool paused = false;
-      Row<P4> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
+      Row<Q> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
       float2 rn = make_float2(0.f, 0.f), rn2 = rn;
       if (i < n) { nxt = R.load(i); rn = R.result(i); }
       if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
       auto walk = [&](auto small_tag) {
       constexpr bool kSmall = decltype(small_tag)::value;
       for (; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
-        const Row<P4> cur = nxt;
+        const Row<Q> cur = nxt;
         const float2 r2 = rn;
         nxt = nx2; rn = rn2;
         if (i + 2 < n) { nx2 = R.load(i + 2); rn2 = R.result(i + 2); }
-        const HitCore h = row_core<P4>(cur);
+        const HitCore h = row_core<Q>(cur);
         if (!(h.score >= (float)scut)) break;
-        uint32_t pth[4 * P4];
-        row_path<P4>(cur, pth);
+        uint32_t pth[PW];
+        row_path<Q>(cur, pth);
         const uint32_t dh = meta_depth(h.meta);
         if (acc_pending && i >= acc_next) {  // pass 0's aggregates for this hit (it is not hit 0: similarity = identities)
           acc_support = max(acc_support, h.ident);
-          acc_d_all = min(acc_d_all, common<P4>(pb, db, pth, dh));  // best = hit 0: pb is its path
+          acc_d_all = min(acc_d_all, common<PW>(pb, db, pth, dh, lbs));  // best = hit 0: pb is its path
           acc_next = i + 1;
         }
         const double qsearchpid = (double)h.ident / L;
@@ -1145,11 +1185,11 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           dist = r2.x;
           ++st.cnt1;
         }
-        band.add(dist, common<P4>(pa, da, pth, dh));  // :641
+        band.add(dist, common<PW>(pa, da, pth, dh, lbs));  // :641
         if (dist == 0.f) {  // :644
           if constexpr (kSmall) fqclr |= 1ull << i; else bit_clear(fq, i);
         } else if (dist <= qdist) {  // :646-650
-          d_lnode = min(d_lnode, common<P4>(pb, db, pth, dh));
+          d_lnode = min(d_lnode, common<PW>(pb, db, pth, dh, lbs));
           if (dist > ldist) ldist = dist;
         } else {  // :651-662
           if (dist < udist) {
@@ -1174,16 +1214,16 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         }
       }
       if (acc_pending && !failed) {  // the hits the loop above did not reach (early exit, pause): identities and path only
-        Row<P4> nx = ra;
+        Row<Q> nx = ra;
         if (acc_next < n) nx = R.load(acc_next);
         for (uint32_t k = acc_next; k < n; ++k) {
-          const Row<P4> cur = nx;
+          const Row<Q> cur = nx;
           if (k + 1 < n) nx = R.load(k + 1);
-          const HitCore h = row_core<P4>(cur);
-          uint32_t pth[4 * P4];
-          row_path<P4>(cur, pth);
+          const HitCore h = row_core<Q>(cur);
+          uint32_t pth[PW];
+          row_path<Q>(cur, pth);
           acc_support = max(acc_support, h.ident);
-          acc_d_all = min(acc_d_all, common<P4>(pb, db, pth, meta_depth(h.meta)));
+          acc_d_all = min(acc_d_all, common<PW>(pb, db, pth, meta_depth(h.meta), lbs));
         }
         st.support = acc_support; st.d_lca_all = acc_d_all;
         acc_pending = false;
@@ -1192,9 +1232,9 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         st.loop_live = 1; st.i_next = i; st.d_lnode = d_lnode; st.ldist = ldist; st.udist = udist;
         if (small) { st.nog = (uint32_t)ogmask; st.pad_ = (uint32_t)(ogmask >> 32); } else st.nog = nog;
         st.qpid_upper = qpid_upper; st.cut_g = cut_g; st.cut_h = cut_h; st.scut = scut;
-        band.save(w.band_save + (size_t)s * 2 * (kMaxDepth + 1));
+        band.save(w.band_save + (size_t)s * 2 * w.band_ranks);
         st.chunk_hi = p.spec1 ? min(n, i + (p.grow ? max(p.spec1, i) : p.spec1)) : n;
-        em.mode = 2; em.anchor = a; em.anchor_len = ha.seglen; em.i_lo = i; em.i_hi = st.chunk_hi;
+        em.mode = 2; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.i_lo = i; em.i_hi = st.chunk_hi;
       } else
       if (!failed) {
         const float bandfactor = band.factor();  // :667
@@ -1240,10 +1280,10 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           if (small) { io = (uint32_t)__ffsll((long long)mleft) - 1u; mleft &= mleft - 1ull; dist = (float)(int)R.result(io).x; }
           else { io = ogi[k]; dist = (float)ogd[k]; }
           if (dist > min_upper_dist) continue;
-          const Row<P4> ri = R.load(io);
-          uint32_t pth[4 * P4];
-          row_path<P4>(ri, pth);
-          const uint32_t cb = common<P4>(pb, db, pth, meta_depth(row_core<P4>(ri).meta));
+          const Row<Q> ri = R.load(io);
+          uint32_t pth[PW];
+          row_path<Q>(ri, pth);
+          const uint32_t cb = common<PW>(pb, db, pth, meta_depth(row_core<Q>(ri).meta), lbs);
           d_unode = min(d_unode, cb);                          // unode = LCA(cnode, unode)
           const uint32_t lca_root_dist = min(st.d_rtax, cb);   // depth(LCA(cnode, rtax))
           if (lca_root_dist > st.lrd_min) continue;
@@ -1265,19 +1305,19 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       }
     } else if (st.phase == kPass2Wait) {  // ---- pass 2 for one anchor, :750-820 ----
       const uint32_t a = st.anchor;
-      const Row<P4> ra = R.load(a);
-      const Row<P4> rb = R.load(st.best);
-      const HitCore ha = row_core<P4>(ra);
-      uint32_t pb[4 * P4];
-      row_path<P4>(rb, pb);
-      const uint32_t db = meta_depth(row_core<P4>(rb).meta);
+      const Row<Q> ra = R.load(a);
+      const Row<Q> rb = R.load(st.best);
+      const HitCore ha = row_core<Q>(ra);
+      uint32_t pb[PW];
+      row_path<Q>(rb, pb);
+      const uint32_t db = meta_depth(row_core<Q>(rb).meta);
       float qd_a = ha.qd, qs_a = ha.qs;
       const EmitInfo sel = w.emit[s];            // thresholds were fixed when the anchor was selected (:750-754)
       const double qpid_thresh = sel.qpid_thresh;
       const float scut = sel.fcut;
       bool paused = false;
       uint32_t i = st.loop_live ? st.i_next : 0u;
-      Row<P4> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
+      Row<Q> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
       float2 rn = make_float2(0.f, 0.f), rn2 = rn;
       if (i < n) { nxt = R.load(i); rn = R.result(i); }
       if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
@@ -1289,17 +1329,17 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       auto walk = [&](auto small_tag) {
       constexpr bool kSmall = decltype(small_tag)::value;
       for (; i < n; ++i) {  // :757
-        const Row<P4> cur = nxt;
+        const Row<Q> cur = nxt;
         const float2 r2 = rn;
         nxt = nx2; rn = rn2;
         if (i + 2 < n) { nx2 = R.load(i + 2); rn2 = R.result(i + 2); }
-        const HitCore h = row_core<P4>(cur);
+        const HitCore h = row_core<Q>(cur);
         if (!(h.score >= scut)) break;
         const double qpid = (double)(i == a ? qs_a : h.qs) / L;  // the anchor's row may have been updated below
         if (!(qpid >= qpid_thresh)) continue;
-        uint32_t pth[4 * P4];
-        row_path<P4>(cur, pth);
-        const uint32_t cb = common<P4>(pb, db, pth, meta_depth(h.meta));
+        uint32_t pth[PW];
+        row_path<Q>(cur, pth);
+        const uint32_t cb = common<PW>(pb, db, pth, meta_depth(h.meta), lbs);
         float dist;
         if (i == a) dist = 0.f;
         else {
@@ -1354,10 +1394,9 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
         const uint32_t word = fq[k];
         if (word) { const uint32_t bit = (uint32_t)__ffs((int)word) - 1u; a = k * 32u + bit; fq[k] = word & (word - 1u); break; }
       }
-      const HitCore h = R.core(a);
       st.anchor = a; st.phase = kPass1Wait; st.loop_live = 0;
       st.chunk_hi = p.spec1 ? min(n, p.spec1) : n;
-      em.mode = 2; em.anchor = a; em.anchor_len = h.seglen; em.i_lo = 0; em.i_hi = st.chunk_hi;
+      em.mode = 2; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.i_lo = 0; em.i_hi = st.chunk_hi;
     } else if (!failed && st.phase == kPass2Select) {  // :739-747
       bool found = false;
       if (st.d_unode_g == st.d_lca_all) {  // unode_global == lca_allnodes (both on the best hit's path): every anchor is skipped
@@ -1372,7 +1411,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
           const HitCore h = R.core(a);
           st.anchor = a; st.phase = kPass2Wait; found = true; st.loop_live = 0;
           st.chunk_hi = p.spec2 ? min(n, p.spec2) : n;
-          em.mode = 3; em.anchor = a; em.anchor_len = h.seglen; em.best = st.best; em.d_unode_g = st.d_unode_g;
+          em.mode = 3; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.best = st.best; em.d_unode_g = st.d_unode_g;
           em.i_lo = 0; em.i_hi = st.chunk_hi;
           em.emit_query = h.qd == FLT_MAX ? 1u : 0u;             // anchor never aligned to the query yet (:792)
           em.fcut = h.score * X;                                   // qsearchscore_thresh_heuristic, :754
@@ -1383,12 +1422,11 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
       }
       if (!found) {  // :824-833
         if (st.d_unode_g == st.d_lnode_g) st.ival_g = 1.f;
-        uint32_t pb[4 * P4];
-        R.path(st.best, pb);
+        const uint32_t nb = R.core(st.best).node;  // the nodes of the result are points on the best hit's root path
         OutRow row;
         row.begin = st.qrstart; row.end = st.qrstop; row.ival = st.ival_g;
-        row.lower = node_at<P4>(pb, st.d_lnode_g); row.upper = node_at<P4>(pb, st.d_unode_g); row.support = st.support;
-        row.rtax = node_at<P4>(pb, st.d_rtax); row.flags = 0;
+        row.lower = anc_node(tax, nb, st.d_lnode_g); row.upper = anc_node(tax, nb, st.d_unode_g); row.support = st.support;
+        row.rtax = anc_node(tax, nb, st.d_rtax); row.flags = 0;
         rows[s] = row;
         if (stats) stats[s] = OutStats{n, st.cnt0, st.cnt1, st.cnt2};
         if (prof_acc) atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * 4 + 3], (unsigned long long)(st.cnt0 + st.cnt1 + st.cnt2));
@@ -1412,13 +1450,16 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, Params
 
 // ---- tiled row layout: per tile of 64 record sets, 64 x (largest record count of the tile) row slots ----
 __global__ __launch_bounds__(kBlock) void k_tile_caps(const uint32_t* __restrict__ set_offsets, uint32_t n_sets, uint32_t n_tiles,
-                                                       uint32_t* __restrict__ tile_base) {
+                                                       uint32_t* __restrict__ tile_base, uint32_t* __restrict__ max_set, bool keep_caps) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= n_tiles) return;
-  const uint32_t s0 = t * 64u, s1 = min(n_sets, s0 + 64u);
-  uint32_t cap = 0, prev = set_offsets[s0];
-  for (uint32_t s = s0; s < s1; ++s) { const uint32_t nx = set_offsets[s + 1]; cap = max(cap, nx - prev); prev = nx; }
-  tile_base[t] = cap;  // scanned in place by k_tile_scan
+  uint32_t cap = 0;
+  if (t < n_tiles) {
+    const uint32_t s0 = t * 64u, s1 = min(n_sets, s0 + 64u);
+    uint32_t prev = set_offsets[s0];
+    for (uint32_t s = s0; s < s1; ++s) { const uint32_t nx = set_offsets[s + 1]; cap = max(cap, nx - prev); prev = nx; }
+    if (keep_caps) tile_base[t] = cap;  // scanned in place by k_tile_scan
+  }
+  wave_max_to(max_set, cap);  // the largest record set of the batch sets the width of the taxon path labels
 }
 // exclusive prefix sum of 64 * cap over the tiles, one workgroup; saturates at 0xFFFFFFFF (the caller then uses the linear layout)
 __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t n_tiles, uint32_t* __restrict__ tile_base) {
@@ -1443,11 +1484,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t n_tiles, uint32_t* 
   }
 }
 
-hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t* tile_base) {
+hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t* tile_base, uint32_t* max_set, bool scan) {
   const uint32_t n_tiles = (n_sets + 63u) / 64u;
   if (n_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_tile_caps, dim3((n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, st, set_offsets, n_sets, n_tiles, tile_base);
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, n_tiles, tile_base);
+  hipLaunchKernelGGL(k_tile_caps, dim3((n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, st, set_offsets, n_sets, n_tiles, tile_base, max_set, scan);
+  if (scan) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, n_tiles, tile_base);
   return hipGetLastError();
 }
 
@@ -1482,14 +1523,15 @@ hipError_t launch_rebase_offsets(hipStream_t st, const uint32_t* in, uint32_t n,
   return hipGetLastError();
 }
 
-// ---- launchers: P4 = number of 16-byte quads of the taxon path = ceil(max depth / 4) ----
-#define RPA_DISPATCH_P4(P4V, CALL)                 \
-  switch (P4V) {                                   \
-    case 1: { constexpr int P4 = 1; CALL; } break; \
-    case 2: { constexpr int P4 = 2; CALL; } break; \
-    case 3: { constexpr int P4 = 3; CALL; } break; \
-    case 4: { constexpr int P4 = 4; CALL; } break; \
-    default: return hipErrorInvalidValue;          \
+// ---- launchers: Q = 16-byte quads per hit row (WorkDev::row_quads, one of kRowQuadChoices) ----
+#define RPA_DISPATCH_Q(QV, CALL)                 \
+  switch (QV) {                                  \
+    case 2: { constexpr int Q = 2; CALL; } break; \
+    case 3: { constexpr int Q = 3; CALL; } break; \
+    case 4: { constexpr int Q = 4; CALL; } break; \
+    case 6: { constexpr int Q = 6; CALL; } break; \
+    case 8: { constexpr int Q = 8; CALL; } break; \
+    default: return hipErrorInvalidValue;        \
   }
 
 // record set of the first record of every k_rank_records workgroup: largest s with set_offsets[s] <= block * kBlock
@@ -1511,7 +1553,7 @@ hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev&
   if (b.n_records == 0) return hipSuccess;
   const dim3 grid(((b.n_records + kBlock - 1) / kBlock + 7u) / 8u * 8u);  // multiple of 8: see the XCD mapping in the kernel
   hipLaunchKernelGGL(k_block_first, dim3((grid.x + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b.set_offsets, b.n_sets, grid.x, w.block_first);
-  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_rank_records<P4>, grid, dim3(kBlock), 0, st, b, w, tax, q, db, p));
+  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_rank_records<Q>, grid, dim3(kBlock), 0, st, b, w, tax, q, db, p));
   return hipGetLastError();
 }
 
@@ -1519,7 +1561,7 @@ hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w,
                             void* out_rows, void* out_stats) {
   if (b.n_sets == 0) return hipSuccess;
   const dim3 grid((b.n_sets + kBlock - 1) / kBlock);
-  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_plan_sets<P4>, grid, dim3(kBlock), 0, st, b, w, p, (OutRow*)out_rows, (OutStats*)out_stats));
+  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_plan_sets<Q>, grid, dim3(kBlock), 0, st, b, w, tax, p, (OutRow*)out_rows, (OutStats*)out_stats));
   return hipGetLastError();
 }
 
@@ -1527,13 +1569,13 @@ hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, cons
   if (w.live_in) {  // sparse round: one wave per live set
     if (w.n_live_in == 0) return hipSuccess;
     const dim3 grid(((size_t)w.n_live_in * 64 + kSparseBlock - 1) / kSparseBlock);
-    RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_emit_sparse<P4>, grid, dim3(kSparseBlock), 0, st, b, w, p));
+    RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_emit_sparse<Q>, grid, dim3(kSparseBlock), 0, st, b, w, p));
     return hipGetLastError();
   }
   const uint32_t total = b.n_records + b.n_sets;
   if (total == 0) return hipSuccess;
   const dim3 grid((total + kEmitSpan - 1) / kEmitSpan);
-  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_emit<P4>, grid, dim3(kEmitBlock), 0, st, b, w, p));
+  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_emit<Q>, grid, dim3(kEmitBlock), 0, st, b, w, p));
   return hipGetLastError();
 }
 
@@ -1542,7 +1584,7 @@ hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, co
   const uint32_t n_threads = w.live_in ? w.n_live_in : b.n_sets;
   if (n_threads == 0) return hipSuccess;
   const dim3 grid((n_threads + kBlock - 1) / kBlock);
-  RPA_DISPATCH_P4(tax.path_quads, hipLaunchKernelGGL(k_decide<P4>, grid, dim3(kBlock), (size_t)w.band_ranks * kBlock * 2 * sizeof(float), st, b, w, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc));
+  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_decide<Q>, grid, dim3(kBlock), (size_t)w.band_ranks * kBlock * 2 * sizeof(float), st, b, w, tax, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc));
   return hipGetLastError();
 }
 

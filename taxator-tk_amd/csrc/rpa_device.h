@@ -15,7 +15,8 @@ constexpr int kNumBins = kShortWords + kStripBins;  // bins 0..7: one strip of b
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
 constexpr int kProfParts = 64;        // profiling accumulators are split 64 ways (block index & 63) and summed on the host
-constexpr int kMaxDepth = 15;         // deepest taxonomy level the placement kernel's per-rank LDS tables hold (NCBI pruned: 8)
+constexpr int kMaxDepth = 63;         // deepest taxonomy level: the BandFactor rank sets of k_decide are 64-bit masks and its per-rank LDS
+                                      // accumulators hold (depth + 1) x 2 KB (full NCBI: ~40 levels; pruned to the default ranks: 8)
 
 // error codes mirror include/taxator_rpa.h
 enum { kOk = 0, kErrInvalid = 1, kErrDevice = 2, kErrRange = 3, kErrSeqId = 4, kErrAssert = 5, kErrUnsupported = 6 };
@@ -27,11 +28,18 @@ struct TaxDev {
   const uint32_t* right;
   const uint8_t* depth;
   uint32_t n_nodes;
-  // per-node ancestor table built at rpa_create: anc[node * 4*path_quads + (d-1)] = ancestor of node at depth d
-  // (d = 1 .. depth[node]; 0xFFFFFFFF beyond).  Copied into every hit row, so the placement kernels never walk `parent`.
+  // Built at rpa_create from the parent pointers alone (the caller's left / right are only validated):
+  //   pre[node] / last[node]: preorder number of the node / of the last node of its subtree, so that
+  //       x lies in the subtree of a (a itself included)  <=>  pre[a] <= pre[x] <= last[a];
+  //   anc[node * max_depth + (d-1)]    = ancestor of node at depth d (d = 1 .. depth[node]; 0xFFFFFFFF beyond);
+  //   anc_iv[node * max_depth + (d-1)] = (pre, last) of that ancestor ((1, 0), the empty interval, beyond).
+  // k_rank_records turns the intervals into per-record-set taxon path LABELS (see place_kernels.hip), the placement
+  // kernels compare labels and never walk `parent`; anc gives the node at a depth of the best hit's path for the output.
+  const uint32_t* pre;
+  const uint32_t* last;
   const uint32_t* anc;
-  int path_quads;  // ceil(max depth / 4), 1..4
-  uint32_t max_depth;
+  const uint2* anc_iv;
+  uint32_t max_depth;  // deepest level = entries per node of anc / anc_iv (>= 1)
 };
 
 // Resident sequence store: residues packed little-endian into 32-bit words, 4 bit (DNA) or 8 bit (protein) each.
@@ -88,17 +96,17 @@ struct SetState {
   uint32_t pad_;       // sets of up to 64 hits: the high word of that bit set
 };
 
-// One hit of a record set at its SortFilter position: 32 bytes of fields + the taxon path (4*path_quads words),
-// i.e. 64 bytes per hit for taxonomies up to 8 levels deep.  Rows of a set are contiguous.
+// One hit of a record set at its SortFilter position: Q quads of 16 bytes (Q = WorkDev::row_quads, 2 for taxonomies of up
+// to 8 levels and record sets of up to 256 records: 32 bytes per hit).  Words 0-3 = score, identities, node, meta (static
+// after k_rank_records); 4-5 = querydistance, querysimilarity (the only mutable fields); 6 .. 4Q-1 = the hit's taxon path
+// as per-set LABELS (place_kernels.hip).  The length of a hit's reference segment lives in WorkDev::lite.
 struct HitCore {
   float score;       // getScore()
   uint32_t ident;    // getIdentities()
   uint32_t node;     // getReferenceNode()
-  uint32_t rec;      // record index in the batch (informational: segments and results are indexed by ROW position)
+  uint32_t meta;     // kMeta* bits
   float qd;          // querydistance[i]
   float qs;          // querysimilarity[i]
-  uint32_t seglen;   // length of the reference segment
-  uint32_t meta;     // kMeta* bits (static after k_rank_records)
 };
 constexpr uint32_t kLiteLenMask = 0x1FFFFFFFu;  // reference segments of 2^29 residues and more are refused
 constexpr uint32_t kLitePerfect = 0x20000000u;  // alnlen == L && identities == L: a member of qgroup with distance 0 (:511-517)
@@ -142,7 +150,7 @@ __host__ __device__ __forceinline__ uint4 emit_desc(const EmitInfo& e) {
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
 struct WorkDev {
   SetState* state;      // S
-  uint32_t* hits;       // P row slots of (8 + 4*path_quads) words in SortFilter order per set; tiled or linear (SetRows, place_kernels.hip)
+  uint32_t* hits;       // P row slots of row_quads quads in SortFilter order per set; tiled or linear (SetRows, place_kernels.hip)
   const uint32_t* tile_base;  // ceil(S/64) first row slot of every tile of 64 record sets; null = linear layout (slot = row position)
   uint32_t* res_slot;   // H   row position -> slot of pair_res that holds the hit's alignment result (null in rpa_align_pairs)
   uint32_t P;           // row slots (= H in the linear layout); the anchor<->query result of set s is at pair_res[P + s]
@@ -172,7 +180,7 @@ struct WorkDev {
   uint2* bin_list;      // kNumBins * T2 entries (segment A, segment B | kDstIsB)
   uint32_t* counters;   // kNumCounters words, layout below
   // pass-1 scratch (per set region like the pair slots)
-  float* band_save;     // S * 2*(kMaxDepth+1): BandFactor accumulators of paused pass-1 loops
+  float* band_save;     // S * 2*band_ranks: BandFactor accumulators of paused pass-1 loops
   uint32_t band_ranks;  // deepest taxonomy level + 1: rows of the LDS accumulators of k_decide
   // live lists: plan/decide append every set that is still running to live_out; a sparse round (few live sets) runs
   // emit/decide over live_in instead of over the whole batch
@@ -183,7 +191,8 @@ struct WorkDev {
   int32_t* og_dist;     // T
   const uint32_t* set_offsets;  // S+1 (copy of the batch's, for the alignment kernels)
   uint32_t H;    // n_records
-  int row_quads; // 2 + path_quads: 16-byte quads per hit row
+  int row_quads; // Q: 16-byte quads per hit row, one of kRowQuadChoices, chosen per batch (row_quads_for)
+  uint32_t lb_shift;  // log2 of the bits per path label: 3 (record sets of up to 256 records), 4 (up to 65536) or 5
   uint32_t T;    // number of segments
   uint32_t T2;   // number of pair slots = stride of each bin list
 };
@@ -194,6 +203,18 @@ struct WorkDev {
 constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNumBins + 2, kCtrRetryShort = kNumBins + 3, kCtrErr = kNumBins + 4,
               kCtrErrSet = kNumBins + 5, kCtrRetryTotal = kNumBins + 6, kCtrRetryShortTotal = kNumBins + 7, kNumCounters = kNumBins + 8,
               kNumRoundCounters = kNumBins + 4;  // the first kNumRoundCounters are reset every round
+
+// Row shapes the placement kernels are built for.  A row holds 4Q - 6 path words = (4Q - 6) * 32 / label bits levels.
+constexpr int kRowQuadChoices[] = {2, 3, 4, 6, 8};
+// label bits for a batch whose largest record set has `max_set` records (a label is a record's index inside its set)
+__host__ __device__ __forceinline__ uint32_t label_shift_for(uint32_t max_set) { return max_set <= 256u ? 3u : max_set <= 65536u ? 4u : 5u; }
+// smallest row shape that holds `levels` labels of (1 << lb_shift) bits; 0 = none does (levels x label bits > 832)
+__host__ __device__ __forceinline__ int row_quads_for(uint32_t levels, uint32_t lb_shift) {
+  const uint32_t words = ((((levels + 7u) & ~7u) << lb_shift) + 31u) / 32u;  // k_rank_records packs eight levels at a time
+  for (int q : kRowQuadChoices)
+    if ((uint32_t)(4 * q - 6) >= words) return q;
+  return 0;
+}
 
 struct Params {
   int alphabet;
@@ -221,7 +242,8 @@ hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const u
 
 // tiled row layout: tile_base[t] = first row slot of tile t (64 record sets, each padded to the tile's largest record
 // count), tile_base[n_tiles] = total slots.  Two small launches; the caller reads the total back to size the buffers.
-hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t* tile_base);
+// max_set (zeroed by the caller) <- records of the largest record set; scan = false: only that (linear row layout)
+hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t* tile_base, uint32_t* max_set, bool scan);
 
 // err[0..1] (zeroed by the caller) <- kErrInvalid + index when set_offsets / node indices of the batch are not usable
 hipError_t launch_validate_batch(hipStream_t st, const BatchDev& b, uint32_t n_nodes, uint32_t* err);
@@ -437,21 +459,6 @@ __host__ __device__ __forceinline__ int dna_bin(uint32_t m) {
     if (cost < best) { best = cost; best_nw = nw; }
   }
   return kShortWords + best_nw - kStripMinWords;
-}
-
-// ---- small device helpers shared by the placement kernels ----
-__device__ __forceinline__ bool d_is_parent_of(const TaxDev& t, uint32_t a, uint32_t b) {
-  // TaxonomyInterface::isParentOf, core/src/taxonomyinterface.cpp:52-55
-  return t.right[a] > t.left[b] && t.left[a] < t.left[b];
-}
-__device__ __forceinline__ uint32_t d_lca(const TaxDev& t, uint32_t a, uint32_t b) {
-  // TaxonomyInterface::getLCA, core/src/taxonomyinterface.cpp:67-77 (its min(A.left, B.right) kept as is)
-  const uint32_t la = t.left[a], ra = t.right[a], rb = t.right[b];
-  const uint32_t left_min = la < rb ? la : rb;
-  const uint32_t right_max = ra > rb ? ra : rb;
-  uint32_t lca = a;
-  while (t.left[lca] > left_min || t.right[lca] < right_max) lca = t.parent[lca];
-  return lca;
 }
 
 }  // namespace rpa

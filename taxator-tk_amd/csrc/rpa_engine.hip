@@ -75,7 +75,7 @@ struct rpa_engine {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   Params params{};
-  DevBuf tax_parent, tax_left, tax_right, tax_depth, tax_anc;
+  DevBuf tax_parent, tax_left, tax_right, tax_depth, tax_pre, tax_last, tax_anc, tax_anc_iv;
   TaxDev tax{};
   Store stores[2];
   Store pair_store;  // rpa_align_pairs
@@ -91,6 +91,7 @@ struct rpa_engine {
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
+  uint32_t force_label_shift = 0;  // RPA_LABEL_BITS=16|32: wider taxon path labels than the batch needs (tests: the wide row shapes)
   bool poison = false;        // RPA_POISON=1: every working buffer is filled with 0xA5 before each batch (tests: a kernel that
                               // reads a slot nobody wrote this batch then reads garbage every time, not whatever the last batch left)
   // what the bands cost: pairs sent through the banded kernels / re-run wide open, per batch.  A band that sends more
@@ -369,9 +370,10 @@ int profile_end(rpa_engine* e) {
 
 // Working-set allocation shared by predict and align_pairs.  T = segments, T2 = pair slots.
 // P = row slots (tiled layout: padded; linear: H); tiled selects the layout of the rows / results (predict only).
-int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, bool want_ext, WorkDev* w, uint32_t P, bool tiled) {
+int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, bool want_ext, WorkDev* w, uint32_t P, bool tiled,
+               int row_quads = 2, uint32_t lb_shift = 3) {
   HIP_TRY(e, e->state.ensure((size_t)(S ? S : 1) * sizeof(SetState)));
-  HIP_TRY(e, e->hits.ensure((size_t)(P ? P : 1) * (size_t)(2 + e->tax.path_quads) * 16));
+  HIP_TRY(e, e->hits.ensure((size_t)(P ? P : 1) * (size_t)row_quads * 16));
   if (!want_ext) HIP_TRY(e, e->res_slot.ensure((size_t)(H ? H : 1) * 4));
   HIP_TRY(e, e->set_info.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
   HIP_TRY(e, e->set_qseg.ensure((size_t)(S ? S : 1) * sizeof(uint2)));
@@ -393,7 +395,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
   HIP_TRY(e, e->live_a.ensure((size_t)(S ? S : 1) * 4));
   HIP_TRY(e, e->live_b.ensure((size_t)(S ? S : 1) * 4));
-  HIP_TRY(e, e->band_save.ensure((size_t)(S ? S : 1) * 2 * (kMaxDepth + 1) * 4));
+  HIP_TRY(e, e->band_save.ensure((size_t)(S ? S : 1) * 2 * (e->tax.max_depth + 1) * 4));
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
   if (e->poison) {
@@ -409,7 +411,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->lite = e->lite.as<uint32_t>();
   w->seg = e->seg.as<SegDesc>(); w->store_q = nullptr; w->store_db = nullptr;
   w->pair_a = want_ext ? e->pair_a.as<uint32_t>() : nullptr; w->pair_b = want_ext ? e->pair_b.as<uint32_t>() : nullptr;
-  w->set_offsets = nullptr; w->H = H; w->row_quads = 2 + e->tax.path_quads;
+  w->set_offsets = nullptr; w->H = H; w->row_quads = row_quads; w->lb_shift = lb_shift;
   w->P = P; w->tile_base = (!want_ext && tiled) ? e->tile_base.as<const uint32_t>() : nullptr;
   w->res_slot = want_ext ? nullptr : e->res_slot.as<uint32_t>();
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
@@ -449,23 +451,34 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   // row accesses coalesced; it pads every tile to its largest set, so batches whose padding would exceed ~50 % of the
   // rows (wildly different set sizes) keep the linear layout.  The slot count comes back from the device.
   const uint32_t n_tiles = (S + 63u) / 64u;
-  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 4) * 4));  // + total slots, + the two words of k_validate_batch
+  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 5) * 4));  // + total slots, + the two words of k_validate_batch, + largest set
   uint32_t P = H;
   bool tiled = false;
+  uint32_t lb_shift = 3;
+  int row_quads = 2;
   {
     uint32_t* tail = e->tile_base.as<uint32_t>() + n_tiles;
-    HIP_TRY(e, hipMemsetAsync(tail, 0, 12, e->stream));
+    HIP_TRY(e, hipMemsetAsync(tail, 0, 16, e->stream));
     HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, tail + 1));
-    if (!e->linear_rows) HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>()));
-    HIP_TRY(e, launch_publish_words(e->stream, tail, e->h_counters, 3));
+    HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>(), tail + 3, !e->linear_rows));
+    HIP_TRY(e, launch_publish_words(e->stream, tail, e->h_counters, 4));
     RPA_WHERE("predict_part: sync after validate/tile plan");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (e->h_counters[1]) return fail(e, RPA_ERR_INVALID, "batch rejected: set_offsets must run from 0 to n_records without decreasing and every node index must lie inside the taxonomy (set / record %u)", e->h_counters[2]);
     const uint64_t slots = e->h_counters[0];
     if (!e->linear_rows && slots != 0xFFFFFFFFull && slots <= (uint64_t)H + H / 2 + 65536u && slots + S < 0xFFFFFFF0ull) { P = (uint32_t)slots; tiled = true; }
+    // Row shape of this batch: a taxon path label is a record's index inside its set, so its width follows the largest set
+    // (8 bits up to 256 records), and a row must hold one label per taxonomy level.
+    const uint32_t max_set = e->h_counters[3];
+    lb_shift = e->force_label_shift ? e->force_label_shift : label_shift_for(max_set);
+    if (lb_shift < label_shift_for(max_set)) lb_shift = label_shift_for(max_set);
+    row_quads = row_quads_for(e->tax.max_depth, lb_shift);
+    if (!row_quads)
+      return fail(e, RPA_ERR_UNSUPPORTED, "a record set of %u records on a taxonomy of %u levels: %u levels x %u label bits exceed the widest hit row of this build (832 bits)",
+                  max_set, e->tax.max_depth, e->tax.max_depth, 1u << lb_shift);
   }
   WorkDev w{};
-  int rc = alloc_work(e, S, H, T, T, false, &w, P, tiled);
+  int rc = alloc_work(e, S, H, T, T, false, &w, P, tiled, row_quads, lb_shift);
   if (rc) return rc;
 
   rc = profile_begin(e);
@@ -586,7 +599,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison;
+  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift;
   w->fixed_speculation = e->fixed_speculation;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = make_stream(w->device, &w->own_stream);
@@ -735,6 +748,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
   if (const char* v = getenv("RPA_ROW_LAYOUT")) e->linear_rows = !strcmp(v, "linear");
   if (const char* v = getenv("RPA_POISON")) e->poison = atoi(v) != 0;
+  if (const char* v = getenv("RPA_LABEL_BITS")) e->force_label_shift = atoi(v) == 32 ? 5u : atoi(v) == 16 ? 4u : atoi(v) == 8 ? 3u : 0u;
   if (const char* v = getenv("RPA_PARTS")) e->parts_override = atoi(v);
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
@@ -783,27 +797,66 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   CREATE_TRY(hipMemcpy(e->tax_left.p, tax->left, n * 4, hipMemcpyHostToDevice));
   CREATE_TRY(hipMemcpy(e->tax_right.p, tax->right, n * 4, hipMemcpyHostToDevice));
   CREATE_TRY(hipMemcpy(e->tax_depth.p, tax->depth, n, hipMemcpyHostToDevice));
-  // per-node ancestor table (taxon paths): walk the parent pointers once on the host
+  // Preorder numbering from the parent pointers alone (children in index order, iterative walk): pre[x] = position of x,
+  // last[x] = position of the last node of x's subtree.  Then, per node, the ancestors on its root path (ids for the
+  // output, preorder intervals for k_rank_records' path labels).
   uint32_t max_depth = 1;
   for (uint32_t i = 0; i < tax->n_nodes; ++i) max_depth = tax->depth[i] > max_depth ? tax->depth[i] : max_depth;
-  const int path_quads = (int)((max_depth + 3) / 4);
-  const size_t P = (size_t)path_quads * 4;
+  const size_t D = max_depth;
   {
-    std::vector<uint32_t> anc(n * P, 0xFFFFFFFFu);
+    std::vector<uint32_t> child_start(n + 1, 0), child(n ? n - 1 : 0), pre(n, 0), last(n, 0);
+    for (uint32_t i = 1; i < tax->n_nodes; ++i) {
+      if (tax->parent[i] == i) { fail(e, RPA_ERR_INVALID, "rpa_create: node %u is its own parent (only node 0 may be)", i); return bail(RPA_ERR_INVALID); }
+      ++child_start[tax->parent[i] + 1];
+    }
+    for (size_t i = 0; i < n; ++i) child_start[i + 1] += child_start[i];
+    {
+      std::vector<uint32_t> fill(child_start.begin(), child_start.end() - 1);
+      for (uint32_t i = 1; i < tax->n_nodes; ++i) child[fill[tax->parent[i]]++] = i;
+    }
+    std::vector<uint32_t> stack, next_child(n, 0);
+    stack.reserve(max_depth + 2);
+    stack.push_back(0);
+    uint32_t counter = 0, visited = 1;
+    pre[0] = counter++;
+    while (!stack.empty()) {
+      const uint32_t v = stack.back();
+      const uint32_t k = child_start[v] + next_child[v];
+      if (k < child_start[v + 1]) {
+        ++next_child[v];
+        const uint32_t c = child[k];
+        if (tax->depth[c] != tax->depth[v] + 1u) { fail(e, RPA_ERR_INVALID, "rpa_create: depth of node %u is not depth(parent)+1", c); return bail(RPA_ERR_INVALID); }
+        pre[c] = counter++;
+        ++visited;
+        stack.push_back(c);
+      } else {
+        last[v] = counter - 1;
+        stack.pop_back();
+      }
+    }
+    if (visited != tax->n_nodes) { fail(e, RPA_ERR_INVALID, "rpa_create: %u node(s) do not descend from node 0", tax->n_nodes - visited); return bail(RPA_ERR_INVALID); }
+    std::vector<uint32_t> anc(n * D, 0xFFFFFFFFu);
+    std::vector<uint32_t> iv(n * D * 2);
+    for (size_t k = 0; k < n * D; ++k) { iv[2 * k] = 1u; iv[2 * k + 1] = 0u; }  // the empty interval
     for (uint32_t i = 0; i < tax->n_nodes; ++i) {
       uint32_t v = i;
       for (uint32_t d = tax->depth[i]; d >= 1; --d) {
-        if (tax->depth[v] != d) { fail(e, RPA_ERR_INVALID, "rpa_create: depth of node %u is not depth(parent)+1", v); return bail(RPA_ERR_INVALID); }
-        anc[(size_t)i * P + (d - 1)] = v;
+        anc[(size_t)i * D + (d - 1)] = v;
+        iv[2 * ((size_t)i * D + (d - 1))] = pre[v];
+        iv[2 * ((size_t)i * D + (d - 1)) + 1] = last[v];
         v = tax->parent[v];
       }
-      if (v != 0) { fail(e, RPA_ERR_INVALID, "rpa_create: node %u does not descend from node 0", i); return bail(RPA_ERR_INVALID); }
     }
-    CREATE_TRY(e->tax_anc.ensure(n * P * 4));
-    CREATE_TRY(hipMemcpy(e->tax_anc.p, anc.data(), n * P * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(e->tax_pre.ensure(n * 4)); CREATE_TRY(e->tax_last.ensure(n * 4));
+    CREATE_TRY(e->tax_anc.ensure(n * D * 4)); CREATE_TRY(e->tax_anc_iv.ensure(n * D * 8));
+    CREATE_TRY(hipMemcpy(e->tax_pre.p, pre.data(), n * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->tax_last.p, last.data(), n * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->tax_anc.p, anc.data(), n * D * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->tax_anc_iv.p, iv.data(), n * D * 8, hipMemcpyHostToDevice));
   }
   e->tax = TaxDev{e->tax_parent.as<const uint32_t>(), e->tax_left.as<const uint32_t>(), e->tax_right.as<const uint32_t>(),
-                  e->tax_depth.as<const uint8_t>(), tax->n_nodes, e->tax_anc.as<const uint32_t>(), path_quads, max_depth};
+                  e->tax_depth.as<const uint8_t>(), tax->n_nodes, e->tax_pre.as<const uint32_t>(), e->tax_last.as<const uint32_t>(),
+                  e->tax_anc.as<const uint32_t>(), e->tax_anc_iv.as<const uint2>(), max_depth};
   CREATE_TRY(e->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long)));
   CREATE_TRY(hipMemset(e->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
 #undef CREATE_TRY
@@ -827,7 +880,7 @@ void rpa_destroy(rpa_engine* e) {
   (void)hipSetDevice(e->device);
   RPA_WHERE("rpa_destroy: sync own stream");
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_anc, &e->set_qseg, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
+  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_pre, &e->tax_last, &e->tax_anc, &e->tax_anc_iv, &e->set_qseg, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,

@@ -78,8 +78,8 @@ static void usage(std::ostream& o) {
        "  -p [ --processors ] arg (=0)       host threads for parsing and output formatting, 0 = all\n"
        "  -l [ --logfile ] arg (=/dev/null)  per record set STATS lines are appended here\n"
        "  -b [ --dataformat ] arg (=nucleotide)  nucleotide | protein\n"
-       "  advanced: -r ranks..., -s split-alignments (=1), -o alignments-sorted (=0), -d delete-notranks (=1; the engine keeps taxon\n"
-       "            paths of at most 15 levels below the root: -d 0 on the full NCBI tree, or more than 15 ranks, is refused),\n"
+       "  advanced: -r ranks..., -s split-alignments (=1), -o alignments-sorted (=0), -d delete-notranks (=1; -d 0 keeps the whole\n"
+       "            tree: up to 63 levels below the root),\n"
        "            -x heuristic-cutoff (=0.5), -t toppercent (=0.05), -e max-evalue (=1000), -c min-support (=1), -m minscore (=0),\n"
        "            -n nbest (=1), -u ignore-unclassified, --device N (=0), --devices a,b,... (several GPUs), --batch N (record sets per GPU call),\n"
        "            --block-mb N (=128, input block parsed at a time), --timing, --record-objects (per-record object loop)\n";
@@ -350,9 +350,8 @@ static int run(int argc, char** argv) {
     stage("taxonomy");
     std::unique_ptr<Taxonomy> tax(loadTaxonomyFromEnvironment(&o.ranks, o.delete_unmarked));
     if (!tax) return EXIT_FAILURE;
-    if (tax->getMaxDepth() > 15) {  // the placement kernels keep taxon paths of at most 15 levels (rpa_create)
-      std::cerr << "the taxonomy keeps " << (int)tax->getMaxDepth() << " levels below the root; this build supports 15: use -d 1 (delete-notranks) "
-                   "and at most 15 ranks with -r" << std::endl;
+    if (tax->getMaxDepth() > 63) {  // rpa_create's limit (kMaxDepth): the full NCBI tree has ~40 levels
+      std::cerr << "the taxonomy keeps " << (int)tax->getMaxDepth() << " levels below the root; this build supports 63" << std::endl;
       return EXIT_FAILURE;
     }
     stage("seqid->taxid mapping");

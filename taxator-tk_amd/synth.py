@@ -87,6 +87,63 @@ class MockTaxonomy:
                 f.write("%s\t|\t%s\t|\t\t|\tscientific name\t|\n" % (t, "root" if i == 0 else "T" + t))
 
 
+class StretchedTaxonomy:
+    """A taxonomy with the same leaves and the same branching as `tax`, but with chains of extra single-child nodes put
+    into its edges, the way the full NCBI tree ("no rank" clades between the named ranks, taxator -d 0) relates to the
+    one pruned to seven ranks: the edge above node i gets extra(i) nodes.  `new_index[i]` is where node i went; nodes are
+    renumbered parent-before-child with fresh nested-set values.  For the deep-taxonomy tests (up to 63 levels)."""
+
+    def __init__(self, tax, extra):
+        parent = np.asarray(tax.parent)
+        n = len(parent)
+        order = np.argsort(np.asarray(tax.depth), kind="stable")  # parents before children
+        new_parent, new_depth, taxid, rank = [0], [0], [tax.taxid[0]], [tax.rank[0]]
+        self.new_index = np.zeros(n, np.uint32)
+        fresh = [10_000_000]
+        for i in order:
+            if i == 0:
+                continue
+            p_ = int(self.new_index[parent[i]])
+            for _ in range(int(extra(int(i)))):
+                new_parent.append(p_); new_depth.append(new_depth[p_] + 1)
+                fresh[0] += 1
+                taxid.append(str(fresh[0])); rank.append("no rank")
+                p_ = len(new_parent) - 1
+            new_parent.append(p_); new_depth.append(new_depth[p_] + 1)
+            taxid.append(tax.taxid[i]); rank.append(tax.rank[i])
+            self.new_index[i] = len(new_parent) - 1
+        m = len(new_parent)
+        kids = [[] for _ in range(m)]
+        for c in range(1, m):
+            kids[new_parent[c]].append(c)
+        left, right = np.zeros(m, np.uint32), np.zeros(m, np.uint32)
+        counter, stack = 0, [(0, 0)]
+        while stack:
+            v, k = stack.pop()
+            if k == 0:
+                counter += 1; left[v] = counter
+            if k < len(kids[v]):
+                stack.append((v, k + 1)); stack.append((kids[v][k], 0))
+            else:
+                counter += 1; right[v] = counter
+        self.parent = np.array(new_parent, np.uint32)
+        self.depth = np.array(new_depth, np.uint8)
+        self.left, self.right = left, right
+        self.taxid, self.rank = taxid, rank
+        self.species = self.new_index[np.asarray(tax.species)]
+        self.branching = getattr(tax, "branching", None)
+
+    write_ncbi_dump = MockTaxonomy.write_ncbi_dump
+
+
+def stretch_dataset(ds, extra):
+    """The same workload on a StretchedTaxonomy: ds.tax replaced, the batch's node column renumbered.  In place."""
+    st = StretchedTaxonomy(ds.tax, extra)
+    ds.batch["node"] = st.new_index[np.asarray(ds.batch["node"])].astype(np.uint32)
+    ds.tax = st
+    return ds
+
+
 def _mutate(seq, anc, rate, rng, alphabet_size=4):
     n = len(seq)
     r = rng.random(n)

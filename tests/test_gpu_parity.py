@@ -534,6 +534,37 @@ def test_reverse_strand_at_store_edges_and_tiny_segments(pkg, oracle):
     assert int(est["pass1"].sum()) > 0
 
 
+@pytest.mark.parametrize("shape", ["40 levels", "63 levels, uneven", "40 levels, sets of 300 records"])
+def test_deep_taxonomies(pkg, oracle, synth, shape):
+    """Taxonomies far deeper than the seven default ranks (taxator -d 0 keeps every node of the NCBI tree: ~40 levels; the
+    reference walks parents and takes any depth, core/src/taxonomyinterface.cpp:52-77, core/src/taxontree.cpp:55-70,169-178).
+    The same workloads on trees whose edges carry chains of extra nodes: taxon path labels of 40 and 63 levels (rows of 4
+    and 6 quads), 16-bit labels on top (8 quads), BandFactor over up to 64 ranks -- every row and counter against the oracle."""
+    if shape == "40 levels":
+        ds = synth.make_dataset(n_sets=1500, n_hits=20, seg_len=150, branching=4, genome_len=2500, seed=41, variety=True)
+        synth.stretch_dataset(ds, lambda i: 4 if ds.tax.depth[i] < 7 else 10)       # 6 x 5 + 11 = 41 levels
+    elif shape == "63 levels, uneven":
+        ds = synth.make_dataset(n_sets=800, n_hits=12, seg_len=120, branching=3, genome_len=2000, seed=42, variety=True)
+        synth.stretch_dataset(ds, lambda i: (i * 7 + 3) % 10 if ds.tax.depth[i] > 1 else 0)
+        assert int(ds.tax.depth.max()) <= 63
+    else:
+        ds = synth.make_dataset(n_sets=30, n_hits=300, seg_len=100, branching=4, genome_len=1200, seed=43, variety=True)
+        synth.stretch_dataset(ds, lambda i: 4 if ds.tax.depth[i] < 7 else 10)
+    assert int(ds.tax.depth.max()) >= 40
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    assert len(set(ds.tax.depth[rows["lower"]])) > 4   # results at many different depths of the deep tree
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(3, 2))
+
+
+@pytest.mark.parametrize("bits", ["16", "32"])
+def test_wide_path_labels(pkg, oracle, synth, bits, monkeypatch):
+    """RPA_LABEL_BITS forces the label width a batch with record sets of more than 256 / 65536 records would get (rows of 3
+    and 4 quads on the default 8-level tree): same results."""
+    monkeypatch.setenv("RPA_LABEL_BITS", bits)
+    ds = synth.make_dataset(n_sets=2000, n_hits=20, seg_len=200, branching=4, genome_len=3000, seed=44, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+
+
 def test_large_record_sets(pkg, oracle, synth):
     """Record sets far larger than a wavefront (300 hits) and a batch mixing set sizes 2..300."""
     ds = synth.make_dataset(n_sets=40, n_hits=300, seg_len=120, branching=4, genome_len=1500, seed=31, variety=True)

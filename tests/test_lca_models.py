@@ -21,7 +21,8 @@ class Tree:
         depth = np.zeros(n_nodes, np.uint8)
         for i in range(1, n_nodes):
             while True:
-                p = int(rng.integers(0, i))
+                # (deep trees: every other node hangs under one of the most recent nodes, so that long chains form)
+                p = int(rng.integers(max(0, i - 3), i)) if (max_depth > 8 and i % 2) else int(rng.integers(0, i))
                 if depth[p] < max_depth:
                     break
             parent[i], depth[i] = p, depth[p] + 1
@@ -185,6 +186,33 @@ def test_device_models_match_oracle(case):
     tree = Tree(rng, n_nodes=3000)
     uncl = (rng.random(len(tree.parent)) < 0.2).astype(np.uint8)
     offs, qlen, recs, evalue = random_batch(rng, tree, 20000, 40)
+    c = _full(case)
+    tax = O.TaxArrays(tree.parent, tree.left, tree.right, tree.depth)
+    rc, exp = O.lca_predict_batch(tax, c["model"], offs, qlen, recs, evalue, uncl, c["toppercent"], c["minscore"], c["maxevalue"],
+                                  c["minsupport"], c["nbest"], c["ignore_unclassified"])
+    assert rc == 0
+    model = pkg.RPAPredictionModel(tree, alphabet=pkg.DNA)
+    batch = dict(set_offsets=offs, query_len=qlen, filtered=recs["filtered"].astype(np.uint8))
+    for f in ("qstart", "qstop", "score", "node"):
+        batch[f] = recs[f].copy()
+    rows = model.lca_predict(batch, c["model"], evalue=evalue, node_unclassified=uncl, toppercent=c["toppercent"], minscore=c["minscore"],
+                             maxevalue=c["maxevalue"], minsupport=c["minsupport"], nbest=c["nbest"], ignore_unclassified=c["ignore_unclassified"])
+    assert rows.tobytes() == exp.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [dict(model=O.LCA_SIMPLE), dict(model=O.LCA_MEGAN, toppercent=0.3, minsupport=2), dict(model=O.LCA_NBEST, nbest=3)],
+                         ids=lambda c: "-".join("%s=%s" % kv for kv in c.items()))
+def test_device_models_on_a_deep_tree(case):
+    """The alignment-free models on a tree of up to 60 levels (taxator -d 0 on the NCBI tree: ~40): the kernel climbs from
+    the running LCA, any depth (the reference: core/src/taxonomyinterface.cpp:67-77)."""
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    rng = np.random.default_rng(7)
+    tree = Tree(rng, n_nodes=4000, max_depth=60)
+    assert int(tree.depth.max()) > 15
+    uncl = (rng.random(len(tree.parent)) < 0.2).astype(np.uint8)
+    offs, qlen, recs, evalue = random_batch(rng, tree, 15000, 30)
     c = _full(case)
     tax = O.TaxArrays(tree.parent, tree.left, tree.right, tree.depth)
     rc, exp = O.lca_predict_batch(tax, c["model"], offs, qlen, recs, evalue, uncl, c["toppercent"], c["minscore"], c["maxevalue"],
