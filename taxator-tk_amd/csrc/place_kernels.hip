@@ -342,16 +342,23 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     const uint2* __restrict__ iv = tax.anc_iv + (size_t)node * D;
     const bool staged = beg >= w0;  // the records in front of me are all in the LDS window (r itself always is)
     for (uint32_t c = 0; c < D; c += 8u) {
-      uint2 v[8];
+      uint2 v[8];  // (first preorder number, last - first) of my ancestor at levels c .. c+7; (0xFFFFFFFF, 0) = no such ancestor
       uint32_t lab[8];
 #pragma unroll
-      for (int d = 0; d < 8; ++d) { v[d] = c + d < D ? iv[c + d] : make_uint2(1u, 0u); lab[d] = my; }
-      for (uint32_t j = beg; j < r; ++j) {
-        const uint32_t pj = staged ? s_pre[j - w0] : tax.pre[b.node[j]];
-        const uint32_t idx = j - beg;
+      for (int d = 0; d < 8; ++d) { v[d] = c + d < D ? iv[c + d] : make_uint2(0xFFFFFFFFu, 0u); lab[d] = my; }
+      // back to front, so that the record nearest the front of the set has the last word: three vector instructions per
+      // level and record (subtract, compare, select); four records per trip so that their LDS reads are in flight together
+      auto pre_of = [&](uint32_t idx) -> uint32_t { return staged ? s_pre[beg + idx - w0] : tax.pre[b.node[beg + idx]]; };
+      auto apply = [&](uint32_t pj, uint32_t idx) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) lab[d] = (pj >= v[d].x && pj <= v[d].y && idx < lab[d]) ? idx : lab[d];
+        for (int d = 0; d < 8; ++d) lab[d] = (pj - v[d].x <= v[d].y) ? idx : lab[d];
+      };
+      int32_t j = (int32_t)my - 1;
+      for (; j >= 3; j -= 4) {
+        const uint32_t p0 = pre_of((uint32_t)j), p1 = pre_of((uint32_t)j - 1u), p2 = pre_of((uint32_t)j - 2u), p3 = pre_of((uint32_t)j - 3u);
+        apply(p0, (uint32_t)j); apply(p1, (uint32_t)j - 1u); apply(p2, (uint32_t)j - 2u); apply(p3, (uint32_t)j - 3u);
       }
+      for (; j >= 0; --j) apply(pre_of((uint32_t)j), (uint32_t)j);
       // pack the chunk's eight labels behind the chunks before it (levels past D are never compared: left as they are)
       if (w.lb_shift == 3u) {
         my_row[6 + c / 4u] = (lab[0] & 255u) | ((lab[1] & 255u) << 8) | ((lab[2] & 255u) << 16) | (lab[3] << 24);
@@ -377,8 +384,8 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   }  // !me_filtered
   if (set_head) {
     w.seg[b.n_records + s] = qdesc;
-    w.set_info[s] = make_uint4(n, qrstart, qrstop, 0u);
-    w.set_qseg[s] = qp;
+    if (qp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); qp.x = 0; }
+    w.set_info[s] = make_uint4(n, qrstart, qrstop, qp.x | (qp.y << 29));
   }
   w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
   }  // r < n_records
@@ -658,7 +665,15 @@ __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDe
   info.mode = 0;
   if (have) {
     s = w.live_in[wave_id];
-    info = w.emit[s];
+    const uint4 desc = w.emit_lite[s];
+    info.mode = desc.x & 7u;
+    if (info.mode == 3u) info = w.emit[s];  // pass 2: thresholds, best hit, depth of unode_global
+    else {                                  // passes 0 and 1: the descriptor says it all (emit_desc)
+      info.anchor = desc.x >> 3; info.n = desc.z; info.i_hi = desc.z;
+      info.i_lo = info.mode == 4u ? 0u : desc.y;
+      info.qseglen = info.mode == 4u ? desc.y : desc.w;
+      info.anchor_len = desc.w;
+    }
     lo = b.set_offsets[s];
     i_hi = min(info.i_hi, info.n);
     i_lo = info.i_lo;
@@ -751,6 +766,50 @@ __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDe
   wave_max_to(&w.counters[kCtrMaxLen], maxlen);
 }
 
+// ---- a set's state between rounds --------------------------------------------------------------------------------
+// SetStateMem (64 bytes): phase | loop_live << 8 | combined << 9, support, best, anchor | the four global depths, one
+// byte each | lrd_min | ival_g, bf_max | the three alignment counters | i_next, chunk_hi.  The fields of SetState that
+// describe the set itself (n, query range, its segment) come back from set_info; the loop variables of a paused pass-1
+// loop from LoopSave.  A round reads 80 bytes and writes 64 per live set (the unpacked struct: 144 + 144).
+__device__ __forceinline__ void state_store(const WorkDev& w, uint32_t s, const SetState& st, bool save_loop) {
+  SetStateMem m;
+  m.q[0] = make_uint4(st.phase | (st.loop_live << 8) | (st.combined << 9), st.support, st.best, st.anchor);
+  m.q[1] = make_uint4((st.d_lca_all & 255u) | ((st.d_rtax & 255u) << 8) | ((st.d_lnode_g & 255u) << 16) | (st.d_unode_g << 24), st.lrd_min,
+                      __float_as_uint(st.ival_g), __float_as_uint(st.bf_max));
+  m.q[2] = make_uint4(st.cnt0, st.cnt1, st.cnt2, st.i_next);
+  m.q[3] = make_uint4(st.chunk_hi, 0u, 0u, 0u);
+  uint4* dst = w.state[s].q;
+  dst[0] = m.q[0]; dst[1] = m.q[1]; dst[2] = m.q[2]; dst[3] = m.q[3];
+  if (save_loop) {
+    LoopSave ls;
+    ls.nog = st.nog; ls.pad_ = st.pad_; ls.d_lnode = st.d_lnode; ls.scut = st.scut; ls.ldist = st.ldist; ls.udist = st.udist;
+    ls.qpid_upper = st.qpid_upper; ls.cut_g = st.cut_g; ls.cut_h = st.cut_h;
+    w.loop_save[s] = ls;
+  }
+}
+__device__ __forceinline__ void state_fill_static(SetState& st, const uint4 info) {  // from the set's set_info quad
+  st.n = info.x; st.qrstart = info.y; st.qrstop = info.z; st.L = info.z - info.y + 1u;
+  st.qseglen = info.w & kLiteLenMask; st.qsegerr = info.w >> 29;
+}
+__device__ __forceinline__ void state_load(const WorkDev& w, uint32_t s, SetState& st) {
+  const uint4* src = w.state[s].q;
+  const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+  st.phase = a.x & 255u; st.loop_live = (a.x >> 8) & 1u; st.combined = (a.x >> 9) & 1u;
+  st.support = a.y; st.best = a.z; st.anchor = a.w;
+  st.d_lca_all = b.x & 255u; st.d_rtax = (b.x >> 8) & 255u; st.d_lnode_g = (b.x >> 16) & 255u; st.d_unode_g = b.x >> 24;
+  st.lrd_min = b.y; st.ival_g = __uint_as_float(b.z); st.bf_max = __uint_as_float(b.w);
+  st.cnt0 = c.x; st.cnt1 = c.y; st.cnt2 = c.z; st.i_next = c.w; st.chunk_hi = d.x;
+  st.nog = 0; st.pad_ = 0; st.d_lnode = 0; st.scut = 0; st.ldist = 0.f; st.udist = 0.f; st.qpid_upper = st.cut_g = st.cut_h = 0.;
+  if (st.phase != kDone) {
+    state_fill_static(st, w.set_info[s]);
+    if (st.loop_live && st.phase == kPass1Wait) {
+      const LoopSave ls = w.loop_save[s];
+      st.nog = ls.nog; st.pad_ = ls.pad_; st.d_lnode = ls.d_lnode; st.scut = ls.scut; st.ldist = ls.ldist; st.udist = ls.udist;
+      st.qpid_upper = ls.qpid_upper; st.cut_g = ls.cut_g; st.cut_h = ls.cut_h;
+    }
+  }
+}
+
 // Append the record sets that are still running to the next round's live list: one reservation per workgroup
 // (same-address atomics serialise at ~11 ns each; a dense round appends up to n_sets entries).  All threads call.
 __device__ __forceinline__ void append_live(const WorkDev& w, bool running, uint32_t s) {
@@ -789,11 +848,9 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
   if (live) {
     const uint32_t lo = b.set_offsets[s], hi = b.set_offsets[s + 1];
     uint4 info = make_uint4(0u, 0u, 0u, 0u);
-    uint2 qseg = make_uint2(0u, 0u);
-    if (hi > lo) { info = w.set_info[s]; qseg = w.set_qseg[s]; }
+    if (hi > lo) info = w.set_info[s];
     const uint32_t n = info.x, qrstart = info.y, qrstop = info.z;
-    st.n = n; st.qrstart = qrstart; st.qrstop = qrstop; st.L = qrstop - qrstart + 1;
-    st.qseglen = qseg.x; st.qsegerr = qseg.y;
+    state_fill_static(st, info);
     st.support = 0; st.best = 0; st.d_lca_all = 0; st.d_rtax = 0; st.d_lnode_g = 0; st.d_unode_g = 0; st.ival_g = 0.f;
     st.bf_max = 1.f; st.lrd_min = 255; st.anchor = 0; st.cnt0 = st.cnt1 = st.cnt2 = 0; st.loop_live = 0; st.chunk_hi = 0; st.i_next = 0;
     st.combined = 0; st.pad_ = 0;
@@ -870,9 +927,9 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
       rows[s] = row;
       if (stats) stats[s] = OutStats{n, 0, 0, 0};
     }
-    w.emit[s] = em;
-    w.emit_lite[s] = emit_desc(em);
-    w.state[s] = st;
+    w.emit_lite[s] = emit_desc(em);  // (modes 1 and 4: everything k_emit needs)
+    st.nog = 0; st.d_lnode = 0; st.scut = 0; st.ldist = st.udist = 0.f; st.qpid_upper = st.cut_g = st.cut_h = 0.;
+    state_store(w, s, st, false);
   }
   append_live(w, live && st.phase != kDone, s);
 }
@@ -943,8 +1000,11 @@ __device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t
 // its alignment result in flight while it works on the current one; qgroup / outgroup are bit sets in WorkDev::flags,
 // so "first member", "any member left" and "clear" never touch the rows.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef RPA_DECIDE_WAVES
+#define RPA_DECIDE_WAVES 2  // resident waves per SIMD the register budget of k_decide is set for (A/B: tools/build_variant.sh)
+#endif
 template <int Q>
-__global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
+__global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
                                                     OutStats* __restrict__ stats, unsigned long long* prof_acc) {
   constexpr int PW = 4 * Q - 6;
   const uint32_t lbs = w.lb_shift;
@@ -959,7 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
   const uint32_t s = live ? (w.live_in ? w.live_in[tid] : tid) : 0u;
   SetState st;
   st.phase = kDone;
-  if (live) st = w.state[s];
+  if (live) state_load(w, s, st);
   live = live && st.phase != kDone;
   if (live) {
     EmitInfo em{};
@@ -1441,9 +1501,9 @@ __global__ __launch_bounds__(kBlock) void k_decide(BatchDev b, WorkDev w, TaxDev
     em.mode = 0;                // nothing asked for yet: the second trip decides
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
-    w.emit[s] = em;
+    if (em.mode == 3u) w.emit[s] = em;  // pass 2 carries thresholds that only the full record holds
     w.emit_lite[s] = emit_desc(em);
-    w.state[s] = st;
+    state_store(w, s, st, st.loop_live != 0u && st.phase == kPass1Wait);
   }
   append_live(w, live && st.phase != kDone, s);  // still running: next round's live list
 }

@@ -32,7 +32,8 @@ struct TaxDev {
   //   pre[node] / last[node]: preorder number of the node / of the last node of its subtree, so that
   //       x lies in the subtree of a (a itself included)  <=>  pre[a] <= pre[x] <= last[a];
   //   anc[node * max_depth + (d-1)]    = ancestor of node at depth d (d = 1 .. depth[node]; 0xFFFFFFFF beyond);
-  //   anc_iv[node * max_depth + (d-1)] = (pre, last) of that ancestor ((1, 0), the empty interval, beyond).
+  //   anc_iv[node * max_depth + (d-1)] = (pre, last - pre) of that ancestor, so that x lies under it  <=>
+  //       pre[x] - anc_iv.x <= anc_iv.y in unsigned arithmetic ((0xFFFFFFFF, 0) beyond the node's depth: nothing does).
   // k_rank_records turns the intervals into per-record-set taxon path LABELS (see place_kernels.hip), the placement
   // kernels compare labels and never walk `parent`; anc gives the node at a depth of the best hit's path for the output.
   const uint32_t* pre;
@@ -64,7 +65,9 @@ struct BatchDev {
 enum Phase : uint32_t { kDone = 0, kPass0Wait = 1, kPass1Wait = 2, kPass2Wait = 3, kPass1Select = 4, kPass2Select = 5 };
 
 // Per record-set state carried between rounds (one thread owns one set).  Taxon nodes are kept as DEPTHS on the
-// best hit's root path (see place_kernels.hip).
+// best hit's root path (see place_kernels.hip).  This is the form the kernels work on in registers; between rounds a set's
+// state lives in memory as SetStateMem (64 bytes: what changes from round to round) + its set_info quad (what never
+// changes) + a LoopSave record that is written and read only by a pass-1 loop that pauses at the end of its chunk.
 struct SetState {
   uint32_t phase;
   uint32_t n;          // active (unmasked) records
@@ -108,7 +111,14 @@ struct HitCore {
   float qd;          // querydistance[i]
   float qs;          // querysimilarity[i]
 };
-constexpr uint32_t kLiteLenMask = 0x1FFFFFFFu;  // reference segments of 2^29 residues and more are refused
+struct SetStateMem { uint4 q[4]; };  // see state_pack / state_unpack (place_kernels.hip)
+struct LoopSave {                    // a paused pass-1 loop: :596-602 loop variables
+  uint32_t nog, pad_, d_lnode;
+  int32_t scut;
+  float ldist, udist;
+  double qpid_upper, cut_g, cut_h;
+};
+constexpr uint32_t kLiteLenMask = 0x1FFFFFFFu;  // segments (reference or query range) of 2^29 residues and more are refused
 constexpr uint32_t kLitePerfect = 0x20000000u;  // alnlen == L && identities == L: a member of qgroup with distance 0 (:511-517)
 constexpr uint32_t kLiteWant0 = 0x80000000u;    // pass 0 aligns this hit to the query range (not perfect, score >= threshold)
 constexpr uint32_t kLiteZeroQd = 0x40000000u;   // querydistance[i] == 0 after pass 0: pass 1 never aligns it (:620)
@@ -149,14 +159,14 @@ __host__ __device__ __forceinline__ uint4 emit_desc(const EmitInfo& e) {
 
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
 struct WorkDev {
-  SetState* state;      // S
+  SetStateMem* state;   // S
+  LoopSave* loop_save;  // S
   uint32_t* hits;       // P row slots of row_quads quads in SortFilter order per set; tiled or linear (SetRows, place_kernels.hip)
   const uint32_t* tile_base;  // ceil(S/64) first row slot of every tile of 64 record sets; null = linear layout (slot = row position)
   uint32_t* res_slot;   // H   row position -> slot of pair_res that holds the hit's alignment result (null in rpa_align_pairs)
   uint32_t P;           // row slots (= H in the linear layout); the anchor<->query result of set s is at pair_res[P + s]
-  uint4* set_info;      // S   (n active, qrstart, qrstop, -)
-  uint2* set_qseg;      // S   (query segment length, error code)
-  EmitInfo* emit;       // S
+  uint4* set_info;      // S   (n active, qrstart, qrstop, length of the query range segment | its fetch error code << 29)
+  EmitInfo* emit;       // S   written for pass 2 only (mode 3): passes 0 and 1 are described completely by emit_lite
   uint4* emit_lite;     // S   emit_desc(emit[s])
   uint32_t* hit_set;    // H   row position -> record set
   uint32_t* block_first;  // per workgroup of k_rank_records (logical order): record set of its first record

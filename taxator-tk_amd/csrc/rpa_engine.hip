@@ -82,7 +82,7 @@ struct rpa_engine {
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
-  DevBuf state, hits, set_info, set_qseg, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
+  DevBuf state, loop_save, hits, set_info, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
       protein_ws, lanes_counter, retry_list, retry_short;
   uint32_t* h_counters = nullptr;  // pinned
@@ -372,11 +372,11 @@ int profile_end(rpa_engine* e) {
 // P = row slots (tiled layout: padded; linear: H); tiled selects the layout of the rows / results (predict only).
 int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, bool want_ext, WorkDev* w, uint32_t P, bool tiled,
                int row_quads = 2, uint32_t lb_shift = 3) {
-  HIP_TRY(e, e->state.ensure((size_t)(S ? S : 1) * sizeof(SetState)));
+  HIP_TRY(e, e->state.ensure((size_t)(S ? S : 1) * sizeof(SetStateMem)));
+  HIP_TRY(e, e->loop_save.ensure((size_t)(S ? S : 1) * sizeof(LoopSave)));
   HIP_TRY(e, e->hits.ensure((size_t)(P ? P : 1) * (size_t)row_quads * 16));
   if (!want_ext) HIP_TRY(e, e->res_slot.ensure((size_t)(H ? H : 1) * 4));
   HIP_TRY(e, e->set_info.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
-  HIP_TRY(e, e->set_qseg.ensure((size_t)(S ? S : 1) * sizeof(uint2)));
   HIP_TRY(e, e->emit.ensure((size_t)(S ? S : 1) * sizeof(EmitInfo)));
   HIP_TRY(e, e->emit_lite.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
   HIP_TRY(e, e->hit_set.ensure((size_t)(H ? H : 1) * 4));
@@ -399,14 +399,14 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
   if (e->poison) {
-    DevBuf* bufs[] = {&e->state, &e->hits, &e->res_slot, &e->set_info, &e->set_qseg, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first,
+    DevBuf* bufs[] = {&e->state, &e->loop_save, &e->hits, &e->res_slot, &e->set_info, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first,
                       &e->flags, &e->lite, &e->seg, &e->pair_a, &e->pair_b, &e->pair_res, &e->pair_ext, &e->bin_list, &e->live_a, &e->live_b,
                       &e->band_save, &e->og_idx, &e->og_dist, &e->retry_list, &e->retry_short, &e->protein_ws, &e->out_rows, &e->out_stats};
     for (DevBuf* b : bufs)
       if (b->p) HIP_TRY(e, hipMemsetAsync(b->p, 0xA5, b->cap, e->stream));
   }
-  w->state = e->state.as<SetState>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
-  w->set_qseg = e->set_qseg.as<uint2>(); w->emit = e->emit.as<EmitInfo>(); w->emit_lite = e->emit_lite.as<uint4>(); w->hit_set = e->hit_set.as<uint32_t>(); w->block_first = e->block_first.as<uint32_t>();
+  w->state = e->state.as<SetStateMem>(); w->loop_save = e->loop_save.as<LoopSave>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
+  w->emit = e->emit.as<EmitInfo>(); w->emit_lite = e->emit_lite.as<uint4>(); w->hit_set = e->hit_set.as<uint32_t>(); w->block_first = e->block_first.as<uint32_t>();
   w->flags = e->flags.as<uint32_t>();
   w->lite = e->lite.as<uint32_t>();
   w->seg = e->seg.as<SegDesc>(); w->store_q = nullptr; w->store_db = nullptr;
@@ -837,13 +837,13 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
     if (visited != tax->n_nodes) { fail(e, RPA_ERR_INVALID, "rpa_create: %u node(s) do not descend from node 0", tax->n_nodes - visited); return bail(RPA_ERR_INVALID); }
     std::vector<uint32_t> anc(n * D, 0xFFFFFFFFu);
     std::vector<uint32_t> iv(n * D * 2);
-    for (size_t k = 0; k < n * D; ++k) { iv[2 * k] = 1u; iv[2 * k + 1] = 0u; }  // the empty interval
+    for (size_t k = 0; k < n * D; ++k) { iv[2 * k] = 0xFFFFFFFFu; iv[2 * k + 1] = 0u; }  // no ancestor at this depth: nothing is inside
     for (uint32_t i = 0; i < tax->n_nodes; ++i) {
       uint32_t v = i;
       for (uint32_t d = tax->depth[i]; d >= 1; --d) {
         anc[(size_t)i * D + (d - 1)] = v;
         iv[2 * ((size_t)i * D + (d - 1))] = pre[v];
-        iv[2 * ((size_t)i * D + (d - 1)) + 1] = last[v];
+        iv[2 * ((size_t)i * D + (d - 1)) + 1] = last[v] - pre[v];  // x is in the subtree  <=>  pre[x] - pre[v] <= last[v] - pre[v] (unsigned)
         v = tax->parent[v];
       }
     }
@@ -880,7 +880,7 @@ void rpa_destroy(rpa_engine* e) {
   (void)hipSetDevice(e->device);
   RPA_WHERE("rpa_destroy: sync own stream");
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_pre, &e->tax_last, &e->tax_anc, &e->tax_anc_iv, &e->set_qseg, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
+  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_pre, &e->tax_last, &e->tax_anc, &e->tax_anc_iv, &e->loop_save, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,

@@ -123,6 +123,7 @@ SequenceStore::SequenceStore(const std::string& fasta_filename, const std::strin
 void SequenceStore::build_index_by_scan() {
   const char* p = map_;
   const char* end = map_ + map_len_;
+  bool empty_line_pending = false;  // the current record has a line without residues that more residues may still follow
   while (p < end) {
     const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
     const char* le = nl ? nl : end;
@@ -132,6 +133,7 @@ void SequenceStore::build_index_by_scan() {
       add_id(id);
       FaiEntry e{0, (uint64_t)((nl ? nl + 1 : end) - map_), 0, 0};
       entries_.push_back(e);
+      empty_line_pending = false;
     } else if (!entries_.empty()) {
       FaiEntry& e = entries_.back();
       size_t bases = 0;
@@ -140,6 +142,10 @@ void SequenceStore::build_index_by_scan() {
       const uint32_t width = (uint32_t)((nl ? nl + 1 : end) - p);
       if (e.length == 0 && e.linewidth == 0) { e.linebases = (uint32_t)bases; e.linewidth = width; if (blank_inside || bases == 0) e.linebases = 0; }
       else if (e.linebases && (e.length % e.linebases != 0 || bases > e.linebases || blank_inside)) e.linebases = 0;  // a short line that is not the last, or a longer one
+      // an empty line in the MIDDLE of a record (length so far a multiple of the line length, so the tests above let it pass)
+      // shifts every later line by its bytes: such a record is fetched by scanning, as readRegion skips all whitespace
+      if (bases && empty_line_pending) e.linebases = 0;
+      if (!bases && e.length) empty_line_pending = true;
       e.length += bases;
       if (e.linewidth == 0) e.linewidth = width ? width : 1;
     }
@@ -156,7 +162,8 @@ void SequenceStore::fetch(uint32_t i, uint8_t* dst) const {
     while (remaining) {
       const uint64_t take = remaining < e.linebases ? remaining : e.linebases;
       if (p + take > end) throw ParsingError("fasta index points beyond the end of the fasta file (sequence " + ids_[i] + ")");
-      if (memchr(p, ' ', take) || memchr(p, '\t', take)) break;  // blanks inside a line: readRegion skips them -> scan the rest
+      if (memchr(p, ' ', take) || memchr(p, '\t', take) || memchr(p, '\n', take) || memchr(p, '\r', take))
+        break;  // blanks or line ends inside what the index calls a line: readRegion skips them -> scan the rest
       memcpy(dst, p, take);
       dst += take; p += e.linewidth; remaining -= take;
     }

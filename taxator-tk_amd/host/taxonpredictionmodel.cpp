@@ -58,6 +58,7 @@ size_t RPAPredictionModel::makeResident(int which, const uint32_t* idx, size_t n
   // candidates: every host thread scans a slice of the indices against the (read-only) residency marks ...
   const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, n / 65536 + 1));
   std::vector<std::vector<uint32_t>> cand(T);
+  std::vector<uint8_t> out_of_range(T, 0);  // (an exception must not leave a helper thread: noted, thrown after the join)
   auto scan = [&](unsigned t) {
     const size_t lo = n * t / T, hi = n * (t + 1) / T;
     uint32_t last = 0xFFFFFFFFu;
@@ -65,7 +66,7 @@ size_t RPAPredictionModel::makeResident(int which, const uint32_t* idx, size_t n
       const uint32_t i = idx[k];
       if (i == last) continue;
       last = i;
-      if (i >= res.size()) throw SequenceNotFound("sequence index outside the store");
+      if (i >= res.size()) { out_of_range[t] = 1; return; }
       if (!res[i]) cand[t].push_back(i);
     }
   };
@@ -75,11 +76,15 @@ size_t RPAPredictionModel::makeResident(int which, const uint32_t* idx, size_t n
     scan(0);
     for (auto& x : th) x.join();
   }
-  // ... then one pass marks them (a sequence several threads found is taken once)
+  for (uint8_t bad : out_of_range)
+    if (bad) throw SequenceNotFound("sequence index outside the store");
+  // ... then one pass lists them (a sequence several threads found is taken once); they are marked resident only when the
+  // engine has them, so a fetch that fails leaves nothing half done
   std::vector<uint32_t> need;
   for (auto& c : cand)
     for (uint32_t i : c)
-      if (!res[i]) { res[i] = 1; need.push_back(i); }
+      if (!res[i]) { res[i] = 2; need.push_back(i); }  // 2 = listed in this call
+  auto unlist = [&] { for (uint32_t i : need) res[i] = 0; };
   if (need.empty()) return 0;
   fetch_offsets_.assign(need.size() + 1, 0);
   for (size_t k = 0; k < need.size(); ++k) fetch_offsets_[k + 1] = fetch_offsets_[k] + st.length(need[k]);
@@ -100,8 +105,11 @@ size_t RPAPredictionModel::makeResident(int which, const uint32_t* idx, size_t n
     fetch(0);
     for (auto& x : th) x.join();
   }
-  if (err) std::rethrow_exception(err);
-  check(engine_, rpa_store_append(engine_, which, (uint32_t)need.size(), need.data(), fetch_letters_.data(), fetch_offsets_.data()));
+  if (err) { unlist(); std::rethrow_exception(err); }
+  try {
+    check(engine_, rpa_store_append(engine_, which, (uint32_t)need.size(), need.data(), fetch_letters_.data(), fetch_offsets_.data()));
+  } catch (...) { unlist(); throw; }
+  for (uint32_t i : need) res[i] = 1;
   return need.size();
 }
 

@@ -68,6 +68,18 @@ def test_indexed_store_equals_in_memory_store(parsecheck, tmp_path):
                 f.write(chunk + rng.choice([b"\n", b"\r\n", b"\n\n"]))
                 i += n
     assert _check(parsecheck, path, "-") == (0, "OK 40 %d" % total)
+    # an EMPTY line in the middle of a record whose lines are otherwise regular (the length so far is a multiple of the line
+    # length where it sits): the scanned index must not call the record regular (a fetch by line arithmetic would copy the
+    # line break); and a samtools-style .fai that ignores the empty line must still give the right residues
+    path = str(tmp_path / "blank_inside.fna")
+    with open(path, "wb") as f:
+        for k, (name, seq) in enumerate(seqs):
+            f.write(b">" + name + b"\n")
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + b"\n")
+                if k % 3 == 0 and i == 60:
+                    f.write(b"\n")                      # after exactly two full lines
+    assert _check(parsecheck, path, "-") == (0, "OK 40 %d" % total)
     # a .fai that points beyond the file is refused, not followed
     path = str(tmp_path / "w60_1.fna")
     open(path + ".bad.fai", "w").write("s0\t100\t99999999\t60\t61\n")
