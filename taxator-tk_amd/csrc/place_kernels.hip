@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
     const uint32_t rr = w0 + k;
     if (rr < b.n_records) {
       s_rec[k] = make_uint4(__float_as_uint(b.score[rr]), b.identities[rr], b.qstart[rr], b.qstop[rr]);
-      s_pre[k] = tax.pre[b.node[rr]];  // (node indices were checked by k_validate_batch)
+      s_pre[k] = w.rec_pre[rr];  // preorder number of the record's taxon, left by k_validate_batch
       s_filt[k] = rec_filtered(b, rr) ? 1 : 0;
     }
   }
@@ -339,26 +339,26 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   for (int k = 0; k < PW; ++k) my_row[6 + k] = 0xFFFFFFFFu;
   if (n >= 2) {
     const uint32_t D = tax.max_depth, my = r - beg;
-    const uint2* __restrict__ iv = tax.anc_iv + (size_t)node * D;
+    const uint4* __restrict__ iv4 = reinterpret_cast<const uint4*>(tax.anc_iv + (size_t)node * ((D + 7u) & ~7u));  // rows of whole 64-byte chunks
     const bool staged = beg >= w0;  // the records in front of me are all in the LDS window (r itself always is)
     for (uint32_t c = 0; c < D; c += 8u) {
       uint2 v[8];  // (first preorder number, last - first) of my ancestor at levels c .. c+7; (0xFFFFFFFF, 0) = no such ancestor
       uint32_t lab[8];
 #pragma unroll
-      for (int d = 0; d < 8; ++d) { v[d] = c + d < D ? iv[c + d] : make_uint2(0xFFFFFFFFu, 0u); lab[d] = my; }
+      for (int d = 0; d < 8; d += 2) {
+        const uint4 two = iv4[(c + d) / 2u];
+        v[d] = make_uint2(two.x, two.y); v[d + 1] = make_uint2(two.z, two.w);
+        lab[d] = my; lab[d + 1] = my;
+      }
       // back to front, so that the record nearest the front of the set has the last word: three vector instructions per
-      // level and record (subtract, compare, select); four records per trip so that their LDS reads are in flight together
-      auto pre_of = [&](uint32_t idx) -> uint32_t { return staged ? s_pre[beg + idx - w0] : tax.pre[b.node[beg + idx]]; };
-      auto apply = [&](uint32_t pj, uint32_t idx) {
+      // level and record (subtract, compare, select).  (Four records per trip, their LDS reads in flight together, measured
+      // slower: 1.45 against 1.27 ms on config 2 -- the extra registers cost a resident wave.)
+      for (uint32_t j = r; j-- > beg;) {
+        const uint32_t pj = staged ? s_pre[j - w0] : w.rec_pre[j];
+        const uint32_t idx = j - beg;
 #pragma unroll
         for (int d = 0; d < 8; ++d) lab[d] = (pj - v[d].x <= v[d].y) ? idx : lab[d];
-      };
-      int32_t j = (int32_t)my - 1;
-      for (; j >= 3; j -= 4) {
-        const uint32_t p0 = pre_of((uint32_t)j), p1 = pre_of((uint32_t)j - 1u), p2 = pre_of((uint32_t)j - 2u), p3 = pre_of((uint32_t)j - 3u);
-        apply(p0, (uint32_t)j); apply(p1, (uint32_t)j - 1u); apply(p2, (uint32_t)j - 2u); apply(p3, (uint32_t)j - 3u);
       }
-      for (; j >= 0; --j) apply(pre_of((uint32_t)j), (uint32_t)j);
       // pack the chunk's eight labels behind the chunks before it (levels past D are never compared: left as they are)
       if (w.lb_shift == 3u) {
         my_row[6 + c / 4u] = (lab[0] & 255u) | ((lab[1] & 255u) << 8) | ((lab[2] & 255u) << 16) | (lab[3] << 24);
@@ -1555,20 +1555,28 @@ hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_
 // Batch sanity, before any kernel follows an index of the caller's (the C ABI takes device pointers: nothing else stands
 // between a bad index and a page fault): set_offsets runs from 0 to n_records without ever decreasing, every taxonomy node
 // index is inside the taxonomy.  err[0] = error code (first one wins), err[1] = offending set / record.
-__global__ __launch_bounds__(kBlock) void k_validate_batch(BatchDev b, uint32_t n_nodes, uint32_t* __restrict__ err) {
+// rec_pre (may be null): preorder number of every record's taxon (0 for a bad index), for k_rank_records' path labels --
+// this kernel has the node column in its hands anyway, and k_rank_records then stages the numbers like any other column
+// instead of chasing node -> pre at the head of every workgroup.
+__global__ __launch_bounds__(kBlock) void k_validate_batch(BatchDev b, uint32_t n_nodes, uint32_t* __restrict__ err,
+                                                            const uint32_t* __restrict__ pre, uint32_t* __restrict__ rec_pre) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   uint32_t bad = 0xFFFFFFFFu;
   if (t < b.n_sets) {
     const uint32_t lo = b.set_offsets[t], hi = b.set_offsets[t + 1];
     if (lo > hi || hi > b.n_records || (t == 0 && lo != 0u) || (t + 1u == b.n_sets && hi != b.n_records)) bad = t;
   }
-  if (bad == 0xFFFFFFFFu && t < b.n_records && b.node[t] >= n_nodes) bad = t;
+  if (t < b.n_records) {
+    const uint32_t node = b.node[t];
+    if (node >= n_nodes) { if (bad == 0xFFFFFFFFu) bad = t; if (rec_pre) rec_pre[t] = 0u; }
+    else if (rec_pre) rec_pre[t] = pre[node];
+  }
   if (bad != 0xFFFFFFFFu && atomicCAS(&err[0], 0u, (uint32_t)kErrInvalid) == 0u) err[1] = bad;
 }
-hipError_t launch_validate_batch(hipStream_t st, const BatchDev& b, uint32_t n_nodes, uint32_t* err) {
+hipError_t launch_validate_batch(hipStream_t st, const BatchDev& b, uint32_t n_nodes, uint32_t* err, const uint32_t* pre, uint32_t* rec_pre) {
   const uint32_t n = b.n_sets > b.n_records ? b.n_sets : b.n_records;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_validate_batch, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, n_nodes, err);
+  hipLaunchKernelGGL(k_validate_batch, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, b, n_nodes, err, pre, rec_pre);
   return hipGetLastError();
 }
 

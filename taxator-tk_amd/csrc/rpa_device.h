@@ -32,7 +32,7 @@ struct TaxDev {
   //   pre[node] / last[node]: preorder number of the node / of the last node of its subtree, so that
   //       x lies in the subtree of a (a itself included)  <=>  pre[a] <= pre[x] <= last[a];
   //   anc[node * max_depth + (d-1)]    = ancestor of node at depth d (d = 1 .. depth[node]; 0xFFFFFFFF beyond);
-  //   anc_iv[node * max_depth + (d-1)] = (pre, last - pre) of that ancestor, so that x lies under it  <=>
+  //   anc_iv[node * roundup8(max_depth) + (d-1)] = (pre, last - pre) of that ancestor, so that x lies under it  <=>
   //       pre[x] - anc_iv.x <= anc_iv.y in unsigned arithmetic ((0xFFFFFFFF, 0) beyond the node's depth: nothing does).
   // k_rank_records turns the intervals into per-record-set taxon path LABELS (see place_kernels.hip), the placement
   // kernels compare labels and never walk `parent`; anc gives the node at a depth of the best hit's path for the output.
@@ -168,6 +168,7 @@ struct WorkDev {
   uint4* set_info;      // S   (n active, qrstart, qrstop, length of the query range segment | its fetch error code << 29)
   EmitInfo* emit;       // S   written for pass 2 only (mode 3): passes 0 and 1 are described completely by emit_lite
   uint4* emit_lite;     // S   emit_desc(emit[s])
+  const uint32_t* rec_pre;  // H   record -> preorder number of its taxon (k_validate_batch)
   uint32_t* hit_set;    // H   row position -> record set
   uint32_t* block_first;  // per workgroup of k_rank_records (logical order): record set of its first record
   // qgroup / outgroup membership (:480-481,:578) as bit sets: for a set with n >= 2 active hits at rows [lo, lo+n),
@@ -256,7 +257,9 @@ hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const u
 hipError_t launch_tile_plan(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t* tile_base, uint32_t* max_set, bool scan);
 
 // err[0..1] (zeroed by the caller) <- kErrInvalid + index when set_offsets / node indices of the batch are not usable
-hipError_t launch_validate_batch(hipStream_t st, const BatchDev& b, uint32_t n_nodes, uint32_t* err);
+// rec_pre != null: also rec_pre[r] = pre[node[r]] for every record (pre = TaxDev::pre)
+hipError_t launch_validate_batch(hipStream_t st, const BatchDev& b, uint32_t n_nodes, uint32_t* err, const uint32_t* pre = nullptr,
+                                 uint32_t* rec_pre = nullptr);
 hipError_t launch_rebase_offsets(hipStream_t st, const uint32_t* in, uint32_t n, uint32_t* out);
 hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,
                                const StoreDev& db, const Params& p);

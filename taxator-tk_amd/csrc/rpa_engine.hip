@@ -82,7 +82,7 @@ struct rpa_engine {
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
-  DevBuf state, loop_save, hits, set_info, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
+  DevBuf state, loop_save, rec_pre, hits, set_info, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
       protein_ws, lanes_counter, retry_list, retry_short;
   uint32_t* h_counters = nullptr;  // pinned
@@ -407,6 +407,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   }
   w->state = e->state.as<SetStateMem>(); w->loop_save = e->loop_save.as<LoopSave>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
   w->emit = e->emit.as<EmitInfo>(); w->emit_lite = e->emit_lite.as<uint4>(); w->hit_set = e->hit_set.as<uint32_t>(); w->block_first = e->block_first.as<uint32_t>();
+  w->rec_pre = e->rec_pre.as<const uint32_t>();
   w->flags = e->flags.as<uint32_t>();
   w->lite = e->lite.as<uint32_t>();
   w->seg = e->seg.as<SegDesc>(); w->store_q = nullptr; w->store_db = nullptr;
@@ -459,7 +460,8 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   {
     uint32_t* tail = e->tile_base.as<uint32_t>() + n_tiles;
     HIP_TRY(e, hipMemsetAsync(tail, 0, 16, e->stream));
-    HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, tail + 1));
+    HIP_TRY(e, e->rec_pre.ensure((size_t)(H ? H : 1) * 4));
+    HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, tail + 1, e->tax.pre, e->rec_pre.as<uint32_t>()));
     HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>(), tail + 3, !e->linear_rows));
     HIP_TRY(e, launch_publish_words(e->stream, tail, e->h_counters, 4));
     RPA_WHERE("predict_part: sync after validate/tile plan");
@@ -836,23 +838,24 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
     }
     if (visited != tax->n_nodes) { fail(e, RPA_ERR_INVALID, "rpa_create: %u node(s) do not descend from node 0", tax->n_nodes - visited); return bail(RPA_ERR_INVALID); }
     std::vector<uint32_t> anc(n * D, 0xFFFFFFFFu);
-    std::vector<uint32_t> iv(n * D * 2);
-    for (size_t k = 0; k < n * D; ++k) { iv[2 * k] = 0xFFFFFFFFu; iv[2 * k + 1] = 0u; }  // no ancestor at this depth: nothing is inside
+    const size_t Dp = (D + 7) & ~(size_t)7;  // interval rows in whole chunks of eight levels (64 bytes): k_rank_records reads them 16 bytes at a time
+    std::vector<uint32_t> iv(n * Dp * 2);
+    for (size_t k = 0; k < n * Dp; ++k) { iv[2 * k] = 0xFFFFFFFFu; iv[2 * k + 1] = 0u; }  // no ancestor at this depth: nothing is inside
     for (uint32_t i = 0; i < tax->n_nodes; ++i) {
       uint32_t v = i;
       for (uint32_t d = tax->depth[i]; d >= 1; --d) {
         anc[(size_t)i * D + (d - 1)] = v;
-        iv[2 * ((size_t)i * D + (d - 1))] = pre[v];
-        iv[2 * ((size_t)i * D + (d - 1)) + 1] = last[v] - pre[v];  // x is in the subtree  <=>  pre[x] - pre[v] <= last[v] - pre[v] (unsigned)
+        iv[2 * ((size_t)i * Dp + (d - 1))] = pre[v];
+        iv[2 * ((size_t)i * Dp + (d - 1)) + 1] = last[v] - pre[v];  // x is in the subtree  <=>  pre[x] - pre[v] <= last[v] - pre[v] (unsigned)
         v = tax->parent[v];
       }
     }
     CREATE_TRY(e->tax_pre.ensure(n * 4)); CREATE_TRY(e->tax_last.ensure(n * 4));
-    CREATE_TRY(e->tax_anc.ensure(n * D * 4)); CREATE_TRY(e->tax_anc_iv.ensure(n * D * 8));
+    CREATE_TRY(e->tax_anc.ensure(n * D * 4)); CREATE_TRY(e->tax_anc_iv.ensure(n * Dp * 8));
     CREATE_TRY(hipMemcpy(e->tax_pre.p, pre.data(), n * 4, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(e->tax_last.p, last.data(), n * 4, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(e->tax_anc.p, anc.data(), n * D * 4, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(e->tax_anc_iv.p, iv.data(), n * D * 8, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->tax_anc_iv.p, iv.data(), n * Dp * 8, hipMemcpyHostToDevice));
   }
   e->tax = TaxDev{e->tax_parent.as<const uint32_t>(), e->tax_left.as<const uint32_t>(), e->tax_right.as<const uint32_t>(),
                   e->tax_depth.as<const uint8_t>(), tax->n_nodes, e->tax_pre.as<const uint32_t>(), e->tax_last.as<const uint32_t>(),
@@ -880,7 +883,7 @@ void rpa_destroy(rpa_engine* e) {
   (void)hipSetDevice(e->device);
   RPA_WHERE("rpa_destroy: sync own stream");
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_pre, &e->tax_last, &e->tax_anc, &e->tax_anc_iv, &e->loop_save, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
+  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_pre, &e->tax_last, &e->tax_anc, &e->tax_anc_iv, &e->loop_save, &e->rec_pre, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
