@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RPA_ABI_VERSION 2
+#define RPA_ABI_VERSION 3
 
 enum { RPA_DNA = 0, RPA_PROTEIN = 1 };              /* taxator -b nucleotide|protein, core/taxator.cpp:280,362-371 */
 enum { RPA_STORE_QUERY = 0, RPA_STORE_DB = 1 };      /* query_sequences_ / db_sequences_, taxonpredictionmodelsequence.hh:842-843 */
@@ -107,11 +107,34 @@ int rpa_store_load(rpa_engine* e, int which, uint32_t n_seqs, const uint8_t* let
  * empty sequence (RPA_ERR_RANGE).  Appending an index twice wastes arena space but is harmless. */
 int rpa_store_reserve(rpa_engine* e, int which, uint32_t n_seqs);
 int rpa_store_append(rpa_engine* e, int which, uint32_t n, const uint32_t* seq_index, const uint8_t* letters, const uint64_t* offsets);
+/* Region-granular residency (what the reference's indexed store really does: getSequence(id, start, stop) reads only
+ * [start, stop] through the .fai, core/src/sequencestorage.hh:341-369, core/src/faidx.h:315-350 -- a 200 bp hit on a
+ * 50 Mbp chromosome costs 200 bp of I/O, not 50 Mbp).  rpa_store_reserve_windows makes a store whose sequences have the
+ * given lengths and no resident part; rpa_store_append_windows makes the residues [first, first + n) of sequence
+ * seq_index readable (letters of the windows back to back, `offsets` n + 1 entries from 0).  A reference / query segment
+ * of a batch must lie inside ONE window (the driver appends, per block of the alignment stream, tile-aligned windows that
+ * cover every hit's range extended by its record set's query range, merged with the resident windows they touch); a
+ * segment outside every window fails the batch with RPA_ERR_INVALID.  A new window may sit beside the resident windows of
+ * its sequence or cover some of them entirely (they are dropped), never overlap one partly.
+ * rpa_store_reset (any store made with rpa_store_reserve*): nothing is resident any more, the arena is refilled from
+ * its start -- how a driver keeps a store inside an HBM budget (`taxator --store-gb`): reset, then append what the
+ * current block needs.  Both wait for the jobs in flight. */
+typedef struct {
+  uint32_t seq_index;
+  uint32_t reserved;   /* must be zero */
+  uint64_t first;      /* 0-based first residue of the window inside its sequence */
+  uint64_t n;          /* residues */
+} rpa_window;
+int rpa_store_reserve_windows(rpa_engine* e, int which, uint32_t n_seqs, const uint64_t* lengths);
+int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_window* windows, const uint8_t* letters, const uint64_t* offsets);
+int rpa_store_reset(rpa_engine* e, int which);
 typedef struct {
   uint32_t n_seqs;       /* sequences the store knows */
-  uint32_t n_resident;   /* of which resident in HBM */
-  uint64_t residues;     /* residues resident */
-  uint64_t device_bytes; /* HBM bytes held by the store (packed arena incl. growth slack + extent table) */
+  uint32_t n_resident;   /* of which (partly) resident in HBM */
+  uint64_t residues;     /* residues of the arena in use (windowed stores: including replaced windows) */
+  uint64_t device_bytes; /* HBM bytes held by the store (packed arena incl. growth slack + extent / window tables) */
+  uint64_t windows;      /* resident windows (whole-sequence stores: resident sequences) */
+  uint64_t live_residues;/* residues inside resident windows */
 } rpa_store_info;
 int rpa_store_info_get(rpa_engine* e, int which, rpa_store_info* out);
 

@@ -24,6 +24,7 @@ FLAG_IVAL_UNTOUCHED, FLAG_SHORTCUT, FLAG_SINGLE = 1, 2, 4
 PRED_DTYPE = np.dtype([("lower", "<u4"), ("upper", "<u4"), ("rtax", "<u4"), ("support", "<u4"), ("begin", "<u4"),
                        ("end", "<u4"), ("ival", "<f4"), ("flags", "<u4")])
 STATS_DTYPE = np.dtype([("n", "<u4"), ("pass0", "<u4"), ("pass1", "<u4"), ("pass2", "<u4")])
+WINDOW_DTYPE = np.dtype([("seq_index", "<u4"), ("reserved", "<u4"), ("first", "<u8"), ("n", "<u8")])
 ALN_DTYPE = np.dtype([("matches", "<u4"), ("mismatches", "<u4"), ("gaps", "<u4"), ("length", "<u4"),
                       ("distance", "<f4"), ("similarity", "<f4")])
 
@@ -34,7 +35,7 @@ ABI_SYMBOLS = ["rpa_abi_version", "rpa_default_params", "rpa_create", "rpa_destr
                "rpa_store_load", "rpa_predict_batch", "rpa_align_pairs", "rpa_profile_enable", "rpa_profile_get",
                "rpa_profile_reset", "rpa_lca_default_params", "rpa_lca_predict_batch", "rpa_store_reserve", "rpa_store_append",
                "rpa_store_info_get", "rpa_submit_batch", "rpa_wait", "rpa_host_register",
-               "rpa_host_unregister", "rpa_debug_where"]
+               "rpa_host_unregister", "rpa_debug_where", "rpa_store_reserve_windows", "rpa_store_append_windows", "rpa_store_reset"]
 
 LCA_DUMMY, LCA_SIMPLE, LCA_MEGAN, LCA_NBEST = 0, 1, 2, 3  # taxator -a dummy | simple-lca | megan-lca | n-best-lca
 
@@ -116,6 +117,12 @@ def load_library(path=None):
     L.rpa_store_reserve.restype = C.c_int
     L.rpa_store_append.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rpa_store_append.restype = C.c_int
+    L.rpa_store_reserve_windows.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    L.rpa_store_reserve_windows.restype = C.c_int
+    L.rpa_store_append_windows.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rpa_store_append_windows.restype = C.c_int
+    L.rpa_store_reset.argtypes = [C.c_void_p, C.c_int]
+    L.rpa_store_reset.restype = C.c_int
     L.rpa_store_info_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.rpa_store_info_get.restype = C.c_int
     L.rpa_submit_batch.argtypes = [C.c_void_p, C.POINTER(_Batch), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -275,9 +282,30 @@ class RPAPredictionModel:
         offsets = np.ascontiguousarray(offsets, np.uint64)
         self._check(self._L.rpa_store_append(self._h, which, len(idx), _ptr(idx), _ptr(letters), _ptr(offsets)))
 
+    def reserve_windows(self, which, lengths):
+        """A windowed store (region-granular residency): sequence i has lengths[i] residues, nothing resident yet."""
+        lengths = np.ascontiguousarray(lengths, np.uint64)
+        self._check(self._L.rpa_store_reserve_windows(self._h, which, len(lengths), _ptr(lengths)))
+
+    def append_windows(self, which, seq_index, first, letters_list):
+        """Make residues [first[k], first[k] + len(letters_list[k])) of sequence seq_index[k] readable (raw letters, uint8)."""
+        n = len(seq_index)
+        win = np.zeros(n, WINDOW_DTYPE)
+        win["seq_index"] = seq_index
+        win["first"] = first
+        win["n"] = [len(x) for x in letters_list]
+        offsets = np.zeros(n + 1, np.uint64)
+        offsets[1:] = np.cumsum(win["n"])
+        letters = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint8) for x in letters_list]) if n else np.zeros(0, np.uint8))
+        self._check(self._L.rpa_store_append_windows(self._h, which, n, _ptr(win), _ptr(letters), _ptr(offsets)))
+
+    def reset_store(self, which):
+        self._check(self._L.rpa_store_reset(self._h, which))
+
     def store_info(self, which):
         class _Info(C.Structure):
-            _fields_ = [("n_seqs", C.c_uint32), ("n_resident", C.c_uint32), ("residues", C.c_uint64), ("device_bytes", C.c_uint64)]
+            _fields_ = [("n_seqs", C.c_uint32), ("n_resident", C.c_uint32), ("residues", C.c_uint64), ("device_bytes", C.c_uint64),
+                        ("windows", C.c_uint64), ("live_residues", C.c_uint64)]
         out = _Info()
         self._check(self._L.rpa_store_info_get(self._h, which, C.byref(out)))
         return {k: int(getattr(out, k)) for k, _ in _Info._fields_}

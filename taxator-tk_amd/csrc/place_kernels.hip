@@ -176,7 +176,24 @@ __device__ __forceinline__ SegDesc plan_segment_desc(const StoreDev& store, bool
     else {
       if ((uint64_t)stop > slen) stop = (uint32_t)slen;
       if (start < 1 || start > stop) err = kErrRange;
-      else { len = stop - start + 1; src = off + (start - 1); }
+      else if (!store.windows) { len = stop - start + 1; src = off + (start - 1); }
+      else {
+        // windowed store (the region-granular reads of the reference's indexed store, sequencestorage.hh:341-362): the
+        // window that holds residue start-1 must hold the whole segment
+        const uint32_t nw = store.win_count[seq], a = start - 1u, n_seg = stop - start + 1u;
+        const uint4* __restrict__ wv = store.windows + off;
+        uint32_t lo = 0, hi = nw;  // largest k with wv[k].x <= a
+        while (hi - lo > 1u) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (wv[mid].x <= a) lo = mid; else hi = mid;
+        }
+        uint4 win = make_uint4(1u, 0u, 0u, 0u);
+        if (nw) win = wv[lo];
+        if (nw && win.x <= a && (uint64_t)a + n_seg <= (uint64_t)win.x + win.y) {
+          len = n_seg;
+          src = (((uint64_t)win.w << 32) | win.z) + (a - win.x);
+        } else err = kErrNotResident;
+      }
     }
   }
   len_err = make_uint2(len, err);

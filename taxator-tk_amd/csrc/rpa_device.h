@@ -19,7 +19,8 @@ constexpr int kMaxDepth = 63;         // deepest taxonomy level: the BandFactor 
                                       // accumulators hold (depth + 1) x 2 KB (full NCBI: ~40 levels; pruned to the default ranks: 8)
 
 // error codes mirror include/taxator_rpa.h
-enum { kOk = 0, kErrInvalid = 1, kErrDevice = 2, kErrRange = 3, kErrSeqId = 4, kErrAssert = 5, kErrUnsupported = 6 };
+enum { kOk = 0, kErrInvalid = 1, kErrDevice = 2, kErrRange = 3, kErrSeqId = 4, kErrAssert = 5, kErrUnsupported = 6,
+       kErrNotResident = 7 };  // device-only: a segment outside the resident windows of its sequence (reported as RPA_ERR_INVALID)
 
 // Flattened taxonomy (reference: Taxon::leftvalue/rightvalue/root_pathlength, core/src/taxontree.hh:64-66).
 struct TaxDev {
@@ -46,8 +47,16 @@ struct TaxDev {
 // Resident sequence store: residues packed little-endian into 32-bit words, 4 bit (DNA) or 8 bit (protein) each.
 struct StoreDev {
   const uint32_t* words;
-  const ulonglong2* extent;  // sequence i = residues [extent[i].x, extent[i].x + extent[i].y) of the arena; y == 0: not resident
+  // Whole-sequence stores (rpa_store_load / rpa_store_reserve + rpa_store_append): sequence i = residues
+  // [extent[i].x, extent[i].x + extent[i].y) of the arena; y == 0: not resident.
+  // Windowed stores (rpa_store_reserve_windows): extent[i].y = length of sequence i (known from the index file whether
+  // anything of it is resident or not), extent[i].x = first entry of its window list in `windows`, win_count[i] entries:
+  // (first residue of the window inside the sequence, residues, arena offset low, high), sorted by first residue, disjoint.
+  // A segment is readable iff one window holds all of it (the driver appends windows that way).
+  const ulonglong2* extent;
   uint32_t n_seqs;
+  const uint4* windows;       // null: whole-sequence store
+  const uint32_t* win_count;
 };
 
 // Batch (device pointers), same meaning as rpa_batch in include/taxator_rpa.h.
@@ -250,6 +259,11 @@ hipError_t launch_publish_words(hipStream_t st, const uint32_t* src, uint32_t* d
 // extent table of a store: from an offsets table (n_seqs + 1 entries, sequence i at base + offsets[i]) for all sequences,
 // or scattered for the sequences `index[k]` (k < n) of an append
 hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const uint32_t* index, uint32_t n, uint64_t base, ulonglong2* extent);
+// windowed stores: lengths of all sequences into extent[.].y (x = 0), win_count = 0
+hipError_t launch_store_lengths(hipStream_t st, const uint64_t* lengths, uint32_t n, ulonglong2* extent, uint32_t* win_count);
+// ... and the new window lists of the sequences index[k]: extent[index[k]].x = first[k], win_count[index[k]] = count[k]
+hipError_t launch_store_window_lists(hipStream_t st, const uint32_t* index, const uint32_t* first, const uint32_t* count, uint32_t n,
+                                     ulonglong2* extent, uint32_t* win_count);
 
 // tiled row layout: tile_base[t] = first row slot of tile t (64 record sets, each padded to the tile's largest record
 // count), tile_base[n_tiles] = total slots.  Two small launches; the caller reads the total back to size the buffers.

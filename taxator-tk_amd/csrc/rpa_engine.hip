@@ -64,9 +64,25 @@ struct Store {
   uint64_t n_residues = 0;   // residues of the arena in use (appends start at multiples of 8 residues)
   uint64_t cap_words = 0;    // packed words the arena holds (without the slack in front and behind)
   bool loaded = false;
+  // windowed stores (rpa_store_reserve_windows): which parts of which sequence are resident.  The host keeps every
+  // sequence's window list (sorted, disjoint); the device sees them through an append-only pool of window records -- a
+  // sequence whose list changes gets a fresh copy of it at the end of the pool and its (first entry, count) updated.
+  bool windowed = false;
+  std::vector<uint64_t> seq_length;
+  std::vector<std::vector<uint4>> seq_windows;  // (first residue, residues, arena offset low, high)
+  DevBuf win_pool, win_count, tmp_a, tmp_b;
+  uint64_t pool_used = 0, pool_cap = 0;   // window records
+  uint64_t n_windows = 0, live_residues = 0;
   // the packed words sit behind kLeadWords zero words: a reverse-strand reader may fetch a few words below its segment
-  StoreDev view() const { return StoreDev{words.as<const uint32_t>() + kLeadWords, extent.as<const ulonglong2>(), n_seqs}; }
-  void release() { words.release(); extent.release(); tmp_offsets.release(); tmp_index.release(); n_seqs = n_resident = 0; n_residues = cap_words = 0; loaded = false; }
+  StoreDev view() const {
+    return StoreDev{words.as<const uint32_t>() + kLeadWords, extent.as<const ulonglong2>(), n_seqs,
+                    windowed ? win_pool.as<const uint4>() : nullptr, windowed ? win_count.as<const uint32_t>() : nullptr};
+  }
+  void release() {
+    words.release(); extent.release(); tmp_offsets.release(); tmp_index.release(); win_pool.release(); win_count.release(); tmp_a.release(); tmp_b.release();
+    n_seqs = n_resident = 0; n_residues = cap_words = 0; loaded = false; windowed = false;
+    seq_length.clear(); seq_windows.clear(); pool_used = pool_cap = 0; n_windows = live_residues = 0;
+  }
 };
 
 }  // namespace
@@ -179,6 +195,7 @@ const char* kernel_error_text(uint32_t code) {
     case kErrSeqId: return "sequence index outside the store (SequenceNotFound)";
     case kErrAssert: return "a reference assert would abort here (reverse reference coordinates in protein mode, empty best-reference group or inconsistent node range)";
     case kErrUnsupported: return "sequence pair not supported by this build";
+    case kErrNotResident: return "a segment reaches outside the resident windows of its sequence (rpa_store_append_windows must cover every region a batch refers to)";
     default: return "inconsistent batch";
   }
 }
@@ -429,7 +446,7 @@ int check_device_error(rpa_engine* e, const uint32_t* c) {
   if (c[kCtrErr] == 0) return RPA_OK;
   const uint32_t code = c[kCtrErr];
   int rc = code == kErrRange ? RPA_ERR_RANGE : code == kErrSeqId ? RPA_ERR_SEQ_ID : code == kErrAssert ? RPA_ERR_ASSERT
-           : code == kErrUnsupported ? RPA_ERR_UNSUPPORTED : RPA_ERR_INVALID;
+           : code == kErrUnsupported ? RPA_ERR_UNSUPPORTED : RPA_ERR_INVALID;  // (kErrNotResident: the caller's omission)
   return fail(e, rc, "%s (record set / pair %u)", kernel_error_text(code), c[kCtrErrSet]);
 }
 
@@ -987,8 +1004,13 @@ static int store_add(rpa_engine* e, Store* st, uint32_t n, const uint32_t* index
   return RPA_OK;
 }
 
+static void forget_windows(Store* st) {
+  st->windowed = false; st->seq_length.clear(); st->seq_windows.clear(); st->pool_used = 0; st->n_windows = 0; st->live_residues = 0;
+}
+
 static int pack_store(rpa_engine* e, Store* st, uint32_t n_seqs, const uint8_t* letters, const uint64_t* offsets, int mem_kind,
                       DevBuf* letters_buf) {
+  forget_windows(st);
   st->n_residues = 0; st->n_resident = 0; st->n_seqs = n_seqs;
   HIP_TRY(e, st->extent.ensure((size_t)(n_seqs ? n_seqs : 1) * sizeof(ulonglong2)));
   int rc = store_add(e, st, n_seqs, nullptr, letters, offsets, mem_kind, letters_buf);
@@ -1017,6 +1039,7 @@ int rpa_store_reserve(rpa_engine* e, int which, uint32_t n_seqs) {
   HIP_TRY(e, hipSetDevice(e->device));
   quiesce_slots(e);
   Store* st = &e->stores[which];
+  forget_windows(st);
   st->n_residues = 0; st->n_resident = 0; st->n_seqs = n_seqs;
   HIP_TRY(e, st->extent.ensure((size_t)(n_seqs ? n_seqs : 1) * sizeof(ulonglong2)));
   HIP_TRY(e, hipMemsetAsync(st->extent.p, 0, (size_t)(n_seqs ? n_seqs : 1) * sizeof(ulonglong2), e->stream));  // nothing resident: every length 0
@@ -1035,6 +1058,7 @@ int rpa_store_append(rpa_engine* e, int which, uint32_t n, const uint32_t* seq_i
   if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_append: bad store id");
   Store* st = &e->stores[which];
   if (!st->loaded) return fail(e, RPA_ERR_INVALID, "rpa_store_append: reserve (or load) the store first");
+  if (st->windowed) return fail(e, RPA_ERR_INVALID, "rpa_store_append: this store takes windows (rpa_store_append_windows)");
   if (n == 0) return RPA_OK;
   if (!seq_index || !offsets || !letters) return fail(e, RPA_ERR_INVALID, "rpa_store_append: null argument");
   for (uint32_t k = 0; k < n; ++k)
@@ -1045,13 +1069,180 @@ int rpa_store_append(rpa_engine* e, int which, uint32_t n, const uint32_t* seq_i
   return rc;
 }
 
+int rpa_store_reserve_windows(rpa_engine* e, int which, uint32_t n_seqs, const uint64_t* lengths) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_reserve_windows: bad store id");
+  if (n_seqs && !lengths) return fail(e, RPA_ERR_INVALID, "rpa_store_reserve_windows: null argument");
+  for (uint32_t i = 0; i < n_seqs; ++i)
+    if (lengths[i] > 0xFFFFFFFFull) return fail(e, RPA_ERR_UNSUPPORTED, "rpa_store_reserve_windows: sequence %u has %llu residues (batch coordinates are 32 bit)", i, (unsigned long long)lengths[i]);
+  HIP_TRY(e, hipSetDevice(e->device));
+  quiesce_slots(e);
+  Store* st = &e->stores[which];
+  forget_windows(st);
+  st->n_residues = 0; st->n_resident = 0; st->n_seqs = n_seqs;
+  st->windowed = true;
+  st->seq_length.assign(lengths, lengths + n_seqs);
+  st->seq_windows.assign(n_seqs, std::vector<uint4>());
+  const size_t ns = n_seqs ? n_seqs : 1;
+  HIP_TRY(e, st->extent.ensure(ns * sizeof(ulonglong2)));
+  HIP_TRY(e, st->win_count.ensure(ns * 4));
+  HIP_TRY(e, st->win_pool.ensure(1024 * sizeof(uint4)));
+  st->pool_cap = st->win_pool.cap / sizeof(uint4);
+  HIP_TRY(e, st->tmp_offsets.ensure(ns * 8));
+  if (n_seqs) HIP_TRY(e, hipMemcpyAsync(st->tmp_offsets.p, lengths, (size_t)n_seqs * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, launch_store_lengths(e->stream, st->tmp_offsets.as<const uint64_t>(), n_seqs, st->extent.as<ulonglong2>(), st->win_count.as<uint32_t>()));
+  uint64_t first = 0;
+  int rc = store_grow(e, st, 0, &first);  // an (empty) arena with its slack words, so that a view exists
+  if (rc) return rc;
+  RPA_WHERE("rpa_store_reserve_windows: sync");
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  st->loaded = true;
+  return RPA_OK;
+}
+
+int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_window* win, const uint8_t* letters, const uint64_t* offsets) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: bad store id");
+  Store* st = &e->stores[which];
+  if (!st->loaded || !st->windowed) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: reserve the store with rpa_store_reserve_windows first");
+  if (n == 0) return RPA_OK;
+  if (!win || !offsets || !letters) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: null argument");
+  if (offsets[0] != 0) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: offsets[0] must be 0");
+  for (uint32_t k = 0; k < n; ++k) {
+    if (win[k].seq_index >= st->n_seqs) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: sequence index %u outside the store (%u sequences)", win[k].seq_index, st->n_seqs);
+    if (offsets[k + 1] < offsets[k] || offsets[k + 1] - offsets[k] != win[k].n) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: window %u has %llu residues, its letters %llu", k, (unsigned long long)win[k].n, (unsigned long long)(offsets[k + 1] - offsets[k]));
+    if (win[k].n == 0 || win[k].first + win[k].n > st->seq_length[win[k].seq_index]) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: window %u is empty or reaches beyond its sequence", k);
+  }
+  // bookkeeping first, on copies: a window may sit beside the resident windows of its sequence or cover some of them
+  // entirely (those are dropped: the new window is their hull), never overlap one partly -- a segment is only readable
+  // from ONE window, so overlapping windows are the caller's mistake
+  std::vector<uint32_t> changed;
+  std::vector<std::vector<uint4>> lists;
+  auto list_of = [&](uint32_t seq) -> std::vector<uint4>& {
+    for (size_t k = 0; k < changed.size(); ++k) if (changed[k] == seq) return lists[k];
+    changed.push_back(seq); lists.push_back(st->seq_windows[seq]);
+    return lists.back();
+  };
+  uint64_t dropped_residues = 0, dropped_windows = 0;
+  std::vector<uint32_t> order(n);
+  for (uint32_t k = 0; k < n; ++k) order[k] = k;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return win[a].seq_index != win[b].seq_index ? win[a].seq_index < win[b].seq_index : win[a].first < win[b].first; });
+  uint32_t cur_seq = 0xFFFFFFFFu;
+  std::vector<uint4>* cur = nullptr;
+  for (uint32_t oi = 0; oi < n; ++oi) {
+    const uint32_t k = order[oi];
+    if (win[k].seq_index != cur_seq) {  // (windows of one sequence are consecutive in `order`: one lookup per sequence)
+      cur_seq = win[k].seq_index;
+      changed.push_back(cur_seq); lists.push_back(st->seq_windows[cur_seq]);
+      cur = &lists.back();
+    }
+    const uint64_t a = win[k].first, b = a + win[k].n;
+    std::vector<uint4> kept;
+    kept.reserve(cur->size() + 1);
+    for (const uint4& x : *cur) {
+      const uint64_t xa = x.x, xb = (uint64_t)x.x + x.y;
+      if (xb <= a || xa >= b) kept.push_back(x);
+      else if (xa >= a && xb <= b) { dropped_residues += x.y; ++dropped_windows; }
+      else return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: window %u (sequence %u, residues %llu..%llu) overlaps a resident window partly", k, cur_seq, (unsigned long long)a, (unsigned long long)b);
+    }
+    kept.push_back(make_uint4((uint32_t)a, (uint32_t)win[k].n, 0xFFFFFFFFu, k));  // arena offset filled in below (.w = window number for now)
+    std::sort(kept.begin(), kept.end(), [](const uint4& p, const uint4& q) { return p.x < q.x; });
+    cur->swap(kept);
+  }
+  (void)list_of;
+  HIP_TRY(e, hipSetDevice(e->device));
+  quiesce_slots(e);  // the arena and the pool may move: no job may be reading them
+  const uint64_t total = offsets[n];
+  uint64_t first = 0;
+  int rc = store_grow(e, st, total, &first);
+  if (rc) return rc;
+  const int bits = e->params.alphabet == RPA_DNA ? 4 : 8;
+  HIP_TRY(e, e->tmp_letters.ensure((size_t)total + 8));
+  HIP_TRY(e, hipMemcpyAsync(e->tmp_letters.p, letters, (size_t)total, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, launch_pack_letters(e->stream, e->params.alphabet, e->tmp_letters.as<const uint8_t>(), total, st->words.as<uint32_t>() + kLeadWords + first * bits / 32));
+  // the changed lists go to the end of the pool
+  uint64_t need = 0;
+  for (auto& l : lists) need += l.size();
+  if (st->pool_used + need > st->pool_cap) {
+    uint64_t cap = st->pool_cap ? st->pool_cap : 1024;
+    while (cap < st->pool_used + need) cap *= 2;
+    DevBuf bigger;
+    HIP_TRY(e, bigger.ensure((size_t)cap * sizeof(uint4)));
+    if (st->pool_used) HIP_TRY(e, hipMemcpyAsync(bigger.p, st->win_pool.p, (size_t)st->pool_used * sizeof(uint4), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    st->win_pool.release();
+    st->win_pool = bigger;
+    st->pool_cap = st->win_pool.cap / sizeof(uint4);
+  }
+  std::vector<uint4> flat;
+  flat.reserve((size_t)need);
+  std::vector<uint32_t> firsts(changed.size()), counts(changed.size());
+  for (size_t c = 0; c < changed.size(); ++c) {
+    firsts[c] = (uint32_t)(st->pool_used + flat.size());
+    counts[c] = (uint32_t)lists[c].size();
+    for (uint4& x : lists[c]) {
+      if (x.z == 0xFFFFFFFFu) {  // a window of this call: where its residues went
+        const uint64_t at = first + offsets[x.w];
+        x.z = (uint32_t)at; x.w = (uint32_t)(at >> 32);
+      }
+      flat.push_back(x);
+    }
+  }
+  if (st->pool_used + flat.size() > 0xFFFFFFFFull) return fail(e, RPA_ERR_UNSUPPORTED, "rpa_store_append_windows: window pool exhausted (rpa_store_reset compacts it)");
+  HIP_TRY(e, hipMemcpyAsync(st->win_pool.as<uint4>() + st->pool_used, flat.data(), flat.size() * sizeof(uint4), hipMemcpyHostToDevice, e->stream));
+  const size_t nc = changed.size();
+  HIP_TRY(e, st->tmp_index.ensure(nc * 4)); HIP_TRY(e, st->tmp_a.ensure(nc * 4)); HIP_TRY(e, st->tmp_b.ensure(nc * 4));
+  HIP_TRY(e, hipMemcpyAsync(st->tmp_index.p, changed.data(), nc * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(st->tmp_a.p, firsts.data(), nc * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(st->tmp_b.p, counts.data(), nc * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, launch_store_window_lists(e->stream, st->tmp_index.as<const uint32_t>(), st->tmp_a.as<const uint32_t>(), st->tmp_b.as<const uint32_t>(), (uint32_t)nc,
+                                       st->extent.as<ulonglong2>(), st->win_count.as<uint32_t>()));
+  RPA_WHERE("rpa_store_append_windows: sync");
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  // commit
+  st->pool_used += flat.size();
+  for (size_t c = 0; c < nc; ++c) {
+    if (st->seq_windows[changed[c]].empty() && !lists[c].empty()) ++st->n_resident;
+    st->seq_windows[changed[c]].swap(lists[c]);
+  }
+  st->n_residues = first + total;
+  st->n_windows += n; st->n_windows -= dropped_windows;
+  st->live_residues += total; st->live_residues -= dropped_residues;
+  return RPA_OK;
+}
+
+int rpa_store_reset(rpa_engine* e, int which) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_reset: bad store id");
+  Store* st = &e->stores[which];
+  if (!st->loaded) return fail(e, RPA_ERR_INVALID, "rpa_store_reset: nothing to reset");
+  HIP_TRY(e, hipSetDevice(e->device));
+  quiesce_slots(e);
+  // nothing resident any more: the arena and the window pool are refilled from their start (their memory is kept)
+  st->n_residues = 0; st->n_resident = 0; st->pool_used = 0; st->n_windows = 0; st->live_residues = 0;
+  if (st->windowed) {
+    for (auto& l : st->seq_windows) l.clear();
+    HIP_TRY(e, hipMemsetAsync(st->win_count.p, 0, (size_t)(st->n_seqs ? st->n_seqs : 1) * 4, e->stream));
+  } else {
+    HIP_TRY(e, hipMemsetAsync(st->extent.p, 0, (size_t)(st->n_seqs ? st->n_seqs : 1) * sizeof(ulonglong2), e->stream));
+  }
+  RPA_WHERE("rpa_store_reset: sync");
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return RPA_OK;
+}
+
 int rpa_store_info_get(rpa_engine* e, int which, rpa_store_info* out) {
   if (!e || !out) return RPA_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);
   if (which != RPA_STORE_QUERY && which != RPA_STORE_DB) return fail(e, RPA_ERR_INVALID, "rpa_store_info_get: bad store id");
   const Store& st = e->stores[which];
   out->n_seqs = st.n_seqs; out->n_resident = st.n_resident; out->residues = st.n_residues;
-  out->device_bytes = (uint64_t)st.words.cap + st.extent.cap;
+  out->device_bytes = (uint64_t)st.words.cap + st.extent.cap + st.win_pool.cap + st.win_count.cap;
+  out->windows = st.windowed ? st.n_windows : st.n_resident;
+  out->live_residues = st.windowed ? st.live_residues : st.n_residues;
   return RPA_OK;
 }
 

@@ -89,6 +89,34 @@ hipError_t launch_store_extents(hipStream_t st, const uint64_t* offsets, const u
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(kBlock) void k_store_lengths(const uint64_t* __restrict__ lengths, uint32_t n, ulonglong2* __restrict__ extent,
+                                                          uint32_t* __restrict__ win_count) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  extent[k] = make_ulonglong2(0ull, lengths[k]);
+  win_count[k] = 0u;
+}
+hipError_t launch_store_lengths(hipStream_t st, const uint64_t* lengths, uint32_t n, ulonglong2* extent, uint32_t* win_count) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_store_lengths, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, lengths, n, extent, win_count);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(kBlock) void k_store_window_lists(const uint32_t* __restrict__ index, const uint32_t* __restrict__ first,
+                                                               const uint32_t* __restrict__ count, uint32_t n, ulonglong2* __restrict__ extent,
+                                                               uint32_t* __restrict__ win_count) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t i = index[k];
+  extent[i].x = first[k];
+  win_count[i] = count[k];
+}
+hipError_t launch_store_window_lists(hipStream_t st, const uint32_t* index, const uint32_t* first, const uint32_t* count, uint32_t n,
+                                     ulonglong2* extent, uint32_t* win_count) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_store_window_lists, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, index, first, count, n, extent, win_count);
+  return hipGetLastError();
+}
+
 // A few words from device memory into host-mapped (pinned) memory by a kernel instead of a copy command: the per-round
 // counter read-back of the placement loop then never meets another job's 80 MB host->device transfers on a copy queue.
 // (Measured: no change by itself -- what stalled jobs in flight were pooled hardware queues, see make_stream in

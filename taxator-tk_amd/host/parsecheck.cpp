@@ -3,6 +3,7 @@
 // "objects" = AlignmentRecordFactory + RecordSetGenerator (the mirror of the reference's object model), "columnar" =
 // ColumnarReader.  Both print one line per record set and per record and, on failure, "ERROR <text>" (exit code 1), so
 // that tests can require identical bytes from the two (no GPU involved).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +44,21 @@ static int fasta_check(const char* fasta, const char* fai) {
       if (buf[(size_t)idx.length(i)] != 0xEE || memcmp(buf.data(), mem.letters().data() + mem.offsets()[i], (size_t)mem.length(i)) != 0) {
         printf("MISMATCH residues of %s\n", mem.ids()[i].c_str());
         return 1;
+      }
+      // regions (readRegion, faidx.h:322-350): the ends, single residues, line boundaries and a few pseudo-random cuts
+      const uint64_t len = idx.length(i);
+      uint64_t x = 88172645463325252ull + i;
+      for (int k = 0; k < 24 && len; ++k) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        uint64_t first = k == 0 ? 0 : k == 1 ? len - 1 : x % len;
+        uint64_t n = k == 0 ? len : k == 1 ? 1 : 1 + (x >> 20) % (len - first);
+        if (k >= 2 && k < 8) { first = std::min<uint64_t>(len - 1, (uint64_t)(k - 2) * 30); n = std::min<uint64_t>(len - first, 59 + k); }  // around 60 / 61-column line ends
+        buf.assign((size_t)n + 1, 0xEE);
+        idx.fetch_region(i, first, n, buf.data());
+        if (buf[(size_t)n] != 0xEE || memcmp(buf.data(), mem.letters().data() + mem.offsets()[i] + first, (size_t)n) != 0) {
+          printf("MISMATCH region %llu+%llu of %s\n", (unsigned long long)first, (unsigned long long)n, mem.ids()[i].c_str());
+          return 1;
+        }
       }
       total += mem.length(i);
     }

@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -172,6 +173,44 @@ void SequenceStore::fetch(uint32_t i, uint8_t* dst) const {
   for (; remaining && p < end; ++p) {  // irregular lines: every non-blank byte up to `length` of them (faidx.h:340-347)
     const char c = *p;
     if (c == '\n' || c == '\r' || c == ' ' || c == '\t') continue;
+    *dst++ = (uint8_t)c;
+    --remaining;
+  }
+  if (remaining) throw ParsingError("fasta file ends inside sequence " + ids_[i]);
+}
+
+void SequenceStore::fetch_region(uint32_t i, uint64_t first, uint64_t n, uint8_t* dst) const {
+  const FaiEntry& e = entries_[i];
+  if (first + n > e.length) throw SequenceRangeError("region beyond the end of sequence " + ids_[i]);
+  const char* end = map_ + map_len_;
+  uint64_t remaining = n;
+  if (e.linebases) {
+    uint64_t col = first % e.linebases;  // residues to skip on the first line
+    const char* p = map_ + e.offset + (first / e.linebases) * (uint64_t)e.linewidth;
+    while (remaining) {
+      const uint64_t take = std::min<uint64_t>(remaining, e.linebases - col);
+      if (p + col + take > end) throw ParsingError("fasta index points beyond the end of the fasta file (sequence " + ids_[i] + ")");
+      const char* s = p + col;
+      if (memchr(p, ' ', col + take) || memchr(p, '\t', col + take) || memchr(p, '\n', col + take) || memchr(p, '\r', col + take))
+        break;  // this line is not what the index says: count residues from the start of the record instead (below)
+      memcpy(dst, s, take);
+      dst += take; remaining -= take; first += take; col = 0; p += e.linewidth;
+    }
+    if (!remaining) return;
+  }
+  // irregular lines (or a line that broke the index's promise): skip `first` non-blank bytes from the start of the
+  // record, then take the rest -- the reference's readRegion does the same from the line the index points at
+  uint64_t skip = first;
+  const char* p = map_ + e.offset;
+  if (e.linebases) {  // regular up to the line that failed: jump to its start
+    const uint64_t line = first / e.linebases;
+    p += line * (uint64_t)e.linewidth;
+    skip = first - line * e.linebases;
+  }
+  for (; remaining && p < end; ++p) {
+    const char c = *p;
+    if (c == '\n' || c == '\r' || c == ' ' || c == '\t') continue;
+    if (skip) { --skip; continue; }
     *dst++ = (uint8_t)c;
     --remaining;
   }

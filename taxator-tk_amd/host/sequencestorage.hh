@@ -46,6 +46,10 @@ class SequenceStore {
   // indexed stores only: the length(i) residues of sequence i, blanks and line ends removed (what readRegion returns
   // for the whole sequence, faidx.h:336-348); thread-safe
   void fetch(uint32_t i, uint8_t* dst) const;
+  // ... and a region of it: the n residues from residue `first` (0-based) on, i.e. readRegion(first, first + n)
+  // (faidx.h:322-350: seek to offset + (first / linebases) * linewidth + first % linebases, then take n non-blank bytes);
+  // thread-safe.  The caller keeps first + n <= length(i).
+  void fetch_region(uint32_t i, uint64_t first, uint64_t n, uint8_t* dst) const;
 
  private:
   struct FaiEntry { uint64_t length, offset; uint32_t linebases, linewidth; };  // linebases == 0: irregular lines, scan

@@ -62,6 +62,8 @@ struct Options {
   std::vector<int> devices;  // --devices a,b,...; empty: --device
   int device = 0;
   bool timing = false;
+  double store_gb = 0;       // --store-gb: HBM budget per indexed store and engine (0 = none)
+  uint64_t store_tile = 0;   // --store-tile: residues per tile of the indexed stores (0 = 65536)
   size_t batch = 0;  // 0: one GPU call per parsed block (columnar path) / 65536 record sets (record-object path)
 };
 
@@ -82,7 +84,10 @@ static void usage(std::ostream& o) {
        "            tree: up to 63 levels below the root),\n"
        "            -x heuristic-cutoff (=0.5), -t toppercent (=0.05), -e max-evalue (=1000), -c min-support (=1), -m minscore (=0),\n"
        "            -n nbest (=1), -u ignore-unclassified, --device N (=0), --devices a,b,... (several GPUs), --batch N (record sets per GPU call),\n"
-       "            --block-mb N (=128, input block parsed at a time), --timing, --record-objects (per-record object loop)\n";
+       "            --block-mb N (=128, input block parsed at a time), --timing, --record-objects (per-record object loop),\n"
+       "            --store-gb G (HBM budget of an indexed store, -i / -v: when the resident regions would outgrow it the store is\n"
+       "            emptied and refilled with what the block at hand needs; 0 = no limit), --store-tile N (=65536 residues: the\n"
+       "            granularity at which regions of a sequence become resident)\n";
 }
 
 namespace {
@@ -322,6 +327,8 @@ static int run(int argc, char** argv) {
     else if (a == "--timing") o.timing = true;
     else if (a == "--record-objects") o.record_objects = true;
     else if (a == "--block-mb") o.block_mb = atof(val("--block-mb").c_str());
+    else if (a == "--store-gb") o.store_gb = atof(val("--store-gb").c_str());
+    else if (a == "--store-tile") o.store_tile = (uint64_t)atoll(val("--store-tile").c_str());
     else if (a == "--batch") o.batch = (size_t)atoll(val("--batch").c_str());
     else if (a == "-r" || a == "--ranks") { while (i + 1 < argc && argv[i + 1][0] != '-') o.ranks.push_back(argv[++i]); }
     else { std::cerr << "unrecognised option '" << a << "'" << std::endl; return EXIT_FAILURE; }
@@ -397,6 +404,8 @@ static int run(int argc, char** argv) {
     for (int dev : o.devices) {
       engines.emplace_back(new RPAPredictionModel(tax.get(), query_storage, db_storage, o.filterout, o.toppercent, o.dataformat == "protein", dev));
       engines.back()->setHostThreads(std::max(1u, host_threads / (unsigned)o.devices.size()));
+      if (o.store_tile) engines.back()->setTile(o.store_tile);
+      if (o.store_gb > 0) engines.back()->setStoreBudget((uint64_t)(o.store_gb * 1073741824.0));
     }
     RPAPredictionModel& rpa = *engines[0];
     const Clock::time_point t_loaded = Clock::now();
@@ -405,7 +414,8 @@ static int run(int argc, char** argv) {
       for (int which = 0; which < 2; ++which) {
         const rpa_store_info si = rpa.storeInfo(which == 0 ? RPA_STORE_QUERY : RPA_STORE_DB);
         std::cerr << "STORE\t" << (which == 0 ? "query" : "ref") << "\t" << ((which == 0 ? query_storage : db_storage).indexed() ? "indexed" : "in-memory")
-                  << "\tsequences=" << si.n_seqs << "\tresident=" << si.n_resident << "\tresidues=" << si.residues << "\tdevice_bytes=" << si.device_bytes << std::endl;
+                  << "\tsequences=" << si.n_seqs << "\tresident=" << si.n_resident << "\tresidues=" << si.residues << "\tdevice_bytes=" << si.device_bytes
+                  << "\twindows=" << si.windows << "\tlive_residues=" << si.live_residues << std::endl;
       }
     };
     if (!o.record_objects) {

@@ -26,6 +26,7 @@ RPAPredictionModel::RPAPredictionModel(const Taxonomy* tax, const SequenceStore&
                                        float exclude_factor, float reeval_bandwidth, bool protein, int device)
     : TaxonPredictionModel(tax), query_sequences_(q_storage), db_sequences_(db_storage) {
   rpa_taxonomy t{(uint32_t)tax->size(), tax->parent.data(), tax->left.data(), tax->right.data(), tax->depth.data()};
+  rpa_store_bits_ = protein ? 8 : 4;
   rpa_params p;
   rpa_default_params(&p);
   p.alphabet = protein ? RPA_PROTEIN : RPA_DNA;
@@ -40,9 +41,10 @@ RPAPredictionModel::RPAPredictionModel(const Taxonomy* tax, const SequenceStore&
   const int which[2] = {RPA_STORE_QUERY, RPA_STORE_DB};
   for (int k = 0; k < 2; ++k) {
     const SequenceStore& st = *stores[k];
-    if (st.indexed()) {  // nothing resident yet: sequences come in as the alignment stream refers to them
-      check(created, rpa_store_reserve(created, which[k], st.size()));
-      resident_[which[k]].assign(st.size(), 0);
+    if (st.indexed()) {  // nothing resident yet: regions come in as the alignment stream refers to them (makeResident)
+      std::vector<uint64_t> lengths(st.size());
+      for (uint32_t i = 0; i < st.size(); ++i) lengths[i] = st.length(i);
+      check(created, rpa_store_reserve_windows(created, which[k], st.size(), lengths.data()));
     } else {
       check(created, rpa_store_load(created, which[k], st.size(), st.letters().data(), st.offsets().data(), RPA_MEM_HOST));
     }
@@ -50,67 +52,163 @@ RPAPredictionModel::RPAPredictionModel(const Taxonomy* tax, const SequenceStore&
   engine_ = guard.release();
 }
 
-size_t RPAPredictionModel::makeResident(int which, const uint32_t* idx, size_t n) {
-  const SequenceStore& st = which == RPA_STORE_QUERY ? query_sequences_ : db_sequences_;
-  if (!st.indexed() || n == 0) return 0;
+namespace {
+inline bool bit(const std::vector<uint64_t>& v, uint64_t i) { return (v[i >> 6] >> (i & 63)) & 1ull; }
+inline void set_bit(std::vector<uint64_t>& v, uint64_t i) { v[i >> 6] |= 1ull << (i & 63); }
+}  // namespace
+
+size_t RPAPredictionModel::makeResident(const rpa_batch& b) {
+  if ((!query_sequences_.indexed() && !db_sequences_.indexed()) || b.n_sets == 0) return 0;
   std::lock_guard<std::mutex> resident_lock(resident_mu_);
-  std::vector<uint8_t>& res = resident_[which];
-  // candidates: every host thread scans a slice of the indices against the (read-only) residency marks ...
-  const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, n / 65536 + 1));
-  std::vector<std::vector<uint32_t>> cand(T);
-  std::vector<uint8_t> out_of_range(T, 0);  // (an exception must not leave a helper thread: noted, thrown after the join)
-  auto scan = [&](unsigned t) {
-    const size_t lo = n * t / T, hi = n * (t + 1) / T;
-    uint32_t last = 0xFFFFFFFFu;
-    for (size_t k = lo; k < hi; ++k) {
-      const uint32_t i = idx[k];
-      if (i == last) continue;
-      last = i;
-      if (i >= res.size()) { out_of_range[t] = 1; return; }
-      if (!res[i]) cand[t].push_back(i);
+  // how far a hit's reference range can be extended: by the width of its record set's query range (:523; the range of
+  // ALL records of the set here, masked ones included: an upper bound)
+  std::vector<uint32_t> span(b.n_sets, 0);
+  {
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, b.n_sets / 16384 + 1));
+    auto work = [&](unsigned t) {
+      for (size_t s = (size_t)b.n_sets * t / T; s < (size_t)b.n_sets * (t + 1) / T; ++s) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        for (uint32_t r = b.set_offsets[s]; r < b.set_offsets[s + 1]; ++r) { lo = std::min(lo, b.qstart[r]); hi = std::max(hi, b.qstop[r]); }
+        span[s] = hi >= lo ? hi - lo : 0;
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+  }
+  size_t loaded = 0;
+  if (query_sequences_.indexed()) loaded += makeResidentStore(RPA_STORE_QUERY, b, span);
+  if (db_sequences_.indexed()) loaded += makeResidentStore(RPA_STORE_DB, b, span);
+  return loaded;
+}
+
+// One store.  Pass 1 (all host threads): every region the batch reads -> the tiles under it; a tile that is not resident
+// is noted in the thread's own bit set.  Pass 2: the union of those, grown to whole runs of (resident or needed) tiles --
+// a new window swallows the resident windows it touches, so that resident windows never sit side by side and "all tiles
+// of a region resident" means "one window holds the region".  Pass 3: fetch and append.
+size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, const std::vector<uint32_t>& span) {
+  const SequenceStore& st = which == RPA_STORE_QUERY ? query_sequences_ : db_sequences_;
+  std::vector<uint64_t>& base = tile_base_[which];
+  std::vector<uint64_t>& res = resident_[which];
+  if (base.empty()) {
+    base.assign((size_t)st.size() + 1, 0);
+    for (uint32_t i = 0; i < st.size(); ++i) base[i + 1] = base[i] + (st.length(i) + tile_ - 1) / tile_;
+    res.assign((size_t)(base.back() + 63) / 64 + 1, 0);
+  }
+  const uint64_t n_tiles = base.back();
+  const size_t n_units = which == RPA_STORE_QUERY ? b.n_sets : b.n_records;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, n_units / 65536 + 1));
+    std::vector<std::vector<uint64_t>> need(T);
+    std::vector<uint8_t> out_of_range(T, 0), any(T, 0);
+    auto scan = [&](unsigned t) {
+      std::vector<uint64_t>& mine = need[t];
+      auto region = [&](uint32_t seq, uint64_t first, uint64_t end) {  // residues [first, end) of sequence seq, already clipped
+        if (end <= first) return;
+        const uint64_t t0 = base[seq] + first / tile_, t1 = base[seq] + (end - 1) / tile_;
+        for (uint64_t k = t0; k <= t1; ++k)
+          if (!bit(res, k)) {
+            if (mine.empty()) mine.assign(res.size(), 0);
+            set_bit(mine, k);
+            any[t] = 1;
+          }
+      };
+      if (which == RPA_STORE_QUERY) {
+        for (size_t s = (size_t)b.n_sets * t / T; s < (size_t)b.n_sets * (t + 1) / T; ++s) {
+          const uint32_t seq = b.query_seq[s];
+          if (seq >= st.size()) { out_of_range[t] = 1; return; }
+          uint32_t lo = 0xFFFFFFFFu, hi = 0;
+          for (uint32_t r = b.set_offsets[s]; r < b.set_offsets[s + 1]; ++r) { lo = std::min(lo, b.qstart[r]); hi = std::max(hi, b.qstop[r]); }
+          if (hi < lo || lo == 0) continue;
+          region(seq, lo - 1, std::min<uint64_t>(hi, st.length(seq)));
+        }
+      } else {
+        for (size_t s = (size_t)b.n_sets * t / T; s < (size_t)b.n_sets * (t + 1) / T; ++s) {
+          const uint64_t ext = span[s];
+          for (uint32_t r = b.set_offsets[s]; r < b.set_offsets[s + 1]; ++r) {
+            const uint32_t seq = b.ref_seq[r];
+            if (seq >= st.size()) { out_of_range[t] = 1; return; }
+            const uint64_t lo = std::min(b.rstart[r], b.rstop[r]), hi = std::max(b.rstart[r], b.rstop[r]);
+            if (lo == 0) continue;
+            const uint64_t first = lo - 1 > ext ? lo - 1 - ext : 0;
+            region(seq, first, std::min<uint64_t>(hi + ext, st.length(seq)));
+          }
+        }
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < T; ++t) th.emplace_back(scan, t);
+      scan(0);
+      for (auto& x : th) x.join();
     }
-  };
-  {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; ++t) th.emplace_back(scan, t);
-    scan(0);
-    for (auto& x : th) x.join();
-  }
-  for (uint8_t bad : out_of_range)
-    if (bad) throw SequenceNotFound("sequence index outside the store");
-  // ... then one pass lists them (a sequence several threads found is taken once); they are marked resident only when the
-  // engine has them, so a fetch that fails leaves nothing half done
-  std::vector<uint32_t> need;
-  for (auto& c : cand)
-    for (uint32_t i : c)
-      if (!res[i]) { res[i] = 2; need.push_back(i); }  // 2 = listed in this call
-  auto unlist = [&] { for (uint32_t i : need) res[i] = 0; };
-  if (need.empty()) return 0;
-  fetch_offsets_.assign(need.size() + 1, 0);
-  for (size_t k = 0; k < need.size(); ++k) fetch_offsets_[k + 1] = fetch_offsets_[k] + st.length(need[k]);
-  fetch_letters_.resize((size_t)fetch_offsets_.back() + 8);
-  const unsigned F = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, need.size()));
-  std::exception_ptr err;
-  std::mutex err_mu;
-  auto fetch = [&](unsigned t) {  // slices of equal residue count, not of equal sequence count
+    for (uint8_t bad : out_of_range)
+      if (bad) throw SequenceNotFound("sequence index outside the store");
+    std::vector<uint64_t> want;
+    for (unsigned t = 0; t < T; ++t) {
+      if (!any[t]) continue;
+      if (want.empty()) want.swap(need[t]);
+      else for (size_t k = 0; k < want.size(); ++k) want[k] |= need[t][k];
+    }
+    if (want.empty()) return 0;
+    // runs of (resident | wanted) tiles that hold a wanted tile, sequence by sequence
+    std::vector<rpa_window> wins;
+    fetch_offsets_.assign(1, 0);
+    for (size_t wi = 0; wi < want.size(); ++wi) {
+      uint64_t word = want[wi];
+      while (word) {
+        const uint64_t k = (uint64_t)wi * 64 + (uint64_t)__builtin_ctzll(word);
+        word &= word - 1;
+        if (k >= n_tiles) break;
+        const uint32_t seq = (uint32_t)(std::upper_bound(base.begin(), base.end(), k) - base.begin() - 1);
+        if (!wins.empty() && wins.back().seq_index == seq && k < base[seq] + (wins.back().first + wins.back().n + tile_ - 1) / tile_) continue;  // inside the run just made
+        uint64_t a = k, e = k + 1;
+        while (a > base[seq] && (bit(res, a - 1) || bit(want, a - 1))) --a;
+        while (e < base[seq + 1] && (bit(res, e) || bit(want, e))) ++e;
+        rpa_window w{};
+        w.seq_index = seq;
+        w.first = (a - base[seq]) * tile_;
+        w.n = std::min<uint64_t>((e - base[seq]) * tile_, st.length(seq)) - w.first;
+        wins.push_back(w);
+        fetch_offsets_.push_back(fetch_offsets_.back() + w.n);
+      }
+    }
     const uint64_t total = fetch_offsets_.back();
-    const size_t lo = std::lower_bound(fetch_offsets_.begin(), fetch_offsets_.end() - 1, total * t / F) - fetch_offsets_.begin();
-    const size_t hi = t + 1 == F ? need.size() : std::lower_bound(fetch_offsets_.begin(), fetch_offsets_.end() - 1, total * (t + 1) / F) - fetch_offsets_.begin();
-    try { for (size_t k = lo; k < hi; ++k) st.fetch(need[k], fetch_letters_.data() + fetch_offsets_[k]); }
-    catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
-  };
-  {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < F; ++t) th.emplace_back(fetch, t);
-    fetch(0);
-    for (auto& x : th) x.join();
+    if (store_budget_ && attempt == 0) {
+      const rpa_store_info info = storeInfo(which);
+      const uint64_t half_bytes = rpa_store_bits_ / 4;  // per residue: 4-bit DNA = 1 half byte, 8-bit protein = 2
+      if ((info.residues + total) * half_bytes / 2 > store_budget_ && info.residues) {
+        // the store would outgrow its budget: drop everything resident and start over with what this batch needs
+        check(engine_, rpa_store_reset(engine_, which));
+        std::fill(res.begin(), res.end(), 0);
+        continue;
+      }
+    }
+    if (store_budget_ && total * (rpa_store_bits_ / 4) / 2 > store_budget_)
+      throw GeneralError("one block of the alignment stream needs more sequence than --store-gb allows: use smaller blocks (--block-mb) or a larger budget");
+    fetch_letters_.resize((size_t)total + 8);
+    const unsigned F = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, wins.size()));
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto fetch = [&](unsigned t) {  // slices of equal residue count, not of equal window count
+      const size_t lo = std::lower_bound(fetch_offsets_.begin(), fetch_offsets_.end() - 1, total * t / F) - fetch_offsets_.begin();
+      const size_t hi = t + 1 == F ? wins.size() : std::lower_bound(fetch_offsets_.begin(), fetch_offsets_.end() - 1, total * (t + 1) / F) - fetch_offsets_.begin();
+      try { for (size_t k = lo; k < hi; ++k) st.fetch_region(wins[k].seq_index, wins[k].first, wins[k].n, fetch_letters_.data() + fetch_offsets_[k]); }
+      catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+    };
+    {
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < F; ++t) th.emplace_back(fetch, t);
+      fetch(0);
+      for (auto& x : th) x.join();
+    }
+    if (err) std::rethrow_exception(err);
+    check(engine_, rpa_store_append_windows(engine_, which, (uint32_t)wins.size(), wins.data(), fetch_letters_.data(), fetch_offsets_.data()));
+    for (size_t k = 0; k < want.size(); ++k) res[k] |= want[k];  // marked resident only now that the engine has them
+    return wins.size();
   }
-  if (err) { unlist(); std::rethrow_exception(err); }
-  try {
-    check(engine_, rpa_store_append(engine_, which, (uint32_t)need.size(), need.data(), fetch_letters_.data(), fetch_offsets_.data()));
-  } catch (...) { unlist(); throw; }
-  for (uint32_t i : need) res[i] = 1;
-  return need.size();
+  return 0;
 }
 
 void RPAPredictionModel::pinHost(void* p, size_t bytes) const { check(engine_, rpa_host_register(engine_, p, bytes)); }
@@ -152,8 +250,7 @@ void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, s
   b.filtered = filtered_.data(); b.mem_kind = RPA_MEM_HOST;
   rows_.resize(S);
   stats_.resize(S);
-  makeResident(RPA_STORE_QUERY, query_seq_.data(), query_seq_.size());
-  makeResident(RPA_STORE_DB, ref_seq_.data(), ref_seq_.size());
+  makeResident(b);
   check(engine_, rpa_predict_batch(engine_, &b, rows_.data(), stats_.data(), RPA_MEM_HOST));
   for (size_t s = 0; s < S; ++s) {
     const rpa_prediction& r = rows_[s];
@@ -187,8 +284,7 @@ void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size
   b.rstop = cb.rec.rstop.data() + base; b.score = cb.rec.score.data() + base; b.identities = cb.rec.identities.data() + base;
   b.alnlen = cb.rec.alnlen.data() + base; b.ref_seq = cb.rec.ref_seq.data() + base; b.node = cb.rec.node.data() + base;
   b.filtered = cb.rec.filtered.data() + base; b.mem_kind = RPA_MEM_HOST;
-  makeResident(RPA_STORE_QUERY, b.query_seq, b.n_sets);
-  makeResident(RPA_STORE_DB, b.ref_seq, b.n_records);
+  makeResident(b);
   // asynchronous boundary: the engine runs two jobs at a time, the copies of one under the kernels of the other
   rpa_job* job = nullptr;
   check(engine_, rpa_submit_batch(engine_, &b, rows, stats, &job));

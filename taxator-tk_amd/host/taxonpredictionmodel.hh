@@ -38,12 +38,19 @@ class RPAPredictionModel : public TaxonPredictionModel {
   // The same call for record sets that are already in columns (columnar.hh): sets [lo, hi) of `batch`, rows and STATS
   // counters written to rows[0 .. hi-lo) / stats[0 .. hi-lo).  No per-record objects on this path.
   void predictColumns(const struct ColumnarBatch& batch, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats);
-  // Indexed stores (taxator -i / -v): make the sequences idx[0..n) of store `which` (RPA_STORE_QUERY / RPA_STORE_DB)
-  // resident in this engine's HBM if they are not yet -- fetched through the .fai from the mapped FASTA by `threads`
-  // host threads, appended with rpa_store_append.  predict() / predictColumns() call it for what their batch refers to;
-  // a no-op for in-memory stores.  Returns the number of sequences that had to be loaded.
-  size_t makeResident(int which, const uint32_t* idx, size_t n);
+  // Indexed stores (taxator -i / -v): make every REGION the batch refers to resident in this engine's HBM if it is not yet
+  // -- the reference reads exactly [start, stop] of a sequence through the .fai (sequencestorage.hh:341-369); here a
+  // sequence is cut into tiles (65536 residues unless setTile says otherwise) and the tiles under a hit's range, extended
+  // by its record set's query range, become resident: fetched from the mapped FASTA by the host threads and appended as
+  // windows (rpa_store_append_windows), merged with the resident windows they touch so that any segment lies in one
+  // window.  HBM and load time follow the residues the stream touches, not the sequences, let alone the collection.
+  // With a budget (setStoreBudget, taxator --store-gb) a store that would outgrow it is emptied first (rpa_store_reset)
+  // and refilled with what the batch at hand needs.  predict() / predictColumns() call it; a no-op for in-memory stores.
+  // Returns the number of windows that had to be loaded.
+  size_t makeResident(const rpa_batch& b);
   void setHostThreads(unsigned t) { threads_ = t ? t : 1; }
+  void setTile(uint64_t residues) { tile_ = residues ? residues : 65536; }       // before the first batch
+  void setStoreBudget(uint64_t bytes) { store_budget_ = bytes; }                  // 0 = no limit; per store
   rpa_store_info storeInfo(int which) const;
   // page-lock / release host arrays that are handed to predictColumns() again and again (rpa_host_register)
   void pinHost(void* p, size_t bytes) const;
@@ -51,7 +58,13 @@ class RPAPredictionModel : public TaxonPredictionModel {
  private:
   const SequenceStore& query_sequences_;
   const SequenceStore& db_sequences_;
-  std::vector<uint8_t> resident_[2];   // per store: sequence already appended to this engine
+  // per indexed store: tiles of every sequence, numbered consecutively (tile_base_[i] = first tile of sequence i); a
+  // tile's bit says "resident".  Resident windows are the maximal runs of resident tiles inside a sequence.
+  std::vector<uint64_t> tile_base_[2];
+  std::vector<uint64_t> resident_[2];
+  uint64_t tile_ = 65536, store_budget_ = 0;
+  unsigned rpa_store_bits_ = 4;  // packed bits per residue in the engine (DNA 4, protein 8): what a residue costs against the budget
+  size_t makeResidentStore(int which, const rpa_batch& b, const std::vector<uint32_t>& span);
   std::vector<uint8_t> fetch_letters_;
   std::vector<uint64_t> fetch_offsets_;
   unsigned threads_ = 1;

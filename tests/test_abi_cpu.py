@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(pkg):
     lib = pkg.load_library()
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.rpa_abi_version() == 2
+    assert lib.rpa_abi_version() == 3
 
 
 def test_struct_layouts_match_header(pkg):

@@ -189,9 +189,81 @@ def test_cli_indexed_store_loads_only_what_the_stream_touches(oracle, tmp_path):
     kind, ref_idx = store(idx.stderr, "ref")
     touched = len(set(int(x) for x in ds.batch["ref_seq"]))
     assert kind == "indexed" and ref_idx["sequences"] == len(names) * 101 and ref_idx["resident"] == touched
-    assert ref_idx["residues"] * 20 < ref_mem["residues"] and ref_idx["device_bytes"] * 10 < ref_mem["device_bytes"]
+    assert ref_idx["residues"] * 20 < ref_mem["residues"] and ref_idx["device_bytes"] * 5 < ref_mem["device_bytes"]  # (tables of 6464 sequences: ~130 KB)
     kind, q_idx = store(idx.stderr, "query")
     assert kind == "indexed" and q_idx["resident"] <= q_idx["sequences"] == ds.n_sets
+
+
+def test_cli_region_granular_reads_of_long_references(tmp_path):
+    """SURVEY 8f N1 / the reference's RandomIndexedSeqstoreRO::getSequence (core/src/sequencestorage.hh:341-369,
+    core/src/faidx.h:315-350) reads [start, stop] of a sequence, not the sequence.  Here: one 50 Mbp reference and 63 of
+    300 kbp, each touched only where its species' ~1.5 kbp locus sits.  With -i the GFF3 must equal the in-memory run's byte
+    for byte while the resident residues follow the touched tiles, not the 69 Mbp of the collection; with a budget of
+    100 KB and batches of five record sets the store is emptied and refilled along the stream (--store-gb) and nothing changes."""
+    graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    ds = synth.make_dataset(n_sets=400, n_hits=8, seg_len=150, branching=2, genome_len=1500, seed=9, variety=True)
+    folder = str(tmp_path / "long")
+    synth.write_files(ds, folder)
+    rng = np.random.default_rng(2)
+    # every species' genome becomes a locus inside a long sequence of random filler
+    genomes, name = {}, None
+    for line in open(os.path.join(folder, "ref.fna")):
+        if line.startswith(">"): name = line[1:].strip(); genomes[name] = []
+        else: genomes[name].append(line.strip())
+    names = list(genomes)
+    shift = {}
+    with open(os.path.join(folder, "ref.fna"), "wb") as f, open(os.path.join(folder, "ref.fna.fai"), "w") as fai:
+        for k, nm in enumerate(names):
+            g = "".join(genomes[nm]).encode()
+            total = 50_000_000 if k == 0 else 300_000
+            at = int(rng.integers(total // 3, 2 * total // 3))
+            seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, total)]
+            seq[at:at + len(g)] = np.frombuffer(g, np.uint8)
+            shift[nm] = at
+            f.write(b">" + nm.encode() + b"\n")
+            off = f.tell()
+            full = total // 80
+            body = np.full((full, 81), ord("\n"), np.uint8)
+            body[:, :80] = seq[:full * 80].reshape(full, 80)
+            f.write(body.tobytes())
+            if total % 80:
+                f.write(seq[full * 80:].tobytes() + b"\n")
+            fai.write("%s\t%d\t%d\t80\t81\n" % (nm, total, off))
+    # the alignment rows move with their locus
+    rows = []
+    for line in open(os.path.join(folder, "aln.tsv")):
+        c = line.rstrip("\n").split("\t")
+        at = shift[c[4]]
+        c[5] = str(int(c[5]) + at); c[6] = str(int(c[6]) + at)
+        rows.append("\t".join(c))
+    open(os.path.join(folder, "aln.tsv"), "w").write("\n".join(rows) + "\n")
+    env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
+    base = [BIN, "-g", os.path.join(folder, "mapping.tax"), "-q", os.path.join(folder, "query.fna"), "-f", os.path.join(folder, "ref.fna"), "--timing"]
+    aln = os.path.join(folder, "aln.tsv")
+    mem = run_child(base, timeout=CHILD_LIMIT_S, stdin_path=aln, env=env)
+    idx = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai")], timeout=CHILD_LIMIT_S, stdin_path=aln, env=env)
+    fine = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "2048"], timeout=CHILD_LIMIT_S, stdin_path=aln, env=env)
+    tight = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "2048", "--store-gb", "0.0001", "--block-mb", "0.02", "--record-objects", "--batch", "5"],
+                      timeout=CHILD_LIMIT_S, stdin_path=aln, env=env)
+    for r in (mem, idx, fine, tight):
+        assert r.returncode == 0, r.stderr[-2000:]
+    assert idx.stdout == mem.stdout and fine.stdout == mem.stdout and tight.stdout == mem.stdout and mem.stdout.count("\n") > 400
+
+    def store(stderr):
+        line = [l for l in stderr.splitlines() if l.startswith("STORE\tref")][0].split("\t")
+        return line[2], {k: int(v) for k, v in (x.split("=") for x in line[3:])}
+    total = 50_000_000 + 63 * 300_000
+    kind, s_mem = store(mem.stderr)
+    assert kind == "in-memory" and s_mem["residues"] >= total
+    kind, s_idx = store(idx.stderr)
+    touched = len(set(int(x) for x in ds.batch["ref_seq"]))
+    assert kind == "indexed" and s_idx["resident"] == touched
+    assert s_idx["live_residues"] <= touched * 3 * 65536 and s_idx["live_residues"] < total // 5     # a tile or two per locus, not 69 Mbp
+    kind, s_fine = store(fine.stderr)
+    assert s_fine["live_residues"] <= touched * 4 * 2048 and s_fine["live_residues"] < total // 100 and s_fine["device_bytes"] < s_mem["device_bytes"] // 50
+    kind, s_tight = store(tight.stderr)
+    assert s_tight["residues"] * 0.5 <= 0.0001 * 2 ** 30 * 1.5 and s_tight["residues"] < s_fine["residues"]                                        # emptied and refilled along the stream
 
 
 @pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])

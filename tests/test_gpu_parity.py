@@ -565,6 +565,91 @@ def test_wide_path_labels(pkg, oracle, synth, bits, monkeypatch):
     _engine_vs_oracle(pkg, oracle, synth, ds, 0)
 
 
+def test_windowed_stores(pkg, oracle, synth):
+    """Region-granular residency through the C ABI (rpa_store_reserve_windows / rpa_store_append_windows / rpa_store_reset):
+    only the windows the batch reads are resident -- tile-aligned pieces of the reference sequences, appended in several
+    calls, later ones swallowing earlier ones -- and the rows equal those of whole resident stores.  A segment outside the
+    resident windows fails the batch; a window that overlaps a resident one partly is refused; after a reset the store
+    is refilled from its start."""
+    ds = synth.make_dataset(n_sets=600, n_hits=12, seg_len=150, branching=3, genome_len=3000, seed=51, variety=True)
+    full = pkg.RPAPredictionModel(ds.tax, alphabet=0)
+    full.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    full.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    want_rows, want_stats = full.predict(ds.batch)
+    b = ds.batch
+    roff = ds.ref_offsets.astype(np.int64)
+    rlen = np.diff(roff)
+    TILE = 256
+    m = pkg.RPAPredictionModel(ds.tax, alphabet=0)
+    m.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    m.reserve_windows(pkg.STORE_DB, rlen)
+    # the tiles under every hit's range extended by its record set's query range
+    set_of = np.repeat(np.arange(len(b["set_offsets"]) - 1), np.diff(b["set_offsets"].astype(np.int64)))
+    span = np.array([int(b["qstop"][lo:hi].max()) - int(b["qstart"][lo:hi].min()) if hi > lo else 0
+                     for lo, hi in zip(b["set_offsets"][:-1], b["set_offsets"][1:])], np.int64)
+    lo = np.minimum(b["rstart"], b["rstop"]).astype(np.int64) - 1 - span[set_of]
+    hi = np.maximum(b["rstart"], b["rstop"]).astype(np.int64) + span[set_of]
+    seq = b["ref_seq"].astype(np.int64)
+    ok = seq < len(rlen)
+    lo, hi, seq = np.maximum(lo[ok], 0), np.minimum(hi[ok], rlen[seq[ok]]), seq[ok]
+    ok = hi > lo
+    lo, hi, seq = lo[ok], hi[ok], seq[ok]
+    tiles = {}
+    for s_, a, e in zip(seq, lo // TILE, (hi - 1) // TILE):
+        tiles.setdefault(int(s_), set()).update(range(int(a), int(e) + 1))
+
+    def runs(ts):
+        ts = sorted(ts); out = []; a = p_ = ts[0]
+        for t in ts[1:]:
+            if t != p_ + 1: out.append((a, p_ + 1)); a = t
+            p_ = t
+        out.append((a, p_ + 1))
+        return out
+
+    def letters_of(s_, a, e):
+        return ds.ref_letters[roff[s_] + a: roff[s_] + e]
+
+    # first call: every second run of every sequence; second call: the whole hull of each sequence's tiles (covers and replaces them)
+    first_call, second_call = [], []
+    for s_, ts in tiles.items():
+        rr = runs(ts)
+        for (a, e) in rr[::2]:
+            first_call.append((s_, a * TILE, min(e * TILE, int(rlen[s_]))))
+        second_call.append((s_, rr[0][0] * TILE, min(rr[-1][1] * TILE, int(rlen[s_]))))
+    m.append_windows(pkg.STORE_DB, [x[0] for x in first_call], [x[1] for x in first_call], [letters_of(*x) for x in first_call])
+    info1 = m.store_info(pkg.STORE_DB)
+    assert info1["windows"] == len(first_call) and info1["live_residues"] == sum(x[2] - x[1] for x in first_call)
+    if any(len(runs(ts)) > 1 for ts in tiles.values()):
+        with pytest.raises(pkg.RpaError) as ei:   # some segment lies in a run that is not resident yet
+            m.predict(ds.batch)
+        assert ei.value.code == 1 and "resident windows" in str(ei.value)
+    s0, a0, e0 = first_call[0]
+    if e0 - a0 > 2:
+        with pytest.raises(pkg.RpaError) as ei:   # partial overlap with a resident window
+            m.append_windows(pkg.STORE_DB, [s0], [a0 + 1], [letters_of(s0, a0 + 1, min(int(rlen[s0]), e0 + 1))] if e0 < rlen[s0] else [letters_of(s0, a0 + 1, e0)])
+        assert ei.value.code == 1
+    m.append_windows(pkg.STORE_DB, [x[0] for x in second_call], [x[1] for x in second_call], [letters_of(*x) for x in second_call])
+    info2 = m.store_info(pkg.STORE_DB)
+    assert info2["windows"] == len(second_call) and info2["live_residues"] == sum(x[2] - x[1] for x in second_call)
+    assert info2["n_resident"] == len(tiles) and info2["residues"] >= info1["residues"] + info2["live_residues"]
+    rows, stats = m.predict(ds.batch)
+    assert rows.tobytes() == want_rows.tobytes() and stats.tobytes() == want_stats.tobytes()
+    # asynchronous jobs read the same windows
+    job = m.submit(ds.batch)
+    rows, stats = job.wait()
+    assert rows.tobytes() == want_rows.tobytes()
+    # reset: nothing resident, the arena is refilled from its start
+    m.reset_store(pkg.STORE_DB)
+    info3 = m.store_info(pkg.STORE_DB)
+    assert info3["windows"] == 0 and info3["residues"] == 0 and info3["n_resident"] == 0
+    with pytest.raises(pkg.RpaError):
+        m.predict(ds.batch)
+    m.append_windows(pkg.STORE_DB, [x[0] for x in second_call], [x[1] for x in second_call], [letters_of(*x) for x in second_call])
+    rows, stats = m.predict(ds.batch)
+    assert rows.tobytes() == want_rows.tobytes() and stats.tobytes() == want_stats.tobytes()
+    assert m.store_info(pkg.STORE_DB)["residues"] <= info2["residues"]
+
+
 def test_large_record_sets(pkg, oracle, synth):
     """Record sets far larger than a wavefront (300 hits) and a batch mixing set sizes 2..300."""
     ds = synth.make_dataset(n_sets=40, n_hits=300, seg_len=120, branching=4, genome_len=1500, seed=31, variety=True)
