@@ -541,8 +541,11 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
   return bin;
 }
 
+#ifndef RPA_EMIT_WAVES
+#define RPA_EMIT_WAVES 8  // (A/B: tools/build_variant.sh)
+#endif
 template <int Q>
-__global__ __launch_bounds__(kEmitBlock, 8) void k_emit(BatchDev b, WorkDev w, Params p) {  // two resident blocks per CU: one computes while the other waits on its loads
+__global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b, WorkDev w, Params p) {  // two resident blocks per CU: one computes while the other waits on its loads
   constexpr int kVW = kEmitSpan / 64;  // "virtual waves": runs of 64 consecutive row positions
   static_assert(kVW == 64, "the prefix over virtual waves is done by one wavefront");
   __shared__ uint32_t s_cnt[kNumBins][kVW];  // per bin, per virtual wave: number of active lanes, then its list offset
