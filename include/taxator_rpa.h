@@ -187,6 +187,24 @@ typedef struct {
  * says.  Results are in input order.  Synchronous: returns when the rows are written (asynchronous form: rpa_submit_batch). */
 int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, int out_mem_kind);
 
+/* The reference's per-alignment log ("+ALN i <=> j  dist=..; sim=..", taxonpredictionmodelsequence.hh:533,636,782,802: one
+ * line per alignment its control flow computes, in the order it computes them) as records.  rpa_trace_begin(capacity > 0)
+ * turns recording on for the synchronous rpa_predict_batch calls of this engine (capacity = entries kept per call;
+ * 0 turns it off); rpa_trace_read returns the entries of the last call sorted by (record set, order inside the set) and
+ * how many did not fit.  i, j are hit positions in SortFilter order; j = -1: the query range ("i <=> query"), i = -1:
+ * "query <=> j" (pass 2).  sim is what the reference prints there (pass 0 / "query <=> j": after std::max with the
+ * identities / the stored similarity).  Only alignments the reference would have computed are recorded, never the
+ * engine's speculative ones: per set there are exactly pass0 + pass1 + pass2 (rpa_stats) entries. */
+typedef struct {
+  uint32_t set;   /* record set inside the batch */
+  uint32_t seq;   /* 0, 1, 2, ... inside the set */
+  int32_t pass, i, j;
+  float dist, sim;
+  uint32_t reserved;
+} rpa_trace_entry;
+int rpa_trace_begin(rpa_engine* e, uint64_t capacity);
+int rpa_trace_read(rpa_engine* e, rpa_trace_entry* out, uint64_t capacity, uint64_t* n_entries, uint64_t* n_dropped);
+
 /* Asynchronous form for host batches: the replacement of the reference's producer / consumer pool
  * (core/taxator.cpp:80-124,159-176) at the boundary.  rpa_submit_batch hands the batch to one of the engine's
  * RPA_JOBS_IN_FLIGHT job slots (each with its own HIP stream, working set, staging buffers and host thread) and returns;

@@ -24,6 +24,8 @@ FLAG_IVAL_UNTOUCHED, FLAG_SHORTCUT, FLAG_SINGLE = 1, 2, 4
 PRED_DTYPE = np.dtype([("lower", "<u4"), ("upper", "<u4"), ("rtax", "<u4"), ("support", "<u4"), ("begin", "<u4"),
                        ("end", "<u4"), ("ival", "<f4"), ("flags", "<u4")])
 STATS_DTYPE = np.dtype([("n", "<u4"), ("pass0", "<u4"), ("pass1", "<u4"), ("pass2", "<u4")])
+TRACE_DTYPE = np.dtype([("set", "<u4"), ("seq", "<u4"), ("pass", "<i4"), ("i", "<i4"), ("j", "<i4"), ("dist", "<f4"), ("sim", "<f4"),
+                        ("reserved", "<u4")])
 WINDOW_DTYPE = np.dtype([("seq_index", "<u4"), ("reserved", "<u4"), ("first", "<u8"), ("n", "<u8")])
 ALN_DTYPE = np.dtype([("matches", "<u4"), ("mismatches", "<u4"), ("gaps", "<u4"), ("length", "<u4"),
                       ("distance", "<f4"), ("similarity", "<f4")])
@@ -35,7 +37,7 @@ ABI_SYMBOLS = ["rpa_abi_version", "rpa_default_params", "rpa_create", "rpa_destr
                "rpa_store_load", "rpa_predict_batch", "rpa_align_pairs", "rpa_profile_enable", "rpa_profile_get",
                "rpa_profile_reset", "rpa_lca_default_params", "rpa_lca_predict_batch", "rpa_store_reserve", "rpa_store_append",
                "rpa_store_info_get", "rpa_submit_batch", "rpa_wait", "rpa_host_register",
-               "rpa_host_unregister", "rpa_debug_where", "rpa_store_reserve_windows", "rpa_store_append_windows", "rpa_store_reset"]
+               "rpa_host_unregister", "rpa_debug_where", "rpa_store_reserve_windows", "rpa_store_append_windows", "rpa_store_reset", "rpa_trace_begin", "rpa_trace_read"]
 
 LCA_DUMMY, LCA_SIMPLE, LCA_MEGAN, LCA_NBEST = 0, 1, 2, 3  # taxator -a dummy | simple-lca | megan-lca | n-best-lca
 
@@ -123,6 +125,10 @@ def load_library(path=None):
     L.rpa_store_append_windows.restype = C.c_int
     L.rpa_store_reset.argtypes = [C.c_void_p, C.c_int]
     L.rpa_store_reset.restype = C.c_int
+    L.rpa_trace_begin.argtypes = [C.c_void_p, C.c_uint64]
+    L.rpa_trace_begin.restype = C.c_int
+    L.rpa_trace_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rpa_trace_read.restype = C.c_int
     L.rpa_store_info_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.rpa_store_info_get.restype = C.c_int
     L.rpa_submit_batch.argtypes = [C.c_void_p, C.POINTER(_Batch), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -281,6 +287,19 @@ class RPAPredictionModel:
         letters = np.ascontiguousarray(letters, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         self._check(self._L.rpa_store_append(self._h, which, len(idx), _ptr(idx), _ptr(letters), _ptr(offsets)))
+
+    def trace(self, capacity):
+        """Record the alignments the reference's control flow consumes in the following synchronous predict() calls
+        (capacity entries per call; 0 = off)."""
+        self._check(self._L.rpa_trace_begin(self._h, int(capacity)))
+        self._trace_cap = int(capacity)
+
+    def read_trace(self):
+        """Entries of the last predict() call sorted by (set, seq) as a structured array, and the number that did not fit."""
+        out = np.zeros(self._trace_cap, TRACE_DTYPE)
+        n, dropped = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.rpa_trace_read(self._h, out.ctypes.data, self._trace_cap, C.byref(n), C.byref(dropped)))
+        return out[: n.value], int(dropped.value)
 
     def reserve_windows(self, which, lengths):
         """A windowed store (region-granular residency): sequence i has lengths[i] residues, nothing resident yet."""

@@ -1015,6 +1015,12 @@ __device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t
   return true;
 }
 
+// the log line "+ALN i <=> j  dist=..; sim=.." as a record (tracing on only: rpa_trace_begin)
+__device__ __forceinline__ void trace_put(const WorkDev& w, uint32_t s, uint32_t seq, int pass, int i, int j, float dist, float sim) {
+  const unsigned long long at = atomicAdd(w.trace_n, 1ull);
+  if (at < w.trace_cap) w.trace[at] = TraceEntry{w.trace_set_base + s, seq, pass, i, j, dist, sim, 0u};
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Decide: one thread per record set, one call per round.  Every loop over the hits keeps the NEXT row (64 bytes) and
 // its alignment result in flight while it works on the current one; qgroup / outgroup are bit sets in WorkDev::flags,
@@ -1073,9 +1079,10 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       const float2 r2 = R.result(0);
       if (!result_ok(w, s, meta_err(h0.meta), st.qsegerr, r2.x)) failed = true;
       else {
-        ++st.cnt0;
         const float idf = (float)h0.ident;
         const float sim0 = r2.y < idf ? idf : r2.y;  // std::max(similarity, identities), :531
+        if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 0, 0, -1, r2.x, sim0);
+        ++st.cnt0;
         R.store_qdqs(0u, r2.x, sim0);
         if (r2.x == 0.f) w.lite[lo] = (w.lite[lo] & kLiteLenMask) | kLiteZeroQd;  // (:620-621)
         for (uint32_t k = 0; k < nw; ++k) { fq[k] = 0u; fo[k] = 0u; }  // qgroup = {0}, taken by the anchor selection; outgroup empty
@@ -1127,9 +1134,10 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           member = true;
           if (!result_ok(w, s, meta_err(h.meta), st.qsegerr, r2.x)) { failed = true; break; }
           dist = r2.x;
-          ++st.cnt0;
           const float idf = (float)h.ident;
           sim = r2.y < idf ? idf : r2.y;  // std::max(similarity, identities), :531
+          if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 0, (int)i, -1, dist, sim);
+          ++st.cnt0;
         } else {
           dist = FLT_MAX; sim = (float)h.ident;
         }
@@ -1263,6 +1271,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           if (i >= st.chunk_hi) { paused = true; break; }  // this alignment was not part of the chunk emitted last round
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
+          if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 1, (int)i, (int)a, dist, r2.y);
           ++st.cnt1;
         }
         band.add(dist, common<PW>(pa, da, pth, dh, lbs));  // :641
@@ -1427,6 +1436,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           if (i >= st.chunk_hi) { paused = true; break; }  // not part of the chunk emitted last round
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
+          if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 2, (int)i, (int)a, dist, r2.y);
           ++st.cnt2;
           if constexpr (kSmall) qdmask |= 1ull << i; else R.store_qd(i, dist);  // querydistance[i] = dist, :785
         }
@@ -1442,6 +1452,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
             qd_a = d2; qs_a = s2;
             if constexpr (kSmall) anchor_pair = true; else R.store_qdqs(a, d2, s2);
             qdist_ex = d2 * st.bf_max;
+            if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 2, -1, (int)a, d2, s2);
             ++st.cnt2;
           } else qdist_ex = qd_a * st.bf_max;  // :809
           if (dist <= qdist_ex) st.d_unode_g = min(st.d_unode_g, cb);  // unode_global = LCA(unode_global, cnode), :811-813

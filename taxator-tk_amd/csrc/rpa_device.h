@@ -120,6 +120,9 @@ struct HitCore {
   float qd;          // querydistance[i]
   float qs;          // querysimilarity[i]
 };
+// One alignment the reference's control flow consumed (= one "+ALN" line of its log, taxonpredictionmodelsequence.hh:533,
+// 636,782,802): recorded by k_decide when tracing is on (rpa_trace_begin).  j = -1: the query range; i = -1: "query <=> j".
+struct TraceEntry { uint32_t set, seq; int32_t pass, i, j; float dist, sim; uint32_t reserved; };
 struct SetStateMem { uint4 q[4]; };  // see state_pack / state_unpack (place_kernels.hip)
 struct LoopSave {                    // a paused pass-1 loop: :596-602 loop variables
   uint32_t nog, pad_, d_lnode;
@@ -209,6 +212,10 @@ struct WorkDev {
   uint32_t* live_out;       // S
   uint32_t* og_idx;     // T
   int32_t* og_dist;     // T
+  TraceEntry* trace;            // null: tracing off; else trace_cap entries, trace_n counts every attempt
+  unsigned long long* trace_n;
+  uint64_t trace_cap;
+  uint32_t trace_set_base;      // first record set of this part inside the caller's batch
   const uint32_t* set_offsets;  // S+1 (copy of the batch's, for the alignment kernels)
   uint32_t H;    // n_records
   int row_quads; // Q: 16-byte quads per hit row, one of kRowQuadChoices, chosen per batch (row_quads_for)

@@ -107,6 +107,13 @@ struct rpa_engine {
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
+  // alignment trace (rpa_trace_begin / rpa_trace_read): synchronous calls on the owner engine only
+  DevBuf trace_buf, trace_count;
+  uint64_t trace_cap = 0;
+  TraceEntry* trace_view = nullptr;           // what this engine's kernels write to (parts of a batch: the owner's buffer)
+  unsigned long long* trace_view_n = nullptr;
+  uint64_t trace_view_cap = 0;
+  uint32_t trace_set_base = 0;
   uint32_t force_label_shift = 0;  // RPA_LABEL_BITS=16|32: wider taxon path labels than the batch needs (tests: the wide row shapes)
   bool poison = false;        // RPA_POISON=1: every working buffer is filled with 0xA5 before each batch (tests: a kernel that
                               // reads a slot nobody wrote this batch then reads garbage every time, not whatever the last batch left)
@@ -430,6 +437,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->seg = e->seg.as<SegDesc>(); w->store_q = nullptr; w->store_db = nullptr;
   w->pair_a = want_ext ? e->pair_a.as<uint32_t>() : nullptr; w->pair_b = want_ext ? e->pair_b.as<uint32_t>() : nullptr;
   w->set_offsets = nullptr; w->H = H; w->row_quads = row_quads; w->lb_shift = lb_shift;
+  w->trace = want_ext ? nullptr : e->trace_view; w->trace_n = e->trace_view_n; w->trace_cap = e->trace_view_cap; w->trace_set_base = e->trace_set_base;
   w->P = P; w->tile_base = (!want_ext && tiled) ? e->tile_base.as<const uint32_t>() : nullptr;
   w->res_slot = want_ext ? nullptr : e->res_slot.as<uint32_t>();
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
@@ -648,6 +656,12 @@ int run_parts(rpa_engine* e, const BatchDev& b, const uint32_t* h_offsets, void*
   const uint32_t S = b.n_sets;
   const StoreDev q = e->stores[RPA_STORE_QUERY].view(), db = e->stores[RPA_STORE_DB].view();
   const int K = parts_for(e, S);
+  const bool tracing = e->trace_cap != 0;
+  e->trace_view = tracing ? e->trace_buf.as<TraceEntry>() : nullptr;
+  e->trace_view_n = tracing ? e->trace_count.as<unsigned long long>() : nullptr;
+  e->trace_view_cap = tracing ? e->trace_cap : 0;
+  e->trace_set_base = 0;
+  if (tracing) HIP_TRY(e, hipMemsetAsync(e->trace_count.p, 0, 8, e->stream));
   if (K == 1) {
     PartGate g;
     return predict_part(e, b, q, db, rows_dev, stats_dev, g);
@@ -682,6 +696,7 @@ int run_parts(rpa_engine* e, const BatchDev& b, const uint32_t* h_offsets, void*
     rpa_engine* pe = k == 0 ? e : e->workers[k - 1];
     GateOpener opener{gates[k]};  // whatever happens, the part after this one must not wait forever
     pe->part_mode = true;
+    pe->trace_view = e->trace_view; pe->trace_view_n = e->trace_view_n; pe->trace_view_cap = e->trace_view_cap; pe->trace_set_base = s_lo[k];
     if (k) {
       pe->err.clear();
       pe->profiling = e->profiling;
@@ -900,7 +915,7 @@ void rpa_destroy(rpa_engine* e) {
   (void)hipSetDevice(e->device);
   RPA_WHERE("rpa_destroy: sync own stream");
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_pre, &e->tax_last, &e->tax_anc, &e->tax_anc_iv, &e->loop_save, &e->rec_pre, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
+  DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_pre, &e->tax_last, &e->tax_anc, &e->tax_anc_iv, &e->loop_save, &e->rec_pre, &e->trace_buf, &e->trace_count, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
@@ -1321,6 +1336,43 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
   if (!e) return RPA_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);
   return predict_on(e, e, batch, out, stats, out_mem_kind);
+}
+
+int rpa_trace_begin(rpa_engine* e, uint64_t capacity) {
+  if (!e) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (capacity) {
+    HIP_TRY(e, e->trace_buf.ensure((size_t)capacity * sizeof(TraceEntry)));
+    HIP_TRY(e, e->trace_count.ensure(8));
+    HIP_TRY(e, hipMemsetAsync(e->trace_count.p, 0, 8, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  e->trace_cap = capacity;
+  return RPA_OK;
+}
+
+int rpa_trace_read(rpa_engine* e, rpa_trace_entry* out, uint64_t capacity, uint64_t* n_entries, uint64_t* n_dropped) {
+  if (!e || !n_entries) return RPA_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  *n_entries = 0;
+  if (n_dropped) *n_dropped = 0;
+  if (!e->trace_cap) return fail(e, RPA_ERR_INVALID, "rpa_trace_read: tracing is off (rpa_trace_begin)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  unsigned long long attempts = 0;
+  HIP_TRY(e, hipMemcpy(&attempts, e->trace_count.p, 8, hipMemcpyDeviceToHost));
+  const uint64_t have = attempts < e->trace_cap ? attempts : e->trace_cap;
+  if (n_dropped) *n_dropped = attempts - have;
+  std::vector<TraceEntry> tmp((size_t)have);
+  if (have) HIP_TRY(e, hipMemcpy(tmp.data(), e->trace_buf.p, (size_t)have * sizeof(TraceEntry), hipMemcpyDeviceToHost));
+  std::sort(tmp.begin(), tmp.end(), [](const TraceEntry& a, const TraceEntry& b) { return a.set != b.set ? a.set < b.set : a.seq < b.seq; });
+  const uint64_t n = have < capacity ? have : capacity;
+  if (n && !out) return fail(e, RPA_ERR_INVALID, "rpa_trace_read: null output");
+  static_assert(sizeof(TraceEntry) == sizeof(rpa_trace_entry), "trace entry layout");
+  if (n) memcpy(out, tmp.data(), (size_t)n * sizeof(TraceEntry));
+  *n_entries = n;
+  if (n_dropped) *n_dropped += have - n;
+  return RPA_OK;
 }
 
 int rpa_host_register(rpa_engine* e, void* ptr, size_t bytes) {

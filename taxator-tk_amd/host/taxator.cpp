@@ -96,6 +96,7 @@ struct Work {
   ColumnarBatch batch;
   std::vector<rpa_prediction> rows;
   std::vector<rpa_stats> stats;
+  std::vector<rpa_trace_entry> trace;  // -l: the alignments the control flow consumed, sorted by (set, order)
   bool last = false;            // end of stream (or a failure of the reader): no batch inside
   bool failed = false;          // a GPU call failed on this block: nothing from here on is printed
   std::exception_ptr err;
@@ -141,6 +142,32 @@ void unpin_work(Work& w, const RPAPredictionModel& rpa) {
   for (auto& r : w.pinned) { try { rpa.unpinHost(r.first); } catch (...) {} }
   w.pinned.clear();
   w.pinned_want.clear();  // (an address that comes back after a reallocation is a new mapping: nothing may match it)
+}
+
+// One record set of the log (-l), the lines of the reference's log this build can reproduce (taxonpredictionmodelsequence.hh:
+// 408-409 ID / NUMREF, :533,636,782,802 one "+ALN" line per alignment the control flow computes -- same operands, distance
+// and similarity as there, std::fixed << std::setprecision(2), :347; the other fields of those lines, the printed
+// alignments and the timing columns are left out --, :837 STATS with the timing columns left out).
+inline void append_fixed2(std::string& out, float v) {
+  char buf[64];
+  const int n = snprintf(buf, sizeof(buf), "%.2f", (double)v);
+  out.append(buf, (size_t)(n > 0 ? n : 0));
+}
+inline void append_log_set(std::string& lg, const char* qid, size_t qid_len, const rpa_stats& st, const rpa_trace_entry* tr, size_t n_tr) {
+  lg.append("ID\t"); lg.append(qid, qid_len); lg.append("\n  NUMREF\t"); append_u32(lg, st.n); lg.push_back('\n');
+  for (size_t k = 0; k < n_tr; ++k) {
+    const rpa_trace_entry& e = tr[k];
+    lg.append("    +ALN ");
+    if (e.i < 0) lg.append("query"); else append_u32(lg, (uint32_t)e.i);
+    lg.append(" <=> ");
+    if (e.j < 0) lg.append("query"); else append_u32(lg, (uint32_t)e.j);
+    lg.append("\tpass="); append_u32(lg, (uint32_t)e.pass);
+    lg.append("; dist="); append_fixed2(lg, e.dist); lg.append("; sim="); append_fixed2(lg, e.sim); lg.push_back('\n');
+  }
+  lg.append("STATS\t"); lg.append(qid, qid_len);
+  const uint32_t v[5] = {st.n, st.pass0, st.pass1, st.pass2, st.pass0 + st.pass1 + st.pass2};
+  for (uint32_t x : v) { lg.push_back('\t'); append_u32(lg, x); }
+  lg.push_back('\n');
 }
 
 struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, records = 0; };
@@ -212,14 +239,15 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
           out.reserve((hi - lo) * 112);
           for (size_t s = lo; s < hi; ++s)
             append_gff3(out, tax, b.qid_arena.data() + b.qid_off[s], b.qid_len[s], b.query_len[s], w->rows[s], ival[s]);
-          if (logsink) {  // the STATS line of the reference log (:837), timing columns left out
+          if (logsink) {  // ID / NUMREF / +ALN / STATS per record set (append_log_set)
             std::string& lg = log_parts[t];
+            size_t k = std::lower_bound(w->trace.begin(), w->trace.end(), (uint32_t)lo,
+                                        [](const rpa_trace_entry& e, uint32_t s0) { return e.set < s0; }) - w->trace.begin();
             for (size_t s = lo; s < hi; ++s) {
-              const rpa_stats& st = w->stats[s];
-              lg.append("STATS\t"); lg.append(b.qid_arena.data() + b.qid_off[s], b.qid_len[s]);
-              const uint32_t v[5] = {st.n, st.pass0, st.pass1, st.pass2, st.pass0 + st.pass1 + st.pass2};
-              for (uint32_t x : v) { lg.push_back('\t'); append_u32(lg, x); }
-              lg.push_back('\n');
+              size_t k1 = k;
+              while (k1 < w->trace.size() && w->trace[k1].set == s) ++k1;
+              append_log_set(lg, b.qid_arena.data() + b.qid_off[s], b.qid_len[s], w->stats[s], w->trace.data() + k, k1 - k);
+              k = k1;
             }
           }
         };
@@ -253,9 +281,15 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
       try {
         if (S >= 4096) pin_work(*w, rpa);  // (not worth it for tiny blocks: page-locking costs more than their copies)
         const size_t step = max_sets ? max_sets : S;
+        w->trace.clear();
+        std::vector<rpa_trace_entry> part;
         for (size_t lo = 0; lo < S; lo += step) {
           const size_t hi = std::min(S, lo + step);
-          rpa.predictColumns(w->batch, lo, hi, w->rows.data() + lo, w->stats.data() + lo);
+          rpa.predictColumns(w->batch, lo, hi, w->rows.data() + lo, w->stats.data() + lo, logsink ? &part : nullptr);
+          if (logsink) {
+            for (rpa_trace_entry& e : part) e.set += (uint32_t)lo;
+            w->trace.insert(w->trace.end(), part.begin(), part.end());
+          }
         }
       } catch (...) {
         { std::lock_guard<std::mutex> lk(failure_mu); if (w->seq < fail_seq.load()) { fail_seq = w->seq; failure = std::current_exception(); } }
@@ -408,6 +442,8 @@ static int run(int argc, char** argv) {
       if (o.store_gb > 0) engines.back()->setStoreBudget((uint64_t)(o.store_gb * 1073741824.0));
     }
     RPAPredictionModel& rpa = *engines[0];
+    const bool logging_on = o.logfile != "/dev/null";
+    if (logging_on) rpa.setTrace(true);
     const Clock::time_point t_loaded = Clock::now();
     auto store_report = [&]() {  // what is resident in HBM (per engine; the engines hold the same sequences)
       if (!o.timing) return;
@@ -467,10 +503,20 @@ static int run(int argc, char** argv) {
       outbuf.str("");
       for (size_t s = 0; s < sets.size(); ++s) outbuf << precs[s];
       std::cout << outbuf.str();
-      const std::vector<rpa_stats>& st = rpa.lastStats();
-      for (size_t s = 0; s < sets.size(); ++s)  // the STATS line of the reference log (:837), timing columns as 0
-        logsink << "STATS\t" << precs[s].getQueryIdentifier() << '\t' << st[s].n << '\t' << st[s].pass0 << '\t' << st[s].pass1 << '\t'
-                << st[s].pass2 << '\t' << (st[s].pass0 + st[s].pass1 + st[s].pass2) << "\n";
+      if (logging_on) {
+        const std::vector<rpa_stats>& st = rpa.lastStats();
+        const std::vector<rpa_trace_entry>& tr = rpa.lastTrace();
+        std::string lg;
+        size_t k = 0;
+        for (size_t s = 0; s < sets.size(); ++s) {
+          size_t k1 = k;
+          while (k1 < tr.size() && tr[k1].set == s) ++k1;
+          const std::string& qid = precs[s].getQueryIdentifier();
+          append_log_set(lg, qid.data(), qid.size(), st[s], tr.data() + k, k1 - k);
+          k = k1;
+        }
+        logsink << lg;
+      }
       const Clock::time_point t3 = Clock::now();
       t_parse += secs(t0, t1); t_predict += secs(t1, t2); t_write += secs(t2, t3);
     }

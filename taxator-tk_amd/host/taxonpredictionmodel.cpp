@@ -251,6 +251,14 @@ void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, s
   rows_.resize(S);
   stats_.resize(S);
   makeResident(b);
+  if (trace_on_) {
+    std::lock_guard<std::mutex> turn(trace_mu_);
+    const uint64_t cap = (uint64_t)b.n_records * 64 + 4096;
+    check(engine_, rpa_trace_begin(engine_, cap));
+    check(engine_, rpa_predict_batch(engine_, &b, rows_.data(), stats_.data(), RPA_MEM_HOST));
+    readTrace(cap, trace_);
+    check(engine_, rpa_trace_begin(engine_, 0));
+  } else
   check(engine_, rpa_predict_batch(engine_, &b, rows_.data(), stats_.data(), RPA_MEM_HOST));
   for (size_t s = 0; s < S; ++s) {
     const rpa_prediction& r = rows_[s];
@@ -266,7 +274,16 @@ void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, s
   }
 }
 
-void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats) {
+void RPAPredictionModel::readTrace(uint64_t capacity, std::vector<rpa_trace_entry>& out) {
+  out.resize((size_t)capacity);
+  uint64_t n = 0, dropped = 0;
+  check(engine_, rpa_trace_read(engine_, out.data(), capacity, &n, &dropped));
+  out.resize((size_t)n);
+  if (dropped) throw GeneralError("alignment log: more alignments than the trace buffer holds");
+}
+
+void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats,
+                                        std::vector<rpa_trace_entry>* trace) {
   if (hi <= lo) return;
   // (re-entrant: the driver keeps two batches in flight per engine from two host threads)
   const uint32_t base = cb.set_offsets[lo];
@@ -285,6 +302,15 @@ void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size
   b.alnlen = cb.rec.alnlen.data() + base; b.ref_seq = cb.rec.ref_seq.data() + base; b.node = cb.rec.node.data() + base;
   b.filtered = cb.rec.filtered.data() + base; b.mem_kind = RPA_MEM_HOST;
   makeResident(b);
+  if (trace) {  // logging run: synchronous, one traced call at a time
+    std::lock_guard<std::mutex> turn(trace_mu_);
+    const uint64_t cap = (uint64_t)b.n_records * 64 + 4096;
+    check(engine_, rpa_trace_begin(engine_, cap));
+    check(engine_, rpa_predict_batch(engine_, &b, rows, stats, RPA_MEM_HOST));
+    readTrace(cap, *trace);
+    check(engine_, rpa_trace_begin(engine_, 0));
+    return;
+  }
   // asynchronous boundary: the engine runs two jobs at a time, the copies of one under the kernels of the other
   rpa_job* job = nullptr;
   check(engine_, rpa_submit_batch(engine_, &b, rows, stats, &job));

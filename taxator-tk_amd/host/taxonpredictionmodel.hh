@@ -37,7 +37,13 @@ class RPAPredictionModel : public TaxonPredictionModel {
   const std::vector<rpa_stats>& lastStats() const { return stats_; }
   // The same call for record sets that are already in columns (columnar.hh): sets [lo, hi) of `batch`, rows and STATS
   // counters written to rows[0 .. hi-lo) / stats[0 .. hi-lo).  No per-record objects on this path.
-  void predictColumns(const struct ColumnarBatch& batch, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats);
+  // trace != null: the call runs synchronously with the alignment log on (rpa_trace_begin) and *trace receives, sorted by
+  // (set - lo, order inside the set), one entry per alignment the reference's control flow computes (its "+ALN" lines)
+  void predictColumns(const struct ColumnarBatch& batch, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats,
+                      std::vector<rpa_trace_entry>* trace = nullptr);
+  // the same for predict(): entries of the last call (set = index into its record sets)
+  void setTrace(bool on) { trace_on_ = on; }
+  const std::vector<rpa_trace_entry>& lastTrace() const { return trace_; }
   // Indexed stores (taxator -i / -v): make every REGION the batch refers to resident in this engine's HBM if it is not yet
   // -- the reference reads exactly [start, stop] of a sequence through the .fai (sequencestorage.hh:341-369); here a
   // sequence is cut into tiles (65536 residues unless setTile says otherwise) and the tiles under a hit's range, extended
@@ -70,6 +76,10 @@ class RPAPredictionModel : public TaxonPredictionModel {
   unsigned threads_ = 1;
   std::mutex resident_mu_;
   rpa_engine* engine_ = nullptr;
+  bool trace_on_ = false;
+  std::vector<rpa_trace_entry> trace_;
+  std::mutex trace_mu_;  // traced calls are synchronous and take turns
+  void readTrace(uint64_t capacity, std::vector<rpa_trace_entry>& out);
   float stale_ival_ = -1.f;  // PredictionRecord is reused across calls in the reference (taxator.cpp:66): n==0 keeps the last ival
   std::vector<rpa_stats> stats_;
   std::vector<rpa_prediction> rows_;

@@ -45,6 +45,42 @@ def test_cli_reproduces_reference_gff3(golden_dir, tmp_path, name, ext, extra, p
     assert r.stdout == open(os.path.join(folder, "out.gff3")).read()
 
 
+@pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])
+def test_cli_log_holds_the_references_alignments(golden_dir, tmp_path, name, ext, extra):
+    """taxator -l: one "+ALN i <=> j" line per alignment the control flow computes, with the distance and similarity the
+    reference's log prints there (taxonpredictionmodelsequence.hh:533,636,782,802; std::fixed, two decimals) -- held
+    against the reference's own log of the same input (tests/golden/survey_*/expected.json: per record set the parsed
+    +ALN lines and the STATS counters).  The counters must agree for every set; the sequence of alignments for every set
+    whose records do not tie completely on (score, identities, query range) -- the reference orders such ties by heap
+    address (core/src/alignmentrecord.hh:480), this build by input order -- which is the great majority."""
+    import json
+    folder = _unpack(golden_dir, name, ext, tmp_path)
+    log = str(tmp_path / "aln.log")
+    r = _run(folder, ext, extra + ["--batch", "150"], log=log)
+    assert r.returncode == 0, r.stderr
+    exp = json.load(open(os.path.join(folder, "expected.json")))
+    got, cur = [], None
+    for line in open(log):
+        if line.startswith("ID\t"):
+            cur = dict(id=line.rstrip("\n").split("\t")[1], aln=[], stats=None); got.append(cur)
+        elif line.startswith("    +ALN "):
+            head, fields = line[len("    +ALN "):].rstrip("\n").split("\t")
+            a, b_ = head.split(" <=> ")
+            kv = dict(x.split("=") for x in fields.split("; "))
+            cur["aln"].append([int(kv["pass"]), -1 if a == "query" else int(a), -1 if b_ == "query" else int(b_), float(kv["dist"]), float(kv["sim"])])
+        elif line.startswith("STATS\t"):
+            c = line.rstrip("\n").split("\t")
+            cur["stats"] = [int(c[3]), int(c[4]), int(c[5])]
+    assert len(got) == len(exp)
+    same = 0
+    for g, e in zip(got, exp):
+        assert g["stats"] == e["stats"], (g["id"], g["stats"], e["stats"])
+        assert len(g["aln"]) == sum(e["stats"]) == len(e["aln"])
+        # the reference's log line has "i <=> query" for pass 0 and "query <=> j" for the anchor of pass 2: same convention here
+        same += g["aln"] == [[x[0], x[1], x[2], round(x[3], 2), round(x[4], 2)] for x in e["aln"]]
+    assert same >= 0.9 * len(exp), (same, len(exp))
+
+
 def test_cli_config1_plumbing(oracle, tmp_path):
     """BASELINE config 1 through files: 100 segments x 10 hits, b=2 taxonomy; GFF3 equals the oracle's."""
     graft.load_package()

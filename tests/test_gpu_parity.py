@@ -565,6 +565,57 @@ def test_wide_path_labels(pkg, oracle, synth, bits, monkeypatch):
     _engine_vs_oracle(pkg, oracle, synth, ds, 0)
 
 
+@pytest.mark.parametrize("alphabet,kw", [(0, dict(n_sets=700, n_hits=20, seg_len=200, branching=4, genome_len=3000, seed=61)),
+                                         (0, dict(n_sets=60, n_hits=90, seg_len=120, branching=4, genome_len=1500, seed=62)),
+                                         (1, dict(n_sets=500, n_hits=16, seg_len=70, branching=4, genome_len=1200, seed=63, level_rate=0.06, query_rate=0.08))])
+@pytest.mark.parametrize("parts", [None, "3"])
+def test_alignment_trace_equals_the_oracles(pkg, oracle, synth, alphabet, kw, parts, monkeypatch):
+    """rpa_trace_begin / rpa_trace_read: the alignments the control flow CONSUMES, in the order the reference computes and
+    logs them ("+ALN i <=> j dist=..; sim=..", taxonpredictionmodelsequence.hh:533,636,782,802) -- per record set the same
+    (pass, i, j, distance, similarity) sequence as the oracle's trace callback (which tests/test_oracle_placement.py holds
+    against the reference's own log, tests/golden/survey_*/expected.json), float bit patterns included, whatever the engine
+    computed speculatively on the side; also when the batch is cut into parts."""
+    if parts:
+        monkeypatch.setenv("RPA_PARTS", parts)
+    ds = synth.make_dataset(variety=True, alphabet=alphabet, **kw)
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    model.trace(4_000_000)
+    rows, stats = model.predict(ds.batch)
+    tr, dropped = model.read_trace()
+    assert dropped == 0
+    demanded = stats["pass0"].astype(np.int64) + stats["pass1"] + stats["pass2"]
+    assert len(tr) == int(demanded.sum())
+    tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    q = oracle.StoreArrays(synth.encode(ds.query_letters, alphabet), ds.query_offsets)
+    db = oracle.StoreArrays(synth.encode(ds.ref_letters, alphabet), ds.ref_offsets)
+    recs = synth.records_aos(ds.batch, oracle.RECORD_DTYPE)
+    first = np.concatenate([[0], np.cumsum(demanded)])
+    b = ds.batch
+    checked = 0
+    for s_ in range(0, ds.n_sets, 3 if ds.n_sets > 200 else 1):
+        lo, hi = int(b["set_offsets"][s_]), int(b["set_offsets"][s_ + 1])
+        rc, out, st, want = oracle.predict(tax, q, db, alphabet, int(b["query_seq"][s_]), int(b["query_len"][s_]), recs[lo:hi], want_trace=True)
+        assert rc == 0
+        got = tr[first[s_]:first[s_ + 1]]
+        assert (got["set"] == s_).all() and list(got["seq"]) == list(range(len(got)))
+        assert len(got) == len(want), (s_, len(got), len(want))
+        for g, w_ in zip(got, want):
+            assert (int(g["pass"]), int(g["i"]), int(g["j"])) == (w_[0], w_[1], w_[2]), (s_, g, w_)
+            assert np.float32(g["dist"]).tobytes() == np.float32(w_[3]).tobytes() and np.float32(g["sim"]).tobytes() == np.float32(w_[4]).tobytes(), (s_, g, w_)
+        checked += len(want)
+    assert checked > 500
+    # a capacity that is too small: what fits is a prefix-free sample, the rest is counted
+    model.trace(100)
+    model.predict(ds.batch)
+    tr2, dropped2 = model.read_trace()
+    assert len(tr2) == 100 and dropped2 == len(tr) - 100
+    model.trace(0)
+    rows3, _ = model.predict(ds.batch)
+    assert rows3.tobytes() == rows.tobytes()
+
+
 def test_windowed_stores(pkg, oracle, synth):
     """Region-granular residency through the C ABI (rpa_store_reserve_windows / rpa_store_append_windows / rpa_store_reset):
     only the windows the batch reads are resident -- tile-aligned pieces of the reference sequences, appended in several
