@@ -24,6 +24,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP comes up (torch): a hardware queue per engine stream (rpa_engine.hip: make_stream)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -367,10 +369,10 @@ def main():
            for k, v in ds.batch.items()}
     rows = torch.zeros((ds.n_sets, 8), dtype=torch.int32, device="cuda")
     stats = torch.zeros((ds.n_sets, 4), dtype=torch.int32, device="cuda")
-    # Everything from here on runs on a NON-BLOCKING side stream, never on the legacy null stream: the engine's own streams
-    # are blocking ones (they were created with a CU mask to get hardware queues of their own), and any null-stream
-    # operation -- e.g. the event a collective records on the current stream before it starts -- is a barrier across all
-    # of them, i.e. across the jobs in flight.
+    # Everything from here on runs on a NON-BLOCKING side stream, never on the legacy null stream: a null-stream operation
+    # -- e.g. the event a collective records on the current stream before it starts -- is a barrier across every blocking
+    # stream of the process (round 2's CU-masked engine streams were blocking ones; since round 3 they are plain
+    # non-blocking streams, RPA_CU_MASK_QUEUES=1 brings the old kind back).
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream() if os.environ.get("RPA_BENCH_NULL_STREAM") else torch.cuda.Stream()  # (A/B)
     torch.cuda.set_stream(stream)

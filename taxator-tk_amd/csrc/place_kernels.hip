@@ -439,8 +439,10 @@ __global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, 
   const uint64_t total = (uint64_t)maxrank * Q * ns;
   uint4* __restrict__ hits4 = reinterpret_cast<uint4*>(w.hits);
   if (tiled && s_lim[2] == 0u && ns <= (uint32_t)kBlock && total <= 24ull * kBlock) {
+    // idx / ns by one multiply: exact for idx < 2^32 / ns (here idx < 6144, ns <= 256); a 32-bit division is ~35 instructions
+    const uint32_t ns_magic = ns == 1u ? 0u : (uint32_t)(0x100000000ull / ns) + 1u;
     for (uint32_t idx = tid; idx < (uint32_t)total; idx += kBlock) {
-      const uint32_t sl = idx % ns, t2 = idx / ns, q = t2 % (uint32_t)Q, i = t2 / (uint32_t)Q;
+      const uint32_t t2 = ns == 1u ? idx : __umulhi(idx, ns_magic), sl = idx - t2 * ns, q = t2 % (uint32_t)Q, i = t2 / (uint32_t)Q;
       const uint32_t begs = s_off[sl];
       if (i >= s_off[sl + 1] - begs) continue;          // the set has fewer records than that
       const uint32_t widx = begs - s_off[0] + i;

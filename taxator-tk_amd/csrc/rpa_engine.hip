@@ -598,16 +598,21 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   return profile_end(e);
 }
 
-// A stream with a hardware queue of its own.  The HIP runtime multiplexes ordinary streams onto a small pool of
-// hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams that land on one queue run in the order their
-// packets were written: a job's kernels then sit behind the barrier packet another job's 80 MB host-to-device copy
-// waits on.  Measured with three jobs in flight over host buffers (config 2): 20.9 ms per step on pooled queues,
-// 14.4 ms (the copy bound) with a queue per stream.  A stream created with a CU mask is never pooled, so an all-ones
-// mask buys the dedicated queue without taking any CU away.  Such a stream is a blocking one (it orders itself
-// against the legacy null stream); RPA_POOLED_QUEUES=1 returns to the plain non-blocking stream.
+// Streams and hardware queues.  The HIP runtime multiplexes ordinary streams onto a small pool of hardware queues
+// (GPU_MAX_HW_QUEUES, 4 by default), and two streams that land on one queue run in the order their packets were written:
+// a job's kernels then sit behind the barrier packet another job's 80 MB host-to-device copy waits on.  Measured with
+// three jobs in flight over host buffers (config 2): 19.6 ms per step on the default pool, 14.3 ms (the copy bound) when
+// every stream has a queue of its own.  Round 2 got the queues by creating the streams with an all-ones CU mask (such a
+// stream is never pooled) -- and that turned out to be what makes the runtime's exit handler spin for ever in a process
+// that leaves within milliseconds of creating one (15 of 850 short-lived drivers, none of 2200 with plain
+// streams).  Since round 3 the streams are plain non-blocking ones and the pool is made large enough instead:
+// rpa_create puts GPU_MAX_HW_QUEUES=8 into the environment if nobody set it and the runtime has not been initialised yet
+// (taxator, any ctypes caller; a process that initialises HIP first -- PyTorch -- sets it itself, bench.py does): 14.3 ms
+// again (profiles/r03_ab_hostbuf.txt); device-resident batches never cared (9.5-9.6 ms either way).
+// RPA_CU_MASK_QUEUES=1 brings the CU-masked streams back (A/B, tools/hang_hunt.py's control arm).
 static hipError_t make_stream(int device, hipStream_t* out) {
-  const char* pooled = getenv("RPA_POOLED_QUEUES");
-  if (!(pooled && atoi(pooled) != 0)) {
+  const char* masked = getenv("RPA_CU_MASK_QUEUES");
+  if (masked && atoi(masked) != 0) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
       std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0xffffffffu);
@@ -765,6 +770,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
     if (i && !(tax->left[tax->parent[i]] < tax->left[i] && tax->right[tax->parent[i]] > tax->right[i]))
       return fail(nullptr, RPA_ERR_INVALID, "rpa_create: nested-set values of node %u are not inside its parent's", i);
   }
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);  // a hardware queue per stream of the jobs in flight (make_stream); no effect once HIP is up
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(nullptr, RPA_ERR_DEVICE, "rpa_create: no HIP device visible (this engine has no CPU path)");
@@ -1135,11 +1141,6 @@ int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_win
   // from ONE window, so overlapping windows are the caller's mistake
   std::vector<uint32_t> changed;
   std::vector<std::vector<uint4>> lists;
-  auto list_of = [&](uint32_t seq) -> std::vector<uint4>& {
-    for (size_t k = 0; k < changed.size(); ++k) if (changed[k] == seq) return lists[k];
-    changed.push_back(seq); lists.push_back(st->seq_windows[seq]);
-    return lists.back();
-  };
   uint64_t dropped_residues = 0, dropped_windows = 0;
   std::vector<uint32_t> order(n);
   for (uint32_t k = 0; k < n; ++k) order[k] = k;
@@ -1166,7 +1167,6 @@ int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_win
     std::sort(kept.begin(), kept.end(), [](const uint4& p, const uint4& q) { return p.x < q.x; });
     cur->swap(kept);
   }
-  (void)list_of;
   HIP_TRY(e, hipSetDevice(e->device));
   quiesce_slots(e);  // the arena and the pool may move: no job may be reading them
   const uint64_t total = offsets[n];

@@ -540,13 +540,14 @@ static int run(int argc, char** argv) {
 // Leaving.  When run() returns, every engine has been destroyed (rpa_destroy: streams synchronised and destroyed, device
 // and pinned memory freed), stdout / the log file are complete, and nothing of this process is left on the GPU that the
 // kernel driver does not reclaim by itself.  What a plain `return` from main would still do is run the exit handlers of the
-// HIP / HSA runtime -- and those can spin for ever when the process leaves within a few milliseconds of creating its
-// first stream: tools/hang_hunt.py caught it twice in 676 runs of `taxator --record-objects` on an input whose first line
+// HIP / HSA runtime -- and those can spin for ever when the process leaves within a few milliseconds of creating a
+// CU-masked stream (round 2's engine streams; plain streams since): tools/hang_hunt.py caught it twice in 676 runs of `taxator --record-objects` on an input whose first line
 // does not parse (stage "exit handlers", engine "rpa_destroy: done", main thread running inside the runtime's teardown,
 // its helper threads asleep in kfd_wait_on_events; DESIGN.md section 5 has the stacks).  It is what hung round 2's GPU
 // test run.  So the driver flushes its streams and leaves with _exit: no handler of anybody's runs, the exit code is the
 // same.  TAXATOR_RUN_EXIT_HANDLERS=1 restores the plain return (the hunt's control arm).
 int main(int argc, char** argv) {
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);  // before the HIP runtime comes up: a hardware queue per stream of the jobs in flight (rpa_engine.hip: make_stream)
   install_stage_reporter();  // SIGUSR1 / SIGTERM / TAXATOR_WATCHDOG_S: say where the process is (stage.hh)
   atexit([] { stage("exit handlers (runtime teardown)"); });
   const int rc = run(argc, argv);

@@ -8,6 +8,8 @@ card), every child under a watchdog.  A child that overruns is examined the way 
 /proc state, then SIGUSR1 for the driver's own "stage / engine" report -- and killed; the hunt goes on.  Every so often a
 large batch goes through a fresh engine in this process (--dirty-every) so that device allocations the children get are
 not factory-fresh.  RPA_POISON=1 in the environment is inherited by the children (every work buffer 0xA5 per batch).
+Arms (environment): TAXATOR_RUN_EXIT_HANDLERS=1 = plain return from main (the runtime's exit handlers run);
+RPA_CU_MASK_QUEUES=1 = round 2's CU-masked engine streams (the combination of the two is what hung).
 
 Writes a progress line per 50 children and a JSON summary at the end to --out (default gpurun_out/hang_hunt.json).
 Exit code 0 whatever was found: the summary says it.
