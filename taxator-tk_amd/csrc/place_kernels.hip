@@ -214,8 +214,11 @@ __device__ __forceinline__ uint2 plan_segment(const WorkDev& w, uint32_t seg, co
 // preorder numbers of the records in front of it in its set, then writes its row at the sorted position.  The thread of a
 // set's first record also plans the query-range segment and writes the set header.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef RPA_RANK_WAVES
+#define RPA_RANK_WAVES 1  // (A/B of the register budget: tools/build_variant.sh; 1 = whatever 256 threads allow)
+#endif
 template <int Q>
-__global__ __launch_bounds__(kBlock) void k_rank_records(BatchDev b, WorkDev w, TaxDev tax, StoreDev qstore, StoreDev dbstore, Params p) {
+__global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDev b, WorkDev w, TaxDev tax, StoreDev qstore, StoreDev dbstore, Params p) {
   // Record -> record set.  The records of a workgroup are consecutive, so their sets are consecutive too: the set of
   // the block's first record comes from k_block_first (one binary search per workgroup, all of them in one small launch
   // instead of 4 dependent probes at the head of every workgroup), the block stages the next kBlock+1 offsets in LDS and

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/soak.py [N_SEEDS] -- differential soak on the GPU box: many seeded batches of every shape the parity tests use
-(DNA / protein, ragged sets, edge-case injection, random speculation chunks and round-scheduling knobs) through the engine
-and the CPU oracle; stops at the first row or counter that differs.  Test infrastructure (uses oracle/)."""
+(DNA / protein, ragged sets, edge-case injection, random speculation chunks and round-scheduling knobs, taxonomies of up to
+63 levels, 8- / 16- / 32-bit path labels, whole or windowed reference stores) through the engine and the CPU oracle; stops at the first row or counter that differs.  Test infrastructure (uses oracle/)."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,9 +9,41 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as graft
 from helpers import oracle as O
 
-KNOBS = ("RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
+KNOBS = ("RPA_LABEL_BITS", "RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
          "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL",
          "RPA_PROTEIN_LANES")
+
+
+def fill_windows(pkg, model, ds, tile):
+    """The reference store as a windowed one: the tiles under every hit's range extended by its set's query range, as maximal
+    runs (what the host driver's makeResident appends), in one call."""
+    b = ds.batch
+    roff = ds.ref_offsets.astype(np.int64)
+    rlen = np.diff(roff)
+    model.reserve_windows(pkg.STORE_DB, rlen)
+    so = b["set_offsets"].astype(np.int64)
+    set_of = np.repeat(np.arange(len(so) - 1), np.diff(so))
+    span = np.array([int(b["qstop"][lo:hi].max()) - int(b["qstart"][lo:hi].min()) if hi > lo else 0 for lo, hi in zip(so[:-1], so[1:])], np.int64)
+    seq = b["ref_seq"].astype(np.int64)
+    ok = (seq < len(rlen)) & (np.minimum(b["rstart"], b["rstop"]) >= 1)
+    lo = np.minimum(b["rstart"], b["rstop"]).astype(np.int64)[ok] - 1 - span[set_of][ok]
+    hi = np.maximum(b["rstart"], b["rstop"]).astype(np.int64)[ok] + span[set_of][ok]
+    seq = seq[ok]
+    lo, hi = np.maximum(lo, 0), np.minimum(hi, rlen[seq])
+    keep = hi > lo
+    tiles = {}
+    for s_, a, e in zip(seq[keep], lo[keep] // tile, (hi[keep] - 1) // tile):
+        tiles.setdefault(int(s_), set()).update(range(int(a), int(e) + 1))
+    wins = []
+    for s_, ts in tiles.items():
+        ts = sorted(ts); a = p_ = ts[0]
+        for t in ts[1:] + [None]:
+            if t is None or t != p_ + 1:
+                wins.append((s_, a * tile, min((p_ + 1) * tile, int(rlen[s_]))))
+                a = t
+            p_ = t
+    if wins:
+        model.append_windows(pkg.STORE_DB, [w[0] for w in wins], [w[1] for w in wins], [ds.ref_letters[roff[w[0]] + w[1]: roff[w[0]] + w[2]] for w in wins])
 
 
 def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
@@ -39,11 +71,23 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
       n_hits = min(n_hits, n_species)
       ds = synth.make_dataset(n_sets=n_sets, n_hits=n_hits, seg_len=seg, branching=branching, genome_len=max(4 * seg, 1200),
                               seed=first_seed + k, alphabet=alphabet, variety=True, **kw)
+      # round 3: deep taxonomies (chains of extra nodes in the edges: up to 63 levels), wider path labels than needed,
+      # and the reference store filled through windows (only the tiles the batch reads) instead of whole
+      deep = rng.random() < 0.3
+      if deep:
+          mode = int(rng.integers(0, 3))
+          depth0 = ds.tax.depth.copy()
+          extra = {0: (lambda i: 1), 1: (lambda i: 4 if depth0[i] < 7 else 10), 2: (lambda i: (i * 7 + 3) % 10 if depth0[i] > 1 else 0)}[mode]
+          synth.stretch_dataset(ds, extra)
+      windowed = alphabet == 0 and rng.random() < 0.3
       env = {}
+      if rng.random() < 0.2:  # (the widest row holds 832 bits of labels: wider labels only where the tree's depth leaves room)
+          bits = int(rng.choice([16, 32]))
+          if ((int(ds.tax.depth.max()) + 7) // 8 * 8) * bits <= 832: env["RPA_LABEL_BITS"] = str(bits)
       if rng.random() < 0.5:
-          env = {"RPA_SPEC1": str(int(rng.integers(0, 9))), "RPA_SPEC2": str(int(rng.integers(0, 9))),
-                 "RPA_SPEC_GROW": str(int(rng.integers(0, 2))), "RPA_SPARSE_DECIDE": str(int(rng.choice([1, 3, 6, 24, 100000]))),
-                 "RPA_SPARSE_EMIT": str(int(rng.choice([1, 6, 24, 100000])))}
+          env.update({"RPA_SPEC1": str(int(rng.integers(0, 9))), "RPA_SPEC2": str(int(rng.integers(0, 9))),
+                      "RPA_SPEC_GROW": str(int(rng.integers(0, 2))), "RPA_SPARSE_DECIDE": str(int(rng.choice([1, 3, 6, 24, 100000]))),
+                      "RPA_SPARSE_EMIT": str(int(rng.choice([1, 6, 24, 100000])))})
           if rng.random() < 0.3:
               env["RPA_NO_COMBINED"] = "1"
           if rng.random() < 0.3:
@@ -63,7 +107,10 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
       os.environ.update(env)
       model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
       model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
-      model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+      if not windowed:
+          model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+      else:
+          fill_windows(pkg, model, ds, int(rng.choice([64, 256, 1000])))
       tax = O.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
       q = O.StoreArrays(synth.encode(ds.query_letters, alphabet), ds.query_offsets)
       db = O.StoreArrays(synth.encode(ds.ref_letters, alphabet), ds.ref_offsets)
@@ -80,8 +127,8 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           what = "both abort (oracle rc %d, engine %d)" % (rc, e.code) if ok else "MISMATCH: engine error %d %s, oracle rc %d" % (e.code, e, rc)
       total_sets += n_sets
       if verbose or not ok:
-        print("seed %d: %s sets=%d hits=%d seg=%d b=%d env=%s -> %s  (%.0f s)" % (first_seed + k, "protein" if alphabet else "dna", n_sets, n_hits, seg,
-                                                                           branching, env, what, time.time() - t0), flush=True)
+        print("seed %d: %s sets=%d hits=%d seg=%d b=%d depth=%d%s env=%s -> %s  (%.0f s)" % (first_seed + k, "protein" if alphabet else "dna", n_sets, n_hits, seg,
+                                                                           branching, int(ds.tax.depth.max()), " windows" if windowed else "", env, what, time.time() - t0), flush=True)
       if not ok:
           for f in (rows.dtype.names if rows is not None else ()):
               bad = np.nonzero(rows[f] != exp[f])[0]

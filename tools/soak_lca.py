@@ -15,7 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(2024)
 t0 = time.time(); total = 0
 for k in range(n):
-    tree = T.Tree(rng, n_nodes=int(rng.integers(5, 6000)))
+    tree = T.Tree(rng, n_nodes=int(rng.integers(5, 6000)), max_depth=int(rng.choice([8, 8, 25, 60])))  # (deep trees: chains, see T.Tree)
     uncl = (rng.random(len(tree.parent)) < rng.choice([0.0, 0.2, 0.6])).astype(np.uint8)
     n_sets, max_hits = int(rng.integers(1, 5000)), int(rng.integers(1, 70))
     offs, qlen, recs, evalue = T.random_batch(rng, tree, n_sets, max_hits)
