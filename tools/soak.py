@@ -79,7 +79,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           depth0 = ds.tax.depth.copy()
           extra = {0: (lambda i: 1), 1: (lambda i: 4 if depth0[i] < 7 else 10), 2: (lambda i: (i * 7 + 3) % 10 if depth0[i] > 1 else 0)}[mode]
           synth.stretch_dataset(ds, extra)
-      windowed = alphabet == 0 and rng.random() < 0.3
+      windowed = rng.random() < 0.3
       env = {}
       if rng.random() < 0.2:  # (the widest row holds 832 bits of labels: wider labels only where the tree's depth leaves room)
           bits = int(rng.choice([16, 32]))
