@@ -529,7 +529,7 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
     const SetRows<Q> R = set_rows<Q>(w, s, lo);
     const uint32_t i = pos - lo;
     const HitCore h = R.core(i);
-    if (h.score >= info.fcut && (double)h.qs / info.L >= info.qpid_thresh) {
+    if (h.score >= info.fcut && h.qs >= info.qs_min) {  // qs_min: the float form of "(double)qs / L >= qpid_thresh" (qs_threshold)
       uint32_t pb[4 * Q - 6], pth[4 * Q - 6];
       R.path(info.best, pb);
       R.path(i, pth);
@@ -1018,6 +1018,20 @@ __device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t
   if (err_a | err_b) { raise_error(w, err_a ? err_a : err_b, s); return false; }
   if (dist != dist) { raise_error(w, kErrAssert, s); return false; }
   return true;
+}
+
+// The smallest float q with (double)q / L >= t.  IEEE division by a positive constant is monotone, so for every float qs
+//     (double)qs / L >= t   <=>   qs >= qs_threshold(t, L)
+// exactly: k_emit tests a pass-2 candidate's similarity with one float compare instead of a double division per row (the
+// division's registers were what made that kernel spill).  Computed once per pass-2 anchor by k_decide.
+__device__ __forceinline__ float qs_threshold(double t, uint32_t L) {
+  const double dl = (double)L;
+  auto ok = [&](float q) { return (double)q / dl >= t; };
+  float q = (float)(t * dl);
+  if (!(q == q)) return __uint_as_float(0x7F800000u);          // (t is finite in practice; NaN: nothing passes, as with the division)
+  for (int k = 0; k < 8 && ok(q) && q > -FLT_MAX; ++k) q = nextafterf(q, -INFINITY);   // below the boundary ...
+  for (int k = 0; k < 16 && !ok(q) && q < FLT_MAX; ++k) q = nextafterf(q, INFINITY);   // ... and up to the first float that passes
+  return ok(q) ? q : __uint_as_float(0x7F800000u);
 }
 
 // the log line "+ALN i <=> j  dist=..; sim=.." as a record (tracing on only: rpa_trace_begin)
@@ -1514,6 +1528,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           const double qpid_anchor = (double)h.qs / L;             // :750-753
           const double g2 = qpid_anchor * 2. - 1., h3 = qpid_anchor * X;
           em.qpid_thresh = g2 < h3 ? h3 : g2;
+          em.qs_min = qs_threshold(em.qpid_thresh, L);
         }
       }
       if (!found) {  // :824-833
