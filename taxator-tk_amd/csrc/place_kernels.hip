@@ -529,7 +529,7 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
     const SetRows<Q> R = set_rows<Q>(w, s, lo);
     const uint32_t i = pos - lo;
     const HitCore h = R.core(i);
-    if (h.score >= info.fcut && h.qs >= info.qs_min) {  // qs_min: the float form of "(double)qs / L >= qpid_thresh" (qs_threshold)
+    if (h.score >= info.fcut && h.qs >= info.qs_min) {  // qs_min: never stricter than "(double)qs / L >= qpid_thresh" (qs_threshold)
       uint32_t pb[4 * Q - 6], pth[4 * Q - 6];
       R.path(info.best, pb);
       R.path(i, pth);
@@ -1020,18 +1020,21 @@ __device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t
   return true;
 }
 
-// The smallest float q with (double)q / L >= t.  IEEE division by a positive constant is monotone, so for every float qs
-//     (double)qs / L >= t   <=>   qs >= qs_threshold(t, L)
-// exactly: k_emit tests a pass-2 candidate's similarity with one float compare instead of a double division per row (the
-// division's registers were what made that kernel spill).  Computed once per pass-2 anchor by k_decide.
+// A float q with   (double)qs / L >= t  =>  qs >= q   for every float qs, and equality of the two tests except within an
+// ulp or two of the boundary: IEEE division by a positive constant is monotone, so the similarities that pass the
+// reference's test (:765, a double division per hit) are exactly those from some float q* on; q* is one of the two floats
+// around t * L (a quotient just below t may still round up to t), and the float below the rounded product is never above
+// it.  k_emit uses this as its similarity test for pass-2 candidates -- emission may be a superset (a hit that squeezes
+// through here but not through the reference's test gets an alignment nobody reads; k_decide applies the division) --
+// instead of a double division per row, whose registers made that kernel spill.  One multiply, once per pass-2 anchor.
 __device__ __forceinline__ float qs_threshold(double t, uint32_t L) {
-  const double dl = (double)L;
-  auto ok = [&](float q) { return (double)q / dl >= t; };
-  float q = (float)(t * dl);
-  if (!(q == q)) return __uint_as_float(0x7F800000u);          // (t is finite in practice; NaN: nothing passes, as with the division)
-  for (int k = 0; k < 8 && ok(q) && q > -FLT_MAX; ++k) q = nextafterf(q, -INFINITY);   // below the boundary ...
-  for (int k = 0; k < 16 && !ok(q) && q < FLT_MAX; ++k) q = nextafterf(q, INFINITY);   // ... and up to the first float that passes
-  return ok(q) ? q : __uint_as_float(0x7F800000u);
+  const float q = (float)(t * (double)L);
+  uint32_t bits = __float_as_uint(q);
+  if (!(q == q)) return q;                                   // NaN (t is finite in practice): nothing passes either test
+  if ((bits & 0x7FFFFFFFu) == 0u) return __uint_as_float(0x80000001u);  // +-0 -> the negative float next to it
+  if (q == -INFINITY) return q;
+  bits += (bits >> 31) ? 1u : 0xFFFFFFFFu;                   // one float towards -infinity
+  return __uint_as_float(bits);
 }
 
 // the log line "+ALN i <=> j  dist=..; sim=.." as a record (tracing on only: rpa_trace_begin)
@@ -1048,7 +1051,7 @@ __device__ __forceinline__ void trace_put(const WorkDev& w, uint32_t s, uint32_t
 #ifndef RPA_DECIDE_WAVES
 #define RPA_DECIDE_WAVES 2  // resident waves per SIMD the register budget of k_decide is set for (A/B: tools/build_variant.sh)
 #endif
-template <int Q>
+template <int Q, bool kTrace>  // kTrace: the variant that records the consumed alignments (rpa_trace_begin); the other carries no trace code
 __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b, WorkDev w, TaxDev tax, Params p, OutRow* __restrict__ rows,
                                                     OutStats* __restrict__ stats, unsigned long long* prof_acc) {
   constexpr int PW = 4 * Q - 6;
@@ -1100,7 +1103,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       else {
         const float idf = (float)h0.ident;
         const float sim0 = r2.y < idf ? idf : r2.y;  // std::max(similarity, identities), :531
-        if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 0, 0, -1, r2.x, sim0);
+        if constexpr (kTrace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 0, 0, -1, r2.x, sim0);
         ++st.cnt0;
         R.store_qdqs(0u, r2.x, sim0);
         if (r2.x == 0.f) w.lite[lo] = (w.lite[lo] & kLiteLenMask) | kLiteZeroQd;  // (:620-621)
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           dist = r2.x;
           const float idf = (float)h.ident;
           sim = r2.y < idf ? idf : r2.y;  // std::max(similarity, identities), :531
-          if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 0, (int)i, -1, dist, sim);
+          if constexpr (kTrace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 0, (int)i, -1, dist, sim);
           ++st.cnt0;
         } else {
           dist = FLT_MAX; sim = (float)h.ident;
@@ -1290,7 +1293,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           if (i >= st.chunk_hi) { paused = true; break; }  // this alignment was not part of the chunk emitted last round
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
-          if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 1, (int)i, (int)a, dist, r2.y);
+          if constexpr (kTrace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 1, (int)i, (int)a, dist, r2.y);
           ++st.cnt1;
         }
         band.add(dist, common<PW>(pa, da, pth, dh, lbs));  // :641
@@ -1455,7 +1458,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           if (i >= st.chunk_hi) { paused = true; break; }  // not part of the chunk emitted last round
           if (!result_ok(w, s, meta_err(h.meta), meta_err(ha.meta), r2.x)) { failed = true; break; }
           dist = r2.x;
-          if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 2, (int)i, (int)a, dist, r2.y);
+          if constexpr (kTrace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 2, (int)i, (int)a, dist, r2.y);
           ++st.cnt2;
           if constexpr (kSmall) qdmask |= 1ull << i; else R.store_qd(i, dist);  // querydistance[i] = dist, :785
         }
@@ -1471,7 +1474,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
             qd_a = d2; qs_a = s2;
             if constexpr (kSmall) anchor_pair = true; else R.store_qdqs(a, d2, s2);
             qdist_ex = d2 * st.bf_max;
-            if (w.trace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 2, -1, (int)a, d2, s2);
+            if constexpr (kTrace) trace_put(w, s, st.cnt0 + st.cnt1 + st.cnt2, 2, -1, (int)a, d2, s2);
             ++st.cnt2;
           } else qdist_ex = qd_a * st.bf_max;  // :809
           if (dist <= qdist_ex) st.d_unode_g = min(st.d_unode_g, cb);  // unode_global = LCA(unode_global, cnode), :811-813
@@ -1703,7 +1706,8 @@ hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, co
   const uint32_t n_threads = w.live_in ? w.n_live_in : b.n_sets;
   if (n_threads == 0) return hipSuccess;
   const dim3 grid((n_threads + kBlock - 1) / kBlock);
-  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_decide<Q>, grid, dim3(kBlock), (size_t)w.band_ranks * kBlock * 2 * sizeof(float), st, b, w, tax, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc));
+  if (w.trace) { RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL((k_decide<Q, true>), grid, dim3(kBlock), (size_t)w.band_ranks * kBlock * 2 * sizeof(float), st, b, w, tax, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc)); }
+  else { RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL((k_decide<Q, false>), grid, dim3(kBlock), (size_t)w.band_ranks * kBlock * 2 * sizeof(float), st, b, w, tax, p, (OutRow*)out_rows, (OutStats*)out_stats, prof_acc)); }
   return hipGetLastError();
 }
 

@@ -160,7 +160,7 @@ struct EmitInfo {
   uint32_t i_lo, i_hi;  // only hits with i_lo <= i < i_hi are emitted this round (speculation chunk of the running loop)
   uint32_t emit_query;  // pass 2: also emit the anchor <-> query alignment (first chunk of an anchor whose querydistance is unset)
   uint32_t anchor_len;  // pass 1/2: length of the anchor's reference segment
-  float qs_min;         // pass 2: smallest querysimilarity with (double)qs / L >= qpid_thresh (place_kernels.hip: qs_threshold)
+  float qs_min;         // pass 2: a similarity below which (double)qs / L >= qpid_thresh cannot hold (place_kernels.hip: qs_threshold)
 };
 
 // The 16 bytes of EmitInfo that k_emit needs in passes 0 and 1 (one load instead of the 56-byte struct):
