@@ -501,21 +501,28 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
     // the first lane of a pair: row 0 above its strip, and A's self scores (the other lanes add from a table of zeros)
     const bool first = sub == 0u;
     const int32_t* __restrict__ sd = selfdiag + (first ? 0 : 32);
-    const bool corner_mine = mine && sub + 1u == nstrips;  // the pair's last strip: its bottom cell of column la is the corner
     uint32_t res = K;                                      // no columns or no rows: score 0, no steps
     uint32_t ad_cur = residues(0u);
     uint32_t bottom = K;
+    // Per column beside the cells: one counter, one compare shared by the residue select and the corner pick (res follows
+    // the bottom cell while my columns last: what it holds at the end is column la's, and only the pair's last strip reads
+    // it), row 0 as a running value (M[0][j] = -j: one subtraction per step; only a pair's first lane uses it).
+    uint32_t c = 0u - sub;                                 // wraps for the steps in front of my first column
+    uint32_t row0 = ((bias - 1u) << kPkScore) | c_one;     // (first lanes: c == the step)
+    const uint32_t row0_step = 1u << kPkScore;
     for (uint32_t u4 = 0; u4 < n_steps; u4 += 4u) {
       const uint32_t ad_nxt = residues(u4 + 4u);
 #pragma unroll
       for (uint32_t q = 0; q < 4u; ++q) {
         const uint32_t above = from_lane_below(bottom);
-        const uint32_t c = u4 + q - sub;  // wraps for the steps in front of my first column
-        const uint32_t a = c < cols ? (ad_cur >> (8u * q)) & 0xFFu : (uint32_t)kAA;  // (kAA: the null residue)
-        const uint32_t top = first ? ((bias - (c + 1u)) << kPkScore) | c_one : above;   // row 0: M[0][j] = -j
+        const bool valid = c < cols;
+        const uint32_t a = valid ? (ad_cur >> (8u * q)) & 0xFFu : (uint32_t)kAA;  // (kAA: the null residue)
+        const uint32_t top = first ? row0 : above;
         selfscore += sd[a];
         bottom = column(a, top);
-        res = corner_mine && c + 1u == la ? bottom : res;
+        res = valid ? bottom : res;
+        row0 -= row0_step;
+        ++c;
       }
       ad_cur = ad_nxt;
     }
