@@ -21,7 +21,7 @@ __device__ __forceinline__ uint32_t from_lane_below(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
 }
 
-template <int MODE, int BLOCK>
+template <int MODE, int BLOCK, int SEL = 0>
 __global__ __launch_bounds__(BLOCK) void k(uint32_t* out, uint32_t seed, uint32_t n_steps) {
   __shared__ uint32_t tab[kAX * kAX * 32];
   for (int idx = threadIdx.x; idx < kAX * kAX * 32; idx += BLOCK) {
@@ -43,6 +43,8 @@ __global__ __launch_bounds__(BLOCK) void k(uint32_t* out, uint32_t seed, uint32_
   }
   uint32_t dtop = L[0], bottom = L[0], res = 0;
   const bool first = (threadIdx.x % 3u) == 0u;
+  uint32_t fmask = first ? ~0u : 0u, row0 = (1000u << kPkScore) | c_one;
+  asm volatile("" : "+v"(fmask));
   auto cells = [&](const uint32_t* tv, int r0, int r1, uint32_t& up, uint32_t& dg) {
 #pragma unroll
     for (int r = r0; r < r1; ++r) {
@@ -67,7 +69,10 @@ __global__ __launch_bounds__(BLOCK) void k(uint32_t* out, uint32_t seed, uint32_
     const uint32_t a = (ad >> 24) % 27u;  // (the kernel: a byte of a prefetched dword + a select)
     const uint32_t colterm = a * 128u;
     const uint32_t above = from_lane_below(bottom);
-    const uint32_t top = first ? ((1000u - u) << kPkScore) | c_one : above;
+    uint32_t top;
+    if (SEL == 0) top = first ? ((1000u - u) << kPkScore) | c_one : above;
+    else if (SEL == 1) top = __builtin_amdgcn_bitop3_b32(above, row0, fmask, 0xCA);  // fmask ? row0 : above, bit by bit
+    else top = above + row0;
     uint32_t up = top, dg = dtop;
     dtop = top;
     if (MODE == 0 || MODE == 1) {
@@ -116,7 +121,10 @@ __global__ __launch_bounds__(BLOCK) void k(uint32_t* out, uint32_t seed, uint32_
       __builtin_amdgcn_sched_barrier(0);
     }
     bottom = up;
-    res = (u & 63u) == 17u ? bottom : res;
+    if (SEL == 0) res = (u & 63u) == 17u ? bottom : res;
+    else if (SEL == 1) { const uint32_t vm = (uint32_t)((int32_t)((u & 63u) - 18u) >> 31) & ~(uint32_t)((int32_t)((u & 63u) - 17u) >> 31); res = __builtin_amdgcn_bitop3_b32(res, bottom, vm, 0xCA); }
+    else res ^= bottom;
+    row0 -= 1u << kPkScore;
   }
   uint32_t acc = res ^ bottom;
 #pragma unroll
@@ -124,19 +132,19 @@ __global__ __launch_bounds__(BLOCK) void k(uint32_t* out, uint32_t seed, uint32_
   out[blockIdx.x * BLOCK + threadIdx.x] = acc;
 }
 
-template <int MODE, int BLOCK>
+template <int MODE, int BLOCK, int SEL = 0>
 void run(const char* name, uint32_t* d_out, uint32_t n_steps) {
   const int blocks = 256;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<MODE, BLOCK>), dim3(blocks), dim3(BLOCK), 0, 0, d_out, 12345u, 64u);
+  hipLaunchKernelGGL((k<MODE, BLOCK, SEL>), dim3(blocks), dim3(BLOCK), 0, 0, d_out, 12345u, 64u);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k<MODE, BLOCK>), dim3(blocks), dim3(BLOCK), 0, 0, d_out, 12345u, n_steps);
+  hipLaunchKernelGGL((k<MODE, BLOCK, SEL>), dim3(blocks), dim3(BLOCK), 0, 0, d_out, 12345u, n_steps);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-  hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k<MODE, BLOCK>));
+  hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k<MODE, BLOCK, SEL>));
   const double cell_waves_per_simd = (double)(BLOCK / 64) / 4.0 * n_steps * R;  // per SIMD (256 CUs x 4 SIMDs, one block per CU)
   printf("%-44s %2d waves/SIMD %3d VGPRs %4zu B scratch: %8.3f ms  %6.2f ns per cell-wave per SIMD  (%.2f T cells/s)\n", name, BLOCK / 256,
          fa.numRegs, (size_t)fa.localSizeBytes, ms, ms * 1e6 / cell_waves_per_simd, (double)blocks * BLOCK * n_steps * R / ms / 1e9);
@@ -160,5 +168,8 @@ int main() {
   run<3, 512>("3 reads one column ahead", d_out, n);
   run<5, 1024>("5 reads half a column ahead", d_out, n);
   run<5, 768>("5 reads half a column ahead", d_out, n);
+  run<0, 1024, 1>("0 + the two selects as bitop3 masks", d_out, n);
+  run<0, 1024, 2>("0 + no selects (add / xor instead)", d_out, n);
+  run<1, 1024, 2>("1 no table, no selects", d_out, n);
   return 0;
 }
