@@ -525,7 +525,12 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
   if (info.mode == 1) want = (lite & kLiteWant0) != 0u;
   else if (info.mode == 4) want = vs_query ? (lite & kLiteWant0) != 0u : !(lite & kLiteZeroQd);
   else if (info.mode == 2) want = !(lite & kLiteZeroQd);
-  else {
+  else if (info.mode == 5) {  // the paused loop's own tests (:604 score cut-off, :612 qpid threshold) with the values at the pause: they only rise
+    if (!(lite & kLiteZeroQd)) {
+      const HitCore h = set_rows<Q>(w, s, lo).core(pos - lo);
+      want = h.score >= info.fcut && h.qs >= info.qs_min;
+    }
+  } else {
     const SetRows<Q> R = set_rows<Q>(w, s, lo);
     const uint32_t i = pos - lo;
     const HitCore h = R.core(i);
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
     uint32_t ml = 0;
     if (pos < H) {
       if (mode != 0u && (mode == 4u || i >= desc[k].y) && i < desc[k].z && (mode == 1u || mode == 4u || i != anchor)) {
-        if (mode != 3u) {  // passes 0 and 1: the lite word decides
+        if (mode != 3u && mode != 5u) {  // passes 0 and 1: the lite word decides
           const bool vs_query = mode == 1u || (mode == 4u && i == anchor);
           const bool want = vs_query ? (lite[k] & kLiteWant0) != 0u : !(lite[k] & kLiteZeroQd);
           if (want) {
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDe
     s = w.live_in[wave_id];
     const uint4 desc = w.emit_lite[s];
     info.mode = desc.x & 7u;
-    if (info.mode == 3u) info = w.emit[s];  // pass 2: thresholds, best hit, depth of unode_global
+    if (info.mode == 3u || info.mode == 5u) info = w.emit[s];  // pass 2: thresholds, best hit, depth of unode_global; 5: thresholds
     else {                                  // passes 0 and 1: the descriptor says it all (emit_desc)
       info.anchor = desc.x >> 3; info.n = desc.z; info.i_hi = desc.z;
       info.i_lo = info.mode == 4u ? 0u : desc.y;
@@ -1346,6 +1351,10 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
         band.save(w.band_save + (size_t)s * 2 * w.band_ranks);
         st.chunk_hi = p.spec1 ? min(n, i + (p.grow ? max(p.spec1, i) : p.spec1)) : n;
         em.mode = 2; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.i_lo = i; em.i_hi = st.chunk_hi;
+        const double cut = cut_g < cut_h ? cut_h : cut_g;
+        if (p.filter1 && (scut != 0 || cut > 0.)) {  // the chunk without the hits the loop will break at or step over anyway
+          em.mode = 5; em.fcut = (float)scut; em.qs_min = qs_threshold(cut, L);
+        }
       } else
       if (!failed) {
         const float bandfactor = band.factor();  // :667
@@ -1555,7 +1564,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     em.mode = 0;                // nothing asked for yet: the second trip decides
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
-    if (em.mode == 3u) w.emit[s] = em;  // pass 2 carries thresholds that only the full record holds
+    if (em.mode == 3u || em.mode == 5u) w.emit[s] = em;  // thresholds that only the full record holds
     w.emit_lite[s] = emit_desc(em);
     state_store(w, s, st, st.loop_live != 0u && st.phase == kPass1Wait);
   }

@@ -149,10 +149,11 @@ struct EmitInfo {
   uint32_t mode;        // 0 nothing, 1 pass 0 (vs query range), 2 pass 1 (vs anchor), 3 pass 2 (vs anchor),
                         // 4 pass 0 + pass 1 in one round: the only hit pass 0 aligns (hit `anchor` = 0) vs the query range,
                         //   every other hit vs that hit (see k_plan_sets)
+                        // 5 pass 1 like 2, made when the paused loop already has thresholds: hits they exclude are left out
   uint32_t anchor;      // index_anchor
   uint32_t n;           // active hits
   uint32_t L;           // qrlength
-  float fcut;           // pass 0: re-evaluation score threshold (:499); pass 2: qsearchscore_thresh_heuristic (:754)
+  float fcut;           // pass 0: re-evaluation score threshold (:499); pass 2: qsearchscore_thresh_heuristic (:754); mode 5: (:604, :659)
   uint32_t d_unode_g;   // pass 2: depth of unode_global on the best hit's path
   double qpid_thresh;   // pass 2 (:750-753)
   uint32_t best;        // pass 2: index_best
@@ -160,7 +161,7 @@ struct EmitInfo {
   uint32_t i_lo, i_hi;  // only hits with i_lo <= i < i_hi are emitted this round (speculation chunk of the running loop)
   uint32_t emit_query;  // pass 2: also emit the anchor <-> query alignment (first chunk of an anchor whose querydistance is unset)
   uint32_t anchor_len;  // pass 1/2: length of the anchor's reference segment
-  float qs_min;         // pass 2: a similarity below which (double)qs / L >= qpid_thresh cannot hold (place_kernels.hip: qs_threshold)
+  float qs_min;         // pass 2, mode 5: a similarity below which (double)qs / L >= qpid_thresh cannot hold (place_kernels.hip: qs_threshold)
 };
 
 // The 16 bytes of EmitInfo that k_emit needs in passes 0 and 1 (one load instead of the 56-byte struct):
@@ -252,6 +253,8 @@ struct Params {
   int force_bin;          // >= 0: put every pair into this bin (experiments: RPA_FORCE_BIN); -1 normally
   int protein_lanes;      // 0: packed protein pairs all go to K3p (one lane per pair), none to K3l (A/B: RPA_PROTEIN_LANES=0)
   int no_combined;        // 1: never ask for pass 0 and the first pass-1 loop in one round (A/B: RPA_NO_COMBINED)
+  int filter1;            // 1 (default): a pass-1 chunk leaves out the hits that the loop's thresholds at the pause already exclude
+                          //    (A/B: RPA_PASS1_FILTER=0)
   int grow;               // 1: a loop that pauses asks for as many hits again as it has already walked (chunks 2,2,4,8,...):
                           //    a loop that has not stopped early so far probably will not; log2(n) rounds instead of n/chunk
 };

@@ -795,6 +795,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.protein_lanes = 1;
   if (const char* v = getenv("RPA_PROTEIN_LANES")) e->params.protein_lanes = atoi(v) != 0;
   e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
+  e->params.filter1 = 1;
+  if (const char* v = getenv("RPA_PASS1_FILTER")) e->params.filter1 = atoi(v) != 0;
   e->params.grow = 0;
   if (const char* v = getenv("RPA_SPEC_GROW")) e->params.grow = atoi(v);
   if (const char* v = getenv("RPA_BAND")) e->band_long = atoi(v) != 0;

@@ -339,7 +339,8 @@ def test_speculation_chunks_never_change_results(pkg, oracle, synth, speculation
     {"RPA_SPARSE_DECIDE": "1", "RPA_SPARSE_EMIT": "1"},                         # every round after the first through the live list
     {"RPA_SPARSE_DECIDE": "1000000", "RPA_SPARSE_EMIT": "1000000"},             # never
     {"RPA_NO_COMBINED": "1", "RPA_SPARSE_DECIDE": "2", "RPA_SPARSE_EMIT": "50"},
-], ids=["grow", "adaptive", "always-sparse", "never-sparse", "split-rounds"])
+    {"RPA_SPEC1": "2", "RPA_SPEC2": "3", "RPA_PASS1_FILTER": "0"},              # pass-1 chunks without the paused loop's thresholds
+], ids=["grow", "adaptive", "always-sparse", "never-sparse", "split-rounds", "unfiltered-chunks"])
 def test_round_scheduling_knobs_never_change_results(pkg, oracle, synth, env, monkeypatch):
     """How the rounds are cut (chunk growth, when a round walks the live list instead of every row, pass 0 and pass 1 in
     one round or two) decides who computes what when -- never the rows or the demanded-alignment counters."""
@@ -349,6 +350,27 @@ def test_round_scheduling_knobs_never_change_results(pkg, oracle, synth, env, mo
     _engine_vs_oracle(pkg, oracle, synth, ds, 0)
     dp = synth.make_dataset(n_sets=300, n_hits=16, seg_len=60, branching=3, genome_len=1500, seed=24, alphabet=1,
                             level_rate=0.06, query_rate=0.08, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, dp, 1)
+
+
+def test_pass1_chunks_leave_out_what_the_loop_already_excludes(pkg, oracle, synth, monkeypatch):
+    """A pass-1 loop that pauses asks for its next chunk without the hits that its score cut-off and similarity threshold
+    at the pause already exclude (they only rise): fewer alignments computed, the same rows and demanded counters."""
+    dp = synth.make_dataset(n_sets=2000, n_hits=20, seg_len=67, branching=4, genome_len=1500, seed=31, alphabet=1,
+                            level_rate=0.06, query_rate=0.08)
+    pairs = {}
+    for flt in ("0", "1"):
+        monkeypatch.setenv("RPA_PASS1_FILTER", flt)
+        monkeypatch.setenv("RPA_SPEC1", "3"); monkeypatch.setenv("RPA_SPEC2", "10")
+        model = pkg.RPAPredictionModel(dp.tax, alphabet=pkg.PROTEIN)
+        model.load_store(pkg.STORE_QUERY, dp.query_letters, dp.query_offsets)
+        model.load_store(pkg.STORE_DB, dp.ref_letters, dp.ref_offsets)
+        model.profile(enable=True, reset=True)
+        rows, stats = model.predict(dp.batch)
+        prof = model.profile()
+        pairs[flt] = (prof["pairs"], prof["demanded"], rows.tobytes(), stats.tobytes())
+    assert pairs["0"][1:] == pairs["1"][1:]
+    assert pairs["1"][0] < 0.97 * pairs["0"][0], (pairs["0"][0], pairs["1"][0])
     _engine_vs_oracle(pkg, oracle, synth, dp, 1)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/soak.py [N_SEEDS] -- differential soak on the GPU box: many seeded batches of every shape the parity tests use
-(DNA / protein, ragged sets, edge-case injection, random speculation chunks and round-scheduling knobs, taxonomies of up to
+(DNA / protein, ragged sets, edge-case injection, random speculation chunks (with and without the paused loop's thresholds) and round-scheduling knobs, taxonomies of up to
 63 levels, 8- / 16- / 32-bit path labels, whole or windowed reference stores) through the engine and the CPU oracle; stops at the first row or counter that differs.  Test infrastructure (uses oracle/)."""
 import importlib, os, sys, time
 import numpy as np
@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as graft
 from helpers import oracle as O
 
-KNOBS = ("RPA_LABEL_BITS", "RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
+KNOBS = ("RPA_PASS1_FILTER", "RPA_LABEL_BITS", "RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
          "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL",
          "RPA_PROTEIN_LANES")
 
@@ -88,6 +88,8 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           env.update({"RPA_SPEC1": str(int(rng.integers(0, 9))), "RPA_SPEC2": str(int(rng.integers(0, 9))),
                       "RPA_SPEC_GROW": str(int(rng.integers(0, 2))), "RPA_SPARSE_DECIDE": str(int(rng.choice([1, 3, 6, 24, 100000]))),
                       "RPA_SPARSE_EMIT": str(int(rng.choice([1, 6, 24, 100000])))})
+          if rng.random() < 0.3:
+              env["RPA_PASS1_FILTER"] = "0"
           if rng.random() < 0.3:
               env["RPA_NO_COMBINED"] = "1"
           if rng.random() < 0.3:
