@@ -89,6 +89,7 @@ struct SetRows {
     c.qd = b.x; c.qs = b.y;
     return c;
   }
+  __device__ __forceinline__ float score(uint32_t i) const { return __uint_as_float(reinterpret_cast<const uint32_t*>(p + (size_t)i * si)[0]); }
   __device__ __forceinline__ void path(uint32_t i, uint32_t (&path)[4 * Q - 6]) const {
     const uint4* r = p + (size_t)i * si;
     const uint2 h = reinterpret_cast<const uint2*>(r + sq)[1];
@@ -860,6 +861,28 @@ __device__ __forceinline__ void append_live(const WorkDev& w, bool running, uint
   if (running) w.live_out[s_live[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
 }
 
+// Where a pass-1 chunk ends.  The loop of an anchor stops at the first hit whose score is below its cut-off (:604), and
+// the cut-off is X times the score of the first hit the loop finds farther from the anchor than the query is (:659).  A
+// chunk is made on the assumption that its FIRST hit -- the one the loop paused at, or the first one a new loop aligns --
+// will be that hit (if the loop has no cut-off yet): hits are in score order, so the chunk ends where the scores fall
+// below X times the first hit's (binary search over the score words).  When the assumption fails the loop pauses at the
+// chunk end like at any other; when the cut-off is already set the end is exact.  tools/spec_waste.py: config 4 asks for
+// 1.08 alignments per demanded one instead of 1.20, with the whole loop in one request (1.5 request rounds per set after
+// pass 0 instead of 1.95); RPA_PASS1_FILTER=1 switches the assumption off.
+template <int Q>
+__device__ __forceinline__ uint32_t chunk_end_by_score(const SetRows<Q>& R, uint32_t first, uint32_t hi, int scut_now, float X) {
+  if (first + 1u >= hi) return hi;
+  const int scut = scut_now ? scut_now : (int)(R.score(first) * X);
+  const float fcut = (float)scut;
+  if (R.score(hi - 1u) >= fcut) return hi;  // (scores within a factor X of each other: the usual DNA case, one probe)
+  uint32_t a = first + 1u, b = hi - 1u;  // smallest r in (first, hi) with !(score_r >= fcut)
+  while (a < b) {
+    const uint32_t m = (a + b) >> 1;
+    if (R.score(m) >= fcut) a = m + 1u; else b = m;
+  }
+  return a;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Plan: one thread per record set.  Handles everything predict() decides before any alignment (:341-472): n == 0,
 // n == 1, perfect-best-hit shortcut; otherwise emits pass 0.  (Masking, query range, sorting and segment plans were
@@ -948,6 +971,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
         if (members == 1 && (w.lite[lo] & kLiteWant0) && !p.no_combined) {
           em.mode = 4; em.anchor = 0; em.anchor_len = w.lite[lo] & kLiteLenMask;
           em.i_hi = p.spec1 ? min(n, p.spec1) : n;  // the first speculation chunk of the pass-1 loop (hit 0 is part of it)
+          if (p.filter1 >= 2) em.i_hi = chunk_end_by_score(set_rows<Q>(w, s, lo), 1u, em.i_hi, 0, p.exclude_factor);  // (no perfect hit here: hit 1 is the first one aligned)
           st.chunk_hi = em.i_hi;                    // remembered: k_decide may run with another chunk size by then
           st.combined = 1;
         }
@@ -1350,6 +1374,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
         st.qpid_upper = qpid_upper; st.cut_g = cut_g; st.cut_h = cut_h; st.scut = scut;
         band.save(w.band_save + (size_t)s * 2 * w.band_ranks);
         st.chunk_hi = p.spec1 ? min(n, i + (p.grow ? max(p.spec1, i) : p.spec1)) : n;
+        if (p.filter1 >= 2) st.chunk_hi = chunk_end_by_score(R, i, st.chunk_hi, scut, X);
         em.mode = 2; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.i_lo = i; em.i_hi = st.chunk_hi;
         const double cut = cut_g < cut_h ? cut_h : cut_g;
         if (p.filter1 && (scut != 0 || cut > 0.)) {  // the chunk without the hits the loop will break at or step over anyway
@@ -1518,6 +1543,11 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       }
       st.anchor = a; st.phase = kPass1Wait; st.loop_live = 0;
       st.chunk_hi = p.spec1 ? min(n, p.spec1) : n;
+      if (p.filter1 >= 2) {  // the first hit this loop aligns: not the anchor, not at distance 0 from the query (:620)
+        uint32_t r = 0;
+        while (r < st.chunk_hi && (r == a || (w.lite[lo + r] & kLiteZeroQd))) ++r;
+        if (r < st.chunk_hi) st.chunk_hi = chunk_end_by_score(R, r, st.chunk_hi, 0, X);
+      }
       em.mode = 2; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.i_lo = 0; em.i_hi = st.chunk_hi;
     } else if (!failed && st.phase == kPass2Select) {  // :739-747
       bool found = false;

@@ -783,7 +783,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.reeval_factor = (float)(1. - params->reeval_bandwidth);  // reeval_bandwidth_factor_(1. - reeval_bandwidth), :334
   // speculation chunks (hits whose alignment is requested per round of a pass-1 / pass-2 loop): results never depend on
   // them, only the number of alignments computed beyond what the reference demands and the number of rounds
-  e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 0u : 4u) : params->speculation_pass1;
+  e->params.spec1 = params->speculation_pass1 == RPA_SPECULATION_DEFAULT ? 0u : params->speculation_pass1;  // the whole loop, cut by chunk_end_by_score (tools/spec_sweep9.sh; protein: 4 hits until round 3)
   e->params.spec2 = params->speculation_pass2 == RPA_SPECULATION_DEFAULT ? (params->alphabet == RPA_DNA ? 10u : 10u) : params->speculation_pass2;  // tools/spec_sweep.sh, tools/spec_sweep4.sh
   e->trace_rounds = getenv("RPA_TRACE_ROUNDS") != nullptr;
   if (const char* v = getenv("RPA_ROW_LAYOUT")) e->linear_rows = !strcmp(v, "linear");
@@ -795,8 +795,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.protein_lanes = 1;
   if (const char* v = getenv("RPA_PROTEIN_LANES")) e->params.protein_lanes = atoi(v) != 0;
   e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
-  e->params.filter1 = 1;
-  if (const char* v = getenv("RPA_PASS1_FILTER")) e->params.filter1 = atoi(v) != 0;
+  e->params.filter1 = 2;
+  if (const char* v = getenv("RPA_PASS1_FILTER")) e->params.filter1 = atoi(v);
   e->params.grow = 0;
   if (const char* v = getenv("RPA_SPEC_GROW")) e->params.grow = atoi(v);
   if (const char* v = getenv("RPA_BAND")) e->band_long = atoi(v) != 0;

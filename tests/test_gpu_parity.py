@@ -340,7 +340,8 @@ def test_speculation_chunks_never_change_results(pkg, oracle, synth, speculation
     {"RPA_SPARSE_DECIDE": "1000000", "RPA_SPARSE_EMIT": "1000000"},             # never
     {"RPA_NO_COMBINED": "1", "RPA_SPARSE_DECIDE": "2", "RPA_SPARSE_EMIT": "50"},
     {"RPA_SPEC1": "2", "RPA_SPEC2": "3", "RPA_PASS1_FILTER": "0"},              # pass-1 chunks without the paused loop's thresholds
-], ids=["grow", "adaptive", "always-sparse", "never-sparse", "split-rounds", "unfiltered-chunks"])
+    {"RPA_SPEC1": "5", "RPA_SPEC2": "3", "RPA_PASS1_FILTER": "1"},              # ... with them, without the first-hit assumption
+], ids=["grow", "adaptive", "always-sparse", "never-sparse", "split-rounds", "unfiltered-chunks", "thresholds-only"])
 def test_round_scheduling_knobs_never_change_results(pkg, oracle, synth, env, monkeypatch):
     """How the rounds are cut (chunk growth, when a round walks the live list instead of every row, pass 0 and pass 1 in
     one round or two) decides who computes what when -- never the rows or the demanded-alignment counters."""
@@ -355,22 +356,28 @@ def test_round_scheduling_knobs_never_change_results(pkg, oracle, synth, env, mo
 
 def test_pass1_chunks_leave_out_what_the_loop_already_excludes(pkg, oracle, synth, monkeypatch):
     """A pass-1 loop that pauses asks for its next chunk without the hits that its score cut-off and similarity threshold
-    at the pause already exclude (they only rise): fewer alignments computed, the same rows and demanded counters."""
+    at the pause already exclude (they only rise: level 1), and a chunk ends where the scores fall below the cut-off that
+    its first hit would set (an assumption: level 2, the default): fewer alignments computed at every level, the same rows
+    and demanded counters."""
     dp = synth.make_dataset(n_sets=2000, n_hits=20, seg_len=67, branching=4, genome_len=1500, seed=31, alphabet=1,
                             level_rate=0.06, query_rate=0.08)
-    pairs = {}
-    for flt in ("0", "1"):
+    got = {}
+    for flt, spec1 in (("0", "3"), ("1", "3"), ("2", "3"), ("2", "0")):
         monkeypatch.setenv("RPA_PASS1_FILTER", flt)
-        monkeypatch.setenv("RPA_SPEC1", "3"); monkeypatch.setenv("RPA_SPEC2", "10")
+        monkeypatch.setenv("RPA_SPEC1", spec1); monkeypatch.setenv("RPA_SPEC2", "10")
         model = pkg.RPAPredictionModel(dp.tax, alphabet=pkg.PROTEIN)
         model.load_store(pkg.STORE_QUERY, dp.query_letters, dp.query_offsets)
         model.load_store(pkg.STORE_DB, dp.ref_letters, dp.ref_offsets)
         model.profile(enable=True, reset=True)
         rows, stats = model.predict(dp.batch)
         prof = model.profile()
-        pairs[flt] = (prof["pairs"], prof["demanded"], rows.tobytes(), stats.tobytes())
-    assert pairs["0"][1:] == pairs["1"][1:]
-    assert pairs["1"][0] < 0.97 * pairs["0"][0], (pairs["0"][0], pairs["1"][0])
+        got[(flt, spec1)] = (prof["pairs"], prof["demanded"], rows.tobytes(), stats.tobytes())
+    base = got[("0", "3")]
+    assert all(g[1:] == base[1:] for g in got.values())
+    assert got[("1", "3")][0] < 0.97 * base[0], (base[0], got[("1", "3")][0])
+    assert got[("2", "3")][0] <= got[("1", "3")][0], (got[("1", "3")][0], got[("2", "3")][0])  # (three-hit chunks leave it little to cut)
+    assert got[("2", "0")][0] < 1.15 * base[1], (got[("2", "0")][0], base[1])  # the whole loop in one request: < 1.15 computed per demanded
+    monkeypatch.delenv("RPA_SPEC1"); monkeypatch.delenv("RPA_SPEC2"); monkeypatch.delenv("RPA_PASS1_FILTER")
     _engine_vs_oracle(pkg, oracle, synth, dp, 1)
 
 

@@ -7,9 +7,14 @@ exactly the traced alignments, and then plays the engine's request policies over
 asks for (computed), how many of them the loops consume (demanded), how many request rounds a record set needs.
 
 Policies (pass-1 chunk S1, pass-2 chunk S2; 0 = the whole loop at once):
-  plain      rows [lo, hi) of the loop that can need an alignment at all (the engine's pass-1 requests, modes 1 / 2 / 4)
-  filtered   the same minus the rows that the thresholds known when the chunk is made already exclude
-  pass 2 always applies the thresholds of its anchor and the unode test at the time the chunk is made (mode 3).
+  plain        rows [lo, hi) of the loop that can need an alignment at all (RPA_PASS1_FILTER=0)
+  filtered     the same minus the rows that the thresholds known when the chunk is made already exclude (=1)
+  first        filtered + the chunk's first hit is taken for the loop's next outgroup hit: its thresholds apply to the hits
+               behind it; first-score / first-pid: only its score cut-off / only its identity thresholds.  first-score is
+               what the engine does (=2, chunk_end_by_score: hits are in score order, the cut-off is a chunk end)
+  cautious     every hit already in the chunk is taken for an outgroup hit (pass 1) / to lift unode_global (pass 2)
+  pass 2 otherwise applies the thresholds of its anchor and the unode test at the time the chunk is made (mode 3).
+Extra arguments key=value override the dataset (level_rate=0.02 query_rate=0.1 variety=1 ...).
 """
 import importlib
 import os
@@ -25,6 +30,7 @@ CONFIGS = {
     "c4": dict(hits=20, seg_len=67, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08, seed=2),
     "c4_200": dict(hits=20, seg_len=200, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08, seed=2),
 }
+LIFT_STATS = {}
 F32 = np.float32
 FLT_MAX = F32(np.finfo(np.float32).max)
 
@@ -190,7 +196,11 @@ def replay(tax, recs, qrlength, D, X=F32(0.5), reeval=0.05):
                         d2, s2 = get(2, -1, a)
                         qd[a] = F32(d2); qs[a] = F32(s2); L.extra = True
                     qdist_ex = F32(qd[a] * bf_max)
-                    if dist <= qdist_ex: unode_g = tax.lca(unode_g, int(node[i]))
+                    lifted = bool(dist <= qdist_ex)
+                    if i != a:
+                        di = int(tax.depth[tax.lca(int(node[i]), rtax)]); da = int(tax.depth[tax.lca(rtax, int(node[a]))])
+                        LIFT_STATS.setdefault(di - da, [0, 0])[0 if lifted else 1] += 1
+                    if lifted: unode_g = tax.lca(unode_g, int(node[i]))
             else:
                 L.rows.append((i, "skip", unode_g))
             i += 1
@@ -199,63 +209,88 @@ def replay(tax, recs, qrlength, D, X=F32(0.5), reeval=0.05):
     return demanded, pass0_rows, loops, qd_after0
 
 
-def play(tax, recs, loops, qd0, qrlength, S1, S2, filtered, stop_aware=False):
-    """Requests of the engine's policy over the recorded loops.  Returns (computed, demanded, request rounds after pass 0)."""
+def play(tax, recs, loops, qd0, qrlength, S1, S2, mode):
+    """Requests of a policy over the recorded loops.  mode: "plain" | "filtered" | "cautious" (pass 1: filtered + every hit
+    already in the chunk is taken for the loop's next outgroup hit, i.e. its thresholds are applied to the hits behind it;
+    pass 2: every hit already in the chunk is taken to lift unode_global).  A loop pauses at the first alignment it needs
+    that its current chunk does not hold.  "first": like cautious in pass 1 but only the chunk's first hit (the one the loop
+    paused at, or the first one behind the anchor) is taken for an outgroup hit; pass 2 as filtered.  Returns (computed, demanded, request rounds after pass 0)."""
     n = len(recs)
     score = recs["score"].astype(F32)
+    ident = recs["identities"].astype(np.int64)
     node = recs["node"].astype(np.int64)
+    X = 0.5
     computed = demanded = rounds = 0
+    cat = {"p1 first chunk": [0, 0], "p1 later chunks": [0, 0], "p2 first chunk": [0, 0], "p2 later chunks": [0, 0]}  # asked, used
     for L in loops:
-        visited = {i: (what, st) for (i, what, st) in L.rows}
-        hi = 0
+        n_chunk = 0
+        emitted = {}
         for (i, what, st) in L.rows:
             if what != "align":
                 continue
             demanded += 1
-            if i >= hi:  # pause: a new chunk from row i
+            if i not in emitted:  # pause: a new chunk from row i
+                n_chunk += 1
+                key = ("p1 " if L.kind == 1 else "p2 ") + ("first chunk" if n_chunk == 1 else "later chunks")
                 lo = i
                 S = S1 if L.kind == 1 else S2
                 hi = n if S == 0 else min(n, lo + S)
                 rounds += 1
-                for r in range(lo, hi):
-                    if r == L.anchor: continue
-                    if L.kind == 1:
-                        if qd0[r] == 0: continue                  # kLiteZeroQd
-                        if filtered:
-                            thr, scut = st
-                            if score[r] < F32(scut): break        # the loop ends at this row whatever happens before it
-                            # (querysimilarity of a row is fixed after pass 0 for pass 1)
+                if L.kind == 1:
+                    thr, scut = st if mode != "plain" else (0.0, 0)
+                    for r in range(lo, hi):
+                        if r == L.anchor or qd0[r] == 0: continue   # the anchor; kLiteZeroQd
+                        if mode != "plain":
+                            if score[r] < F32(scut): break
                             if float(recs["_qs"][r]) / qrlength < thr: continue
-                        computed += 1
-                    else:
+                        computed += 1; cat[key][0] += 1; emitted[r] = key
+                        if mode == "cautious" or (mode in ("first", "first-score", "first-pid") and r == lo):
+                            pid = float(ident[r]) / qrlength
+                            if mode != "first-score": thr = max(thr, pid * 2.0 - 1.0, pid * X)
+                            if not scut and mode != "first-pid": scut = int(F32(score[r] * F32(X)))
+                else:
+                    un = st
+                    for r in range(lo, hi):
+                        if r == L.anchor: continue
                         if score[r] < L.fcut: break
                         if float(recs["_qs"][r]) / qrlength < L.thr: continue
                         cn = int(node[r])
-                        if tax.is_parent_of(st, cn) or cn == st: continue  # unode_global when the chunk is made
-                        computed += 1
+                        if tax.is_parent_of(un, cn) or cn == un: continue  # unode_global when the chunk is made
+                        computed += 1; cat[key][0] += 1; emitted[r] = key
+                        if mode == "cautious": un = tax.lca(un, cn)
+            cat[emitted[i]][1] += 1
         if L.kind == 2 and L.extra:
             computed += 1; demanded += 1   # anchor <-> query range: asked for with the chunk that needs it, always used
+    play.cat = cat
     return computed, demanded, rounds
 
 
 def main():
     cfg_name = sys.argv[1] if len(sys.argv) > 1 else "c2"
     n_sets = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
-    cfg = CONFIGS[cfg_name]
+    cfg = dict(CONFIGS[cfg_name])
+    variety = False
+    for kv in sys.argv[3:]:
+        k, v = kv.split("=")
+        if k == "variety": variety = bool(int(v))
+        else: cfg[k] = type(cfg[k])(v)
     sys.path.insert(0, ROOT)
     import __graft_entry__ as graft
     graft.load_package()
     synth = importlib.import_module("taxator_tk_amd.synth")
     ds = synth.make_dataset(n_sets=n_sets, n_hits=cfg["hits"], seg_len=cfg["seg_len"], branching=4, genome_len=cfg["genome_len"], seed=cfg["seed"],
-                            alphabet=cfg["alphabet"], level_rate=cfg["level_rate"], query_rate=cfg["query_rate"])
+                            alphabet=cfg["alphabet"], level_rate=cfg["level_rate"], query_rate=cfg["query_rate"], variety=variety)
     tax = O.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
     q = O.StoreArrays(synth.encode(ds.query_letters, cfg["alphabet"]), ds.query_offsets)
     db = O.StoreArrays(synth.encode(ds.ref_letters, cfg["alphabet"]), ds.ref_offsets)
     aos = synth.records_aos(ds.batch, O.RECORD_DTYPE)
     so = ds.batch["set_offsets"]
-    policies = [("plain", S1, S2, False) for (S1, S2) in ((0, 10), (4, 10), (2, 10), (8, 10), (0, 0), (4, 4))] + \
-               [("filtered", S1, S2, True) for (S1, S2) in ((4, 10), (2, 10), (3, 10), (6, 10), (8, 10))]
+    policies = [("plain", S1, S2) for (S1, S2) in ((0, 10), (4, 10))] + \
+               [("filtered", S1, S2) for (S1, S2) in ((0, 10), (4, 10))] + \
+               [("cautious", S1, S2) for (S1, S2) in ((0, 10),)] + \
+               [("first", S1, S2) for (S1, S2) in ((0, 10), (4, 10), (8, 10))] + [("first-score", 0, 10), ("first-pid", 0, 10)]
     totals = {p: [0, 0, 0] for p in policies}
+    cats = {p: {} for p in policies}
     pass0 = 0
     per_pass = [0, 0, 0]
     n_done = 0
@@ -285,15 +320,19 @@ def main():
         act2["_qs"] = qs
         pass0 += len(pass0_rows)
         for p in policies:
-            c, d, r = play(tax, act2, loops, qd0, qrlength, p[1], p[2], p[3])
+            c, d, r = play(tax, act2, loops, qd0, qrlength, p[1], p[2], p[0])
             totals[p][0] += c; totals[p][1] += d; totals[p][2] += r
+            for k, (a_, u_) in play.cat.items():
+                e = cats[p].setdefault(k, [0, 0]); e[0] += a_; e[1] += u_
         n_done += 1
     print("%s: %d record sets replayed (%d with alignments); demanded per pass: %s" % (cfg_name, n_sets, n_done, per_pass))
     dem_all = sum(per_pass)
+    print("pass-2 hits by depth(lca(hit, rtax)) - depth(lca(anchor, rtax)) -> [lifted unode_global, did not]:", dict(sorted(LIFT_STATS.items())))
     for p in policies:
         c, d, r = totals[p]
         print("  %-9s S1=%d S2=%-2d  computed/demanded %.3f  (pass 1+2: asked %d, used %d = %.0f %%)  request rounds after pass 0 per set %.2f"
               % (p[0], p[1], p[2], (pass0 + c) / dem_all, c, d, 100.0 * d / max(1, c), r / max(1, n_done)))
+        print("            " + ";  ".join("%s asked %d used %d" % (k, v[0], v[1]) for k, v in cats[p].items()))
 
 
 if __name__ == "__main__":
