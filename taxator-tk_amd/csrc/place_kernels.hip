@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           const uint32_t a = k * 32u + bit;
           const HitCore h = R.core(a);
           st.anchor = a; st.phase = kPass2Wait; found = true; st.loop_live = 0;
-          st.chunk_hi = p.spec2 ? min(n, p.spec2) : n;
+          st.chunk_hi = p.spec2 ? min(n, p.spec2_first ? p.spec2_first : p.spec2) : n;
           em.mode = 3; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.best = st.best; em.d_unode_g = st.d_unode_g;
           em.i_lo = 0; em.i_hi = st.chunk_hi;
           em.emit_query = h.qd == FLT_MAX ? 1u : 0u;             // anchor never aligned to the query yet (:792)

@@ -258,6 +258,8 @@ struct Params {
                           //    (chunk_end_by_score; A/B: RPA_PASS1_FILTER=0|1)
   int grow;               // 1: a loop that pauses asks for as many hits again as it has already walked (chunks 2,2,4,8,...):
                           //    a loop that has not stopped early so far probably will not; log2(n) rounds instead of n/chunk
+  uint32_t spec2_first;   // pass 2: the FIRST chunk of an anchor's loop (0: spec2).  The hits that lift unode_global come early
+                          // in a loop and take most of the hits behind them out of it: a short first chunk, then spec2
 };
 
 struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells

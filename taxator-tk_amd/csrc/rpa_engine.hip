@@ -578,11 +578,12 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     // it fills, and a launch of 1.7 rounds of lanes runs faster than two of 0.85 (config 5: 3 rounds instead of 6).
     Params pr = e->params;
     if (!e->fixed_speculation) {
-      if (sparse_decide) { pr.spec1 = 0; pr.spec2 = 0; }
+      if (sparse_decide) { pr.spec1 = 0; pr.spec2 = 0; pr.spec2_first = 0; }
       else {
         const uint32_t fill = e->fill_lanes / (live_now ? live_now : 1u);
         if (pr.spec1 && fill > pr.spec1) pr.spec1 = fill;
         if (pr.spec2 && fill > pr.spec2) pr.spec2 = fill;
+        if (pr.spec2_first && fill > pr.spec2_first) pr.spec2_first = fill;
       }
     }
     HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, pr, rows_dev, stats_dev,
@@ -808,6 +809,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->fixed_speculation = params->speculation_pass1 != RPA_SPECULATION_DEFAULT || params->speculation_pass2 != RPA_SPECULATION_DEFAULT;
   if (const char* v = getenv("RPA_SPEC1")) { e->params.spec1 = (uint32_t)atoi(v); e->fixed_speculation = true; }
   if (const char* v = getenv("RPA_SPEC2")) { e->params.spec2 = (uint32_t)atoi(v); e->fixed_speculation = true; }
+  e->params.spec2_first = 0;
+  if (const char* v = getenv("RPA_SPEC2_FIRST")) e->params.spec2_first = (uint32_t)atoi(v);
   e->fill_lanes = 3u * kResidentLanes;  // RPA_FILL_LANES sweep: config 5 1174 / 1137 / 1053 ms at 1x / 2x / 3x, configs 2 and 4 indifferent
   if (const char* v = getenv("RPA_FILL_LANES")) e->fill_lanes = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SPARSE_EMIT")) e->sparse_div_emit = (uint32_t)atoi(v);

@@ -31,6 +31,7 @@ CONFIGS = {
     "c4_200": dict(hits=20, seg_len=200, alphabet=1, genome_len=1500, level_rate=0.06, query_rate=0.08, seed=2),
 }
 LIFT_STATS = {}
+P2_FIRST = 0  # pass 2: size of an anchor's first chunk (0: S2)
 F32 = np.float32
 FLT_MAX = F32(np.finfo(np.float32).max)
 
@@ -233,7 +234,7 @@ def play(tax, recs, loops, qd0, qrlength, S1, S2, mode):
                 n_chunk += 1
                 key = ("p1 " if L.kind == 1 else "p2 ") + ("first chunk" if n_chunk == 1 else "later chunks")
                 lo = i
-                S = S1 if L.kind == 1 else S2
+                S = S1 if L.kind == 1 else (S2 if (n_chunk > 1 or not P2_FIRST) else P2_FIRST)
                 hi = n if S == 0 else min(n, lo + S)
                 rounds += 1
                 if L.kind == 1:
@@ -288,7 +289,8 @@ def main():
     policies = [("plain", S1, S2) for (S1, S2) in ((0, 10), (4, 10))] + \
                [("filtered", S1, S2) for (S1, S2) in ((0, 10), (4, 10))] + \
                [("cautious", S1, S2) for (S1, S2) in ((0, 10),)] + \
-               [("first", S1, S2) for (S1, S2) in ((0, 10), (4, 10), (8, 10))] + [("first-score", 0, 10), ("first-pid", 0, 10)]
+               [("first", S1, S2) for (S1, S2) in ((0, 10), (4, 10), (8, 10))] + [("first-score", 0, 10), ("first-pid", 0, 10)] + \
+               [("first-score+p2first", 0, 10, k) for k in (1, 2, 3, 4, 6)] + [("first-score+p2first", 0, 20, k) for k in (2, 3)]
     totals = {p: [0, 0, 0] for p in policies}
     cats = {p: {} for p in policies}
     pass0 = 0
@@ -320,7 +322,9 @@ def main():
         act2["_qs"] = qs
         pass0 += len(pass0_rows)
         for p in policies:
-            c, d, r = play(tax, act2, loops, qd0, qrlength, p[1], p[2], p[0])
+            global P2_FIRST
+            P2_FIRST = p[3] if len(p) > 3 else 0
+            c, d, r = play(tax, act2, loops, qd0, qrlength, p[1], p[2], p[0].split("+")[0])
             totals[p][0] += c; totals[p][1] += d; totals[p][2] += r
             for k, (a_, u_) in play.cat.items():
                 e = cats[p].setdefault(k, [0, 0]); e[0] += a_; e[1] += u_
@@ -330,8 +334,8 @@ def main():
     print("pass-2 hits by depth(lca(hit, rtax)) - depth(lca(anchor, rtax)) -> [lifted unode_global, did not]:", dict(sorted(LIFT_STATS.items())))
     for p in policies:
         c, d, r = totals[p]
-        print("  %-9s S1=%d S2=%-2d  computed/demanded %.3f  (pass 1+2: asked %d, used %d = %.0f %%)  request rounds after pass 0 per set %.2f"
-              % (p[0], p[1], p[2], (pass0 + c) / dem_all, c, d, 100.0 * d / max(1, c), r / max(1, n_done)))
+        print("  %-9s" % (p[0] + (str(p[3]) if len(p) > 3 else "")) + " S1=%d S2=%-2d  computed/demanded %.3f  (pass 1+2: asked %d, used %d = %.0f %%)  request rounds after pass 0 per set %.2f"
+              % (p[1], p[2], (pass0 + c) / dem_all, c, d, 100.0 * d / max(1, c), r / max(1, n_done)))
         print("            " + ";  ".join("%s asked %d used %d" % (k, v[0], v[1]) for k, v in cats[p].items()))
 
 
