@@ -869,6 +869,10 @@ __device__ __forceinline__ void append_live(const WorkDev& w, bool running, uint
 // chunk end like at any other; when the cut-off is already set the end is exact.  tools/spec_waste.py: config 4 asks for
 // 1.08 alignments per demanded one instead of 1.20, with the whole loop in one request (1.5 request rounds per set after
 // pass 0 instead of 1.95); RPA_PASS1_FILTER=1 switches the assumption off.
+// Measured (tools/spec_sweep9/11.sh): protein (config 4, scores spread over more than a factor 1/X) 20 % faster per step;
+// nucleotide (configs 2 and 5: the scores of a set lie within that factor, the chunk end is almost always the set's end)
+// 1 % slower -- the probes, and in config 5 one round more.  filter1 = 2: protein only, 3: always.
+__device__ __forceinline__ bool assume_first_hit_cutoff(const Params& p) { return p.filter1 >= 3 || (p.filter1 == 2 && p.alphabet != 0); }
 template <int Q>
 __device__ __forceinline__ uint32_t chunk_end_by_score(const SetRows<Q>& R, uint32_t first, uint32_t hi, int scut_now, float X) {
   if (first + 1u >= hi) return hi;
@@ -971,7 +975,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
         if (members == 1 && (w.lite[lo] & kLiteWant0) && !p.no_combined) {
           em.mode = 4; em.anchor = 0; em.anchor_len = w.lite[lo] & kLiteLenMask;
           em.i_hi = p.spec1 ? min(n, p.spec1) : n;  // the first speculation chunk of the pass-1 loop (hit 0 is part of it)
-          if (p.filter1 >= 2) em.i_hi = chunk_end_by_score(set_rows<Q>(w, s, lo), 1u, em.i_hi, 0, p.exclude_factor);  // (no perfect hit here: hit 1 is the first one aligned)
+          if (assume_first_hit_cutoff(p)) em.i_hi = chunk_end_by_score(set_rows<Q>(w, s, lo), 1u, em.i_hi, 0, p.exclude_factor);  // (no perfect hit here: hit 1 is the first one aligned)
           st.chunk_hi = em.i_hi;                    // remembered: k_decide may run with another chunk size by then
           st.combined = 1;
         }
@@ -1374,7 +1378,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
         st.qpid_upper = qpid_upper; st.cut_g = cut_g; st.cut_h = cut_h; st.scut = scut;
         band.save(w.band_save + (size_t)s * 2 * w.band_ranks);
         st.chunk_hi = p.spec1 ? min(n, i + (p.grow ? max(p.spec1, i) : p.spec1)) : n;
-        if (p.filter1 >= 2) st.chunk_hi = chunk_end_by_score(R, i, st.chunk_hi, scut, X);
+        if (assume_first_hit_cutoff(p) || (p.filter1 && scut)) st.chunk_hi = chunk_end_by_score(R, i, st.chunk_hi, scut, X);  // (a cut-off the loop already has: exact)
         em.mode = 2; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.i_lo = i; em.i_hi = st.chunk_hi;
         const double cut = cut_g < cut_h ? cut_h : cut_g;
         if (p.filter1 && (scut != 0 || cut > 0.)) {  // the chunk without the hits the loop will break at or step over anyway
@@ -1543,7 +1547,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       }
       st.anchor = a; st.phase = kPass1Wait; st.loop_live = 0;
       st.chunk_hi = p.spec1 ? min(n, p.spec1) : n;
-      if (p.filter1 >= 2) {  // the first hit this loop aligns: not the anchor, not at distance 0 from the query (:620)
+      if (assume_first_hit_cutoff(p)) {  // the first hit this loop aligns: not the anchor, not at distance 0 from the query (:620)
         uint32_t r = 0;
         while (r < st.chunk_hi && (r == a || (w.lite[lo + r] & kLiteZeroQd))) ++r;
         if (r < st.chunk_hi) st.chunk_hi = chunk_end_by_score(R, r, st.chunk_hi, 0, X);

@@ -254,8 +254,9 @@ struct Params {
   int protein_lanes;      // 0: packed protein pairs all go to K3p (one lane per pair), none to K3l (A/B: RPA_PROTEIN_LANES=0)
   int no_combined;        // 1: never ask for pass 0 and the first pass-1 loop in one round (A/B: RPA_NO_COMBINED)
   int filter1;            // >= 1: a pass-1 chunk leaves out the hits that the loop's thresholds at the pause already exclude;
-                          // 2 (default): and ends where the scores fall below the cut-off its first hit would set
-                          //    (chunk_end_by_score; A/B: RPA_PASS1_FILTER=0|1)
+                          // 2 (default) / 3: and ends where the scores fall below the cut-off its first hit would set, for
+                          //    protein / always
+                          //    (chunk_end_by_score; A/B: RPA_PASS1_FILTER=0|1|3)
   int grow;               // 1: a loop that pauses asks for as many hits again as it has already walked (chunks 2,2,4,8,...):
                           //    a loop that has not stopped early so far probably will not; log2(n) rounds instead of n/chunk
   uint32_t spec2_first;   // pass 2: the FIRST chunk of an anchor's loop (0: spec2).  The hits that lift unode_global come early

@@ -341,7 +341,8 @@ def test_speculation_chunks_never_change_results(pkg, oracle, synth, speculation
     {"RPA_NO_COMBINED": "1", "RPA_SPARSE_DECIDE": "2", "RPA_SPARSE_EMIT": "50"},
     {"RPA_SPEC1": "2", "RPA_SPEC2": "3", "RPA_PASS1_FILTER": "0"},              # pass-1 chunks without the paused loop's thresholds
     {"RPA_SPEC1": "5", "RPA_SPEC2": "3", "RPA_PASS1_FILTER": "1"},              # ... with them, without the first-hit assumption
-], ids=["grow", "adaptive", "always-sparse", "never-sparse", "split-rounds", "unfiltered-chunks", "thresholds-only"])
+    {"RPA_PASS1_FILTER": "3"},                                                  # the first-hit assumption for short nucleotide segments too
+], ids=["grow", "adaptive", "always-sparse", "never-sparse", "split-rounds", "unfiltered-chunks", "thresholds-only", "assume-always"])
 def test_round_scheduling_knobs_never_change_results(pkg, oracle, synth, env, monkeypatch):
     """How the rounds are cut (chunk growth, when a round walks the live list instead of every row, pass 0 and pass 1 in
     one round or two) decides who computes what when -- never the rows or the demanded-alignment counters."""
