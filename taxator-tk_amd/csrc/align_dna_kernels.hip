@@ -75,29 +75,96 @@ __device__ __forceinline__ void peq_word(NtStream& ps, uint32_t wi, uint32_t m, 
     mask[0] = ~(p0 | p1 | pn) & vm;  // A
   }
 }
-// One text column: NW chained word updates (add carry via v_addc_co, shift carries via v_alignbit); e[wi * STRIDE] is
-// the match mask of word wi for the column's symbol.  10 VALU ops per word: or, and, addc, 3x v_bitop3 (gfx950
-// three-input boolean; truth tables use a=0xF0, b=0xCC, c=0xAA), 2x and, 2x alignbit.
-template <int NW, int STRIDE>
-__device__ __forceinline__ void myers_column(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ e) {
-  uint32_t carry = 0, hp_prev = 0x80000000u /* global alignment: +1 enters row 0 */, hn_prev = 0;
+// ---- the word update of a column, shared by the lane-per-pair kernels ---------------------------------------------------
+// Words W0 .. W0 + C - 1 (C <= 4) of VP / VN for one text symbol: the add chain word by word (v_addc_co), then the two
+// shifts by one (HP << 1 | carry, HN << 1 | carry) per PAIR of words -- one v_lshl_add_u64 moves two words in 2.3 ns where
+// two v_alignbit_b32 take 2 x 1.8 and more inside this instruction mix (tools/valu_rate5.hip; tools/myers_pair.hip: 19.6
+// -> 15.9 ns per word for the whole step); the carry into an upper pair is the top bit of the word below it (one shift),
+// into a column's first word (kFirst) the constants 1 and 0: global alignment, +1 enters row 0.  An odd last word takes
+// v_alignbit.  eq(wi) = the match mask of word wi; carry = the add carry in / out; hp_in / hn_in = HP / HN of the word
+// below W0 (their top bits enter) in, of the last word out.  10 VALU ops per word with v_alignbit (or, and, addc, 3x
+// v_bitop3 -- gfx950's three-input boolean; truth tables use a=0xF0, b=0xCC, c=0xAA --, 2x and, 2x alignbit), 9.5 in pairs.
+#ifndef RPA_PAIR_SHIFT
+#define RPA_PAIR_SHIFT 1
+#endif
+__device__ __forceinline__ uint64_t shl1_add(uint32_t lo, uint32_t hi, uint32_t carry_in) {
+  const uint64_t x = ((uint64_t)hi << 32) | lo, c = carry_in;
+  uint64_t r;
+  asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(x), "v"(c));
+  return r;
+}
+template <int IMM>
+__device__ __forceinline__ uint64_t shl1_add_imm(uint32_t lo, uint32_t hi) {
+  const uint64_t x = ((uint64_t)hi << 32) | lo;
+  uint64_t r;
+  if (IMM) asm("v_lshl_add_u64 %0, %1, 1, 1" : "=v"(r) : "v"(x));
+  else asm("v_lshl_add_u64 %0, %1, 1, 0" : "=v"(r) : "v"(x));
+  return r;
+}
+template <int NW, int W0, int C, bool kFirst, bool kPairs, typename EqF>
+__device__ __forceinline__ void myers_words(uint32_t (&VP)[NW], uint32_t (&VN)[NW], EqF&& eq, uint32_t& carry, uint32_t& hp_in, uint32_t& hn_in) {
+  static_assert(C >= 1 && C <= 4 && W0 + C <= NW, "a group of up to four words");
+  uint32_t D0[C], HP[C], HN[C], Xs[C], Hs[C];
 #pragma unroll
-  for (int wi = 0; wi < NW; ++wi) {
-    const uint32_t vp = VP[wi], vn = VN[wi];
-    const uint32_t X = e[wi * STRIDE] | vn;
+  for (int k = 0; k < C; ++k) {
+    const uint32_t vp = VP[W0 + k], vn = VN[W0 + k];
+    const uint32_t X = eq(W0 + k) | vn;
     uint32_t cout;
     const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
     carry = cout;
-    const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);         // (sum ^ vp) | X
-    const uint32_t HN = vp & D0;
-    const uint32_t HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);         // vn | ~(vp | D0)
-    const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);            // (HP << 1) | (hp_prev >> 31)
-    const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
-    hp_prev = HP;
-    hn_prev = HN;
-    VN[wi] = Xs & D0;
-    VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);                    // Hs | ~(Xs | D0)
+    D0[k] = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);         // (sum ^ vp) | X
+    HN[k] = vp & D0[k];
+    HP[k] = __builtin_amdgcn_bitop3_b32(vn, vp, D0[k], 0xF1);      // vn | ~(vp | D0)
   }
+  if constexpr (kPairs) {
+  constexpr int U = C >= 2 ? 1 : 0;  // (the upper word of a pair; C == 1 has no pair and never gets here)
+#pragma unroll
+  for (int k = 0; k + 1 < C; k += 2) {
+    uint64_t xs, hs;
+    if (k == 0 && kFirst) { xs = shl1_add_imm<1>(HP[0], HP[U]); hs = shl1_add_imm<0>(HN[0], HN[U]); }
+    else {
+      xs = shl1_add(HP[k], HP[k + U], (k ? HP[k ? k - 1 : 0] : hp_in) >> 31);
+      hs = shl1_add(HN[k], HN[k + U], (k ? HN[k ? k - 1 : 0] : hn_in) >> 31);
+    }
+    Xs[k] = (uint32_t)xs; Xs[k + U] = (uint32_t)(xs >> 32); Hs[k] = (uint32_t)hs; Hs[k + U] = (uint32_t)(hs >> 32);
+  }
+  if constexpr (C & 1) {
+    constexpr int k = C - 1;
+    Xs[k] = __builtin_amdgcn_alignbit(HP[k], k ? HP[k ? k - 1 : 0] : hp_in, 31);  // (HP << 1) | (below >> 31)
+    Hs[k] = __builtin_amdgcn_alignbit(HN[k], k ? HN[k ? k - 1 : 0] : hn_in, 31);
+  }
+  } else {
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    Xs[k] = __builtin_amdgcn_alignbit(HP[k], k ? HP[k ? k - 1 : 0] : hp_in, 31);
+    Hs[k] = __builtin_amdgcn_alignbit(HN[k], k ? HN[k ? k - 1 : 0] : hn_in, 31);
+  }
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    VN[W0 + k] = Xs[k] & D0[k];
+    VP[W0 + k] = __builtin_amdgcn_bitop3_b32(Hs[k], Xs[k], D0[k], 0xF1);  // Hs | ~(Xs | D0)
+  }
+  hp_in = HP[C - 1]; hn_in = HN[C - 1];
+}
+// words W0 .. W1 of a column in groups of four
+template <int NW, int W0, int W1, bool kFirst, bool kPairs = (RPA_PAIR_SHIFT != 0), typename EqF>
+__device__ __forceinline__ void myers_word_range(uint32_t (&VP)[NW], uint32_t (&VN)[NW], EqF&& eq, uint32_t& carry, uint32_t& hp_in, uint32_t& hn_in) {
+  constexpr int C = W1 - W0 + 1 < 4 ? W1 - W0 + 1 : 4;
+  myers_words<NW, W0, C, kFirst, kPairs>(VP, VN, eq, carry, hp_in, hn_in);
+  if constexpr (W0 + C <= W1) myers_word_range<NW, W0 + C, W1, false, kPairs>(VP, VN, eq, carry, hp_in, hn_in);
+}
+#ifndef RPA_PAIR_SHIFT_STRIPS
+#define RPA_PAIR_SHIFT_STRIPS 1   // k_myers_band / k_myers_band_duo (strips of 5..8 words)
+#endif
+#ifndef RPA_PAIR_SHIFT_FULL
+#define RPA_PAIR_SHIFT_FULL 1     // k_myers_short (every word of the pattern)
+#endif
+// One text column: NW chained word updates; e[wi * STRIDE] is the match mask of word wi for the column's symbol.
+template <int NW, int STRIDE>
+__device__ __forceinline__ void myers_column(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ e) {
+  uint32_t carry = 0, hp_prev = 0x80000000u /* global alignment: +1 enters row 0 */, hn_prev = 0;
+  myers_word_range<NW, 0, NW - 1, true, (RPA_PAIR_SHIFT_FULL != 0)>(VP, VN, [&](int wi) { return e[wi * STRIDE]; }, carry, hp_prev, hn_prev);
 }
 // Walk the text front to back and call column(symbol) once per nucleotide.  The n mod 8 leading columns go first (a
 // short loop that every lane of the wave runs at the same time), so that the main loop only ever sees full dwords: 8
@@ -228,23 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
 template <int NW, int WLO, int WHI>
 __device__ __forceinline__ void myers_column_window(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ e) {
   uint32_t carry = 0, hp_prev = 0x80000000u, hn_prev = 0;
-#pragma unroll
-  for (int wi = WLO; wi <= WHI; ++wi) {
-    const uint32_t vp = VP[wi], vn = VN[wi];
-    const uint32_t X = e[wi * kBlock] | vn;
-    uint32_t cout;
-    const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
-    carry = cout;
-    const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);         // (sum ^ vp) | X
-    const uint32_t HN = vp & D0;
-    const uint32_t HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);         // vn | ~(vp | D0)
-    const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
-    const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
-    hp_prev = HP;
-    hn_prev = HN;
-    VN[wi] = Xs & D0;
-    VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);                    // Hs | ~(Xs | D0)
-  }
+  if constexpr (WLO <= WHI) myers_word_range<NW, WLO, WHI, true>(VP, VN, [&](int wi) { return e[wi * kBlock]; }, carry, hp_prev, hn_prev);
 }
 
 template <int NW, int HW, int G>
@@ -343,23 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band(const uint2* __rest
 template <int NW, int WLO, int WHI>
 __device__ __forceinline__ void myers_column_ring(uint32_t (&VP)[NW], uint32_t (&VN)[NW], const uint32_t* __restrict__ e) {
   uint32_t carry = 0, hp_prev = 0x80000000u, hn_prev = 0;
-#pragma unroll
-  for (int wi = WLO; wi <= WHI; ++wi) {
-    const uint32_t vp = VP[wi], vn = VN[wi];
-    const uint32_t X = e[(wi & 3) * kBlock] | vn;
-    uint32_t cout;
-    const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
-    carry = cout;
-    const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);
-    const uint32_t HN = vp & D0;
-    const uint32_t HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);
-    const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
-    const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
-    hp_prev = HP;
-    hn_prev = HN;
-    VN[wi] = Xs & D0;
-    VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);
-  }
+  if constexpr (WLO <= WHI) myers_word_range<NW, WLO, WHI, true>(VP, VN, [&](int wi) { return e[(wi & 3) * kBlock]; }, carry, hp_prev, hn_prev);
 }
 
 template <int NW, int WLO, int WHI>
@@ -649,27 +684,10 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
       uint32_t Pout = 0, Nout = 0;
       auto column = [&](uint32_t c, uint32_t hp_prev, uint32_t hn_prev) {
         const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
-        uint32_t HP = 0, HN = 0;
         uint32_t carry = hn_prev >> 31;  // the add carry out of the strip above == its HN bit
-#pragma unroll
-        for (int wi = 0; wi < NW; ++wi) {
-          const uint32_t vp = VP[wi], vn = VN[wi];
-          const uint32_t X = e[wi * kBlock] | vn;
-          uint32_t cout;
-          const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
-          carry = cout;
-          const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);   // (sum ^ vp) | X
-          HN = vp & D0;
-          HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);                  // vn | ~(vp | D0)
-          const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
-          const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
-          hp_prev = HP;
-          hn_prev = HN;
-          VN[wi] = Xs & D0;
-          VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);              // Hs | ~(Xs | D0)
-        }
-        Pout = __builtin_amdgcn_alignbit(Pout, HP, 31);  // (Pout << 1) | (HP >> 31): column k of a group ends up at bit 31-k
-        Nout = __builtin_amdgcn_alignbit(Nout, HN, 31);
+        myers_word_range<NW, 0, NW - 1, false, (RPA_PAIR_SHIFT_STRIPS != 0)>(VP, VN, [&](int wi) { return e[wi * kBlock]; }, carry, hp_prev, hn_prev);  // (leaves the last word's HP / HN)
+        Pout = __builtin_amdgcn_alignbit(Pout, hp_prev, 31);  // (Pout << 1) | (HP >> 31): column k of a group ends up at bit 31-k
+        Nout = __builtin_amdgcn_alignbit(Nout, hn_prev, 31);
       };
 
       // Per 32 columns: one 16-byte load of text and two dword loads of the planes of the strip above (all asked for a
@@ -847,27 +865,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_myers_band_duo(const uint2* __res
       uint32_t Pout = 0, Nout = 0;
       auto column = [&](uint32_t c, uint32_t hp_prev, uint32_t hn_prev) {
         const uint32_t* __restrict__ e = peq + c * (NW * kBlock) + tid;
-        uint32_t HP = 0, HN = 0;
-        uint32_t carry = hn_prev >> 31;
-#pragma unroll
-        for (int wi = 0; wi < NW; ++wi) {
-          const uint32_t vp = VP[wi], vn = VN[wi];
-          const uint32_t X = e[wi * kBlock] | vn;
-          uint32_t cout;
-          const uint32_t sum = __builtin_addc(vp, X & vp, carry, &cout);
-          carry = cout;
-          const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, vp, X, 0xBE);
-          HN = vp & D0;
-          HP = __builtin_amdgcn_bitop3_b32(vn, vp, D0, 0xF1);
-          const uint32_t Xs = __builtin_amdgcn_alignbit(HP, hp_prev, 31);
-          const uint32_t Hs = __builtin_amdgcn_alignbit(HN, hn_prev, 31);
-          hp_prev = HP;
-          hn_prev = HN;
-          VN[wi] = Xs & D0;
-          VP[wi] = __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1);
-        }
-        Pout = __builtin_amdgcn_alignbit(Pout, HP, 31);
-        Nout = __builtin_amdgcn_alignbit(Nout, HN, 31);
+        uint32_t carry = hn_prev >> 31;  // the add carry out of the strip above == its HN bit
+        myers_word_range<NW, 0, NW - 1, false, (RPA_PAIR_SHIFT_STRIPS != 0)>(VP, VN, [&](int wi) { return e[wi * kBlock]; }, carry, hp_prev, hn_prev);  // (leaves the last word's HP / HN)
+        Pout = __builtin_amdgcn_alignbit(Pout, hp_prev, 31);  // (Pout << 1) | (HP >> 31): column k of a group ends up at bit 31-k
+        Nout = __builtin_amdgcn_alignbit(Nout, hn_prev, 31);
       };
       NtStream ts;
       uint4 pending = make_uint4(0u, 0u, 0u, 0u);
