@@ -675,12 +675,13 @@ hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* li
 #define RPA_LAUNCH_LANES(GV) \
   case GV: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, GV>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
   switch (lanes) {
-    RPA_LAUNCH_LANES(1) RPA_LAUNCH_LANES(2) RPA_LAUNCH_LANES(3) RPA_LAUNCH_LANES(4) RPA_LAUNCH_LANES(6) RPA_LAUNCH_LANES(8) RPA_LAUNCH_LANES(13)
+    RPA_LAUNCH_LANES(1) RPA_LAUNCH_LANES(2) RPA_LAUNCH_LANES(3) RPA_LAUNCH_LANES(4) RPA_LAUNCH_LANES(5) RPA_LAUNCH_LANES(6) RPA_LAUNCH_LANES(7)
+    RPA_LAUNCH_LANES(8) RPA_LAUNCH_LANES(9) RPA_LAUNCH_LANES(10) RPA_LAUNCH_LANES(11) RPA_LAUNCH_LANES(12) RPA_LAUNCH_LANES(13)
     default: return hipErrorInvalidValue;
   }
 #undef RPA_LAUNCH_LANES
   return hipGetLastError();
 }
-static_assert(kProteinMaxLanes == 13 && kProteinLaneClasses == 7, "launch_align_protein_lanes dispatches the classes of protein_class_lanes()");
+static_assert(kProteinMaxLanes == 13 && kProteinLaneClasses == 13, "launch_align_protein_lanes dispatches the classes of protein_class_lanes()");
 
 }  // namespace rpa

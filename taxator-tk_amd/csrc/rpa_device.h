@@ -11,7 +11,8 @@ constexpr uint32_t kRoot = 0;        // taxonomy node 0 is the root
 constexpr int kShortWords = 8;       // per-lane Myers kernel: pattern <= 8*32 = 256 residues in one register strip
 constexpr int kStripMinWords = 5;    // longer patterns: register strips of 5..8 words, whichever wastes the fewest rows
 constexpr int kStripBins = kShortWords - kStripMinWords + 1;
-constexpr int kNumBins = kShortWords + kStripBins;  // bins 0..7: one strip of bin+1 words ; bins 8..11: strips of bin-3 words
+constexpr int kDnaBins = kShortWords + kStripBins;  // bins 0..7: one strip of bin+1 words ; bins 8..11: strips of bin-3 words
+constexpr int kNumBins = 18;         // work lists per round: the nucleotide bins above, or the 18 protein bins below
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
 constexpr int kProfParts = 64;        // profiling accumulators are split 64 ways (block index & 63) and summed on the host
@@ -368,21 +369,21 @@ __device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
 // Bin 4: the pair fits the packed-cell kernel (K3p, align_protein_kernels.hip): its two 9-bit path counters hold up to
 // 511 steps and its 12-bit score field holds la + lb + 11 * min(la, lb) + 32 (row-relative score + bias, BLOSUM62's
 // largest entry is 11) -- 312 x 312 residues, or e.g. 511 x 100.
-// Bins 5..11: a packed pair whose vertical sequence needs up to 13 strips of kProteinLaneRows rows (lb <= 312; every pair
-// of the 67 aa workload: three) goes to K3l, the same cell with the strips of a pair in adjacent lanes.  Seven classes of
-// lanes per pair -- 1, 2, 3, 4, 6, 8, 13 -- a pair takes the narrowest one that holds its strips (bin = 5 + class).
+// Bins 5..17: a packed pair whose vertical sequence needs up to 13 strips of kProteinLaneRows rows (lb <= 312; every pair
+// of the 67 aa workload: three) goes to K3l, the same cell with the strips of a pair in adjacent lanes: one class per
+// strip count (bin = 4 + strips), 64 / strips pairs per wavefront.  (Until round 3 seven classes -- 1, 2, 3, 4, 6, 8, 13
+// lanes -- shared twelve bins with the nucleotide kernels: a 200 aa pair, nine strips, ran in the 13-lane class with four
+// pairs per wavefront instead of seven.)
 constexpr uint32_t kPackedMaxLen = 511;
-constexpr int kProteinBins = 12;
+constexpr int kProteinBins = 18;
 constexpr int kProteinPackedBin = 4;
 #ifndef RPA_LANE_ROWS
 #define RPA_LANE_ROWS 24
 #endif
 constexpr int kProteinLaneRows = RPA_LANE_ROWS;
-constexpr int kProteinLaneClasses = 7;
+constexpr int kProteinLaneClasses = 13;
 constexpr int kProteinMaxLanes = 13;
-__host__ __device__ __forceinline__ int protein_class_lanes(int cls) {  // lanes per pair of a class
-  return cls < 4 ? cls + 1 : cls == 4 ? 6 : cls == 5 ? 8 : 13;
-}
+__host__ __device__ __forceinline__ int protein_class_lanes(int cls) { return cls + 1; }  // lanes per pair of a class
 __host__ __device__ __forceinline__ bool protein_fits_packed(uint32_t la, uint32_t lb) {
   return la <= kPackedMaxLen && lb <= kPackedMaxLen && la + lb + 11u * (la < lb ? la : lb) + 32u <= 4095u;
 }
@@ -390,12 +391,12 @@ __host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb, bo
   if (!protein_fits_packed(la, lb)) return 2;
   const uint32_t strips = (lb + kProteinLaneRows - 1u) / kProteinLaneRows;
   if (lanes && strips <= (uint32_t)kProteinMaxLanes) {
-    const int cls = strips <= 4u ? (strips ? (int)strips - 1 : 0) : strips <= 6u ? 4 : strips <= 8u ? 5 : 6;
+    const int cls = strips ? (int)strips - 1 : 0;
     return kProteinPackedBin + 1 + cls;
   }
   return kProteinPackedBin;
 }
-static_assert(kProteinPackedBin + 1 + kProteinLaneClasses <= kProteinBins && kProteinBins <= kNumBins, "protein bins");
+static_assert(kProteinPackedBin + 1 + kProteinLaneClasses <= kProteinBins && kProteinBins <= kNumBins && kDnaBins <= kNumBins, "bins");
 
 // ---- reading a segment out of the packed store --------------------------------------------------------------
 __device__ __forceinline__ uint32_t revcomp8(uint32_t x) {  // 8 packed nt: reverse the nibble order, A<->T, C<->G, N stays

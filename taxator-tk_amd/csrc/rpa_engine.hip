@@ -415,7 +415,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   const size_t n_res = (size_t)(want_ext ? (T > T2 ? T : T2) : (size_t)P + S) + 1;  // predict: one per row slot + one per set; align_pairs: one per pair
   HIP_TRY(e, e->pair_res.ensure(n_res * 8));
   if (want_ext) HIP_TRY(e, e->pair_ext.ensure(n_res * 16));
-  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kNumBins : kProteinBins)));
+  HIP_TRY(e, e->bin_list.ensure((size_t)(T2 ? T2 : 1) * sizeof(uint2) * (e->params.alphabet == RPA_DNA ? kDnaBins : kProteinBins)));
   HIP_TRY(e, e->counters.ensure(sizeof(uint32_t) * (kNumCounters + 1)));  // +1: scan total
   HIP_TRY(e, e->live_a.ensure((size_t)(S ? S : 1) * 4));
   HIP_TRY(e, e->live_b.ensure((size_t)(S ? S : 1) * 4));

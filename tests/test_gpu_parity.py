@@ -266,9 +266,10 @@ def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir, lanes, monkeyp
         mm = rng.random(lb) < 0.15
         b[mm] = rng.integers(0, 20, int(mm.sum()))
         a_codes.append(a); b_codes.append(b)
-    # every class of the lanes-per-pair kernel (1, 2, 3, 4, 6, 8, 13 strips of 24 rows) and its edges (columns go in groups
-    # of four; lanes of one wavefront with different column counts), more pairs than one run of a wavefront holds
-    for lb in [1, 2, 23, 24, 25, 47, 48, 49, 71, 72, 73, 95, 96, 97, 120, 121, 144, 145, 150, 192, 193, 250, 311, 312]:
+    # every class of the lanes-per-pair kernel (1 .. 13 strips of 24 rows) and its edges (columns go in groups of four;
+    # lanes of one wavefront with different column counts), more pairs than one run of a wavefront holds
+    for lb in [1, 2, 23, 24, 25, 47, 48, 49, 71, 72, 73, 95, 96, 97, 120, 121, 144, 145, 150, 168, 169, 192, 193, 216, 217, 240, 241, 250, 264,
+               265, 288, 289, 311, 312]:
         for la in [1, 2, 3, 4, 5, 7, 8, 9, lb, lb + 1, 2 * lb + 3, 150]:
             a = rng.integers(0, 20, la).astype(np.uint8)
             b = np.resize(a, lb).copy()
