@@ -13,7 +13,9 @@ Policies (pass-1 chunk S1, pass-2 chunk S2; 0 = the whole loop at once):
                behind it; first-score / first-pid: only its score cut-off / only its identity thresholds.  first-score is
                what the engine does (=2, chunk_end_by_score: hits are in score order, the cut-off is a chunk end)
   cautious     every hit already in the chunk is taken for an outgroup hit (pass 1) / to lift unode_global (pass 2)
-  pass 2 otherwise applies the thresholds of its anchor and the unode test at the time the chunk is made (mode 3).
+  pass 2 otherwise applies the thresholds of its anchor and the unode test at the time the chunk is made (mode 3);
+  +p2firstK: an anchor's first pass-2 chunk holds K hits (RPA_SPEC2_FIRST); +p2groupK: at most K hits per chunk that would
+  lift unode_global to the same node (or below one already asked for K times) -- both cut pass 2's waste, both cost rounds.
 Extra arguments key=value override the dataset (level_rate=0.02 query_rate=0.1 variety=1 ...).
 """
 import importlib
@@ -32,6 +34,7 @@ CONFIGS = {
 }
 LIFT_STATS = {}
 P2_FIRST = 0  # pass 2: size of an anchor's first chunk (0: S2)
+P2_GROUP = 0  # pass 2: hits per chunk and lift target (0: no limit)
 F32 = np.float32
 FLT_MAX = F32(np.finfo(np.float32).max)
 
@@ -251,12 +254,19 @@ def play(tax, recs, loops, qd0, qrlength, S1, S2, mode):
                             if not scut and mode != "first-pid": scut = int(F32(score[r] * F32(X)))
                 else:
                     un = st
+                    groups = {}
                     for r in range(lo, hi):
                         if r == L.anchor: continue
                         if score[r] < L.fcut: break
                         if float(recs["_qs"][r]) / qrlength < L.thr: continue
                         cn = int(node[r])
                         if tax.is_parent_of(un, cn) or cn == un: continue  # unode_global when the chunk is made
+                        if P2_GROUP:  # at most P2_GROUP hits per chunk that would lift unode_global to the same node
+                            tgt = tax.lca(st, cn)
+                            # a hit is also covered by an emitted group whose target is an ancestor-or-self of its own target
+                            covered = sum(c for (t, c) in groups.items() if t == tgt or tax.is_parent_of(t, tgt))
+                            if covered >= P2_GROUP: continue
+                            groups[tgt] = groups.get(tgt, 0) + 1
                         computed += 1; cat[key][0] += 1; emitted[r] = key
                         if mode == "cautious": un = tax.lca(un, cn)
             cat[emitted[i]][1] += 1
@@ -290,7 +300,7 @@ def main():
                [("filtered", S1, S2) for (S1, S2) in ((0, 10), (4, 10))] + \
                [("cautious", S1, S2) for (S1, S2) in ((0, 10),)] + \
                [("first", S1, S2) for (S1, S2) in ((0, 10), (4, 10), (8, 10))] + [("first-score", 0, 10), ("first-pid", 0, 10)] + \
-               [("first-score+p2first", 0, 10, k) for k in (1, 2, 3, 4, 6)] + [("first-score+p2first", 0, 20, k) for k in (2, 3)]
+               [("first-score+p2first", 0, 10, k) for k in (3, 6)] + [("first-score+p2group", 0, S2, k) for S2 in (10, 20) for k in (1, 2, 3)]
     totals = {p: [0, 0, 0] for p in policies}
     cats = {p: {} for p in policies}
     pass0 = 0
@@ -322,8 +332,9 @@ def main():
         act2["_qs"] = qs
         pass0 += len(pass0_rows)
         for p in policies:
-            global P2_FIRST
-            P2_FIRST = p[3] if len(p) > 3 else 0
+            global P2_FIRST, P2_GROUP
+            P2_FIRST = p[3] if len(p) > 3 and "p2first" in p[0] else 0
+            P2_GROUP = p[3] if len(p) > 3 and "p2group" in p[0] else 0
             c, d, r = play(tax, act2, loops, qd0, qrlength, p[1], p[2], p[0].split("+")[0])
             totals[p][0] += c; totals[p][1] += d; totals[p][2] += r
             for k, (a_, u_) in play.cat.items():
