@@ -383,6 +383,20 @@ def test_pass1_chunks_leave_out_what_the_loop_already_excludes(pkg, oracle, synt
     _engine_vs_oracle(pkg, oracle, synth, dp, 1)
 
 
+@pytest.mark.parametrize("alphabet,step", [(1, 8.0), (1, 32.0), (0, 16.0)])
+def test_pass1_chunk_end_on_tied_and_boundary_scores(pkg, oracle, synth, alphabet, step, monkeypatch):
+    """The end of a pass-1 request is found by a binary search for the first hit whose score is below (float)(int)(X * the
+    first hit's score): scores rounded to a coarse grid put runs of equal scores and hits exactly ON that cut-off into every
+    record set (the cut-off test is >=: they stay in).  Level 3 = the assumption for nucleotide data too."""
+    monkeypatch.setenv("RPA_PASS1_FILTER", "3")
+    kw = dict(seg_len=67, genome_len=1500, level_rate=0.06, query_rate=0.08) if alphabet else dict(seg_len=150, genome_len=3000)
+    ds = synth.make_dataset(n_sets=1500, n_hits=20, branching=4, seed=41 + int(step), alphabet=alphabet, **kw)
+    sc = ds.batch["score"]
+    ds.batch["score"] = (np.maximum(np.round(sc / step), 1.0) * step).astype(sc.dtype)
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, alphabet)
+    assert int(stats["pass1"].sum()) > 1000
+
+
 def test_predict_dna_ragged_sets_and_lengths(pkg, oracle, synth):
     """Record sets of different sizes (1..40 records) and segment lengths from 40 to 700 bp in one batch."""
     parts = [synth.make_dataset(n_sets=150, n_hits=h, seg_len=L, branching=3, genome_len=2500, seed=10 + k, variety=True)
