@@ -388,7 +388,8 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band(const uint2* __rest
 // update words g-2 .. g+1, the last 16 columns words g-1 .. g+2.  A window that slides one word per 32 columns guarantees a
 // band of 16 (words - 1) diagonals either side when it is centred like this: |j - i| <= 48, i.e. h = 48 - |delta|,
 // k = 96 - |delta| (five words, in phase: 64 and 128).  Config 2's pass-1 pairs (55-65 edits, |delta| < 20) still fit; a
-// column costs 3.6 word updates on average instead of 4.3 (of 7).  tools/band_model.py: banded_window_phase.
+// column costs 3.6 word updates on average instead of 4.3 (of 7).  tools/band_model.py: banded_window_phase.  (The default
+// since round 3 drops to THREE words in the middle 16 columns of a group: BandGroups4 below.)
 // The same column over a RING of four table slots: word w's masks sit in slot w & 3 of a [symbol][4][lane] table (the
 // four-word window never holds two words of the same slot), so the table is 20 KB per workgroup whatever NW is.
 template <int NW, int WLO, int WHI>
@@ -420,43 +421,66 @@ __device__ __forceinline__ void ring_store(uint32_t* __restrict__ peq_lane, int 
   for (int c = 0; c < 5; ++c) peq_lane[(c * 4 + (wi & 3)) * kBlock] = mask[c];
 }
 
+// RPA_BAND4_PHASES = 3 (default): of the 32 columns of text group g the first 8 update words g-2 .. g+1, the middle 16
+// words g-1 .. g+1 and the last 8 words g-1 .. g+2: word g-2 leaves a quarter of a group earlier and word g+2 enters a
+// quarter later than with two phases of 16 columns (RPA_BAND4_PHASES = 2, rounds 2-3: four words all the way).  3.5 words
+// per column instead of 4; the guaranteed band is |j - i| <= 40 instead of 48, i.e. k = 80 - |delta| instead of 96 -
+// |delta| (tools/band_model.py: banded_window_phase3 / banded_window_phase, both checked against plain Levenshtein by
+// the CPU suite).  Config 2: 0.5 % of the demanded pairs lie above 75 edits (tools: the distances in the oracle's trace).
+#ifndef RPA_BAND4_PHASES
+#define RPA_BAND4_PHASES 3
+#endif
+constexpr uint32_t kBand4Reach = RPA_BAND4_PHASES == 3 ? 40u : 48u;  // the band holds the diagonals |j - i| <= kBand4Reach
+
 template <int NW, int G>
 struct BandGroups4 {
   static __device__ __forceinline__ void run(uint32_t (&VP)[NW], uint32_t (&VN)[NW], uint32_t* __restrict__ peq_lane, NtStream& ts,
                                              uint4& pending, NtStream& ps, uint32_t m, uint32_t n, uint32_t n_groups, int32_t& T,
                                              int32_t& top) {
     if ((uint32_t)G >= n_groups) return;
-    constexpr int ALO = G - 2 > 0 ? G - 2 : 0, AHI = G + 1 < NW - 1 ? G + 1 : NW - 1;
-    constexpr int BLO = G - 1 > 0 ? G - 1 : 0, BHI = G + 2 < NW - 1 ? G + 2 : NW - 1;
+    constexpr int ALO = G - 2 > 0 ? G - 2 : 0, AHI = G + 1 < NW - 1 ? G + 1 : NW - 1;  // the group's first columns
+    constexpr int BLO = G - 1 > 0 ? G - 1 : 0, BHI = G + 2 < NW - 1 ? G + 2 : NW - 1;  // its last columns
+    constexpr uint32_t kFirst = RPA_BAND4_PHASES == 3 ? 8u : 16u;   // columns before word G - 2 leaves
+    constexpr uint32_t kLast = RPA_BAND4_PHASES == 3 ? 24u : 16u;   // columns before word G + 2 enters
     const uint4 buf = ts.take32(pending);
     if ((uint32_t)G + 1u < n_groups) pending = ts.load4();
     const uint32_t cols = n - (uint32_t)G * 32u < 32u ? n - (uint32_t)G * 32u : 32u;
-    // the pattern word the window takes in at this group's half-way point (word G + 2): asked for now, turned into masks then
+    // the pattern word the window takes in (word G + 2): asked for now, turned into masks when it enters
     constexpr bool takes_in = G + 2 <= NW - 1;
     uint4 pat_pending = make_uint4(0u, 0u, 0u, 0u);
-    const bool has_word = takes_in && cols > 16u && (uint32_t)(G + 2) * 32u < m;
+    const bool has_word = takes_in && cols > kLast && (uint32_t)(G + 2) * 32u < m;
     if (has_word) pat_pending = ps.load4();
-    const uint32_t ca = cols < 16u ? cols : 16u;
-    band_sweep16<NW, ALO, AHI>(VP, VN, peq_lane, buf.x, buf.y, ca);
+    const uint32_t ca = cols < kFirst ? cols : kFirst;
+    if constexpr (RPA_BAND4_PHASES == 3) band_sweep16<NW, ALO, AHI>(VP, VN, peq_lane, buf.x, 0u, ca);
+    else band_sweep16<NW, ALO, AHI>(VP, VN, peq_lane, buf.x, buf.y, ca);
     T += (int32_t)ca;
     top = ALO;
-    if (cols > 16u) {  // columns follow: the window moves down a word
+    if (cols > kFirst) {  // columns follow: word G - 2 leaves the window
       if constexpr (G - 2 >= 0 && G - 2 <= NW - 1) T += (int32_t)__popc(VP[G - 2]) - (int32_t)__popc(VN[G - 2]);
       top = BLO;
-      if constexpr (takes_in) {  // word G + 2 enters the ring in the slot word G - 2 has just left
-        uint32_t mask[5] = {0u, 0u, 0u, 0u, 0u};
-        if (has_word) {
-          const uint4 x = ps.take32(pat_pending);
-          uint32_t p0, p1, pn;
-          planes32(x, p0, p1, pn);
-          const uint32_t rem = m - (uint32_t)(G + 2) * 32u;
-          const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
-          mask[4] = pn & vm; mask[3] = p1 & p0 & vm; mask[2] = p1 & ~p0 & vm; mask[1] = p0 & ~p1 & ~pn & vm; mask[0] = ~(p0 | p1 | pn) & vm;
-        }
-        ring_store(peq_lane, G + 2, mask);
+      if constexpr (RPA_BAND4_PHASES == 3) {  // the middle 16 columns: three words
+        constexpr int MHI = G + 1 < NW - 1 ? G + 1 : NW - 1;
+        const uint32_t cm = (cols < kLast ? cols : kLast) - kFirst;
+        band_sweep16<NW, BLO, MHI>(VP, VN, peq_lane, buf.y, buf.z, cm);
+        T += (int32_t)cm;
       }
-      band_sweep16<NW, BLO, BHI>(VP, VN, peq_lane, buf.z, buf.w, cols - 16u);
-      T += (int32_t)(cols - 16u);
+      if (cols > kLast) {
+        if constexpr (takes_in) {  // word G + 2 enters the ring in the slot word G - 2 has left
+          uint32_t mask[5] = {0u, 0u, 0u, 0u, 0u};
+          if (has_word) {
+            const uint4 x = ps.take32(pat_pending);
+            uint32_t p0, p1, pn;
+            planes32(x, p0, p1, pn);
+            const uint32_t rem = m - (uint32_t)(G + 2) * 32u;
+            const uint32_t vm = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+            mask[4] = pn & vm; mask[3] = p1 & p0 & vm; mask[2] = p1 & ~p0 & vm; mask[1] = p0 & ~p1 & ~pn & vm; mask[0] = ~(p0 | p1 | pn) & vm;
+          }
+          ring_store(peq_lane, G + 2, mask);
+        }
+        if constexpr (RPA_BAND4_PHASES == 3) band_sweep16<NW, BLO, BHI>(VP, VN, peq_lane, buf.w, 0u, cols - kLast);
+        else band_sweep16<NW, BLO, BHI>(VP, VN, peq_lane, buf.z, buf.w, cols - kLast);
+        T += (int32_t)(cols - kLast);
+      }
     }
     if constexpr (G + 1 < NW + 2) BandGroups4<NW, G + 1>::run(VP, VN, peq_lane, ts, pending, ps, m, n, n_groups, T, top);
   }
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
   if (prof_acc) profile_add(prof_acc, active, n, m);
   if (!active) return;
   const uint32_t ad = n > m ? n - m : m - n;
-  if (ad >= 48u) { retry[atomicAdd(retry_n, 1u)] = entry; return; }  // no band of this shape holds the corridor
+  if (ad >= kBand4Reach) { retry[atomicAdd(retry_n, 1u)] = entry; return; }  // no band of this shape holds the corridor
   NtStream ps;
   ps.init(pat, 0u);
 #pragma unroll
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
   uint32_t VP[NW], VN[NW];
 #pragma unroll
   for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
-  const uint32_t n_groups = (n + 31u) >> 5;  // <= NW + 2: n < m + 48 <= 32 NW + 48
+  const uint32_t n_groups = (n + 31u) >> 5;  // <= NW + 2: n < m + kBand4Reach <= 32 NW + 48
   int32_t T = 0, top = 0;
   if (n_groups) {
     NtStream ts;
@@ -516,7 +540,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
     const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
     if (wi >= top) dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
   }
-  if ((uint32_t)dist <= 96u - ad) store_dna_result(w, dst, dist, n, m);
+  if ((uint32_t)dist <= 2u * kBand4Reach - ad) store_dna_result(w, dst, dist, n, m);
   else retry[atomicAdd(retry_n, 1u)] = entry;
 }
 
