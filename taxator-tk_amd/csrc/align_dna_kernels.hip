@@ -421,18 +421,17 @@ __device__ __forceinline__ void ring_store(uint32_t* __restrict__ peq_lane, int 
   for (int c = 0; c < 5; ++c) peq_lane[(c * 4 + (wi & 3)) * kBlock] = mask[c];
 }
 
-// RPA_BAND4_PHASES = 3 (default): of the 32 columns of text group g the first 8 update words g-2 .. g+1, the middle 16
+// PH = 3 (default): of the 32 columns of text group g the first 8 update words g-2 .. g+1, the middle 16
 // words g-1 .. g+1 and the last 8 words g-1 .. g+2: word g-2 leaves a quarter of a group earlier and word g+2 enters a
-// quarter later than with two phases of 16 columns (RPA_BAND4_PHASES = 2, rounds 2-3: four words all the way).  3.5 words
+// quarter later than with two phases of 16 columns (PH = 2, rounds 2-3: four words all the way).  3.5 words
 // per column instead of 4; the guaranteed band is |j - i| <= 40 instead of 48, i.e. k = 80 - |delta| instead of 96 -
 // |delta| (tools/band_model.py: banded_window_phase3 / banded_window_phase, both checked against plain Levenshtein by
 // the CPU suite).  Config 2: 0.5 % of the demanded pairs lie above 75 edits (tools: the distances in the oracle's trace).
-#ifndef RPA_BAND4_PHASES
-#define RPA_BAND4_PHASES 3
-#endif
-constexpr uint32_t kBand4Reach = RPA_BAND4_PHASES == 3 ? 40u : 48u;  // the band holds the diagonals |j - i| <= kBand4Reach
+// Both are compiled (PH = 3 | 2): the engine falls back to the wide band for a while when more than an eighth of a
+// batch's banded pairs left the narrow one (rpa_engine.hip: band4_wide), RPA_BAND4_PHASES=2|3 fixes the choice.
+__host__ __device__ constexpr uint32_t band4_reach(int ph) { return ph == 3 ? 40u : 48u; }  // the band holds the diagonals |j - i| <= reach
 
-template <int NW, int G>
+template <int NW, int G, int PH>
 struct BandGroups4 {
   static __device__ __forceinline__ void run(uint32_t (&VP)[NW], uint32_t (&VN)[NW], uint32_t* __restrict__ peq_lane, NtStream& ts,
                                              uint4& pending, NtStream& ps, uint32_t m, uint32_t n, uint32_t n_groups, int32_t& T,
@@ -440,8 +439,8 @@ struct BandGroups4 {
     if ((uint32_t)G >= n_groups) return;
     constexpr int ALO = G - 2 > 0 ? G - 2 : 0, AHI = G + 1 < NW - 1 ? G + 1 : NW - 1;  // the group's first columns
     constexpr int BLO = G - 1 > 0 ? G - 1 : 0, BHI = G + 2 < NW - 1 ? G + 2 : NW - 1;  // its last columns
-    constexpr uint32_t kFirst = RPA_BAND4_PHASES == 3 ? 8u : 16u;   // columns before word G - 2 leaves
-    constexpr uint32_t kLast = RPA_BAND4_PHASES == 3 ? 24u : 16u;   // columns before word G + 2 enters
+    constexpr uint32_t kFirst = PH == 3 ? 8u : 16u;   // columns before word G - 2 leaves
+    constexpr uint32_t kLast = PH == 3 ? 24u : 16u;   // columns before word G + 2 enters
     const uint4 buf = ts.take32(pending);
     if ((uint32_t)G + 1u < n_groups) pending = ts.load4();
     const uint32_t cols = n - (uint32_t)G * 32u < 32u ? n - (uint32_t)G * 32u : 32u;
@@ -451,14 +450,14 @@ struct BandGroups4 {
     const bool has_word = takes_in && cols > kLast && (uint32_t)(G + 2) * 32u < m;
     if (has_word) pat_pending = ps.load4();
     const uint32_t ca = cols < kFirst ? cols : kFirst;
-    if constexpr (RPA_BAND4_PHASES == 3) band_sweep16<NW, ALO, AHI>(VP, VN, peq_lane, buf.x, 0u, ca);
+    if constexpr (PH == 3) band_sweep16<NW, ALO, AHI>(VP, VN, peq_lane, buf.x, 0u, ca);
     else band_sweep16<NW, ALO, AHI>(VP, VN, peq_lane, buf.x, buf.y, ca);
     T += (int32_t)ca;
     top = ALO;
     if (cols > kFirst) {  // columns follow: word G - 2 leaves the window
       if constexpr (G - 2 >= 0 && G - 2 <= NW - 1) T += (int32_t)__popc(VP[G - 2]) - (int32_t)__popc(VN[G - 2]);
       top = BLO;
-      if constexpr (RPA_BAND4_PHASES == 3) {  // the middle 16 columns: three words
+      if constexpr (PH == 3) {  // the middle 16 columns: three words
         constexpr int MHI = G + 1 < NW - 1 ? G + 1 : NW - 1;
         const uint32_t cm = (cols < kLast ? cols : kLast) - kFirst;
         band_sweep16<NW, BLO, MHI>(VP, VN, peq_lane, buf.y, buf.z, cm);
@@ -477,16 +476,16 @@ struct BandGroups4 {
           }
           ring_store(peq_lane, G + 2, mask);
         }
-        if constexpr (RPA_BAND4_PHASES == 3) band_sweep16<NW, BLO, BHI>(VP, VN, peq_lane, buf.w, 0u, cols - kLast);
+        if constexpr (PH == 3) band_sweep16<NW, BLO, BHI>(VP, VN, peq_lane, buf.w, 0u, cols - kLast);
         else band_sweep16<NW, BLO, BHI>(VP, VN, peq_lane, buf.z, buf.w, cols - kLast);
         T += (int32_t)(cols - kLast);
       }
     }
-    if constexpr (G + 1 < NW + 2) BandGroups4<NW, G + 1>::run(VP, VN, peq_lane, ts, pending, ps, m, n, n_groups, T, top);
+    if constexpr (G + 1 < NW + 2) BandGroups4<NW, G + 1, PH>::run(VP, VN, peq_lane, ts, pending, ps, m, n, n_groups, T, top);
   }
 };
 
-template <int NW>
+template <int NW, int PH>
 __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __restrict__ list, uint32_t n_list,
                                                                const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
                                                                uint2* __restrict__ retry, uint32_t* __restrict__ retry_n,
@@ -513,7 +512,8 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
   if (prof_acc) profile_add(prof_acc, active, n, m);
   if (!active) return;
   const uint32_t ad = n > m ? n - m : m - n;
-  if (ad >= kBand4Reach) { retry[atomicAdd(retry_n, 1u)] = entry; return; }  // no band of this shape holds the corridor
+  constexpr uint32_t kReach = band4_reach(PH);
+  if (ad >= kReach) { retry[atomicAdd(retry_n, 1u)] = entry; return; }  // no band of this shape holds the corridor
   NtStream ps;
   ps.init(pat, 0u);
 #pragma unroll
@@ -525,13 +525,13 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
   uint32_t VP[NW], VN[NW];
 #pragma unroll
   for (int wi = 0; wi < NW; ++wi) { VP[wi] = 0xFFFFFFFFu; VN[wi] = 0u; }
-  const uint32_t n_groups = (n + 31u) >> 5;  // <= NW + 2: n < m + kBand4Reach <= 32 NW + 48
+  const uint32_t n_groups = (n + 31u) >> 5;  // <= NW + 2: n < m + kReach <= 32 NW + 48
   int32_t T = 0, top = 0;
   if (n_groups) {
     NtStream ts;
     ts.init(txt, 0u);
     uint4 pending = ts.load4();
-    BandGroups4<NW, 0>::run(VP, VN, peq + tid, ts, pending, ps, m, n, n_groups, T, top);
+    BandGroups4<NW, 0, PH>::run(VP, VN, peq + tid, ts, pending, ps, m, n, n_groups, T, top);
   }
   int32_t dist = T;
 #pragma unroll
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
     const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
     if (wi >= top) dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
   }
-  if ((uint32_t)dist <= 2u * kBand4Reach - ad) store_dna_result(w, dst, dist, n, m);
+  if ((uint32_t)dist <= 2u * kReach - ad) store_dna_result(w, dst, dist, n, m);
   else retry[atomicAdd(retry_n, 1u)] = entry;
 }
 
@@ -567,7 +567,7 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
 bool dna_short_band_available(int words) { return words >= 5 && words <= kShortWords; }
 
 hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
-                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, unsigned long long* prof_acc) {
+                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, bool wide, unsigned long long* prof_acc) {
   if ((uint64_t)n + n2 == 0) return hipSuccess;
   if ((uint64_t)n + n2 > 0xFFFFFF00ull || !retry || !retry_n) return hipErrorInvalidValue;
   const uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
@@ -583,7 +583,8 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
 #define RPA_LAUNCH_MYERS_BAND(NWV) \
   case NWV: \
     if (five) hipLaunchKernelGGL((k_myers_short_band<NWV, 2>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
-    else hipLaunchKernelGGL((k_myers_short_band4<NWV>), dim3(blocks), dim3(kBlock), pad4, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
+    else if (wide) hipLaunchKernelGGL((k_myers_short_band4<NWV, 2>), dim3(blocks), dim3(kBlock), pad4, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
+    else hipLaunchKernelGGL((k_myers_short_band4<NWV, 3>), dim3(blocks), dim3(kBlock), pad4, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
     break;
   switch (words) {
     RPA_LAUNCH_MYERS_BAND(5) RPA_LAUNCH_MYERS_BAND(6) RPA_LAUNCH_MYERS_BAND(7) RPA_LAUNCH_MYERS_BAND(8)

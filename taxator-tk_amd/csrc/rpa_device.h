@@ -323,7 +323,7 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
 // outside it are appended to retry[*retry_n] instead of being answered
 bool dna_short_band_available(int words);
 hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
-                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, unsigned long long* prof_acc);
+                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, bool wide, unsigned long long* prof_acc);
 // multi-strip per-lane kernel inside Ukkonen's band; scratch holds two boundary bits per text column per thread in
 // flight.  A pair whose distance lies outside its band is appended to retry[*retry_n] (wide_open: never happens).
 // margin / 16 = safety factor on the probe's distance estimate (21 by default; tests use tiny ones to force retries).

@@ -121,6 +121,8 @@ struct rpa_engine {
   // than a quarter of its pairs to the retry list (unrelated sequences) is switched off for the next 16 batches.
   uint64_t banded_short_batch = 0, banded_long_batch = 0;
   int band_short_pause = 0, band_long_pause = 0;
+  int band4_wide = 0;        // > 0: the one-strip band with four words all the way (k = 96 - |delta|) for this many more batches:
+                             //      too many pairs of a batch left the narrow one (k = 80 - |delta|); -1 / -2: fixed by RPA_BAND4_PHASES=2 / 3
   bool band_short = true;     // RPA_BAND_SHORT=0: the one-strip kernel computes every cell of 5..8-word patterns too
   uint32_t band_short_min = 65536;  // fewer pairs than this in a launch: not worth a second (retry) launch
   bool band_long = true;      // RPA_BAND=0: the strip kernel computes every cell (A/B; results are the same either way)
@@ -274,7 +276,8 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
         // onto a retry list).  A launch of the dense rounds only: the sparse rounds put every class into one list.
         if (use_band_short && dna_short_band_available(bin + 1) && (uint64_t)n + n2 >= e->band_short_min) {
           HIP_TRY(e, launch_align_dna_short_band(e->stream, bin + 1, list, n, list2, n2, w, e->retry_short.as<uint2>(),
-                                                 w.counters + kCtrRetryShort, e->owner != nullptr /* a job slot: other batches are in flight */, acc));
+                                                 w.counters + kCtrRetryShort, e->owner != nullptr /* a job slot: other batches are in flight */,
+                                                 e->band4_wide > 0 || e->band4_wide == -1, acc));
           banded_short += (uint64_t)n + n2;
           widest_short = bin + 1;
         } else HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, nullptr, 0, list2, n2, w, acc));
@@ -537,6 +540,15 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     if (live_now == 0) {  // the batch is done: what did the bands cost? (totals added up by the retry launches)
       if (e->banded_short_batch >= 65536 && (uint64_t)e->h_counters[kCtrRetryShortTotal] * 4 > e->banded_short_batch) e->band_short_pause = 16;
       else if (e->band_short_pause) --e->band_short_pause;
+      // the narrow band: a pair that leaves it costs the band and every cell (2.2 x the wide band's price), one that stays saves an
+      // eighth -- beyond one pair in sixteen the wide band is cheaper
+      if (e->trace_rounds && e->banded_short_batch)
+        fprintf(stderr, "[rpa] batch done: %u of %llu pairs left the one-strip band (%s)\n", e->h_counters[kCtrRetryShortTotal],
+                (unsigned long long)e->banded_short_batch, (e->band4_wide > 0 || e->band4_wide == -1) ? "four words: 96 - |delta|" : "three-word middle: 80 - |delta|");
+      if (e->band4_wide >= 0) {
+        if (e->band4_wide == 0 && e->banded_short_batch >= 65536 && (uint64_t)e->h_counters[kCtrRetryShortTotal] * 16 > e->banded_short_batch) e->band4_wide = 16;
+        else if (e->band4_wide > 0) --e->band4_wide;
+      }
       if (e->banded_long_batch >= 1024 && (uint64_t)e->h_counters[kCtrRetryTotal] * 4 > e->banded_long_batch) e->band_long_pause = 16;
       else if (e->band_long_pause) --e->band_long_pause;
       e->banded_short_batch = 0; e->banded_long_batch = 0;
@@ -796,6 +808,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.protein_lanes = 1;
   if (const char* v = getenv("RPA_PROTEIN_LANES")) e->params.protein_lanes = atoi(v) != 0;
   e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
+  if (const char* v = getenv("RPA_BAND4_PHASES")) e->band4_wide = atoi(v) == 2 ? -1 : -2;
   e->params.filter1 = 2;
   if (const char* v = getenv("RPA_PASS1_FILTER")) e->params.filter1 = atoi(v);
   e->params.grow = 0;

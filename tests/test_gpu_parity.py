@@ -108,7 +108,7 @@ def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
     assert out.tobytes() == out2.tobytes()
 
 
-@pytest.mark.parametrize("band", ["forced", "five-words", "off"])
+@pytest.mark.parametrize("band", ["forced", "four-words", "five-words", "off"])
 def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     """Patterns of 5..8 words (129..256 nt) go through a one-strip kernel that only updates the pattern words within two
     words of the diagonal; pairs whose distance lies outside that band (or whose lengths differ by 64 and more) are
@@ -116,7 +116,8 @@ def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     equal to the oracle -- from identical pairs to unrelated ones, with N's, and every length difference class."""
     monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")
     if band == "off": monkeypatch.setenv("RPA_BAND_SHORT", "0")
-    if band == "five-words": monkeypatch.setenv("RPA_BAND_WORDS", "5")  # the in-phase window (k = 128 - |delta|); default: four words, out of phase (96)
+    if band == "five-words": monkeypatch.setenv("RPA_BAND_WORDS", "5")  # the in-phase window (k = 128 - |delta|)
+    if band == "four-words": monkeypatch.setenv("RPA_BAND4_PHASES", "2")  # four words all the way, out of phase (96); default: a three-word middle (80)
     rng = np.random.default_rng(12)
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
     a_codes, b_codes = [], []
@@ -395,6 +396,35 @@ def test_pass1_chunk_end_on_tied_and_boundary_scores(pkg, oracle, synth, alphabe
     ds.batch["score"] = (np.maximum(np.round(sc / step), 1.0) * step).astype(sc.dtype)
     rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, alphabet)
     assert int(stats["pass1"].sum()) > 1000
+
+
+def test_band_widens_when_too_many_pairs_leave_it(pkg, oracle, synth, monkeypatch, capfd):
+    """The one-strip band has a three-word middle (exact up to 80 - |delta| edits); a batch in which more than one banded
+    pair in sixteen lies beyond that makes the engine use four words all the way (96 - |delta|) for the following batches.
+    Divergent references: the first batch re-runs many pairs, the next ones fewer -- and all of them equal the oracle."""
+    monkeypatch.setenv("RPA_TRACE_ROUNDS", "1")
+    monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")  # (launches of any size go through the band: the pairs of a batch are spread over three length classes)
+    ds = synth.make_dataset(n_sets=8000, n_hits=20, seg_len=200, branching=4, genome_len=3000, seed=51, level_rate=0.045, query_rate=0.06)
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    q = oracle.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+    db = oracle.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+    rc, exp, est = oracle.predict_batch(tax, q, db, 0, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
+                                        synth.records_aos(ds.batch, oracle.RECORD_DTYPE))
+    assert rc == 0
+    import re
+    left = []
+    for _ in range(3):
+        capfd.readouterr()
+        rows, stats = model.predict(ds.batch)
+        assert rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes()
+        m = re.search(r"batch done: (\d+) of (\d+) pairs left the one-strip band \((three|four)", capfd.readouterr().err)
+        assert m, "no band summary in the round trace"
+        left.append((int(m.group(1)), int(m.group(2)), m.group(3)))
+    assert left[0][2] == "three" and left[0][0] * 16 > left[0][1], left       # the narrow band loses more than one pair in sixteen
+    assert left[1][2] == "four" and left[2][2] == "four" and left[1][0] < left[0][0], left  # ... so the next batches run in the wide one
 
 
 def test_predict_dna_ragged_sets_and_lengths(pkg, oracle, synth):

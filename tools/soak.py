@@ -10,7 +10,7 @@ import __graft_entry__ as graft
 from helpers import oracle as O
 
 KNOBS = ("RPA_PASS1_FILTER", "RPA_LABEL_BITS", "RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
-         "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL",
+         "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND4_PHASES", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL",
          "RPA_PROTEIN_LANES")
 
 
@@ -99,6 +99,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           env["RPA_BAND_SHORT_MIN"] = "1"
           env["RPA_BAND_MARGIN"] = str(int(rng.choice([1, 8, 16, 21, 40])))
           if rng.random() < 0.3: env["RPA_BAND_WORDS"] = "5"
+          elif rng.random() < 0.3: env["RPA_BAND4_PHASES"] = "2"
           if rng.random() < 0.3: env["RPA_BAND_DUO"] = "0"
           if rng.random() < 0.15: env["RPA_BAND"] = "0"
           if rng.random() < 0.15: env["RPA_BAND_SHORT"] = "0"

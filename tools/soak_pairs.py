@@ -30,7 +30,7 @@ def mutate(a, rng, asize, rate):
     return b.astype(np.uint8)
 
 
-KNOBS = ("RPA_LONG_KERNEL", "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND_DUO")
+KNOBS = ("RPA_LONG_KERNEL", "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND4_PHASES", "RPA_BAND_DUO")
 
 
 def run(n_batches=20, rng_seed=777, verbose=True):
@@ -52,6 +52,7 @@ def run(n_batches=20, rng_seed=777, verbose=True):
                 os.environ["RPA_BAND_SHORT_MIN"] = "1"
                 os.environ["RPA_BAND_MARGIN"] = str(int(rng.choice([1, 8, 16, 21, 40])))
                 if rng.random() < 0.3: os.environ["RPA_BAND_WORDS"] = "5"
+                elif rng.random() < 0.3: os.environ["RPA_BAND4_PHASES"] = "2"
                 if rng.random() < 0.3: os.environ["RPA_BAND_DUO"] = "0"
         else:
             top = int(rng.choice([30, 80, 260, 330, 520, 800]))
