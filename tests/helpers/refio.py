@@ -198,9 +198,10 @@ def parse_alignments(path_or_lines):
     return recs
 
 
-def record_sets(recs, split=True):
+def record_sets(recs, split=True, presorted=False):
     """src/alignmentrecord.hh:457-504 (RecordSetGeneratorUnsorted<split=true>): consecutive lines of one query id,
-    sorted by (qstart, qstop, <allocation order>), cut where qstart > running max qstop.  split=False: :543-566."""
+    sorted by (qstart, qstop, <allocation order>), cut where qstart > running max qstop.  split=False: :543-566.
+    presorted (`-o 1`, RecordSetGeneratorSorted<split=true>, :569-631): the same cut rule over the lines in INPUT order."""
     out = []
     i = 0
     while i < len(recs):
@@ -212,7 +213,8 @@ def record_sets(recs, split=True):
         if not split:
             out.append(group)
             continue
-        group = sorted(group, key=lambda r: (r.qstart, r.qstop, r.serial))
+        if not presorted:
+            group = sorted(group, key=lambda r: (r.qstart, r.qstop, r.serial))
         cur, rstop = [group[0]], group[0].qstop
         for r in group[1:]:
             if r.qstart > rstop:
@@ -257,7 +259,7 @@ def gff3_line(qid, qlen, pred, tax, prev_ival):
 class Dataset:
     """A directory with tax/{nodes,names}.dmp, mapping.tax, a reference FASTA, a query FASTA and an alignments TSV."""
 
-    def __init__(self, folder, alphabet=0, ref_name=None, query_name=None, aln_name="aln.tsv"):
+    def __init__(self, folder, alphabet=0, ref_name=None, query_name=None, aln_name="aln.tsv", split=True, presorted=False):
         ext = ".fna" if alphabet == 0 else ".faa"
         self.alphabet = alphabet
         self.tax = FlatTaxonomy(os.path.join(folder, "tax"))
@@ -265,7 +267,7 @@ class Dataset:
         self.ref = Fasta(os.path.join(folder, ref_name or ("ref" + ext)), alphabet)
         self.query = Fasta(os.path.join(folder, query_name or ("query" + ext)), alphabet)
         self.records = parse_alignments(os.path.join(folder, aln_name))
-        self.sets = record_sets(self.records)
+        self.sets = record_sets(self.records, split=split, presorted=presorted)
 
     def batch(self):
         """Flatten to the SoA/AoS arrays the oracle and the engine take."""

@@ -141,6 +141,87 @@ def test_cli_config1_plumbing(oracle, tmp_path):
     assert [int(l[3]) + int(l[4]) + int(l[5]) for l in stats_lines] == [int(x) for x in st["pass0"] + st["pass1"] + st["pass2"]]
 
 
+def _multi_segment_dataset(synth, folder, seed, shuffle):
+    """A synthetic data set whose queries carry SEVERAL segments (1-4 record sets of the generator joined into one query,
+    some of them overlapping so that the split rule has to merge them), lines of a query position-sorted or shuffled."""
+    ds = synth.make_dataset(n_sets=260, n_hits=8, seg_len=120, branching=3, genome_len=2000, seed=seed, variety=True)
+    synth.write_files(ds, folder)  # taxonomy, mapping, reference FASTA + .fai; the query FASTA and the TSV are rewritten below
+    rng = np.random.default_rng(seed)
+    b = ds.batch
+    qoff = ds.query_offsets.astype(np.int64)
+    tsv, fasta = [], []
+    s = k = 0
+    while s < ds.n_sets:
+        g = min(ds.n_sets - s, int(rng.integers(1, 5)))
+        letters = np.zeros(0, np.uint8)
+        group = []
+        for t in range(s, s + g):
+            seg = ds.query_letters[qoff[t]:qoff[t + 1]]
+            pos = len(letters)
+            if t > s and rng.random() < 0.35:
+                pos -= int(rng.integers(1, 30))          # overlaps the segment before it: no cut there
+            elif t > s and rng.random() < 0.5:
+                letters = np.concatenate([letters, ds.query_letters[qoff[s]:qoff[s] + int(rng.integers(1, 40))]])  # a gap
+                pos = len(letters)
+            letters = np.concatenate([letters[:pos], seg])
+            for r in range(int(b["set_offsets"][t]), int(b["set_offsets"][t + 1])):
+                group.append(["*" if b["filtered"][r] else "", int(b["qstart"][r]) + pos, int(b["qstop"][r]) + pos, int(b["ref_seq"][r]), int(b["rstart"][r]),
+                              int(b["rstop"][r]), float(b["score"][r]), int(b["identities"][r]), int(b["alnlen"][r])])
+        if shuffle:
+            rng.shuffle(group)
+        else:
+            group.sort(key=lambda x: (x[1], x[2]))
+        for x in group:
+            tsv.append("%sm%d\t%d\t%d\t%d\tref%d\t%d\t%d\t%g\t0\t%d\t%d\n" % (x[0], k, x[1], x[2], len(letters), x[3], x[4], x[5], x[6], x[7], x[8]))
+        fasta.append(b">m%d\n" % k + letters.tobytes() + b"\n")
+        s += g
+        k += 1
+    with open(os.path.join(folder, "aln.tsv"), "w") as f:
+        f.writelines(tsv)
+    with open(os.path.join(folder, "query.fna"), "wb") as f:
+        f.writelines(fasta)
+    return k
+
+
+@pytest.mark.parametrize("order", ["position-sorted", "shuffled"])
+def test_cli_alignments_sorted_split_and_cutoff_options(oracle, tmp_path, order):
+    """The options the reference's pipelines really pass (extended/binning-last.bash:108-109: `-x $taxator_speedup -o 1`)
+    and the ones next to them: `-o 1` (RecordSetGeneratorSorted: input order, core/src/alignmentrecord.hh:569-631), `-s 0`
+    (one record set per query identifier, :543-566), `-x`, `-t` (taxator.cpp:284-287) -- on queries with several segments,
+    through the columnar reader and the record-object loop: byte-identical to each other and to the GFF3 made from the
+    oracle's rows over the record sets a literal Python reading of the reference's generators builds."""
+    graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    folder = str(tmp_path / "ms")
+    n_queries = _multi_segment_dataset(synth, folder, seed=81, shuffle=order == "shuffled")
+    n_sets = {}
+    for name, flags, kw in (("default", [], {}),
+                            ("-o 1", ["-o", "1"], dict(presorted=True)),
+                            ("-s 0", ["-s", "0"], dict(split=False)),
+                            ("-o 1 -x 1 -t 0.3", ["-o", "1", "-x", "1", "-t", "0.3"], dict(presorted=True, x=1.0, t=0.3)),
+                            ("-x 0 -t 0", ["-x", "0", "-t", "0"], dict(x=0.0, t=0.0)),
+                            ("-s 0 -x 0.8 -t 0.1", ["-s", "0", "-x", "0.8", "-t", "0.1"], dict(split=False, x=0.8, t=0.1))):
+        fds = R.Dataset(folder, 0, split=kw.get("split", True), presorted=kw.get("presorted", False))
+        b = fds.batch()
+        tax = oracle.TaxArrays(fds.tax.parent, fds.tax.left, fds.tax.right, fds.tax.depth)
+        q = oracle.StoreArrays(fds.query.residues, fds.query.offsets)
+        db = oracle.StoreArrays(fds.ref.residues, fds.ref.offsets)
+        rc, out, st = oracle.predict_batch(tax, q, db, 0, b["offsets"], b["qseq"], b["qlen"], b["recs"], exclude_factor=kw.get("x", 0.5),
+                                           reeval_bandwidth=kw.get("t", 0.05))
+        assert rc == 0
+        want = fds.gff3(out, b["qids"], b["qlen"])
+        n_sets[name] = len(out)
+        for path in ([], ["--record-objects"], ["--block-mb", "0.004", "-p", "3"]):
+            r = _run(folder, ".fna", extra=flags + path + ["--batch", "61"])
+            assert r.returncode == 0, (name, path, r.stderr)
+            assert r.stdout == want, (name, path)
+    assert n_sets["-s 0"] == n_queries < n_sets["default"]
+    if order == "shuffled":
+        assert n_sets["-o 1"] < n_sets["default"]     # input order: a late segment's line first lifts the running stop over the earlier segments
+    else:
+        assert n_sets["-o 1"] == n_sets["default"]
+
+
 @pytest.mark.parametrize("path", [[], ["--record-objects"]])
 def test_cli_errors_like_the_reference(golden_dir, tmp_path, path):
     folder = os.path.join(golden_dir, "survey_edge")

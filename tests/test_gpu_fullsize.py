@@ -90,11 +90,12 @@ def test_full_size_properties(name):
     db = O.StoreArrays(synth.encode(ds.ref_letters, alphabet), ds.ref_offsets)
     b = ds.batch
 
-    def check(lo, hi):  # record sets [lo, hi) through the oracle (the C library releases the GIL: chunks run side by side)
+    def check(lo, hi, r=r, st=st, x=0.5, t=0.05):  # record sets [lo, hi) through the oracle (the C library releases the GIL: chunks run side by side)
         r0, r1 = int(b["set_offsets"][lo]), int(b["set_offsets"][hi])
         sub = {k: (v[r0:r1] if len(v) == len(b["qstart"]) else v) for k, v in b.items()}
         offs = (b["set_offsets"][lo:hi + 1] - b["set_offsets"][lo]).astype(np.uint32)
-        rc, exp, est = O.predict_batch(otax, q, db, alphabet, offs, b["query_seq"][lo:hi], b["query_len"][lo:hi], synth.records_aos(sub, O.RECORD_DTYPE))
+        rc, exp, est = O.predict_batch(otax, q, db, alphabet, offs, b["query_seq"][lo:hi], b["query_len"][lo:hi], synth.records_aos(sub, O.RECORD_DTYPE),
+                                       exclude_factor=x, reeval_bandwidth=t)
         return rc == 0 and r[lo:hi].tobytes() == exp.tobytes() and st[lo:hi].tobytes() == est.tobytes()
 
     from concurrent.futures import ThreadPoolExecutor
@@ -105,3 +106,26 @@ def test_full_size_properties(name):
         results = list(ex.map(lambda sp: check(*sp), spans))
     assert all(results), [sp for sp, ok in zip(spans, results) if not ok][:5]
     assert 2 * W * 10 >= S or name == "config5"   # the two windows cover 10 % of configs 2 and 4
+
+    # `-x` / `-t` off their defaults at full size (the production pipelines pass -x; extended/binning-last.bash:108): the whole
+    # batch through an engine with the setting, one oracle window each (front for the first, back for the second)
+    if name in ("config2", "config4"):
+        del model
+        for k, (x, t) in enumerate(((0.0, 0.1), (1.0, 0.0))):
+            mx = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet, exclude_factor=x, reeval_bandwidth=t)
+            mx.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+            mx.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+            rows_x = torch.zeros((S, 8), dtype=torch.int32, device="cuda")
+            stats_x = torch.zeros((S, 4), dtype=torch.int32, device="cuda")
+            mx.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows_x, stats=stats_x)
+            torch.cuda.synchronize()
+            rx = rows_x.cpu().numpy().view(pkg.PRED_DTYPE).reshape(-1)
+            sx = stats_x.cpu().numpy().view(pkg.STATS_DTYPE).reshape(-1)
+            dem_x = int(sx["pass0"].astype(np.int64).sum() + sx["pass1"].astype(np.int64).sum() + sx["pass2"].astype(np.int64).sum())
+            assert (dem_x >= demanded) if x == 0.0 else (dem_x < demanded), (x, dem_x, demanded)  # X = 0: no heuristic cut-off; X = 1: nearly everything cut
+            w0 = 0 if k == 0 else S - W // 2
+            spans_x = [(lo, min(lo + chunk, w0 + W // 2)) for lo in range(w0, w0 + W // 2, chunk)]
+            with ThreadPoolExecutor(workers) as ex:
+                results = list(ex.map(lambda sp: check(sp[0], sp[1], r=rx, st=sx, x=x, t=t), spans_x))
+            assert all(results), (x, t, [sp for sp, ok in zip(spans_x, results) if not ok][:5])
+            del mx

@@ -290,8 +290,9 @@ def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir, lanes, monkeyp
         assert np.float32(got["similarity"]).tobytes() == np.float32(o["similarity"]).tobytes(), k
 
 
-def _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, speculation=None):
-    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet, speculation=speculation)
+def _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, speculation=None, exclude_factor=0.5, reeval_bandwidth=0.05):
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet, speculation=speculation, exclude_factor=exclude_factor,
+                                   reeval_bandwidth=reeval_bandwidth)
     model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
     model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
     rows, stats = model.predict(ds.batch)
@@ -299,7 +300,8 @@ def _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, speculation=None):
     q = oracle.StoreArrays(synth.encode(ds.query_letters, alphabet), ds.query_offsets)
     db = oracle.StoreArrays(synth.encode(ds.ref_letters, alphabet), ds.ref_offsets)
     rc, exp, est = oracle.predict_batch(tax, q, db, alphabet, ds.batch["set_offsets"], ds.batch["query_seq"],
-                                        ds.batch["query_len"], synth.records_aos(ds.batch, oracle.RECORD_DTYPE))
+                                        ds.batch["query_len"], synth.records_aos(ds.batch, oracle.RECORD_DTYPE),
+                                        exclude_factor=exclude_factor, reeval_bandwidth=reeval_bandwidth)
     assert rc == 0
     for f in ("lower", "upper", "rtax", "support", "begin", "end", "flags"):
         bad = np.nonzero(rows[f] != exp[f])[0]
@@ -396,6 +398,61 @@ def test_pass1_chunk_end_on_tied_and_boundary_scores(pkg, oracle, synth, alphabe
     ds.batch["score"] = (np.maximum(np.round(sc / step), 1.0) * step).astype(sc.dtype)
     rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, alphabet)
     assert int(stats["pass1"].sum()) > 1000
+
+
+_DS_CACHE = {}
+
+
+def _cached_dataset(synth, **kw):
+    """Datasets that many parametrisations of one test share (never modified by the tests that use this)."""
+    key = tuple(sorted(kw.items()))
+    if key not in _DS_CACHE:
+        _DS_CACHE[key] = synth.make_dataset(**kw)
+    return _DS_CACHE[key]
+
+
+X_VALUES = (0.0, 0.25, 0.5, 0.8, 1.0)   # taxator -x ("1 is fastest, 0 means using all alignments", extended/binning-last.bash:108)
+T_VALUES = (0.0, 0.05, 0.1, 0.3)         # taxator -t
+
+
+@pytest.mark.parametrize("mode", ["default", "assume-always", "chunks-1-1", "chunks-3-2"])
+@pytest.mark.parametrize("t", T_VALUES)
+@pytest.mark.parametrize("x", X_VALUES)
+def test_heuristic_cutoff_and_reevaluation_band(pkg, oracle, synth, x, t, mode, monkeypatch):
+    """`-x` (exclude_alignments_factor_) and `-t` (reeval_bandwidth) off their defaults.  X feeds an int truncation in pass 1
+    ((int)(score * X), :657-659: X = 0 leaves the cut-off "unset" at every hit, so every later farther hit sets it again)
+    and a float product in pass 2 (:752-757); t decides who joins the query group in pass 0 ((float)(1. - t) * best score,
+    :334,:499: t = 0 keeps only ties with the best score, 0.3 a third of a set).  The pass-1 request rules (thresholds of a
+    paused loop, the first-hit cut-off assumption) are built on exactly these values: every mode must give the oracle's
+    rows, STATS counters and (below) trace for every pair of settings."""
+    if mode == "assume-always": monkeypatch.setenv("RPA_PASS1_FILTER", "3")
+    spec = {"chunks-1-1": (1, 1), "chunks-3-2": (3, 2)}.get(mode)
+    ds = _cached_dataset(synth, n_sets=500, n_hits=20, seg_len=150, branching=4, genome_len=3000, seed=71, variety=True)
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=spec, exclude_factor=x, reeval_bandwidth=t)
+    assert int(stats["pass1"].sum()) > 400
+    dp = _cached_dataset(synth, n_sets=200, n_hits=16, seg_len=60, branching=3, genome_len=1500, seed=72, alphabet=1,
+                         level_rate=0.06, query_rate=0.08, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, dp, 1, speculation=spec, exclude_factor=x, reeval_bandwidth=t)
+
+
+@pytest.mark.parametrize("x,t", [(0.0, 0.3), (1.0, 0.0), (0.8, 0.1), (0.25, 0.05), (1.5, 0.5), (0.5, 1.0), (0.999, 0.999)])
+def test_cutoff_settings_on_coarse_scores_and_big_sets(pkg, oracle, synth, x, t, monkeypatch):
+    """The same on scores rounded to a coarse grid (runs of tied scores and hits exactly ON (float)(int)(X * score)), on
+    record sets beyond the 64-hit bit sets, and with values outside the documented range (X > 1: the cut-off lies above the
+    score that set it; t = 1: the pass-0 threshold is 0 and every hit is re-aligned) -- the reference does not range-check
+    either option (taxator.cpp:286-287)."""
+    monkeypatch.setenv("RPA_PASS1_FILTER", "3")
+    ds = synth.make_dataset(n_sets=400, n_hits=20, seg_len=150, branching=4, genome_len=3000, seed=73)
+    sc = ds.batch["score"]
+    ds.batch["score"] = (np.maximum(np.round(sc / 16.0), 1.0) * 16.0).astype(sc.dtype)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0, exclude_factor=x, reeval_bandwidth=t)
+    monkeypatch.delenv("RPA_PASS1_FILTER")
+    big = synth.make_dataset(n_sets=80, n_hits=70, seg_len=120, branching=3, genome_len=2000, seed=74, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, big, 0, speculation=(5, 3), exclude_factor=x, reeval_bandwidth=t)
+    dp = synth.make_dataset(n_sets=150, n_hits=20, seg_len=67, branching=4, genome_len=1500, seed=75, alphabet=1, level_rate=0.06, query_rate=0.08)
+    sp = dp.batch["score"]
+    dp.batch["score"] = (np.maximum(np.round(sp / 8.0), 1.0) * 8.0).astype(sp.dtype)
+    _engine_vs_oracle(pkg, oracle, synth, dp, 1, exclude_factor=x, reeval_bandwidth=t)
 
 
 def test_band_widens_when_too_many_pairs_leave_it(pkg, oracle, synth, monkeypatch, capfd):
@@ -640,20 +697,10 @@ def test_wide_path_labels(pkg, oracle, synth, bits, monkeypatch):
     _engine_vs_oracle(pkg, oracle, synth, ds, 0)
 
 
-@pytest.mark.parametrize("alphabet,kw", [(0, dict(n_sets=700, n_hits=20, seg_len=200, branching=4, genome_len=3000, seed=61)),
-                                         (0, dict(n_sets=60, n_hits=90, seg_len=120, branching=4, genome_len=1500, seed=62)),
-                                         (1, dict(n_sets=500, n_hits=16, seg_len=70, branching=4, genome_len=1200, seed=63, level_rate=0.06, query_rate=0.08))])
-@pytest.mark.parametrize("parts", [None, "3"])
-def test_alignment_trace_equals_the_oracles(pkg, oracle, synth, alphabet, kw, parts, monkeypatch):
-    """rpa_trace_begin / rpa_trace_read: the alignments the control flow CONSUMES, in the order the reference computes and
-    logs them ("+ALN i <=> j dist=..; sim=..", taxonpredictionmodelsequence.hh:533,636,782,802) -- per record set the same
-    (pass, i, j, distance, similarity) sequence as the oracle's trace callback (which tests/test_oracle_placement.py holds
-    against the reference's own log, tests/golden/survey_*/expected.json), float bit patterns included, whatever the engine
-    computed speculatively on the side; also when the batch is cut into parts."""
-    if parts:
-        monkeypatch.setenv("RPA_PARTS", parts)
-    ds = synth.make_dataset(variety=True, alphabet=alphabet, **kw)
-    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
+def _trace_vs_oracle(pkg, oracle, synth, ds, alphabet, x=0.5, t=0.05, min_checked=500):
+    """The engine's trace of consumed alignments against the oracle's trace callback, per record set; returns what the
+    caller needs to go on (model, rows, trace)."""
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet, exclude_factor=x, reeval_bandwidth=t)
     model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
     model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
     model.trace(4_000_000)
@@ -671,7 +718,7 @@ def test_alignment_trace_equals_the_oracles(pkg, oracle, synth, alphabet, kw, pa
     checked = 0
     for s_ in range(0, ds.n_sets, 3 if ds.n_sets > 200 else 1):
         lo, hi = int(b["set_offsets"][s_]), int(b["set_offsets"][s_ + 1])
-        rc, out, st, want = oracle.predict(tax, q, db, alphabet, int(b["query_seq"][s_]), int(b["query_len"][s_]), recs[lo:hi], want_trace=True)
+        rc, out, st, want = oracle.predict(tax, q, db, alphabet, int(b["query_seq"][s_]), int(b["query_len"][s_]), recs[lo:hi], exclude_factor=x, reeval_bandwidth=t, want_trace=True)
         assert rc == 0
         got = tr[first[s_]:first[s_ + 1]]
         assert (got["set"] == s_).all() and list(got["seq"]) == list(range(len(got)))
@@ -680,7 +727,24 @@ def test_alignment_trace_equals_the_oracles(pkg, oracle, synth, alphabet, kw, pa
             assert (int(g["pass"]), int(g["i"]), int(g["j"])) == (w_[0], w_[1], w_[2]), (s_, g, w_)
             assert np.float32(g["dist"]).tobytes() == np.float32(w_[3]).tobytes() and np.float32(g["sim"]).tobytes() == np.float32(w_[4]).tobytes(), (s_, g, w_)
         checked += len(want)
-    assert checked > 500
+    assert checked > min_checked
+    return model, rows, tr
+
+
+@pytest.mark.parametrize("alphabet,kw", [(0, dict(n_sets=700, n_hits=20, seg_len=200, branching=4, genome_len=3000, seed=61)),
+                                         (0, dict(n_sets=60, n_hits=90, seg_len=120, branching=4, genome_len=1500, seed=62)),
+                                         (1, dict(n_sets=500, n_hits=16, seg_len=70, branching=4, genome_len=1200, seed=63, level_rate=0.06, query_rate=0.08))])
+@pytest.mark.parametrize("parts", [None, "3"])
+def test_alignment_trace_equals_the_oracles(pkg, oracle, synth, alphabet, kw, parts, monkeypatch):
+    """rpa_trace_begin / rpa_trace_read: the alignments the control flow CONSUMES, in the order the reference computes and
+    logs them ("+ALN i <=> j dist=..; sim=..", taxonpredictionmodelsequence.hh:533,636,782,802) -- per record set the same
+    (pass, i, j, distance, similarity) sequence as the oracle's trace callback (which tests/test_oracle_placement.py holds
+    against the reference's own log, tests/golden/survey_*/expected.json), float bit patterns included, whatever the engine
+    computed speculatively on the side; also when the batch is cut into parts."""
+    if parts:
+        monkeypatch.setenv("RPA_PARTS", parts)
+    ds = synth.make_dataset(variety=True, alphabet=alphabet, **kw)
+    model, rows, tr = _trace_vs_oracle(pkg, oracle, synth, ds, alphabet)
     # a capacity that is too small: what fits is a prefix-free sample, the rest is counted
     model.trace(100)
     model.predict(ds.batch)
@@ -689,6 +753,17 @@ def test_alignment_trace_equals_the_oracles(pkg, oracle, synth, alphabet, kw, pa
     model.trace(0)
     rows3, _ = model.predict(ds.batch)
     assert rows3.tobytes() == rows.tobytes()
+
+
+@pytest.mark.parametrize("x,t", [(0.0, 0.3), (1.0, 0.0), (0.8, 0.1), (0.25, 0.3)])
+@pytest.mark.parametrize("alphabet", [0, 1])
+def test_alignment_trace_under_cutoff_settings(pkg, oracle, synth, alphabet, x, t):
+    """The consumed-alignment trace (= the reference's +ALN log lines) with `-x` / `-t` off their defaults: same alignments
+    in the same order with the same float bit patterns as the oracle at the same settings."""
+    kw = dict(n_sets=240, n_hits=16, seg_len=60, branching=3, genome_len=1500, seed=64, level_rate=0.06, query_rate=0.08) if alphabet else \
+        dict(n_sets=400, n_hits=20, seg_len=150, branching=4, genome_len=3000, seed=63)
+    ds = synth.make_dataset(variety=True, alphabet=alphabet, **kw)
+    _trace_vs_oracle(pkg, oracle, synth, ds, alphabet, x=x, t=t, min_checked=60)  # (X = 1 cuts nearly every loop short)
 
 
 def test_windowed_stores(pkg, oracle, synth):

@@ -112,3 +112,80 @@ def test_large_group_and_long_line(parsecheck, golden_dir):
     lines.append("e1\t1\t2\t200\tref3\t1\t2\t3\t0\t1\t1\t" + "x" * 20000)
     rc, out = _both(parsecheck, folder, ("\n".join(lines) + "\n").encode())
     assert rc == 0
+
+
+def _model_sets(data, split, presorted):
+    """The record sets the reference's generators would build (tests/helpers/refio.py: a literal Python reading of
+    core/src/alignmentrecord.hh:457-504, :543-566, :569-631) as (qid, [(qstart, qstop, rstart, rstop)...]) tuples."""
+    from helpers import refio as R
+    recs = R.parse_alignments([l for l in data.decode().split("\n") if l != ""])
+    return [(g[0].qid, [(r.qstart, r.qstop, r.rstart, r.rstop) for r in g]) for g in R.record_sets(recs, split=split, presorted=presorted)]
+
+
+def _dump_sets(out):
+    sets = []
+    for line in out.decode().split("\n"):
+        f = line.split("\t")
+        if f[0] == "SET":
+            sets.append((f[1], []))
+        elif len(f) == 10:
+            sets[-1][1].append((int(f[1]), int(f[2]), int(f[3]), int(f[4])))
+    return sets
+
+
+@pytest.mark.parametrize("order", ["position-sorted", "as-it-comes"])
+def test_alignments_sorted_option(parsecheck, golden_dir, monkeypatch, order):
+    """`taxator -o 1` (the flag the LAST pipeline runs with, extended/binning-last.bash:109) = RecordSetGeneratorSorted
+    (core/src/alignmentrecord.hh:569-631): no sort per query; a new record set starts where a line's query start lies
+    beyond the running maximum of the query stops -- in INPUT order.  On position-sorted input that is what the default
+    generator builds; on unsorted input it is not (and that, too, must be what the reference does: other sets).
+    Both readers, every block / thread geometry, against a literal Python reading of the reference's loop."""
+    folder = os.path.join(golden_dir, "survey_edge")
+    refs = [l.split("\t")[0] for l in open(os.path.join(folder, "mapping.tax")) if l.strip() and not l.startswith("#")][:40]
+    qids = [l[1:].split()[0] for l in open(os.path.join(folder, "query_edge.fna")) if l.startswith(">")]
+    rng = random.Random(29)
+    differs = 0
+    for trial in range(12):
+        lines = []
+        qid = None
+        for _ in range(rng.randint(1, 25)):
+            qid = rng.choice([q for q in qids if q != qid])  # (two groups of one id in a row would be ONE group)
+            group = []
+            pos = 1
+            for _ in range(rng.randint(1, 5)):               # segments of the query, some touching, some apart
+                for _ in range(rng.randint(1, 8)):
+                    qs = pos + rng.randint(0, 5)
+                    qe = qs + rng.randint(0, 120)
+                    group.append("%s%s\t%d\t%d\t5000\t%s\t%d\t%d\t%d\t0\t%d\t%d" % ("*" if rng.random() < 0.05 else "", qid, qs, qe, rng.choice(refs), rng.randint(1, 3000),
+                                                                                rng.randint(1, 3000), rng.randint(1, 400), rng.randint(0, 100), qe - qs + 1))
+                pos += rng.choice([60, 126, 127, 140, 300])
+            if order == "position-sorted":
+                group.sort(key=lambda l: (int(l.split("\t")[1]), int(l.split("\t")[2])))
+            else:
+                rng.shuffle(group)
+            lines += group
+            if rng.random() < 0.2:
+                lines.append("# comment")
+        data = ("\n".join(lines) + "\n").encode()
+        monkeypatch.setenv("PARSECHECK_SORTED", "1")
+        rc, out = _both(parsecheck, folder, data, split=1)
+        assert rc == 0
+        got = _dump_sets(out)
+        assert got == _model_sets(data, True, True)
+        monkeypatch.delenv("PARSECHECK_SORTED")
+        rc0, out0 = _both(parsecheck, folder, data, split=1)
+        assert _dump_sets(out0) == _model_sets(data, True, False)
+        if order == "position-sorted":
+            assert [sorted(s[1]) for s in got] == [sorted(s[1]) for s in _dump_sets(out0)]  # same cuts (ties may sit in another order)
+        else:
+            differs += got != _dump_sets(out0)
+        # -s 0: one record set per query identifier, lines in input order, whatever -o says (:543-566; the reference's
+        # `-o 1 -s 0` never returns -- RecordSetGeneratorSorted<false> does not advance, :612 -- here it is `-s 0`)
+        want_whole = _model_sets(data, False, False)
+        for env_sorted in (False, True):
+            if env_sorted: monkeypatch.setenv("PARSECHECK_SORTED", "1")
+            rc1, out1 = _both(parsecheck, folder, data, split=0)
+            assert rc1 == 0 and _dump_sets(out1) == want_whole
+            monkeypatch.delenv("PARSECHECK_SORTED", raising=False)
+    if order != "position-sorted":
+        assert differs > 6

@@ -108,7 +108,12 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
       for kk in KNOBS:
           os.environ.pop(kk, None)
       os.environ.update(env)
-      model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet)
+      # round 4: `-x` / `-t` off their defaults in half of the batches (taxator.cpp:286-287; no range check there)
+      x, t = 0.5, 0.05
+      if rng.random() < 0.5:
+          x = float(rng.choice([0.0, 0.1, 0.25, 0.5, 0.8, 0.95, 1.0, 1.3]))
+          t = float(rng.choice([0.0, 0.01, 0.05, 0.1, 0.3, 0.7, 1.0]))
+      model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet, exclude_factor=x, reeval_bandwidth=t)
       model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
       if not windowed:
           model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
@@ -118,7 +123,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
       q = O.StoreArrays(synth.encode(ds.query_letters, alphabet), ds.query_offsets)
       db = O.StoreArrays(synth.encode(ds.ref_letters, alphabet), ds.ref_offsets)
       rc, exp, est = O.predict_batch(tax, q, db, alphabet, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
-                                     synth.records_aos(ds.batch, O.RECORD_DTYPE))
+                                     synth.records_aos(ds.batch, O.RECORD_DTYPE), exclude_factor=x, reeval_bandwidth=t)
       try:
           rows, stats = model.predict(ds.batch)
           ok = rc == 0 and rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes()
@@ -130,8 +135,8 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           what = "both abort (oracle rc %d, engine %d)" % (rc, e.code) if ok else "MISMATCH: engine error %d %s, oracle rc %d" % (e.code, e, rc)
       total_sets += n_sets
       if verbose or not ok:
-        print("seed %d: %s sets=%d hits=%d seg=%d b=%d depth=%d%s env=%s -> %s  (%.0f s)" % (first_seed + k, "protein" if alphabet else "dna", n_sets, n_hits, seg,
-                                                                           branching, int(ds.tax.depth.max()), " windows" if windowed else "", env, what, time.time() - t0), flush=True)
+        print("seed %d: %s sets=%d hits=%d seg=%d b=%d depth=%d%s x=%g t=%g env=%s -> %s  (%.0f s)" % (first_seed + k, "protein" if alphabet else "dna", n_sets, n_hits, seg,
+                                                                           branching, int(ds.tax.depth.max()), " windows" if windowed else "", x, t, env, what, time.time() - t0), flush=True)
       if not ok:
           for f in (rows.dtype.names if rows is not None else ()):
               bad = np.nonzero(rows[f] != exp[f])[0]
