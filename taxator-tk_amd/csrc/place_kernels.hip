@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
   }
   // ---- stores ----
   w.seg[pos] = sdesc;  // (all zero for a set of one record: never aligned)
-  w.res_slot[pos] = slot;  // where the alignment kernels put this hit's result
+  if (w.res_slot) w.res_slot[pos] = slot;  // where the alignment kernels put this hit's result (linear layout: the row position itself)
   if (sp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); sp.x = 0; }
   // compact per-row word for k_emit: segment length + "pass 0 re-aligns this hit" (:511-518, threshold :499)
   w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u) | (perfect ? kLitePerfect : 0u);

@@ -358,7 +358,7 @@ __device__ __forceinline__ void resolve_pair(const WorkDev& w, uint2 entry, uint
 
 // where an alignment kernel stores the result of destination id `dst` (a row position, or H + s for anchor <-> query)
 __device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
-  if (!w.res_slot) return dst;  // rpa_align_pairs: one slot per pair
+  if (!w.res_slot) return dst;  // rpa_align_pairs: one slot per pair; linear row layout: slot = row position and P = H
   return dst < w.H ? w.res_slot[dst] : w.P + (dst - w.H);
 }
 

@@ -402,7 +402,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->state.ensure((size_t)(S ? S : 1) * sizeof(SetStateMem)));
   HIP_TRY(e, e->loop_save.ensure((size_t)(S ? S : 1) * sizeof(LoopSave)));
   HIP_TRY(e, e->hits.ensure((size_t)(P ? P : 1) * (size_t)row_quads * 16));
-  if (!want_ext) HIP_TRY(e, e->res_slot.ensure((size_t)(H ? H : 1) * 4));
+  if (!want_ext && tiled) HIP_TRY(e, e->res_slot.ensure((size_t)(H ? H : 1) * 4));
   HIP_TRY(e, e->set_info.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
   HIP_TRY(e, e->emit.ensure((size_t)(S ? S : 1) * sizeof(EmitInfo)));
   HIP_TRY(e, e->emit_lite.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
@@ -442,7 +442,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->set_offsets = nullptr; w->H = H; w->row_quads = row_quads; w->lb_shift = lb_shift;
   w->trace = want_ext ? nullptr : e->trace_view; w->trace_n = e->trace_view_n; w->trace_cap = e->trace_view_cap; w->trace_set_base = e->trace_set_base;
   w->P = P; w->tile_base = (!want_ext && tiled) ? e->tile_base.as<const uint32_t>() : nullptr;
-  w->res_slot = want_ext ? nullptr : e->res_slot.as<uint32_t>();
+  w->res_slot = (want_ext || !tiled) ? nullptr : e->res_slot.as<uint32_t>();  // linear layout: result slot = row position (P = H)
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
   w->bin_list = e->bin_list.as<uint2>(); w->counters = e->counters.as<uint32_t>();
   w->og_idx = e->og_idx.as<uint32_t>(); w->band_save = e->band_save.as<float>();
