@@ -191,7 +191,8 @@ int rpa_predict_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out
  * line per alignment its control flow computes, in the order it computes them) as records.  rpa_trace_begin(capacity > 0)
  * turns recording on for the synchronous rpa_predict_batch calls of this engine (capacity = entries kept per call;
  * 0 turns it off); rpa_trace_read returns the entries of the last call sorted by (record set, order inside the set) and
- * how many did not fit.  i, j are hit positions in SortFilter order; j = -1: the query range ("i <=> query"), i = -1:
+ * how many did not fit (capacity 0, out NULL: nothing is copied, *n_dropped = the number of entries the call produced --
+ * ask, size a buffer, read).  i, j are hit positions in SortFilter order; j = -1: the query range ("i <=> query"), i = -1:
  * "query <=> j" (pass 2).  sim is what the reference prints there (pass 0 / "query <=> j": after std::max with the
  * identities / the stored similarity).  Only alignments the reference would have computed are recorded, never the
  * engine's speculative ones: per set there are exactly pass0 + pass1 + pass2 (rpa_stats) entries. */

@@ -1381,6 +1381,10 @@ int rpa_trace_read(rpa_engine* e, rpa_trace_entry* out, uint64_t capacity, uint6
   HIP_TRY(e, hipMemcpy(&attempts, e->trace_count.p, 8, hipMemcpyDeviceToHost));
   const uint64_t have = attempts < e->trace_cap ? attempts : e->trace_cap;
   if (n_dropped) *n_dropped = attempts - have;
+  if (capacity == 0) {  // "how many are there?": nothing is copied (n_dropped = every alignment the call consumed)
+    if (n_dropped) *n_dropped = attempts;
+    return RPA_OK;
+  }
   std::vector<TraceEntry> tmp((size_t)have);
   if (have) HIP_TRY(e, hipMemcpy(tmp.data(), e->trace_buf.p, (size_t)have * sizeof(TraceEntry), hipMemcpyDeviceToHost));
   std::sort(tmp.begin(), tmp.end(), [](const TraceEntry& a, const TraceEntry& b) { return a.set != b.set ? a.set < b.set : a.seq < b.seq; });

@@ -145,29 +145,37 @@ void unpin_work(Work& w, const RPAPredictionModel& rpa) {
 }
 
 // One record set of the log (-l), the lines of the reference's log this build can reproduce (taxonpredictionmodelsequence.hh:
-// 408-409 ID / NUMREF, :533,636,782,802 one "+ALN" line per alignment the control flow computes -- same operands, distance
-// and similarity as there, std::fixed << std::setprecision(2), :347; the other fields of those lines, the printed
-// alignments and the timing columns are left out --, :837 STATS with the timing columns left out).
+// 360-364 / 375-380 / 407-409 "ID <qrstart>:<qrstop>@<query id>" ("-1:-1@id" for a set without active alignments) and NUMREF,
+// :533,636,782,802 one "+ALN" line per alignment the control flow computes -- same operands, distance and similarity as
+// there, std::fixed << std::setprecision(2), :347; the reference's other fields of those lines (search scores, cut-offs),
+// the printed alignments and the timing columns are left out; "pass=" is this build's own field and comes last --, :837
+// "STATS <name> n pass0 pass1 pass2 total" with the timing columns left out, followed by the blank line the reference prints).
 inline void append_fixed2(std::string& out, float v) {
   char buf[64];
   const int n = snprintf(buf, sizeof(buf), "%.2f", (double)v);
   out.append(buf, (size_t)(n > 0 ? n : 0));
 }
-inline void append_log_set(std::string& lg, const char* qid, size_t qid_len, const rpa_stats& st, const rpa_trace_entry* tr, size_t n_tr) {
-  lg.append("ID\t"); lg.append(qid, qid_len); lg.append("\n  NUMREF\t"); append_u32(lg, st.n); lg.push_back('\n');
+inline void append_seqname(std::string& lg, const char* qid, size_t qid_len, const rpa_stats& st, const rpa_prediction& row) {
+  if (st.n == 0) lg.append("-1:-1@");  // seqname_fmt % -1 % -1 % qid, :360
+  else { append_u32(lg, row.begin); lg.push_back(':'); append_u32(lg, row.end); lg.push_back('@'); }  // "%d:%d@%s", :344,375,407
+  lg.append(qid, qid_len);
+}
+inline void append_log_set(std::string& lg, const char* qid, size_t qid_len, const rpa_stats& st, const rpa_prediction& row,
+                           const rpa_trace_entry* tr, size_t n_tr) {
+  lg.append("ID\t"); append_seqname(lg, qid, qid_len, st, row); lg.append("\n  NUMREF\t"); append_u32(lg, st.n); lg.push_back('\n');
   for (size_t k = 0; k < n_tr; ++k) {
     const rpa_trace_entry& e = tr[k];
     lg.append("    +ALN ");
     if (e.i < 0) lg.append("query"); else append_u32(lg, (uint32_t)e.i);
     lg.append(" <=> ");
     if (e.j < 0) lg.append("query"); else append_u32(lg, (uint32_t)e.j);
-    lg.append("\tpass="); append_u32(lg, (uint32_t)e.pass);
-    lg.append("; dist="); append_fixed2(lg, e.dist); lg.append("; sim="); append_fixed2(lg, e.sim); lg.push_back('\n');
+    lg.append("\tdist="); append_fixed2(lg, e.dist); lg.append("; sim="); append_fixed2(lg, e.sim);
+    lg.append("; pass="); append_u32(lg, (uint32_t)e.pass); lg.push_back('\n');
   }
-  lg.append("STATS\t"); lg.append(qid, qid_len);
+  lg.append("STATS\t"); append_seqname(lg, qid, qid_len, st, row);
   const uint32_t v[5] = {st.n, st.pass0, st.pass1, st.pass2, st.pass0 + st.pass1 + st.pass2};
   for (uint32_t x : v) { lg.push_back('\t'); append_u32(lg, x); }
-  lg.push_back('\n');
+  lg.append("\n\n");
 }
 
 struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, records = 0; };
@@ -246,7 +254,7 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
             for (size_t s = lo; s < hi; ++s) {
               size_t k1 = k;
               while (k1 < w->trace.size() && w->trace[k1].set == s) ++k1;
-              append_log_set(lg, b.qid_arena.data() + b.qid_off[s], b.qid_len[s], w->stats[s], w->trace.data() + k, k1 - k);
+              append_log_set(lg, b.qid_arena.data() + b.qid_off[s], b.qid_len[s], w->stats[s], w->rows[s], w->trace.data() + k, k1 - k);
               k = k1;
             }
           }
@@ -512,7 +520,7 @@ static int run(int argc, char** argv) {
           size_t k1 = k;
           while (k1 < tr.size() && tr[k1].set == s) ++k1;
           const std::string& qid = precs[s].getQueryIdentifier();
-          append_log_set(lg, qid.data(), qid.size(), st[s], tr.data() + k, k1 - k);
+          append_log_set(lg, qid.data(), qid.size(), st[s], rpa.lastRows()[s], tr.data() + k, k1 - k);
           k = k1;
         }
         logsink << lg;

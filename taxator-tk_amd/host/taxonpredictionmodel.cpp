@@ -2,6 +2,7 @@
 #include "taxonpredictionmodel.hh"
 
 #include <algorithm>
+#include <iostream>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -57,9 +58,41 @@ inline bool bit(const std::vector<uint64_t>& v, uint64_t i) { return (v[i >> 6] 
 inline void set_bit(std::vector<uint64_t>& v, uint64_t i) { v[i >> 6] |= 1ull << (i & 63); }
 }  // namespace
 
-size_t RPAPredictionModel::makeResident(const rpa_batch& b) {
-  if ((!query_sequences_.indexed() && !db_sequences_.indexed()) || b.n_sets == 0) return 0;
-  std::lock_guard<std::mutex> resident_lock(resident_mu_);
+void RPAPredictionModel::releaseResident() {
+  { std::lock_guard<std::mutex> g(resident_mu_); if (in_flight_) --in_flight_; }
+  resident_cv_.notify_all();
+}
+
+namespace {
+struct ResidentHold {  // releases the hold on every way out of a predict call
+  RPAPredictionModel& m; bool held;
+  ~ResidentHold() { if (held) m.releaseResident(); }
+};
+}  // namespace
+
+// SURVEY quirk 6, consciously normalised: the reference's IN-MEMORY store answers getSequenceReverseComplement with the whole
+// forward sequence (core/src/sequencestorage.hh:122-130: the body is commented out, `return db_seq`), so `taxator -f ref.fna`
+// without `-i` aligns every reverse-strand hit's query range against the entire reference sequence; its indexed store
+// (:364-369, what the pipelines use: extended/binning-last.bash:104-105) reverse-complements the segment.  This engine
+// does the latter for both kinds of store; the first reverse-strand hit against an in-memory reference store says so once.
+void RPAPredictionModel::noteReverseStrand(const rpa_batch& b) {
+  if (rpa_store_bits_ != 4 || db_sequences_.indexed() || reverse_noted_.load(std::memory_order_relaxed)) return;
+  const uint32_t n = std::min<uint32_t>(b.n_records, 65536u);  // (a sample per batch: a note, not a check)
+  for (uint32_t r = 0; r < n; ++r)
+    if (b.rstart[r] > b.rstop[r]) {
+      if (!reverse_noted_.exchange(true))
+        std::cerr << "taxator: note: reverse-strand alignments are re-aligned against the reverse complement of their reference segment.  The reference "
+                     "implementation does that only with an indexed reference store (-i); its in-memory store (-f without -i) hands back the whole "
+                     "forward sequence instead (core/src/sequencestorage.hh:122-130), so its output differs from this one on such alignments." << std::endl;
+      return;
+    }
+}
+
+size_t RPAPredictionModel::makeResident(const rpa_batch& b, bool hold) {
+  noteReverseStrand(b);
+  if (!query_sequences_.indexed() && !db_sequences_.indexed()) return 0;
+  std::unique_lock<std::mutex> resident_lock(resident_mu_);
+  if (b.n_sets == 0) { if (hold) ++in_flight_; return 0; }
   // how far a hit's reference range can be extended: by the width of its record set's query range (:523; the range of
   // ALL records of the set here, masked ones included: an upper bound)
   std::vector<uint32_t> span(b.n_sets, 0);
@@ -78,8 +111,9 @@ size_t RPAPredictionModel::makeResident(const rpa_batch& b) {
     for (auto& x : th) x.join();
   }
   size_t loaded = 0;
-  if (query_sequences_.indexed()) loaded += makeResidentStore(RPA_STORE_QUERY, b, span);
-  if (db_sequences_.indexed()) loaded += makeResidentStore(RPA_STORE_DB, b, span);
+  if (query_sequences_.indexed()) loaded += makeResidentStore(RPA_STORE_QUERY, b, span, resident_lock);
+  if (db_sequences_.indexed()) loaded += makeResidentStore(RPA_STORE_DB, b, span, resident_lock);
+  if (hold) ++in_flight_;
   return loaded;
 }
 
@@ -87,7 +121,7 @@ size_t RPAPredictionModel::makeResident(const rpa_batch& b) {
 // is noted in the thread's own bit set.  Pass 2: the union of those, grown to whole runs of (resident or needed) tiles --
 // a new window swallows the resident windows it touches, so that resident windows never sit side by side and "all tiles
 // of a region resident" means "one window holds the region".  Pass 3: fetch and append.
-size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, const std::vector<uint32_t>& span) {
+size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, const std::vector<uint32_t>& span, std::unique_lock<std::mutex>& lk) {
   const SequenceStore& st = which == RPA_STORE_QUERY ? query_sequences_ : db_sequences_;
   std::vector<uint64_t>& base = tile_base_[which];
   std::vector<uint64_t>& res = resident_[which];
@@ -98,7 +132,8 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
   }
   const uint64_t n_tiles = base.back();
   const size_t n_units = which == RPA_STORE_QUERY ? b.n_sets : b.n_records;
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  bool emptied = false;  // the store was emptied for this batch: what it needs now is all there will be
+  for (;;) {
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, n_units / 65536 + 1));
     std::vector<std::vector<uint64_t>> need(T);
     std::vector<uint8_t> out_of_range(T, 0), any(T, 0);
@@ -175,13 +210,17 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
       }
     }
     const uint64_t total = fetch_offsets_.back();
-    if (store_budget_ && attempt == 0) {
+    if (store_budget_ && !emptied) {
       const rpa_store_info info = storeInfo(which);
       const uint64_t half_bytes = rpa_store_bits_ / 4;  // per residue: 4-bit DNA = 1 half byte, 8-bit protein = 2
       if ((info.residues + total) * half_bytes / 2 > store_budget_ && info.residues) {
-        // the store would outgrow its budget: drop everything resident and start over with what this batch needs
+        // The store would outgrow its budget: drop everything resident and start over with what this batch needs -- once no
+        // batch that was made resident earlier is still running on what is there (the wait lets go of the lock: another
+        // thread may come through here meanwhile, so the scan above is stale afterwards and is done again either way).
+        if (in_flight_) { resident_cv_.wait(lk, [&] { return in_flight_ == 0; }); continue; }
         check(engine_, rpa_store_reset(engine_, which));
         std::fill(res.begin(), res.end(), 0);
+        emptied = true;
         continue;
       }
     }
@@ -250,16 +289,10 @@ void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, s
   b.filtered = filtered_.data(); b.mem_kind = RPA_MEM_HOST;
   rows_.resize(S);
   stats_.resize(S);
-  makeResident(b);
-  if (trace_on_) {
-    std::lock_guard<std::mutex> turn(trace_mu_);
-    const uint64_t cap = (uint64_t)b.n_records * 64 + 4096;
-    check(engine_, rpa_trace_begin(engine_, cap));
-    check(engine_, rpa_predict_batch(engine_, &b, rows_.data(), stats_.data(), RPA_MEM_HOST));
-    readTrace(cap, trace_);
-    check(engine_, rpa_trace_begin(engine_, 0));
-  } else
-  check(engine_, rpa_predict_batch(engine_, &b, rows_.data(), stats_.data(), RPA_MEM_HOST));
+  makeResident(b, true);
+  ResidentHold hold{*this, query_sequences_.indexed() || db_sequences_.indexed()};
+  if (trace_on_) predictTraced(b, rows_.data(), stats_.data(), trace_);
+  else check(engine_, rpa_predict_batch(engine_, &b, rows_.data(), stats_.data(), RPA_MEM_HOST));
   for (size_t s = 0; s < S; ++s) {
     const rpa_prediction& r = rows_[s];
     PredictionRecord& prec = precs[s];
@@ -274,12 +307,29 @@ void RPAPredictionModel::predict(const std::vector<RecordSetType>& recordsets, s
   }
 }
 
-void RPAPredictionModel::readTrace(uint64_t capacity, std::vector<rpa_trace_entry>& out) {
-  out.resize((size_t)capacity);
-  uint64_t n = 0, dropped = 0;
-  check(engine_, rpa_trace_read(engine_, out.data(), capacity, &n, &dropped));
-  out.resize((size_t)n);
-  if (dropped) throw GeneralError("alignment log: more alignments than the trace buffer holds");
+// A logging run: synchronous, one traced call at a time.  The trace holds one 32-byte entry per alignment the control flow
+// consumes -- pass0 + pass1 + pass2 of the STATS line, about 1.3 per record on typical data, at most a few per record.
+// Sized for 4 per record first (a 128 MB block of 1.5 M records: 190 MB instead of the 3 GB that 64 per record cost, and no
+// zero-filled host buffer of that size per call); a batch that needs more is run again with exactly what its counters ask for.
+void RPAPredictionModel::predictTraced(const rpa_batch& b, rpa_prediction* rows, rpa_stats* stats, std::vector<rpa_trace_entry>& out) {
+  std::lock_guard<std::mutex> turn(trace_mu_);
+  uint64_t cap = (uint64_t)b.n_records * 4 + 4096;
+  for (int attempt = 0;; ++attempt) {
+    check(engine_, rpa_trace_begin(engine_, cap));
+    check(engine_, rpa_predict_batch(engine_, &b, rows, stats, RPA_MEM_HOST));
+    uint64_t n = 0, dropped = 0;
+    check(engine_, rpa_trace_read(engine_, nullptr, 0, &n, &dropped));  // how many there are
+    const uint64_t total = n + dropped;
+    if (total <= cap) {
+      trace_buf_.reset(new rpa_trace_entry[(size_t)total + 1]);  // (not value-initialised)
+      check(engine_, rpa_trace_read(engine_, trace_buf_.get(), total, &n, &dropped));
+      out.assign(trace_buf_.get(), trace_buf_.get() + n);
+      break;
+    }
+    if (attempt) { check(engine_, rpa_trace_begin(engine_, 0)); throw GeneralError("alignment log: more alignments than the trace buffer holds"); }
+    cap = total + 16;  // results do not depend on tracing: the second run consumes the same alignments
+  }
+  check(engine_, rpa_trace_begin(engine_, 0));
 }
 
 void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size_t hi, rpa_prediction* rows, rpa_stats* stats,
@@ -301,16 +351,9 @@ void RPAPredictionModel::predictColumns(const ColumnarBatch& cb, size_t lo, size
   b.rstop = cb.rec.rstop.data() + base; b.score = cb.rec.score.data() + base; b.identities = cb.rec.identities.data() + base;
   b.alnlen = cb.rec.alnlen.data() + base; b.ref_seq = cb.rec.ref_seq.data() + base; b.node = cb.rec.node.data() + base;
   b.filtered = cb.rec.filtered.data() + base; b.mem_kind = RPA_MEM_HOST;
-  makeResident(b);
-  if (trace) {  // logging run: synchronous, one traced call at a time
-    std::lock_guard<std::mutex> turn(trace_mu_);
-    const uint64_t cap = (uint64_t)b.n_records * 64 + 4096;
-    check(engine_, rpa_trace_begin(engine_, cap));
-    check(engine_, rpa_predict_batch(engine_, &b, rows, stats, RPA_MEM_HOST));
-    readTrace(cap, *trace);
-    check(engine_, rpa_trace_begin(engine_, 0));
-    return;
-  }
+  makeResident(b, true);
+  ResidentHold hold{*this, query_sequences_.indexed() || db_sequences_.indexed()};  // until the batch has left the engine
+  if (trace) { predictTraced(b, rows, stats, *trace); return; }
   // asynchronous boundary: the engine runs two jobs at a time, the copies of one under the kernels of the other
   rpa_job* job = nullptr;
   check(engine_, rpa_submit_batch(engine_, &b, rows, stats, &job));

@@ -5,6 +5,9 @@
 // and fills one PredictionRecord per set, in input order (what the reference's serial loop prints, taxator.cpp:69-74).
 // All computation happens behind the C ABI (include/taxator_rpa.h) in hand-written HIP; there is no CPU path.
 #pragma once
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <ostream>
 #include <vector>
@@ -44,6 +47,7 @@ class RPAPredictionModel : public TaxonPredictionModel {
   // the same for predict(): entries of the last call (set = index into its record sets)
   void setTrace(bool on) { trace_on_ = on; }
   const std::vector<rpa_trace_entry>& lastTrace() const { return trace_; }
+  const std::vector<rpa_prediction>& lastRows() const { return rows_; }
   // Indexed stores (taxator -i / -v): make every REGION the batch refers to resident in this engine's HBM if it is not yet
   // -- the reference reads exactly [start, stop] of a sequence through the .fai (sequencestorage.hh:341-369); here a
   // sequence is cut into tiles (65536 residues unless setTile says otherwise) and the tiles under a hit's range, extended
@@ -53,7 +57,12 @@ class RPAPredictionModel : public TaxonPredictionModel {
   // With a budget (setStoreBudget, taxator --store-gb) a store that would outgrow it is emptied first (rpa_store_reset)
   // and refilled with what the batch at hand needs.  predict() / predictColumns() call it; a no-op for in-memory stores.
   // Returns the number of windows that had to be loaded.
-  size_t makeResident(const rpa_batch& b);
+  // hold = true: the batch counts as "in flight" from here until releaseResident() -- a store is only ever emptied
+  // (budget reached) while no batch that has been made resident is still unfinished; the two GPU threads per engine of
+  // the columnar pipeline would otherwise empty the store under each other's batches (a spurious "not resident" failure).
+  size_t makeResident(const rpa_batch& b, bool hold = false);
+  void releaseResident();
+  void noteReverseStrand(const rpa_batch& b);  // quirk 6 (in-memory store and reverse-strand hits): said once on stderr
   void setHostThreads(unsigned t) { threads_ = t ? t : 1; }
   void setTile(uint64_t residues) { tile_ = residues ? residues : 65536; }       // before the first batch
   void setStoreBudget(uint64_t bytes) { store_budget_ = bytes; }                  // 0 = no limit; per store
@@ -70,7 +79,10 @@ class RPAPredictionModel : public TaxonPredictionModel {
   std::vector<uint64_t> resident_[2];
   uint64_t tile_ = 65536, store_budget_ = 0;
   unsigned rpa_store_bits_ = 4;  // packed bits per residue in the engine (DNA 4, protein 8): what a residue costs against the budget
-  size_t makeResidentStore(int which, const rpa_batch& b, const std::vector<uint32_t>& span);
+  size_t makeResidentStore(int which, const rpa_batch& b, const std::vector<uint32_t>& span, std::unique_lock<std::mutex>& lk);
+  std::atomic<bool> reverse_noted_{false};
+  unsigned in_flight_ = 0;             // batches between makeResident(hold) and releaseResident(); guarded by resident_mu_
+  std::condition_variable resident_cv_;
   std::vector<uint8_t> fetch_letters_;
   std::vector<uint64_t> fetch_offsets_;
   unsigned threads_ = 1;
@@ -79,7 +91,8 @@ class RPAPredictionModel : public TaxonPredictionModel {
   bool trace_on_ = false;
   std::vector<rpa_trace_entry> trace_;
   std::mutex trace_mu_;  // traced calls are synchronous and take turns
-  void readTrace(uint64_t capacity, std::vector<rpa_trace_entry>& out);
+  void predictTraced(const rpa_batch& b, rpa_prediction* rows, rpa_stats* stats, std::vector<rpa_trace_entry>& out);
+  std::unique_ptr<rpa_trace_entry[]> trace_buf_;
   float stale_ival_ = -1.f;  // PredictionRecord is reused across calls in the reference (taxator.cpp:66): n==0 keeps the last ival
   std::vector<rpa_stats> stats_;
   std::vector<rpa_prediction> rows_;

@@ -96,6 +96,8 @@ def test_cli_log_holds_the_references_alignments(oracle, golden_dir, tmp_path, n
     r_ = _run(folder, ext, extra + ["--batch", "37"], aln="aln_ordered.tsv", log=log)
     assert r_.returncode == 0, r_.stderr
     got, cur = [], None
+    text = open(log).read()
+    assert text.count("\nSTATS\t") == text.count("\n\nID\t") + 1 and text.endswith("\n\n")  # a blank line behind every STATS line (:837)
     for line in open(log):
         if line.startswith("ID\t"):
             cur = dict(id=line.rstrip("\n").split("\t")[1], aln=[], stats=None); got.append(cur)
@@ -112,6 +114,7 @@ def test_cli_log_holds_the_references_alignments(oracle, golden_dir, tmp_path, n
         assert len(g["aln"]) == sum(g["stats"])
         if not found[s_]:
             continue
+        assert g["id"] == e["id"]  # "<qrstart>:<qrstop>@<query id>", taxonpredictionmodelsequence.hh:344,407-408
         assert g["stats"] == e["stats"], (g["id"], g["stats"], e["stats"])
         assert g["aln"] == [[x[0], x[1], x[2], round(x[3], 2), round(x[4], 2)] for x in e["aln"]], (g["id"], g["aln"][:6], e["aln"][:6])
 
@@ -401,6 +404,20 @@ def test_cli_region_granular_reads_of_long_references(tmp_path):
     for r in (mem, idx, fine, tight):
         assert r.returncode == 0, r.stderr[-2000:]
     assert idx.stdout == mem.stdout and fine.stdout == mem.stdout and tight.stdout == mem.stdout and mem.stdout.count("\n") > 400
+    # The same budget on the DEFAULT path: the columnar pipeline keeps two batches in flight per engine from two host
+    # threads, so one thread's "store full: empty it" must wait for the other thread's batch that is still running on what
+    # is resident (round 3 emptied the store under it: a spurious "not resident" failure of the whole run).  Tiny blocks,
+    # one and two engines, a few repetitions: dozens of resets each, racing with batches in flight.
+    for extra_args in (["-p", "4"], ["-p", "4", "--devices", "0,0"], ["-p", "2"]):
+        for _ in range(3):
+            r = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "2048", "--store-gb", "0.0001", "--block-mb", "0.004"] + extra_args,
+                          timeout=CHILD_LIMIT_S, stdin_path=aln, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+            assert r.stdout == mem.stdout
+    # quirk 6: reverse-strand hits against an IN-MEMORY reference store are reverse-complemented here (the reference's
+    # in-memory store returns the whole forward sequence, core/src/sequencestorage.hh:122-130): said once, only then
+    assert mem.stderr.count("its in-memory store (-f without -i) hands back the whole") == 1
+    assert "hands back the whole" not in idx.stderr
 
     def store(stderr):
         line = [l for l in stderr.splitlines() if l.startswith("STORE\tref")][0].split("\t")
