@@ -1157,32 +1157,39 @@ int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_win
   // bookkeeping first, on copies: a window may sit beside the resident windows of its sequence or cover some of them
   // entirely (those are dropped: the new window is their hull), never overlap one partly -- a segment is only readable
   // from ONE window, so overlapping windows are the caller's mistake
+  struct WinRec { uint4 w; int64_t k; };  // k >= 0: window number k of THIS call (its arena offset is filled in below); -1: resident
   std::vector<uint32_t> changed;
-  std::vector<std::vector<uint4>> lists;
+  std::vector<std::vector<WinRec>> lists;
   uint64_t dropped_residues = 0, dropped_windows = 0;
   std::vector<uint32_t> order(n);
   for (uint32_t k = 0; k < n; ++k) order[k] = k;
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return win[a].seq_index != win[b].seq_index ? win[a].seq_index < win[b].seq_index : win[a].first < win[b].first; });
   uint32_t cur_seq = 0xFFFFFFFFu;
-  std::vector<uint4>* cur = nullptr;
+  std::vector<WinRec>* cur = nullptr;
   for (uint32_t oi = 0; oi < n; ++oi) {
     const uint32_t k = order[oi];
     if (win[k].seq_index != cur_seq) {  // (windows of one sequence are consecutive in `order`: one lookup per sequence)
       cur_seq = win[k].seq_index;
-      changed.push_back(cur_seq); lists.push_back(st->seq_windows[cur_seq]);
+      changed.push_back(cur_seq);
+      lists.emplace_back();
       cur = &lists.back();
+      cur->reserve(st->seq_windows[cur_seq].size() + 1);
+      for (const uint4& x : st->seq_windows[cur_seq]) cur->push_back(WinRec{x, -1});
     }
     const uint64_t a = win[k].first, b = a + win[k].n;
-    std::vector<uint4> kept;
+    std::vector<WinRec> kept;
     kept.reserve(cur->size() + 1);
-    for (const uint4& x : *cur) {
+    for (const WinRec& r : *cur) {
+      const uint4& x = r.w;
       const uint64_t xa = x.x, xb = (uint64_t)x.x + x.y;
-      if (xb <= a || xa >= b) kept.push_back(x);
-      else if (xa >= a && xb <= b) { dropped_residues += x.y; ++dropped_windows; }
-      else return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: window %u (sequence %u, residues %llu..%llu) overlaps a resident window partly", k, cur_seq, (unsigned long long)a, (unsigned long long)b);
+      if (xb <= a || xa >= b) kept.push_back(r);
+      else if (xa >= a && xb <= b) {  // swallowed by the new window: its residues stay behind in the arena (two windows of one call that overlap are the caller's mistake)
+        if (r.k >= 0) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: windows %u and %lld of this call overlap", k, (long long)r.k);
+        dropped_residues += x.y; ++dropped_windows;
+      } else return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: window %u (sequence %u, residues %llu..%llu) overlaps a resident window partly", k, cur_seq, (unsigned long long)a, (unsigned long long)b);
     }
-    kept.push_back(make_uint4((uint32_t)a, (uint32_t)win[k].n, 0xFFFFFFFFu, k));  // arena offset filled in below (.w = window number for now)
-    std::sort(kept.begin(), kept.end(), [](const uint4& p, const uint4& q) { return p.x < q.x; });
+    kept.push_back(WinRec{make_uint4((uint32_t)a, (uint32_t)win[k].n, 0u, 0u), (int64_t)k});
+    std::sort(kept.begin(), kept.end(), [](const WinRec& p, const WinRec& q) { return p.w.x < q.w.x; });
     cur->swap(kept);
   }
   HIP_TRY(e, hipSetDevice(e->device));
@@ -1215,12 +1222,13 @@ int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_win
   for (size_t c = 0; c < changed.size(); ++c) {
     firsts[c] = (uint32_t)(st->pool_used + flat.size());
     counts[c] = (uint32_t)lists[c].size();
-    for (uint4& x : lists[c]) {
-      if (x.z == 0xFFFFFFFFu) {  // a window of this call: where its residues went
-        const uint64_t at = first + offsets[x.w];
-        x.z = (uint32_t)at; x.w = (uint32_t)(at >> 32);
+    for (WinRec& r : lists[c]) {
+      if (r.k >= 0) {  // a window of this call: where its residues went
+        const uint64_t at = first + offsets[r.k];
+        r.w.z = (uint32_t)at; r.w.w = (uint32_t)(at >> 32);
+        r.k = -1;
       }
-      flat.push_back(x);
+      flat.push_back(r.w);
     }
   }
   if (st->pool_used + flat.size() > 0xFFFFFFFFull) return fail(e, RPA_ERR_UNSUPPORTED, "rpa_store_append_windows: window pool exhausted (rpa_store_reset compacts it)");
@@ -1238,7 +1246,10 @@ int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_win
   st->pool_used += flat.size();
   for (size_t c = 0; c < nc; ++c) {
     if (st->seq_windows[changed[c]].empty() && !lists[c].empty()) ++st->n_resident;
-    st->seq_windows[changed[c]].swap(lists[c]);
+    std::vector<uint4>& dst = st->seq_windows[changed[c]];
+    dst.clear();
+    dst.reserve(lists[c].size());
+    for (const WinRec& r : lists[c]) dst.push_back(r.w);
   }
   st->n_residues = first + total;
   st->n_windows += n; st->n_windows -= dropped_windows;

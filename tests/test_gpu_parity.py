@@ -688,6 +688,82 @@ def test_deep_taxonomies(pkg, oracle, synth, shape):
     _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(3, 2))
 
 
+def _random_big_tree(n, max_depth, rng):
+    """A random taxonomy of n nodes and up to max_depth levels as (parent, left, right, depth): node i hangs under an earlier
+    node, four of five times one of the previous batch (so the tree gains a level per batch), nested-set numbers by a walk."""
+    parent = np.zeros(n, np.uint32)
+    depth = np.zeros(n, np.uint8)
+    lo, prev_lo = 1, 0
+    while lo < n:
+        hi = min(n, lo + 1000 if lo < 4000 else int(lo * 1.22))
+        deep = rng.random(hi - lo) < 0.8
+        cand = np.where(deep, rng.integers(prev_lo, lo, hi - lo), rng.integers(0, lo, hi - lo))
+        cand[depth[cand] >= max_depth] = 0
+        parent[lo:hi] = cand
+        depth[lo:hi] = depth[cand] + 1
+        prev_lo, lo = lo, hi
+    order = np.argsort(parent[1:], kind="stable") + 1
+    start = np.searchsorted(parent[order], np.arange(n + 1))
+    left = np.zeros(n, np.uint32)
+    right = np.zeros(n, np.uint32)
+    nxt = start[:-1].copy()
+    stack, ctr = [0], 1
+    left[0] = 1
+    while stack:
+        v = stack[-1]
+        if nxt[v] < start[v + 1]:
+            c = int(order[nxt[v]])
+            nxt[v] += 1
+            ctr += 1
+            left[c] = ctr
+            stack.append(c)
+        else:
+            ctr += 1
+            right[v] = ctr
+            stack.pop()
+    return parent, left, right, depth
+
+
+def test_taxonomy_of_ncbi_shape(pkg, oracle, synth):
+    """`taxator -d 0` keeps every node of the NCBI tree (~2.5 M nodes, ~40 levels).  Here a random tree of 500 k nodes and up to
+    37 levels (tools/big_taxonomy.py runs the full size: profiles/r03_big_taxonomy.txt): rpa_create builds its preorder /
+    ancestor tables from the parent pointers, an RPA batch whose taxa are random nodes of the big tree and a megan-lca batch
+    over it equal the oracle, and the results sit at depths beyond the pruned tree's eight levels."""
+    rng = np.random.default_rng(7)
+    n = 500_000
+    parent, left, right, depth = _random_big_tree(n, 37, rng)
+    assert int(depth.max()) >= 30
+
+    class T:
+        pass
+    tax = T()
+    tax.parent, tax.left, tax.right, tax.depth = parent, left, right, depth
+    model = pkg.RPAPredictionModel(tax, alphabet=pkg.DNA)
+    ds = synth.make_dataset(n_sets=2000, n_hits=20, seg_len=150, branching=4, genome_len=2500, seed=5, variety=True)
+    remap = rng.integers(1, n, len(ds.tax.parent)).astype(np.uint32)
+    ds.batch["node"] = remap[ds.batch["node"]]
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    rows, stats = model.predict(ds.batch)
+    otax = oracle.TaxArrays(parent, left, right, depth)
+    q = oracle.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+    db = oracle.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+    rc, exp, est = oracle.predict_batch(otax, q, db, 0, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
+                                        synth.records_aos(ds.batch, oracle.RECORD_DTYPE))
+    assert rc == 0 and rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes()
+    assert int(depth[rows["lower"]].max()) > 8
+    import test_lca_models as TL
+    offs, qlen, recs, evalue = TL.random_batch(rng, tax, 20000, 30)
+    uncl = (rng.random(n) < 0.1).astype(np.uint8)
+    rc, exp = oracle.lca_predict_batch(otax, oracle.LCA_MEGAN, offs, qlen, recs, evalue, uncl, 0.3, 0.0, 1000.0, 2, 1, True)
+    batch = dict(set_offsets=offs, query_len=qlen, filtered=recs["filtered"].astype(np.uint8))
+    for f in ("qstart", "qstop", "score", "node"):
+        batch[f] = recs[f].copy()
+    got = model.lca_predict(batch, pkg.LCA_MEGAN, evalue=evalue, node_unclassified=uncl, toppercent=0.3, minscore=0.0, maxevalue=1000.0,
+                            minsupport=2, nbest=1, ignore_unclassified=True)
+    assert rc == 0 and got.tobytes() == exp.tobytes()
+
+
 @pytest.mark.parametrize("bits", ["16", "32"])
 def test_wide_path_labels(pkg, oracle, synth, bits, monkeypatch):
     """RPA_LABEL_BITS forces the label width a batch with record sets of more than 256 / 65536 records would get (rows of 3
