@@ -506,12 +506,14 @@ def main():
         step()
     while in_flight:
         finish_one()
+    t_jobs = time.perf_counter() - t0    # this rank's own K steps are done (their rows computed)
     for pg in pending_gather:
         if pg is not None:
             pg[0].wait()
     if ring is not None:
         ring.drain()
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0   # ... and its part of every exchange
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -531,6 +533,29 @@ def main():
         torch.cuda.synchronize()
         sync_ms = (time.perf_counter() - t1) / prof_steps * 1e3
         prof = model.profile()
+
+    # What each rank saw, for the first multi-GPU run to be diagnosable from its one JSON line: per rank the time its own K
+    # steps took, the time until its share of the exchanges was done, and the cost of ONE gather of a step's rows on an
+    # otherwise idle job (a blocking gather between barriers, after the timed region; 5 repetitions).
+    per_rank, gather_ms = None, None
+    if use_dist:
+        mine = torch.tensor([t_jobs / args.steps * 1e3, t_local / args.steps * 1e3, elapsed / args.steps * 1e3], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[round(float(x), 4) for x in r_.tolist()] for r_ in allr]
+        g_rows = rows.cpu() if gloo else rows
+        g_out = [torch.empty((max(gather_sizes), 8), dtype=torch.int32, device=cdev) for _ in range(world)] if rank == 0 else None
+        if not gloo:
+            torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(5):
+            sharding.gather_rows(g_rows, dst=0, sizes=gather_sizes, out=g_out, force=True)
+        if not gloo:
+            torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - tg) / 5 * 1e3
+        del g_out
 
     demanded = int(stats[:, 1:].to(torch.int64).sum().item())  # per step, this rank
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -638,7 +663,12 @@ def main():
         if use_dist:  # what the collective layer saw: an 8-GPU line must show eight ranks on RCCL
             out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                            "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if not gloo else None),
-                           "gather": "asynchronous, ring of %d receive-buffer sets (sharding.RowGatherRing)" % n_pipe if ring is not None else "blocking"}
+                           "gather": "asynchronous, ring of %d receive-buffer sets (sharding.RowGatherRing)" % n_pipe if ring is not None else "blocking",
+                           # per rank, ms per step: its own steps done | its share of the exchanges done | released by the closing barrier
+                           "per_rank_ms": [r_[0] for r_ in per_rank], "per_rank_exchange_done_ms": [r_[1] for r_ in per_rank],
+                           "per_rank_barrier_ms": [r_[2] for r_ in per_rank],
+                           "gather_ms": gather_ms, "gather_bytes": int(sum(gather_sizes)) * 32,
+                           "gather_note": "one blocking gather of a step's rows to rank 0 between barriers, nothing else running (5 repetitions); in the timed region the gathers run beside the steps that follow"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, ds)
             ref = cpu_reference_pairs(synth, ds)

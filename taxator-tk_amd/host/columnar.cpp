@@ -165,27 +165,103 @@ static bool field_f64_valid(const char* p, const char* e) {
 }
 
 // ---- reader ----
+static void count_lines_fwd(const char* begin, const char* end, size_t& lines, size_t& data_lines);
 
-ColumnarReader::ColumnarReader(FILE* in, const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db,
-                               const SequenceStore* query, bool split_alignments, unsigned threads, size_t block_bytes, bool alignments_sorted)
-    : in_(in), legacy_(acc2taxid, tax, db), query_(query), split_(split_alignments), sorted_(alignments_sorted), threads_(threads), block_bytes_(block_bytes) {
-  if (threads_ == 0) threads_ = usable_cpus();
-  if (block_bytes_ < 4096) block_bytes_ = 4096;
+ReaderTables::ReaderTables(const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db, const SequenceStore* query) {
   // reference identifier -> (taxonomy node, index in the reference store); identifiers with a broken link are left out
   // of the table, so that their lines fall through to the strict parser, which raises the matching exception
   const std::vector<std::string>& ids = db->ids();
-  ref_map_.reserve(ids.size());
+  ref_map.reserve(ids.size());
   for (size_t i = 0; i < ids.size(); ++i) {
-    if (ref_map_.find(ids[i].data(), ids[i].size()) != FlatStringMap::npos) continue;  // first occurrence wins (getIndex)
+    if (ref_map.find(ids[i].data(), ids[i].size()) != FlatStringMap::npos) continue;  // first occurrence wins (getIndex)
     uint32_t node;
     try { node = tax->getNode(acc2taxid[ids[i]]); } catch (Exception&) { continue; }
-    ref_map_.insert(ids[i], (uint32_t)ref_node_.size());
-    ref_node_.push_back(node);
-    ref_seqidx_.push_back((uint32_t)i);
+    ref_map.insert(ids[i], (uint32_t)ref_node.size());
+    ref_node.push_back(node);
+    ref_seqidx.push_back((uint32_t)i);
   }
   const std::vector<std::string>& qids = query->ids();
-  query_map_.reserve(qids.size());
-  for (size_t i = 0; i < qids.size(); ++i) query_map_.insert(qids[i], (uint32_t)i);
+  query_map.reserve(qids.size());
+  for (size_t i = 0; i < qids.size(); ++i) query_map.insert(qids[i], (uint32_t)i);
+}
+
+ColumnarReader::ColumnarReader(FILE* in, const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db,
+                               const SequenceStore* query, bool split_alignments, unsigned threads, size_t block_bytes, bool alignments_sorted,
+                               std::shared_ptr<const ReaderTables> tables)
+    : in_(in), legacy_(acc2taxid, tax, db), query_(query), split_(split_alignments), sorted_(alignments_sorted), threads_(threads), block_bytes_(block_bytes),
+      tab_(tables ? std::move(tables) : std::make_shared<const ReaderTables>(acc2taxid, tax, db, query)) {
+  if (threads_ == 0) threads_ = usable_cpus();
+  if (block_bytes_ < 4096) block_bytes_ = 4096;
+}
+
+// ---- slices of a mapped file ----
+SliceCutter::SliceCutter(FILE* in, size_t block_bytes) : block_(block_bytes < 4096 ? 4096 : block_bytes) {
+  struct stat st;
+  const int fd = fileno(in);
+  const off_t at = fd >= 0 ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
+  if (!getenv("TAXATOR_NO_MMAP") && fd >= 0 && at >= 0 && ftell(in) == (long)at && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > at) {
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m != MAP_FAILED) { map_ = static_cast<const char*>(m); map_size_ = (size_t)st.st_size; start_ = pos_ = (size_t)at; }
+  }
+}
+SliceCutter::~SliceCutter() { if (map_) munmap(const_cast<char*>(map_), map_size_); }
+
+// query identifier of the line at s (a leading '*' masks the record and is not part of the name, alignmentrecord.hh:98-104)
+static inline void line_qid(const char* s, const char* end, const char*& b, size_t& n) {
+  if (s < end && *s == '*') ++s;
+  const char* e = s;
+  while (e < end && *e != '\t' && *e != '\n') ++e;
+  b = s; n = (size_t)(e - s);
+}
+const char* SliceCutter::group_boundary(const char* lo, const char* q, const char* hi) {
+  if (q >= hi) return hi;
+  if (q <= lo) return lo;
+  // s = the first line start at or behind q
+  const char* s = q;
+  if (s[-1] != '\n') { s = (const char*)memchr(s, '\n', (size_t)(hi - s)); if (!s) return hi; ++s; }
+  // the data line in front of it (comment lines, fileparser.hh:61-67, belong to no group)
+  const char* pb = nullptr; size_t pn = 0;
+  for (const char* e = s; e > lo;) {            // e = one past the '\n' of the line we look at
+    const char* b = e - 1;                      // its '\n'
+    while (b > lo && b[-1] != '\n') --b;        // its first byte
+    if (!(*b == '#' && b != e - 1)) { line_qid(b, e - 1, pb, pn); break; }
+    e = b;
+  }
+  if (!pb) return s;  // nothing but comments in front: any line start will do
+  for (const char* l = s; l < hi;) {
+    const char* nl = (const char*)memchr(l, '\n', (size_t)(hi - l));
+    const char* le = nl ? nl : hi;
+    if (!(*l == '#' && l != le)) {
+      const char* b; size_t n;
+      line_qid(l, le, b, n);
+      if (n != pn || memcmp(b, pb, n)) return l;
+      pb = b; pn = n;
+    }
+    l = nl ? nl + 1 : hi;
+  }
+  return hi;
+}
+bool SliceCutter::next(const char*& begin, const char*& end, uint64_t& index) {
+  std::lock_guard<std::mutex> lk(mu_);
+  index = index_;
+  if (!map_ || pos_ >= map_size_) return false;
+  const char* lo = map_ + pos_;
+  const char* hi = map_ + map_size_;
+  const char* cut = (size_t)(hi - lo) > block_ ? group_boundary(lo, lo + block_, hi) : hi;
+  begin = lo; end = cut;
+  pos_ = (size_t)(cut - map_);
+  ++index_;
+  return true;
+}
+void SliceCutter::close() {
+  std::lock_guard<std::mutex> lk(mu_);
+  pos_ = map_size_;
+}
+uint64_t SliceCutter::lines_before(const char* p) const {
+  size_t lines = 0, data = 0;
+  const char* b = map_ + start_;
+  if (p > b) count_lines_fwd(b, p, lines, data);
+  return lines;
 }
 
 struct ColumnarReader::Chunk {
@@ -262,6 +338,28 @@ static inline void count_lines(const char* begin, const char* end, size_t& lines
   data_lines = lines - comment;
 }
 
+static void count_lines_fwd(const char* begin, const char* end, size_t& lines, size_t& data_lines) { count_lines(begin, end, lines, data_lines); }
+
+void ColumnarReader::raise_failure() {
+  if (!fail_query_.empty()) throw SequenceNotFound("seqid " + fail_query_);
+  AlignmentRecordTaxonomy rec;
+  try { legacy_.parse(fail_line_, rec); }
+  catch (Exception& e) { throw ParsingError(std::string(e.what()) + " [line " + std::to_string(fail_line_no_) + "]"); }
+  throw GeneralError("alignment line rejected by the columnar reader but accepted by the record parser [line " +
+                     std::to_string(fail_line_no_) + "]");
+}
+
+void ColumnarReader::parse_slice(const SliceCutter& cutter, const char* begin, const char* end, ColumnarBatch& out, std::exception_ptr& err) {
+  carry_ = 0; carry_qid_.clear(); failed_ = false; fail_query_.clear(); line_base_ = 0; eof_ = false;
+  err = nullptr;
+  parse_block(begin, end, true, out);
+  if (failed_ || !fail_query_.empty()) {
+    fail_line_no_ += cutter.lines_before(begin);  // (counted only now: a failure is the end of the run)
+    try { raise_failure(); } catch (...) { err = std::current_exception(); }
+    failed_ = false; fail_query_.clear();
+  }
+}
+
 void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, ColumnarBatch& out) {
   typedef std::chrono::steady_clock Clock;
   static const bool trace = getenv("TAXATOR_READER_TRACE") != nullptr;
@@ -328,14 +426,14 @@ void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, C
            field_u32(fb[3], fe[3], cols_.qlen[r]) && field_u32(fb[5], fe[5], cols_.rstart[r]) && field_u32(fb[6], fe[6], cols_.rstop[r]) &&
            field_f32(fb[7], fe[7], cols_.score[r]) && field_f64_valid(fb[8], fe[8]) && field_u32(fb[9], fe[9], cols_.identities[r]) &&
            field_u32(fb[10], fe[10], cols_.alnlen[r]) &&
-           (refv = ref_map_.find(fb[4], (size_t)(fe[4] - fb[4]))) != FlatStringMap::npos;
+           (refv = tab_->ref_map.find(fb[4], (size_t)(fe[4] - fb[4]))) != FlatStringMap::npos;
       if (!ok) {
         c.bad = true; c.bad_line = ln; c.bad_begin = s; c.bad_end = e; c.bad_record = r;
         return;
       }
       cols_.filtered[r] = filt;
-      cols_.node[r] = ref_node_[refv];
-      cols_.ref_seq[r] = ref_seqidx_[refv];
+      cols_.node[r] = tab_->ref_node[refv];
+      cols_.ref_seq[r] = tab_->ref_seqidx[refv];
       qid_ptr_[r] = fb[0];
       qid_len_[r] = (uint32_t)(fe[0] - fb[0]);
       if (prev_qid && (qid_len_[r] != prev_len || memcmp(fb[0], prev_qid, prev_len))) c.new_group.push_back(r);
@@ -435,7 +533,7 @@ void ColumnarReader::emit_groups(ColumnarBatch& out) {
     };
     for (size_t g = G * t / T; g < G * (t + 1) / T; ++g) {
       const size_t lo = gstart_[g], n = gstart_[g + 1] - lo;
-      const uint32_t qseq = query_map_.find(qid_ptr_[lo], qid_len_[lo]);
+      const uint32_t qseq = tab_->query_map.find(qid_ptr_[lo], qid_len_[lo]);
       if (qseq == FlatStringMap::npos) { flush_run(lo); part.unknown = g; return; }  // SequenceStore::getIndex in RPAPredictionModel::predict's staging
       bool reorder = false;
       if (split_ && !sorted_) {  // stable by (qstart, qstop), ties keep input order (alignmentrecord.hh:476-481); -o 1: the input is
@@ -547,14 +645,7 @@ bool ColumnarReader::next(ColumnarBatch& out) {
   }
   if (map_) {
     for (;;) {
-      if (failed_) {
-        if (!fail_query_.empty()) throw SequenceNotFound("seqid " + fail_query_);
-        AlignmentRecordTaxonomy rec;
-        try { legacy_.parse(fail_line_, rec); }
-        catch (Exception& e) { throw ParsingError(std::string(e.what()) + " [line " + std::to_string(fail_line_no_) + "]"); }
-        throw GeneralError("alignment line rejected by the columnar reader but accepted by the record parser [line " +
-                           std::to_string(fail_line_no_) + "]");
-      }
+      if (failed_) raise_failure();
       if (eof_) return false;
       const char* begin = map_ + map_pos_;
       const char* file_end = map_ + map_size_;
@@ -593,14 +684,7 @@ bool ColumnarReader::next(ColumnarBatch& out) {
     });
   }
   for (;;) {
-    if (failed_) {
-      if (!fail_query_.empty()) throw SequenceNotFound("seqid " + fail_query_);
-      AlignmentRecordTaxonomy rec;
-      try { legacy_.parse(fail_line_, rec); }
-      catch (Exception& e) { throw ParsingError(std::string(e.what()) + " [line " + std::to_string(fail_line_no_) + "]"); }
-      throw GeneralError("alignment line rejected by the columnar reader but accepted by the record parser [line " +
-                         std::to_string(fail_line_no_) + "]");
-    }
+    if (failed_) raise_failure();
     if (eof_) return false;
     IoBuf* b = io_->full_q.pop();
     eof_ = b->eof;

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -72,11 +73,46 @@ struct ColumnarBatch {
   void make_room(size_t n_records, size_t n_sets);
 };
 
+// What every reader of one run looks identifiers up in: reference identifier -> (taxonomy node, index in the reference
+// store), query identifier -> index in the query store.  Built once, shared by the reader teams of a multi-GPU run.
+struct ReaderTables {
+  FlatStringMap ref_map, query_map;
+  std::vector<uint32_t> ref_node, ref_seqidx;  // per ref_map value
+  ReaderTables(const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db, const SequenceStore* query);
+};
+
+// A regular file on stdin, mapped once and handed out in SLICES that begin and end where the query identifier changes
+// (or at the ends of the file): every slice holds complete groups, so slices are parsed independently -- by several
+// reader teams at a time (taxator --devices a,b,c,...: one team per engine) -- and the block index a slice gets here is its
+// place in the output.  next() is thread-safe.
+class SliceCutter {
+ public:
+  explicit SliceCutter(FILE* in, size_t block_bytes);  // mapped() is false for a pipe (or TAXATOR_NO_MMAP): use ColumnarReader::next
+  ~SliceCutter();
+  bool mapped() const { return map_ != nullptr; }
+  // the next slice and its index; false when the file is exhausted (`index` is then the number of slices handed out)
+  bool next(const char*& begin, const char*& end, uint64_t& index);
+  void close();  // no further slices (next() returns false from now on)
+  uint64_t lines_before(const char* p) const;  // lines of the file in front of p (error messages only)
+  static const char* group_boundary(const char* lo, const char* q, const char* hi);  // first line start >= q in [lo, hi] at which the query identifier changes
+ private:
+  const char* map_ = nullptr;
+  size_t map_size_ = 0, start_ = 0, pos_ = 0, block_;
+  uint64_t index_ = 0;
+  std::mutex mu_;
+};
+
 class ColumnarReader {
  public:
   // threads = 0: all hardware threads.  block_bytes: how much of the stream is parsed (and becomes one batch) at a time.
   ColumnarReader(FILE* in, const StrIDConverter& acc2taxid, const Taxonomy* tax, const SequenceStore* db, const SequenceStore* query,
-                 bool split_alignments, unsigned threads, size_t block_bytes, bool alignments_sorted = false);
+                 bool split_alignments, unsigned threads, size_t block_bytes, bool alignments_sorted = false,
+                 std::shared_ptr<const ReaderTables> tables = nullptr);
+  // One slice of a SliceCutter (complete groups): its record sets into `out`.  A line that does not parse / an unknown
+  // query identifier: `out` holds the record sets in front of it and `err` what next() would have thrown after them
+  // ("[line N]" counted from the start of the file through cutter.lines_before).
+  void parse_slice(const SliceCutter& cutter, const char* begin, const char* end, ColumnarBatch& out, std::exception_ptr& err);
+  std::shared_ptr<const ReaderTables> tables() const { return tab_; }
   // Fills `out` with the record sets of the next block; false when the stream is exhausted (out is then empty).
   // Throws what RecordSetGenerator would throw (ParsingError ... [line N]) or what RPAPredictionModel::predict's staging
   // would throw (SequenceNotFound for an unknown query identifier), but only after every record set that precedes the
@@ -89,6 +125,7 @@ class ColumnarReader {
   struct Chunk;
   void parse_block(const char* begin, const char* end, bool eof, ColumnarBatch& out);
   void emit_groups(ColumnarBatch& out);
+  [[noreturn]] void raise_failure();  // the deferred error of parse_block, as the reference's generator words it
 
   FILE* in_;
   AlignmentRecordFactory legacy_;  // error texts
@@ -97,8 +134,7 @@ class ColumnarReader {
   bool sorted_;  // -o 1: groups are not sorted before they are cut (core/src/alignmentrecord.hh:569-631)
   unsigned threads_;
   size_t block_bytes_;
-  FlatStringMap ref_map_, query_map_;
-  std::vector<uint32_t> ref_node_, ref_seqidx_;  // per ref_map_ value
+  std::shared_ptr<const ReaderTables> tab_;
 
   // A background thread reads the stream one block ahead of the parser.  Each block lands behind `kHeadroom` spare bytes
   // so that the unparsed tail of the previous block (normally a fraction of one line) can be put in front of it.

@@ -95,6 +95,24 @@ int main(int argc, char** argv) {
           print_rec(r.blacklist_this, r.query_start, r.query_stop, r.reference_start, r.reference_stop, r.score, r.identities,
                     r.alignment_length, r.reference_seq, r.reference_node);
       }
+    } else if (mode == "slices") {  // the reader teams' path: the mapped file cut at query identifier boundaries, slice by slice
+      SliceCutter cutter(stdin, block);
+      if (!cutter.mapped()) { fprintf(stderr, "parsecheck slices: stdin must be a regular file\n"); return 2; }
+      ColumnarReader reader(stdin, acc, tax.get(), &db, &query, split, threads, block, getenv("PARSECHECK_SORTED") != nullptr);
+      ColumnarBatch b;
+      const char *sb, *se;
+      uint64_t index;
+      while (cutter.next(sb, se, index)) {
+        std::exception_ptr err;
+        reader.parse_slice(cutter, sb, se, b, err);
+        for (size_t s = 0; s < b.n_sets(); ++s) {
+          print_set(b.qid_arena.data() + b.qid_off[s], b.qid_len[s], b.query_len[s], b.query_seq[s], b.set_offsets[s + 1] - b.set_offsets[s]);
+          for (uint32_t r = b.set_offsets[s]; r < b.set_offsets[s + 1]; ++r)
+            print_rec(b.rec.filtered[r], b.rec.qstart[r], b.rec.qstop[r], b.rec.rstart[r], b.rec.rstop[r], b.rec.score[r],
+                      b.rec.identities[r], b.rec.alnlen[r], b.rec.ref_seq[r], b.rec.node[r]);
+        }
+        if (err) std::rethrow_exception(err);
+      }
     } else {
       ColumnarReader reader(stdin, acc, tax.get(), &db, &query, split, threads, block, getenv("PARSECHECK_SORTED") != nullptr);
       ColumnarBatch b;

@@ -53,6 +53,7 @@ struct Options {
   std::vector<std::string> ranks;
   bool split_alignments = true, alignments_sorted = false, delete_unmarked = true;
   float filterout = 0.5f, toppercent = 0.05f, minscore = 0.0f;
+  size_t readers = 0;  // --readers N: reader teams over a regular input file (0: one per engine when there are several engines)
   double maxevalue = 1000.0;
   unsigned minsupport = 1, nbest = 1;
   bool ignore_unclassified = false;
@@ -87,7 +88,9 @@ static void usage(std::ostream& o) {
        "            --block-mb N (=128, input block parsed at a time), --timing, --record-objects (per-record object loop),\n"
        "            --store-gb G (HBM budget of an indexed store, -i / -v: when the resident regions would outgrow it the store is\n"
        "            emptied and refilled with what the block at hand needs; 0 = no limit), --store-tile N (=65536 residues: the\n"
-       "            granularity at which regions of a sequence become resident)\n";
+       "            granularity at which regions of a sequence become resident), --readers N (reader teams over a regular input file:\n"
+       "            the file is cut into slices where the query identifier changes and the teams parse slices side by side;\n"
+       "            0 = one team per engine when --devices names several, else one reader)\n";
 }
 
 namespace {
@@ -99,6 +102,7 @@ struct Work {
   std::vector<rpa_trace_entry> trace;  // -l: the alignments the control flow consumed, sorted by (set, order)
   bool last = false;            // end of stream (or a failure of the reader): no batch inside
   bool failed = false;          // a GPU call failed on this block: nothing from here on is printed
+  bool err_after = false;       // the input failed BEHIND the record sets of this block (reader teams): they are printed, then the run ends with err
   std::exception_ptr err;
   uint64_t seq = 0;             // position in the input: the writer prints in this order
   std::vector<std::pair<void*, size_t>> pinned;       // the arrays below that are page-locked
@@ -187,31 +191,61 @@ double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::dura
 // reference's doPredictionsParallel (core/taxator.cpp:181-210) has N consumer threads call predict() on one model and
 // prints in whatever order they finish; here a parsed block goes to whichever GPU is free and the writer puts the
 // blocks back into input order (what the reference's serial loop prints, :69-74).
-void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& models, const Taxonomy& tax, std::ostream* logsink, size_t max_sets,
-                  unsigned threads, Timing& tm) {
+void run_columnar(std::vector<std::unique_ptr<ColumnarReader>>& readers, SliceCutter* cutter, std::vector<RPAPredictionModel*>& models, const Taxonomy& tax,
+                  std::ostream* logsink, size_t max_sets, unsigned threads, Timing& tm) {
   // two host threads per engine: each submits a block and waits for it (rpa_submit_batch / rpa_wait), so every engine has
   // two batches in flight -- the host->device copies of one run under the kernels of the other
   const size_t n_gpu = 2 * models.size();
-  std::vector<Work> works(2 * n_gpu + 1);
+  const size_t n_teams = cutter ? readers.size() : 1;
+  std::vector<Work> works(2 * n_gpu + n_teams);
   Channel<Work*> free_q, parsed_q, predicted_q;
   for (Work& w : works) free_q.push(&w);
   std::atomic<bool> stop(false);
-  std::thread reader_thread([&] {
+  std::mutex tm_mu;
+  // ONE reader (a pipe, or a single engine): blocks in stream order, the open group at a block's end carried to the next.
+  // SEVERAL reader teams (a regular file on stdin and more than one engine): the file is cut into slices at query-identifier
+  // boundaries (SliceCutter), every team parses whole slices with its share of the host threads, the slice index is the
+  // block's place in the output -- the feed scales with the host's cores instead of ending at one team's ~50 M lines/s.
+  std::vector<std::thread> reader_threads;
+  std::atomic<bool> last_sent(false);
+  auto reader_loop = [&](size_t team) {
+    ColumnarReader& reader = *readers[team];
     uint64_t seq = 0;
     for (;;) {
       Work* w = free_q.pop();
       if (!w) break;
-      w->last = false; w->failed = false; w->err = nullptr; w->seq = seq++;
-      if (stop.load()) { w->last = true; parsed_q.push(w); break; }  // a GPU call failed: end the stream here
+      w->last = false; w->failed = false; w->err_after = false; w->err = nullptr;
       const Clock::time_point t0 = Clock::now();
       if (!w->batch.before_regrow) w->batch.before_regrow = [w, &models] { unpin_work(*w, *models[0]); };
-      try { if (!reader.next(w->batch)) w->last = true; }
-      catch (...) { w->err = std::current_exception(); w->last = true; }
-      tm.parse += secs(t0, Clock::now());
+      if (!cutter) {
+        w->seq = seq++;
+        if (stop.load()) { w->last = true; parsed_q.push(w); break; }  // a GPU call failed: end the stream here
+        try { if (!reader.next(w->batch)) w->last = true; }
+        catch (...) { w->err = std::current_exception(); w->last = true; }
+      } else {
+        const char *b = nullptr, *e = nullptr;
+        uint64_t index = 0;
+        if (stop.load()) cutter->close();  // the run is ending (a GPU call or a line failed): no further slice is handed out
+        const bool got = cutter->next(b, e, index);
+        if (!got) {  // the file is exhausted or closed: ONE end-of-stream block, behind every slice handed out (index = their number)
+          if (last_sent.exchange(true)) { free_q.push(w); break; }
+          w->batch.clear(); w->seq = index; w->last = true;
+          parsed_q.push(w);
+          break;
+        }
+        w->seq = index;
+        reader.parse_slice(*cutter, b, e, w->batch, w->err);
+        if (w->err) { w->err_after = true; stop.store(true); cutter->close(); }  // what precedes the bad line is printed; no further slice is taken
+      }
+      { std::lock_guard<std::mutex> lk(tm_mu); tm.parse += secs(t0, Clock::now()); }
       parsed_q.push(w);
       if (w->last) break;
     }
-    for (size_t k = 1; k < n_gpu; ++k) parsed_q.push(nullptr);  // every other GPU thread sees the end of the stream too
+  };
+  for (size_t t = 0; t < n_teams; ++t) reader_threads.emplace_back(reader_loop, t);
+  std::thread reader_done([&] {  // every GPU thread sees the end of the stream once the teams have handed over their last block
+    for (auto& t : reader_threads) t.join();
+    for (size_t k = 0; k < n_gpu; ++k) parsed_q.push(nullptr);
   });
   float stale_ival = -1.f;  // predictionrecord.hh:40; the reference reuses one PredictionRecord (taxator.cpp:66)
   std::thread writer_thread([&] {
@@ -266,7 +300,8 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
         for (const std::string& p : parts) fwrite(p.data(), 1, p.size(), stdout);
         if (logsink) for (const std::string& p : log_parts) logsink->write(p.data(), (std::streamsize)p.size());
         tm.write += secs(t0, Clock::now());
-        free_q.push(w);
+        if (w->err_after) discard = true;  // the line behind this block's record sets does not parse: the serial loop dies there;
+        free_q.push(w);                    // slices that were already on their way are recycled unprinted until the end-of-stream block
       }
     }
   });
@@ -281,7 +316,7 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
       if (w->last) {
         if (w->err) { std::lock_guard<std::mutex> lk(failure_mu); if (w->seq < fail_seq.load()) { fail_seq = w->seq; failure = w->err; } }
         predicted_q.push(w);
-        return;
+        continue;  // (the end of the stream for every GPU thread is the nullptr behind it)
       }
       const Clock::time_point t0 = Clock::now();
       const size_t S = w->batch.n_sets();
@@ -306,7 +341,11 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
         predicted_q.push(w);
         continue;          // keep draining: blocks before this one may still be on their way through other GPUs
       }
-      { std::lock_guard<std::mutex> lk(failure_mu); tm.predict += secs(t0, Clock::now()); tm.sets += S; tm.records += w->batch.n_records(); }
+      {
+        std::lock_guard<std::mutex> lk(failure_mu);
+        tm.predict += secs(t0, Clock::now()); tm.sets += S; tm.records += w->batch.n_records();
+        if (w->err_after && w->seq < fail_seq.load()) { fail_seq = w->seq; failure = w->err; }  // (a GPU failure on the same block came first: it keeps the slot)
+      }
       predicted_q.push(w);
     }
   };
@@ -316,8 +355,8 @@ void run_columnar(ColumnarReader& reader, std::vector<RPAPredictionModel*>& mode
   for (auto& t : gpu_threads) t.join();
   writer_thread.join();
   stop.store(true);
-  for (size_t k = 0; k < works.size(); ++k) free_q.push(nullptr);  // wake the reader if it waits for a Work object
-  reader_thread.join();
+  for (size_t k = 0; k < works.size() + n_teams; ++k) free_q.push(nullptr);  // wake the readers if they wait for a Work object
+  reader_done.join();
   for (Work& w : works) unpin_work(w, *models[0]);
   fflush(stdout);
   if (failure) std::rethrow_exception(failure);
@@ -371,6 +410,7 @@ static int run(int argc, char** argv) {
     else if (a == "--block-mb") o.block_mb = atof(val("--block-mb").c_str());
     else if (a == "--store-gb") o.store_gb = atof(val("--store-gb").c_str());
     else if (a == "--store-tile") o.store_tile = (uint64_t)atoll(val("--store-tile").c_str());
+    else if (a == "--readers") o.readers = (size_t)atoll(val("--readers").c_str());
     else if (a == "--batch") o.batch = (size_t)atoll(val("--batch").c_str());
     else if (a == "-r" || a == "--ranks") { while (i + 1 < argc && argv[i + 1][0] != '-') o.ranks.push_back(argv[++i]); }
     else { std::cerr << "unrecognised option '" << a << "'" << std::endl; return EXIT_FAILURE; }
@@ -464,14 +504,31 @@ static int run(int argc, char** argv) {
     };
     if (!o.record_objects) {
       std::cout << GFF3Header() << std::flush;
-      ColumnarReader reader(stdin, *seqid2taxid, tax.get(), &db_storage, &query_storage, o.split_alignments, o.processors,
-                            (size_t)std::max(4096.0, o.block_mb * 1048576.0), o.alignments_sorted);
+      // one reader team per engine when stdin is a regular file and there is more than one engine (--readers N forces N);
+      // a pipe, one engine or --readers 1: ONE reader on all host threads
+      const size_t block_bytes = (size_t)std::max(4096.0, o.block_mb * 1048576.0);
+      size_t teams = o.readers ? o.readers : (engines.size() > 1 ? engines.size() : 1);
+      std::unique_ptr<SliceCutter> cutter;
+      if (teams > 1) {
+        cutter.reset(new SliceCutter(stdin, block_bytes));
+        if (!cutter->mapped()) { cutter.reset(); teams = 1; }
+      }
+      const unsigned reader_threads_total = o.processors ? o.processors : usable_cpus();
+      std::vector<std::unique_ptr<ColumnarReader>> readers;
+      std::shared_ptr<const ReaderTables> tables;
+      for (size_t t = 0; t < teams; ++t) {
+        const unsigned th = teams == 1 ? o.processors : std::max(1u, (unsigned)((reader_threads_total + teams - 1 - t) / teams));
+        readers.emplace_back(new ColumnarReader(stdin, *seqid2taxid, tax.get(), &db_storage, &query_storage, o.split_alignments, th, block_bytes,
+                                                o.alignments_sorted, tables));
+        tables = readers.back()->tables();
+      }
+      if (o.timing) std::cerr << "READERS	teams=" << teams << "	" << (cutter ? "slices of the mapped input file cut at query identifier boundaries" : "one stream") << std::endl;
       Timing tm;
       const bool logging = o.logfile != "/dev/null";
       std::vector<RPAPredictionModel*> models;
       for (auto& m : engines) models.push_back(m.get());
       stage("columnar pipeline (reader / GPU / writer threads)");
-      try { run_columnar(reader, models, *tax, logging ? &logsink : nullptr, o.batch, host_threads, tm); }
+      try { run_columnar(readers, cutter.get(), models, *tax, logging ? &logsink : nullptr, o.batch, host_threads, tm); }
       catch (...) {
         stage("columnar pipeline failed: unwinding (engines are destroyed)");
         if (o.timing) std::cerr << "TIMING\tincomplete" << std::endl;

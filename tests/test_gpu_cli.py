@@ -436,20 +436,33 @@ def test_cli_region_granular_reads_of_long_references(tmp_path):
 
 
 @pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])
-def test_cli_several_engines_keep_input_order(golden_dir, tmp_path, name, ext, extra):
-    """--devices a,b: one engine + one host thread per listed GPU, blocks dealt to whichever is free, GFF3 in input order
-    (the replacement of doPredictionsParallel, core/taxator.cpp:181-210).  The test box has one GPU: two engines on device
-    0 exercise the same pipeline.  Tiny blocks -> dozens of batches in flight across the two engines."""
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+def test_cli_several_engines_keep_input_order(golden_dir, tmp_path, name, ext, extra, devices):
+    """--devices a,b,...: one engine + two host threads per listed GPU, blocks dealt to whichever is free, GFF3 in input order
+    (the replacement of doPredictionsParallel, core/taxator.cpp:181-210).  The input is a regular file, so there is one READER
+    TEAM per engine as well: the mapped file is cut into slices where the query identifier changes and the teams parse slices
+    side by side (the slice index is the block's place in the output).  The test box has one GPU: several engines on device 0
+    exercise the same pipeline.  Tiny blocks -> dozens of batches in flight across the engines."""
     folder = _unpack(golden_dir, name, ext, tmp_path)
-    r = _run(folder, ext, extra + ["--devices", "0,0", "--block-mb", "0.004", "-p", "4"])
+    n_eng = devices.count(",") + 1
+    r = _run(folder, ext, extra + ["--devices", devices, "--block-mb", "0.004", "-p", "4", "--timing"])
     assert r.returncode == 0, r.stderr
     assert r.stdout == open(os.path.join(folder, "out.gff3")).read()
-    # a failure in the middle of the stream: what precedes it is printed, the exit code and message are the serial loop's
+    assert "READERS\tteams=%d\tslices" % n_eng in r.stderr
+    one = _run(folder, ext, extra + ["--devices", devices, "--block-mb", "0.004", "-p", "4", "--timing", "--readers", "1"])
+    assert one.returncode == 0 and one.stdout == r.stdout and "READERS\tteams=1\t" in one.stderr
+    # a failure in the middle of the stream: what precedes it is printed, the exit code and message are the serial loop's --
+    # whichever team meets the bad line, and with the line number counted from the start of the file
     lines = open(os.path.join(folder, "aln.tsv")).read().split("\n")
     bad = lines[:len(lines) // 2] + ["q_unknown\t1\t50\t200\tnope\t1\t50\t10\t0\t50\t50"] + lines[len(lines) // 2:]
     (tmp_path / name / "aln_bad.tsv").write_text("\n".join(bad))
-    r = _run(folder, ext, extra + ["--devices", "0,0", "--block-mb", "0.004"], aln="aln_bad.tsv")
-    assert r.returncode == 1 and "An unrecoverable error occurred" in r.stderr
     good = open(os.path.join(folder, "out.gff3")).read()
-    assert good.startswith(r.stdout) and 0 < len(r.stdout) < len(good)
+    outs = set()
+    for readers in ([], ["--readers", "1"], ["--readers", "3"]):
+        r = _run(folder, ext, extra + ["--devices", devices, "--block-mb", "0.004"] + readers, aln="aln_bad.tsv")
+        assert r.returncode == 1 and "An unrecoverable error occurred" in r.stderr
+        assert "[line %d]" % (len(lines) // 2 + 1) in r.stderr, r.stderr[-500:]
+        assert good.startswith(r.stdout) and 0 < len(r.stdout) < len(good)
+        outs.add(r.stdout)
+    assert len(outs) == 1  # the same prefix of the output however the input was read
 

@@ -38,6 +38,9 @@ def test_bench_one_rank_over_rccl(config, extra):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
     assert "RCCL gather" in out["config"]["parallelism"]
     assert out["dist"]["backend"] == "nccl" and out["dist"]["world_size"] == 1 and out["dist"]["rccl_version"]
+    d = out["dist"]  # per-rank timing and the cost of one gather: what makes the first real multi-GPU line diagnosable
+    assert len(d["per_rank_ms"]) == 1 and 0 < d["per_rank_ms"][0] <= d["per_rank_exchange_done_ms"][0] <= d["per_rank_barrier_ms"][0] * 1.001
+    assert d["gather_ms"] > 0 and d["gather_bytes"] == 32 * sum(out["config"]["shard_sets"])
     assert out["roofline"]["achieved"] > 0 and out["roofline"]["launches"] > 0
 
 
@@ -62,6 +65,10 @@ def test_bench_four_ranks_share_the_gpu(config, extra):
     assert out["n_gpus"] == RANKS and out["value"] > 0
     assert out["dist"]["world_size"] == RANKS and out["dist"]["backend"] == "gloo" and out["dist"]["gather"].startswith("asynchronous")
     assert "steps in flight" in out["submission"]
+    d = out["dist"]
+    assert len(d["per_rank_ms"]) == RANKS and all(x > 0 for x in d["per_rank_ms"]) and len(d["per_rank_exchange_done_ms"]) == RANKS
+    assert max(d["per_rank_barrier_ms"]) <= out["ms_per_step"] * 1.001 and max(d["per_rank_ms"]) <= out["ms_per_step"] * 1.001  # (the line's time is the slowest rank's)
+    assert d["gather_ms"] > 0 and d["gather_bytes"] == 32 * sum(out["config"]["shard_sets"])
     shards = out["config"]["shard_sets"]
     assert len(shards) == RANKS and sum(shards) == RANKS * int(extra[1])
     if config == "c5":

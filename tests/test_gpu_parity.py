@@ -725,14 +725,14 @@ def _random_big_tree(n, max_depth, rng):
 
 
 def test_taxonomy_of_ncbi_shape(pkg, oracle, synth):
-    """`taxator -d 0` keeps every node of the NCBI tree (~2.5 M nodes, ~40 levels).  Here a random tree of 500 k nodes and up to
-    37 levels (tools/big_taxonomy.py runs the full size: profiles/r03_big_taxonomy.txt): rpa_create builds its preorder /
+    """`taxator -d 0` keeps every node of the NCBI tree (~2.5 M nodes, ~40 levels).  Here a random tree of 500 k nodes and close to
+    30 levels (tools/big_taxonomy.py runs the full size, 37 levels: profiles/r03_big_taxonomy.txt): rpa_create builds its preorder /
     ancestor tables from the parent pointers, an RPA batch whose taxa are random nodes of the big tree and a megan-lca batch
     over it equal the oracle, and the results sit at depths beyond the pruned tree's eight levels."""
     rng = np.random.default_rng(7)
     n = 500_000
     parent, left, right, depth = _random_big_tree(n, 37, rng)
-    assert int(depth.max()) >= 30
+    assert int(depth.max()) >= 25
 
     class T:
         pass

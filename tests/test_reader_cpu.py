@@ -44,6 +44,12 @@ def _both(binary, folder, data, split=1, **kw):
                                     (4, 1 << 26, True), (2, 4096, True), (1, 100, True)):
         got = _run(binary, folder, "columnar", split, data, threads=threads, block=block, as_file=as_file, **kw)
         assert got == want, (threads, block, as_file, want[1][-300:], got[1][-300:])
+    # the reader teams' path (taxator --devices a,b,...): the mapped file cut into slices where the query identifier changes,
+    # every slice parsed on its own -- same record sets, same error text with the same "[line N]"
+    if data:
+        for threads, block in ((1, 1 << 26), (2, 4096), (3, 100), (1, 1)):
+            got = _run(binary, folder, "slices", split, data, threads=threads, block=block, as_file=True, **kw)
+            assert got == want, ("slices", threads, block, want[1][-300:], got[1][-300:])
     return want
 
 
