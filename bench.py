@@ -188,7 +188,46 @@ CONFIGS = {
 }
 
 
-def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_flight, device):
+def committed_profile(tcfg):
+    """HBM traffic and vector instructions per alignment launch of configuration `tcfg` from the committed rocprofv3 PMC passes
+    of this same command (profiles/<round>_traffic.json = config 2, profiles/<round>_cN_traffic.json = config N; they cannot be
+    read from inside the process).  Returns (traffic bytes per launch, its file, wave-instructions per launch, its file)."""
+    import glob
+    import re
+    tagged = lambda f, c: ("_%s_" % c) in os.path.basename(f)
+    cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))
+                   if (tagged(f, tcfg) if tcfg != "c2" else not any(tagged(f, c) for c in CONFIGS)))
+    if not cands:
+        return None, None, None, None
+    tj = json.load(open(cands[-1]))
+    traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
+    valu_per_launch, valu_src = None, None
+    sq = cands[-1].replace("_traffic.json", "_pmc_sq.txt")  # the SQ pass of the same profile
+    if os.path.exists(sq):
+        cur, instr, disp = None, 0.0, 0
+        for line in open(sq):
+            m = re.match(r"(?:void )?(rpa::.+?)\s+dispatches=(\d+)", line)
+            if m:
+                cur = m.group(1) if ("k_myers" in m.group(1) or "k_nw_protein" in m.group(1)) else None
+                disp += int(m.group(2)) if cur else 0
+            m = re.search(r"SQ_INSTS_VALU\s+sum=(\S+)", line)
+            if m and cur:
+                instr += float(m.group(1))
+        if disp:
+            valu_per_launch, valu_src = instr / disp, os.path.relpath(sq, ROOT)
+    return traffic, traffic_src, valu_per_launch, valu_src
+
+
+def valu_issue(valu_per_launch, valu_src, align_ms, n_launch):
+    """wave-instructions per launch (SQ_INSTS_VALU of the committed profile) over the live launch duration, per SIMD (1024 of
+    them); a wave64 instruction takes a SIMD-32 two cycles (MI355X_MICROARCH.md) = 1.2 per ns at 2.4 GHz."""
+    if valu_per_launch is None or align_ms <= 0:
+        return None
+    a = valu_per_launch / (align_ms / n_launch * 1e6) / 1024.0
+    return {"achieved": a, "peak": 1.2, "unit": "wave-instr/ns/SIMD", "frac": a / 1.2, "wave_instr_per_launch": valu_per_launch, "source": valu_src}
+
+
+def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_flight, device, profile_tag=None):
     """One of the other BASELINE configurations on this GPU, after the headline has been measured: `steps` steps through
     rpa_submit_batch with `in_flight` of them running (the same timed region as the headline), then `steps` synchronous
     calls for the per-launch profile.  No CPU leg.  Returns a small dict for the line's `secondary` object."""
@@ -236,6 +275,8 @@ def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_fli
         prof = model.profile()
     demanded = int(outs[0][1][:, 1:].to(torch.int64).sum().item())
     align_s = max(prof["align_ms"] / 1e3, 1e-12)
+    traffic, traffic_src, valu_pl, valu_src = committed_profile(profile_tag) if profile_tag else (None, None, None, None)
+    n_launch = max(prof["launches"], 1)
     res = {"workload": "%s: %d record sets x %d hits x %d %s" % (cfg["name"], sets, hits, seg_len, "bp" if cfg["alphabet"] == 0 else "aa"),
            "value": demanded * steps / elapsed, "unit": "realignments/s", "steps": steps, "in_flight": in_flight,
            "ms_per_step": elapsed / steps * 1e3, "sync_ms_per_step": sync_ms, "demanded_per_step": demanded,
@@ -243,7 +284,12 @@ def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_fli
            "align_ms_per_step": prof["align_ms"] / steps,
            "roofline": {"bound": "hbm", "achieved": prof["residue_bytes"] / align_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": prof["residue_bytes"] / align_s / 1e9 / 8000.0, "kernel": cfg["kernel"],
-                        "cell_updates_per_s_in_kernel": prof["cells"] / align_s, "launches": prof["launches"]},
+                        "cell_updates_per_s_in_kernel": prof["cells"] / align_s, "launches": prof["launches"],
+                        "band_cell_updates_per_s_in_kernel": prof["cells_updated"] / align_s,
+                        "band_cells_over_cell_equivalents": prof["cells_updated"] / max(prof["cells"], 1),
+                        "bytes_per_launch": prof["residue_bytes"] / n_launch, "avg_launch_ms": prof["align_ms"] / n_launch,
+                        "traffic": traffic, "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC)", "traffic_source": traffic_src,
+                        "valu_issue": valu_issue(valu_pl, valu_src, prof["align_ms"], n_launch)},
            "datagen_s": t_gen}
     model.close()
     del dev, outs, ds
@@ -589,30 +635,8 @@ def main():
                 n_gathered = sum(gather_sizes)
             assert n_gathered == sum(gather_sizes), "the gather did not return every rank's rows"
         if args.sets == cfg["sets"] and args.hits == cfg["hits"] and args.seg_len == cfg["seg_len"]:
-            import glob
-            # profiles/<round>_traffic.json = config 2 (the headline), profiles/<round>_cN_traffic.json = config N
-            tagged = lambda f, c: ("_%s_" % c) in os.path.basename(f)
             tcfg = "c2" if args.config == "c3" else args.config  # config 3 runs config 2's kernels on config 2's shapes
-            cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))
-                           if (tagged(f, tcfg) if tcfg != "c2" else not any(tagged(f, c) for c in CONFIGS)))
-            if cands:
-                tj = json.load(open(cands[-1]))
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
-                # the SQ pass of the same profile: vector instructions the alignment kernels issued, per launch
-                sq = cands[-1].replace("_traffic.json", "_pmc_sq.txt")
-                if os.path.exists(sq):
-                    import re
-                    cur, instr, disp = None, 0.0, 0
-                    for line in open(sq):
-                        m = re.match(r"(?:void )?(rpa::.+?)\s+dispatches=(\d+)", line)
-                        if m:
-                            cur = m.group(1) if ("k_myers" in m.group(1) or "k_nw_protein" in m.group(1)) else None
-                            disp += int(m.group(2)) if cur else 0
-                        m = re.search(r"SQ_INSTS_VALU\s+sum=(\S+)", line)
-                        if m and cur:
-                            instr += float(m.group(1))
-                    if disp:
-                        valu_per_launch, valu_src = instr / disp, os.path.relpath(sq, ROOT)
+            traffic, traffic_src, valu_per_launch, valu_src = committed_profile(tcfg)
         value = demanded_all * args.steps / elapsed
         n_launch = max(prof["launches"], 1)
         align_s = prof["align_ms"] / 1e3
@@ -641,14 +665,15 @@ def main():
                          "avg_launch_ms": prof["align_ms"] / n_launch, "launches": prof["launches"],
                          "computed_alignments_per_s_in_kernel": prof["pairs"] / max(align_s, 1e-12),
                          "cell_updates_per_s_in_kernel": prof["cells"] / max(align_s, 1e-12),
+                         "cell_updates_note": "cell-EQUIVALENTS: len_a x len_b per computed alignment, whatever part of the matrix the kernel swept",
+                         # cells the kernels really updated (words x 32 rows x columns inside the band / the strips' windows)
+                         "band_cell_updates_per_s_in_kernel": prof["cells_updated"] / max(align_s, 1e-12),
+                         "band_cells_over_cell_equivalents": prof["cells_updated"] / max(prof["cells"], 1),
                          "note": "integer-VALU bound bit-parallel DP: HBM fraction is reported per contract; cell updates/s and valu_issue are the honest bounds",
                          # vector-instruction issue: wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of the committed profile)
                          # over the live launch duration, per SIMD (1024 of them); a wave64 instruction takes a SIMD-32 two cycles
                          # (MI355X_MICROARCH.md) = 1.2 per ns at 2.4 GHz; plain and/or/add measured ~1.0, shifts and carry ops ~0.57
-                         "valu_issue": None if valu_per_launch is None or prof["align_ms"] <= 0 else {
-                             "achieved": valu_per_launch / (prof["align_ms"] / n_launch * 1e6) / 1024.0, "peak": 1.2,
-                             "unit": "wave-instr/ns/SIMD", "frac": valu_per_launch / (prof["align_ms"] / n_launch * 1e6) / 1024.0 / 1.2,
-                             "wave_instr_per_launch": valu_per_launch, "source": valu_src}},
+                         "valu_issue": valu_issue(valu_per_launch, valu_src, prof["align_ms"], n_launch)},
             "device_ms_per_step": prof["total_ms"] / prof_steps, "align_ms_per_step": prof["align_ms"] / prof_steps,
             "computed_over_demanded": prof["pairs"] / max(prof["demanded"], 1), "rounds_per_step": prof["rounds"] / prof_steps,
             "submission": ("rpa_submit_batch / rpa_wait, %d steps in flight on the engine's job slots (the timed region); `roofline`, device_ms_per_step, "
@@ -684,11 +709,12 @@ def main():
             torch.cuda.empty_cache()
             sec = {}
             c4, c5 = CONFIGS["c4"], CONFIGS["c5"]
-            for key, c_, sets_, hits_, len_ in (("c4", c4, c4["sets"], c4["hits"], c4["seg_len"]),
-                                                ("c4_200aa", c4, c4["sets"], c4["hits"], 200),
-                                                ("c5", c5, c5["sets"], c5["hits"], c5["seg_len"])):
+            for key, c_, sets_, hits_, len_, tag in (("c4", c4, c4["sets"], c4["hits"], c4["seg_len"], "c4"),
+                                                     ("c4_200aa", c4, c4["sets"], c4["hits"], 200, None),
+                                                     ("c4_300aa", c4, c4["sets"] // 4, c4["hits"], 300, None),
+                                                     ("c5", c5, c5["sets"], c5["hits"], c5["seg_len"], "c5")):
                 try:
-                    sec[key] = measure_secondary(pkg, synth, torch, c_, sets_, hits_, len_, 3, args.in_flight, local_rank)
+                    sec[key] = measure_secondary(pkg, synth, torch, c_, sets_, hits_, len_, 3, args.in_flight, local_rank, profile_tag=tag)
                 except Exception as e:  # the headline stands whatever happens here
                     sec[key] = {"error": repr(e)}
             out["secondary"] = sec

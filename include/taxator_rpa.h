@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RPA_ABI_VERSION 3
+#define RPA_ABI_VERSION 4
 
 enum { RPA_DNA = 0, RPA_PROTEIN = 1 };              /* taxator -b nucleotide|protein, core/taxator.cpp:280,362-371 */
 enum { RPA_STORE_QUERY = 0, RPA_STORE_DB = 1 };      /* query_sequences_ / db_sequences_, taxonpredictionmodelsequence.hh:842-843 */
@@ -270,6 +270,9 @@ typedef struct {
   double total_ms;         /* device time of whole rpa_predict_batch / rpa_align_pairs calls */
   uint64_t demanded;       /* alignments the reference control flow demanded (sum of pass0+pass1+pass2) */
   uint64_t rounds;         /* plan/align/decide rounds */
+  uint64_t cells_updated;  /* DP cells the alignment kernels really updated: the banded / strip kernels sweep only the words and
+                              column groups their band touches (cells counts len_a * len_b "cell-equivalents" whatever was swept);
+                              protein: every cell of the register strips, padding rows included (ABI 4) */
 } rpa_profile;
 
 int rpa_profile_enable(rpa_engine* e, int on);

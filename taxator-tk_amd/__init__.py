@@ -73,7 +73,8 @@ class _LcaParams(C.Structure):
 
 class _Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("pairs", C.c_uint64), ("residue_bytes", C.c_uint64), ("cells", C.c_uint64),
-                ("align_ms", C.c_double), ("total_ms", C.c_double), ("demanded", C.c_uint64), ("rounds", C.c_uint64)]
+                ("align_ms", C.c_double), ("total_ms", C.c_double), ("demanded", C.c_uint64), ("rounds", C.c_uint64),
+                ("cells_updated", C.c_uint64)]
 
 
 _lib = None

@@ -36,25 +36,62 @@ __device__ __forceinline__ void planes32(const uint4 x, uint32_t& p0, uint32_t& 
   pn = nibble_plane(x.x, 2) | (nibble_plane(x.y, 2) << 8) | (nibble_plane(x.z, 2) << 16) | (nibble_plane(x.w, 2) << 24);
 }
 
-__device__ __forceinline__ void profile_add(unsigned long long* acc, bool active, uint32_t la, uint32_t lb) {
-  // block-level reduction, then 3 atomics per workgroup (only when profiling is on)
-  __shared__ unsigned long long red[3][kBlock / 64];
+// upd = DP cells the kernel really updates for this pair (words x 32 rows x columns it sweeps): what the banded kernels
+// save shows as the ratio to la x lb ("cell-equivalents")
+__device__ __forceinline__ void profile_add(unsigned long long* acc, bool active, uint32_t la, uint32_t lb, unsigned long long upd) {
+  // block-level reduction, then 4 atomics per workgroup (only when profiling is on)
+  __shared__ unsigned long long red[4][kBlock / 64];
   unsigned long long v0 = active ? 1ull : 0ull, v1 = active ? (unsigned long long)la + lb + 8ull : 0ull,
-                     v2 = active ? (unsigned long long)la * lb : 0ull;
+                     v2 = active ? (unsigned long long)la * lb : 0ull, v3 = active ? upd : 0ull;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     v0 += __shfl_down(v0, d, 64);
     v1 += __shfl_down(v1, d, 64);
     v2 += __shfl_down(v2, d, 64);
+    v3 += __shfl_down(v3, d, 64);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { red[0][wave] = v0; red[1][wave] = v1; red[2][wave] = v2; }
+  if (lane == 0) { red[0][wave] = v0; red[1][wave] = v1; red[2][wave] = v2; red[3][wave] = v3; }
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if (threadIdx.x < 4) {
     unsigned long long s = 0;
     for (int k = 0; k < kBlock / 64; ++k) s += red[threadIdx.x][k];
-    atomicAdd(&acc[(blockIdx.x & (kProfParts - 1)) * 4 + threadIdx.x], s);  // partitioned: same-address atomics serialise
+    atomicAdd(&acc[(blockIdx.x & (kProfParts - 1)) * kProfSlots + (threadIdx.x < 3 ? threadIdx.x : 4)], s);  // partitioned: same-address atomics serialise
   }
+}
+// updated cells that are only known behind the work (the strip kernels' adaptive bands): every lane of the workgroup calls
+// this once, converged, at the end of the kernel
+__device__ __forceinline__ void profile_add_updated(unsigned long long* acc, unsigned long long upd) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) upd += __shfl_down(upd, d, 64);
+  if ((threadIdx.x & 63) == 0 && upd) atomicAdd(&acc[(blockIdx.x & (kProfParts - 1)) * kProfSlots + 4], upd);
+}
+// word-columns the banded one-strip kernels sweep for a text of n columns (their compile-time window schedules, restated):
+// HW words either side of word g for the 32 columns of text group g ...
+__device__ __forceinline__ unsigned long long band_word_columns(int NW, int HW, uint32_t n) {
+  unsigned long long wc = 0;
+  for (uint32_t g = 0; g * 32u < n; ++g) {
+    const uint32_t cols = n - g * 32u < 32u ? n - g * 32u : 32u;
+    const int lo = (int)g - HW > 0 ? (int)g - HW : 0, hi = (int)g + HW < NW - 1 ? (int)g + HW : NW - 1;
+    if (hi >= lo) wc += (unsigned long long)cols * (unsigned)(hi - lo + 1);
+  }
+  return wc;
+}
+// ... and the four-word window half a group out of phase, with (PH = 3) or without (PH = 2) the three-word middle (BandGroups4)
+__device__ __forceinline__ unsigned long long band4_word_columns(int NW, int PH, uint32_t n) {
+  unsigned long long wc = 0;
+  const uint32_t kFirst = PH == 3 ? 8u : 16u, kLast = PH == 3 ? 24u : 16u;
+  auto span = [&](int lo, int hi) { lo = lo > 0 ? lo : 0; hi = hi < NW - 1 ? hi : NW - 1; return hi >= lo ? (unsigned)(hi - lo + 1) : 0u; };
+  for (uint32_t g = 0; g * 32u < n; ++g) {
+    const uint32_t cols = n - g * 32u < 32u ? n - g * 32u : 32u;
+    const uint32_t ca = cols < kFirst ? cols : kFirst;
+    wc += (unsigned long long)ca * span((int)g - 2, (int)g + 1);
+    if (cols > kFirst) {
+      if (PH == 3) wc += (unsigned long long)((cols < kLast ? cols : kLast) - kFirst) * span((int)g - 1, (int)g + 1);
+      if (cols > kLast) wc += (unsigned long long)(cols - kLast) * span((int)g - 1, (int)g + 2);
+    }
+  }
+  return wc;
 }
 
 // ---- pieces shared by the one-strip kernels ----------------------------------------------------------------
@@ -258,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict_
       if (a_pat) { txt = vb; pat = va; } else { txt = va; pat = vb; }
       n = txt.len; m = pat.len;
     }
-    if (prof_acc) profile_add(prof_acc, active, n, m);
+    if (prof_acc) profile_add(prof_acc, active, n, m, (unsigned long long)n * (NW * 32u));
 
     // ---- Peq build (bit planes -> five match masks per 32-residue word); the pattern is read 16 bytes per word ----
     NtStream ps;
@@ -348,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band(const uint2* __rest
     if (a_pat) { txt = vb; pat = va; } else { txt = va; pat = vb; }
     n = txt.len; m = pat.len;
   }
-  if (prof_acc) profile_add(prof_acc, active, n, m);
+  if (prof_acc) profile_add(prof_acc, active, n, m, band_word_columns(NW, HW, n) * 32ull);
   NtStream ps;
   if (active) ps.init(pat, 0u);
 #pragma unroll
@@ -509,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
     if (a_pat) { txt = vb; pat = va; } else { txt = va; pat = vb; }
     n = txt.len; m = pat.len;
   }
-  if (prof_acc) profile_add(prof_acc, active, n, m);
+  if (prof_acc) profile_add(prof_acc, active, n, m, band4_word_columns(NW, PH, n) * 32ull);
   if (!active) return;
   const uint32_t ad = n > m ? n - m : m - n;
   constexpr uint32_t kReach = band4_reach(PH);
@@ -638,6 +675,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
   const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
   if (n_list_dev && blockIdx.x == 0 && tid == 0 && total) atomicAdd(&w.counters[kCtrRetryTotal], total);
   uint32_t* __restrict__ sc = scratch + (blockIdx.x * kBlock + tid);  // boundary planes: group g, plane p at sc[(2g + p) * stride]
+  unsigned long long upd_cells = 0;  // (profile) cells this lane updated: NW x 32 rows x 32 columns per group a strip swept
   for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {  // retry launches are sized before the count is known
     const uint32_t t = base + tid;
     const bool active = t < total;
@@ -654,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
       pat = seg_view(w, a); txt = seg_view(w, b);
       n = txt.len; m = pat.len;
     }
-    if (prof_acc) profile_add(prof_acc, active, n, m);
+    if (prof_acc) profile_add(prof_acc, active, n, m, 0ull);  // (updated cells: added up strip by strip, profile_add_updated)
     if (!active) continue;  // no barrier below: a lane only ever touches its own LDS column
 
     const uint32_t words = (m + 31u) / 32u;
@@ -719,6 +757,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
       // group ahead), two dword stores of this strip's planes.  (Memory operations retire in order on gfx9: with a load
       // and a store every four columns each load waited for the previous store to reach HBM.)
       if (g_lo < g_hi) {
+        upd_cells += (unsigned long long)(g_hi - g_lo) * (32u * HS);
         NtStream ts;
         ts.init(txt, g_lo * 32u);
         uint4 pending = ts.load4();
@@ -792,6 +831,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
     if ((uint64_t)(uint32_t)dist <= k) store_dna_result(w, dst, dist, n, m);  // inside the band: this IS the distance (always, when the band is wide open)
     else retry[atomicAdd(retry_n, 1u)] = entry;
   }
+  if (prof_acc) profile_add_updated(prof_acc, upd_cells);
 }
 
 // K1s, two lanes per pair.  Lanes 2p and 2p+1 of a wavefront work on the same alignment: in round t the even lane ("A")
@@ -816,6 +856,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_myers_band_duo(const uint2* __res
   const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
   if (n_list_dev && blockIdx.x == 0 && tid == 0 && total) atomicAdd(&w.counters[kCtrRetryTotal], total);
   uint32_t* __restrict__ sc = scratch + (blockIdx.x * kPairs + ((uint32_t)tid >> 1));  // per PAIR: group g, plane p at sc[(2g + p) * stride]
+  unsigned long long upd_cells = 0;  // (profile) cells this lane updated: NW x 32 rows x 32 columns per group it swept
   for (uint32_t base = blockIdx.x * kPairs; base < total; base += gridDim.x * kPairs) {
     const uint32_t t = base + ((uint32_t)tid >> 1);
     const bool active = t < total;
@@ -827,7 +868,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_myers_band_duo(const uint2* __res
       pat = seg_view(w, a); txt = seg_view(w, b);  // B = the record set's anchor: the same text for ~50 consecutive pairs
       n = txt.len; m = pat.len;
     }
-    if (prof_acc) profile_add(prof_acc, active && lag == 0u, n, m);
+    if (prof_acc) profile_add(prof_acc, active && lag == 0u, n, m, 0ull);  // (updated cells: added up strip by strip, profile_add_updated)
     if (!active) continue;  // both lanes of a pair leave together; no barrier below
 
     const uint32_t words = (m + 31u) / 32u;
@@ -897,7 +938,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_myers_band_duo(const uint2* __res
       };
       NtStream ts;
       uint4 pending = make_uint4(0u, 0u, 0u, 0u);
-      if (g_lo < g_hi) { ts.init(txt, g_lo * 32u); pending = ts.load4(); }
+      if (g_lo < g_hi) { ts.init(txt, g_lo * 32u); pending = ts.load4(); upd_cells += (unsigned long long)(g_hi - g_lo) * (32u * HS); }
       // A lanes: the planes of the strip above come from the scratch, asked for a group ahead
       uint32_t Pn = 0xFFFFFFFFu, Nn = 0u;
       if (lag == 0u && g_lo < g_hi && g_lo >= ab_lo && g_lo < ab_hi) { Pn = sc[(size_t)(2u * g_lo) * stride]; Nn = sc[(size_t)(2u * g_lo + 1u) * stride]; }
@@ -997,6 +1038,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_myers_band_duo(const uint2* __res
       else retry[atomicAdd(retry_n, 1u)] = entry;
     }
   }
+  if (prof_acc) profile_add_updated(prof_acc, upd_cells);
 }
 
 static size_t strip_words_per_thread(uint32_t max_len) { return 2 * (((size_t)max_len + 31) / 32) + 2; }  // two bit planes per 32 columns
@@ -1073,10 +1115,11 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint2* __restrict__ lis
   if (txt.len < pat.len) { const SegView x = txt; txt = pat; pat = x; }
   const uint32_t n = txt.len, m = pat.len;
   if (prof_acc && lane == 0) {
-    unsigned long long* acc = prof_acc + (blockIdx.x & (kProfParts - 1)) * 4;
+    unsigned long long* acc = prof_acc + (blockIdx.x & (kProfParts - 1)) * kProfSlots;
     atomicAdd(&acc[0], 1ull);
     atomicAdd(&acc[1], (unsigned long long)n + m + 8ull);
     atomicAdd(&acc[2], (unsigned long long)n * m);
+    atomicAdd(&acc[4], (unsigned long long)n * (((m + 31u) / 32u) * 32u));  // every word of the pattern, every column
   }
   const uint32_t txt_words = (n + 7u) / 8u;
   const uint32_t total_words = (m + 31u) / 32u;  // <= 64 * WPL by binning

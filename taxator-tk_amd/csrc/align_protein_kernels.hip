@@ -81,17 +81,18 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint2* __restrict__
   }
   if (prof_acc) {
     // same accounting as the DNA kernels: pairs, len_a+len_b+8, cells
-    __shared__ unsigned long long red[3][kBlock / 64];
+    // (+ cells really updated: every cell of the strips, padding rows of the last strip included)
+    __shared__ unsigned long long red[4][kBlock / 64];
     unsigned long long v0 = active ? 1ull : 0ull, v1 = active ? (unsigned long long)la + lb + 8ull : 0ull,
-                       v2 = active ? (unsigned long long)la * lb : 0ull;
+                       v2 = active ? (unsigned long long)la * lb : 0ull, v3 = active ? (unsigned long long)la * (((lb + R - 1) / R) * R) : 0ull;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); v2 += __shfl_down(v2, d, 64); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v0; red[1][threadIdx.x >> 6] = v1; red[2][threadIdx.x >> 6] = v2; }
+    for (int d = 32; d >= 1; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); v2 += __shfl_down(v2, d, 64); v3 += __shfl_down(v3, d, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v0; red[1][threadIdx.x >> 6] = v1; red[2][threadIdx.x >> 6] = v2; red[3][threadIdx.x >> 6] = v3; }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
       unsigned long long s = 0;
       for (int k = 0; k < kBlock / 64; ++k) s += red[threadIdx.x][k];
-      atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * 4 + threadIdx.x], s);
+      atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * kProfSlots + (threadIdx.x < 3 ? threadIdx.x : 4)], s);
     }
   }
   if (!active) return;
@@ -264,12 +265,12 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2*
     }
     if (prof_acc) {  // same accounting as the other alignment kernels: pairs, len_a+len_b+8, cells
       unsigned long long v0 = active ? 1ull : 0ull, v1 = active ? (unsigned long long)la + lb + 8ull : 0ull,
-                         v2 = active ? (unsigned long long)la * lb : 0ull;
+                         v2 = active ? (unsigned long long)la * lb : 0ull, v3 = active ? (unsigned long long)la * (((lb + R - 1) / R) * R) : 0ull;
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); v2 += __shfl_down(v2, d, 64); }
+      for (int d = 32; d >= 1; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); v2 += __shfl_down(v2, d, 64); v3 += __shfl_down(v3, d, 64); }
       if (lane == 0) {
-        unsigned long long* acc = prof_acc + ((run >> 6) & (kProfParts - 1)) * 4;
-        atomicAdd(&acc[0], v0); atomicAdd(&acc[1], v1); atomicAdd(&acc[2], v2);
+        unsigned long long* acc = prof_acc + ((run >> 6) & (kProfParts - 1)) * kProfSlots;
+        atomicAdd(&acc[0], v0); atomicAdd(&acc[1], v1); atomicAdd(&acc[2], v2); atomicAdd(&acc[4], v3);
       }
     }
     if (!active) continue;  // the last run of a list; nothing below is wave-collective
@@ -426,12 +427,12 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
     if (prof_acc) {  // pairs, len_a+len_b+8, cells: counted by the first lane of a pair
       const bool cnt = have && sub == 0u;
       unsigned long long v0 = cnt ? 1ull : 0ull, v1 = cnt ? (unsigned long long)la + lb + 8ull : 0ull,
-                         v2 = cnt ? (unsigned long long)la * lb : 0ull;
+                         v2 = cnt ? (unsigned long long)la * lb : 0ull, v3 = cnt ? (unsigned long long)la * (((lb + R - 1) / R) * R) : 0ull;
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); v2 += __shfl_down(v2, d, 64); }
+      for (int d = 32; d >= 1; d >>= 1) { v0 += __shfl_down(v0, d, 64); v1 += __shfl_down(v1, d, 64); v2 += __shfl_down(v2, d, 64); v3 += __shfl_down(v3, d, 64); }
       if (lane == 0) {
-        unsigned long long* acc = prof_acc + ((run / kPairs) & (kProfParts - 1)) * 4;
-        atomicAdd(&acc[0], v0); atomicAdd(&acc[1], v1); atomicAdd(&acc[2], v2);
+        unsigned long long* acc = prof_acc + ((run / kPairs) & (kProfParts - 1)) * kProfSlots;
+        atomicAdd(&acc[0], v0); atomicAdd(&acc[1], v1); atomicAdd(&acc[2], v2); atomicAdd(&acc[4], v3);
       }
     }
     const uint32_t nstrips = (lb + R - 1) / R;  // <= G by the bin

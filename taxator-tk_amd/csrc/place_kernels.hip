@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
         row.rtax = anc_node(tax, nb, st.d_rtax); row.flags = 0;
         rows[s] = row;
         if (stats) stats[s] = OutStats{n, st.cnt0, st.cnt1, st.cnt2};
-        if (prof_acc) atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * 4 + 3], (unsigned long long)(st.cnt0 + st.cnt1 + st.cnt2));
+        if (prof_acc) atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * kProfSlots + 3], (unsigned long long)(st.cnt0 + st.cnt1 + st.cnt2));
         if (st.d_unode_g > st.d_lnode_g) raise_error(w, kErrAssert, s);  // setNodeRange assert, predictionrecord.hh:153
         st.phase = kDone;
       }

@@ -16,6 +16,7 @@ constexpr int kNumBins = 18;         // work lists per round: the nucleotide bin
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
 constexpr int kProfParts = 64;        // profiling accumulators are split 64 ways (block index & 63) and summed on the host
+constexpr int kProfSlots = 8;         // per part: pairs, residue bytes, cells (len_a x len_b), demanded alignments, cells really UPDATED (band / strip sweeps), 3 spare
 constexpr int kMaxDepth = 63;         // deepest taxonomy level: the BandFactor rank sets of k_decide are 64-bit masks and its per-rank LDS
                                       // accumulators hold (depth + 1) x 2 KB (full NCBI: ~40 levels; pruned to the default ranks: 8)
 
@@ -264,7 +265,7 @@ struct Params {
                           // in a loop and take most of the hits behind them out of it: a short first chunk, then spec2
 };
 
-struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells
+struct ProfDev {  // device-side accumulators (u64): pairs, residue bytes, cells, demanded, cells updated (kProfSlots per part)
   unsigned long long* acc;
 };
 

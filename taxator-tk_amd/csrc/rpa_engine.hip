@@ -387,11 +387,11 @@ int profile_end(rpa_engine* e) {
     HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_pool[pr.first], e->ev_pool[pr.second]));
     e->prof.align_ms += ms;
   }
-  unsigned long long parts[kProfParts * 4], acc[4] = {0, 0, 0, 0};
+  unsigned long long parts[kProfParts * kProfSlots], acc[kProfSlots] = {};
   HIP_TRY(e, hipMemcpy(parts, e->prof_acc.p, sizeof(parts), hipMemcpyDeviceToHost));
   for (int k = 0; k < kProfParts; ++k)
-    for (int j = 0; j < 4; ++j) acc[j] += parts[k * 4 + j];
-  e->prof.pairs = acc[0]; e->prof.residue_bytes = acc[1]; e->prof.cells = acc[2]; e->prof.demanded = acc[3];
+    for (int j = 0; j < kProfSlots; ++j) acc[j] += parts[k * kProfSlots + j];
+  e->prof.pairs = acc[0]; e->prof.residue_bytes = acc[1]; e->prof.cells = acc[2]; e->prof.demanded = acc[3]; e->prof.cells_updated = acc[4];
   return RPA_OK;
 }
 
@@ -649,8 +649,8 @@ rpa_engine* make_worker(rpa_engine* e) {
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = make_stream(w->device, &w->own_stream);
   if (err == hipSuccess) err = hipHostMalloc((void**)&w->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault);
-  if (err == hipSuccess) err = w->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemset(w->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = w->prof_acc.ensure(kProfParts * kProfSlots * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemset(w->prof_acc.p, 0, kProfParts * kProfSlots * sizeof(unsigned long long));
   if (err != hipSuccess) { fail(e, RPA_ERR_DEVICE, "worker engine: %s", hipGetErrorString(err)); rpa_destroy(w); return nullptr; }
   w->stream = w->own_stream;
   return w;
@@ -916,8 +916,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->tax = TaxDev{e->tax_parent.as<const uint32_t>(), e->tax_left.as<const uint32_t>(), e->tax_right.as<const uint32_t>(),
                   e->tax_depth.as<const uint8_t>(), tax->n_nodes, e->tax_pre.as<const uint32_t>(), e->tax_last.as<const uint32_t>(),
                   e->tax_anc.as<const uint32_t>(), e->tax_anc_iv.as<const uint2>(), max_depth};
-  CREATE_TRY(e->prof_acc.ensure(kProfParts * 4 * sizeof(unsigned long long)));
-  CREATE_TRY(hipMemset(e->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
+  CREATE_TRY(e->prof_acc.ensure(kProfParts * kProfSlots * sizeof(unsigned long long)));
+  CREATE_TRY(hipMemset(e->prof_acc.p, 0, kProfParts * kProfSlots * sizeof(unsigned long long)));
 #undef CREATE_TRY
   RPA_WHERE("rpa_create: done");
   *out = e;
@@ -1640,10 +1640,10 @@ int rpa_profile_reset(rpa_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(e, hipSetDevice(e->device));
   memset(&e->prof, 0, sizeof(e->prof));
-  HIP_TRY(e, hipMemset(e->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
+  HIP_TRY(e, hipMemset(e->prof_acc.p, 0, kProfParts * kProfSlots * sizeof(unsigned long long)));
   for (rpa_engine* w : e->workers) {
     memset(&w->prof, 0, sizeof(w->prof));
-    HIP_TRY(e, hipMemset(w->prof_acc.p, 0, kProfParts * 4 * sizeof(unsigned long long)));
+    HIP_TRY(e, hipMemset(w->prof_acc.p, 0, kProfParts * kProfSlots * sizeof(unsigned long long)));
   }
   return RPA_OK;
 }
@@ -1654,7 +1654,7 @@ int rpa_profile_get(rpa_engine* e, rpa_profile* out) {
   *out = e->prof;
   for (const rpa_engine* w : e->workers) {  // parts of a batch that ran on worker engines
     out->launches += w->prof.launches; out->pairs += w->prof.pairs; out->residue_bytes += w->prof.residue_bytes;
-    out->cells += w->prof.cells; out->align_ms += w->prof.align_ms; out->demanded += w->prof.demanded;
+    out->cells += w->prof.cells; out->align_ms += w->prof.align_ms; out->demanded += w->prof.demanded; out->cells_updated += w->prof.cells_updated;
     out->rounds = out->rounds > w->prof.rounds ? out->rounds : w->prof.rounds;
   }
   return RPA_OK;

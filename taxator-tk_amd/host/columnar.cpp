@@ -352,12 +352,29 @@ void ColumnarReader::raise_failure() {
 void ColumnarReader::parse_slice(const SliceCutter& cutter, const char* begin, const char* end, ColumnarBatch& out, std::exception_ptr& err) {
   carry_ = 0; carry_qid_.clear(); failed_ = false; fail_query_.clear(); line_base_ = 0; eof_ = false;
   err = nullptr;
-  parse_block(begin, end, true, out);
+  // The reference's generator closes a group by READING the record behind it (alignmentrecord.hh:464-479): when that line
+  // does not parse, the exception leaves with the group still open -- its record set is never predicted.  A slice ends
+  // where the next group begins, so the line to look at is the first data line behind the slice.
+  const char* file_end = cutter.file_end();
+  std::exception_ptr next_bad;
+  for (const char* l = end; l < file_end;) {
+    const char* nl = (const char*)memchr(l, '\n', (size_t)(file_end - l));
+    const char* le = nl ? nl : file_end;
+    if (*l == '#' && l != le) { l = nl ? nl + 1 : file_end; continue; }  // comment lines are skipped (fileparser.hh:61-67)
+    AlignmentRecordTaxonomy rec;
+    try { legacy_.parse(std::string(l, le), rec); }
+    catch (Exception& e) {
+      try { throw ParsingError(std::string(e.what()) + " [line " + std::to_string(cutter.lines_before(l) + 1) + "]"); } catch (...) { next_bad = std::current_exception(); }
+    }
+    break;
+  }
+  parse_block(begin, end, !next_bad, out);  // (not closed: the slice's last group stays behind as an open group and is dropped)
   if (failed_ || !fail_query_.empty()) {
     fail_line_no_ += cutter.lines_before(begin);  // (counted only now: a failure is the end of the run)
     try { raise_failure(); } catch (...) { err = std::current_exception(); }
     failed_ = false; fail_query_.clear();
-  }
+  } else if (next_bad) err = next_bad;
+  carry_ = 0; carry_qid_.clear();
 }
 
 void ColumnarReader::parse_block(const char* begin, const char* end, bool eof, ColumnarBatch& out) {

@@ -90,6 +90,7 @@ class SliceCutter {
   explicit SliceCutter(FILE* in, size_t block_bytes);  // mapped() is false for a pipe (or TAXATOR_NO_MMAP): use ColumnarReader::next
   ~SliceCutter();
   bool mapped() const { return map_ != nullptr; }
+  const char* file_end() const { return map_ + map_size_; }
   // the next slice and its index; false when the file is exhausted (`index` is then the number of slices handed out)
   bool next(const char*& begin, const char*& end, uint64_t& index);
   void close();  // no further slices (next() returns false from now on)

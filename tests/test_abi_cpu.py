@@ -27,13 +27,14 @@ def test_header_symbols_are_exported(pkg):
     lib = pkg.load_library()
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.rpa_abi_version() == 3
+    assert lib.rpa_abi_version() == 4
 
 
 def test_struct_layouts_match_header(pkg):
     assert pkg.PRED_DTYPE.itemsize == 32 and pkg.STATS_DTYPE.itemsize == 16 and pkg.ALN_DTYPE.itemsize == 24
     assert ctypes.sizeof(pkg._Params) == 32
     assert ctypes.sizeof(pkg._Batch) == 8 + 13 * 8 + 8
+    assert ctypes.sizeof(pkg._Profile) == 9 * 8  # ABI 4: + cells_updated
 
 
 def test_product_does_not_touch_the_oracle():

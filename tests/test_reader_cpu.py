@@ -195,3 +195,31 @@ def test_alignments_sorted_option(parsecheck, golden_dir, monkeypatch, order):
             monkeypatch.delenv("PARSECHECK_SORTED", raising=False)
     if order != "position-sorted":
         assert differs > 6
+
+
+def test_bad_line_right_behind_a_group(parsecheck, golden_dir):
+    """The reference's generator closes a group by reading the record behind it: a line that does not parse there takes the
+    open group with it (its record set is never predicted).  The slice path cuts the file exactly at such boundaries, so
+    it has to look at the line behind a slice before it lets the slice's last group go."""
+    folder = os.path.join(golden_dir, "survey_edge")
+    refs = [l.split("\t")[0] for l in open(os.path.join(folder, "mapping.tax")) if l.strip() and not l.startswith("#")][:10]
+    qids = [l[1:].split()[0] for l in open(os.path.join(folder, "query_edge.fna")) if l.startswith(">")]
+    rng = random.Random(3)
+    for bad in BAD_LINES[:8]:
+        for comments_between in (False, True):
+            lines = []
+            for k in range(60):
+                qid = qids[k % len(qids)] if k % len(qids) else qids[0]
+                if lines and lines[-1].split("\t")[0].lstrip("*") == qid:
+                    qid = qids[(k + 1) % len(qids)]
+                for _ in range(3):
+                    lines.append(_good_line(rng, qid, refs))
+                if k == 40:
+                    if comments_between:
+                        lines.append("# a comment between the group and the bad line")
+                    lines.append(bad)
+            data = ("\n".join(lines) + "\n").encode()
+            rc, out = _both(parsecheck, folder, data)   # (objects == columnar == slices, blocks down to one line)
+            assert rc == 1 and out.rstrip().split(b"\n")[-1].startswith(b"ERROR ")
+            recs = [l for l in out.split(b"\n") if l and not l.startswith(b"SET\t") and not l.startswith(b"ERROR ")]
+            assert len(recs) == 40 * 3                  # groups 0..39: group 40 went down with the line behind it
