@@ -227,6 +227,66 @@ def valu_issue(valu_per_launch, valu_src, align_ms, n_launch):
     return {"achieved": a, "peak": 1.2, "unit": "wave-instr/ns/SIMD", "frac": a / 1.2, "wave_instr_per_launch": valu_per_launch, "source": valu_src}
 
 
+def measure_e2e(synth, ds):
+    """End to end through the product's own driver: the headline's record sets written in the reference's file formats
+    (alignments TSV ~1 GB, query / reference FASTA, mapping, taxonomy dump), then `taxator < aln.tsv > out.gff3` as a child
+    process -- load, parse, GPU, GFF3 -- twice (page cache warm the second time), and once more with small blocks and small
+    GPU calls, whose GFF3 must have the same SHA-1.  Outside every timed region; reported under secondary.e2e."""
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "taxator-tk_amd", "bin", "taxator")
+    if not os.path.exists(exe):
+        return {"error": "taxator-tk_amd/bin/taxator is not built"}
+    folder = tempfile.mkdtemp(prefix="rpa_e2e_")
+    try:
+        t0 = time.perf_counter()
+        synth.write_files(ds, folder)
+        t_write = time.perf_counter() - t0
+        aln = os.path.join(folder, "aln.tsv")
+        env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(folder, "tax"))
+        cmd = [exe, "-g", folder + "/mapping.tax", "-q", folder + "/query.fna", "-f", folder + "/ref.fna", "--timing"]
+
+        def run(extra, out_name):
+            t1 = time.perf_counter()
+            with open(aln) as fin, open(os.path.join(folder, out_name), "wb") as fout:
+                r = subprocess.run(cmd + extra, stdin=fin, stdout=fout, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+            wall = time.perf_counter() - t1
+            timing = {}
+            for line in r.stderr.splitlines():
+                if line.startswith("TIMING\t"):
+                    for tok in line.split("\t")[1:]:
+                        k_, _, v_ = tok.partition("=")
+                        try:
+                            timing[k_] = float(v_)
+                        except ValueError:
+                            pass
+            h = hashlib.sha1()
+            with open(os.path.join(folder, out_name), "rb") as f:
+                for chunk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(chunk)
+            return r.returncode, wall, timing, h.hexdigest()
+
+        runs = [run([], "out.gff3") for _ in range(2)]
+        small = run(["--block-mb", "8", "--batch", "50000"], "out_small.gff3")
+        rc, wall, tm, sha = min(runs, key=lambda x: x[1])
+        n_sets = int(ds.n_sets)
+        return {"workload": "taxator < aln.tsv > out.gff3: %d record sets, %d alignment lines, %.2f GB of TSV, in-memory FASTA stores" % (
+                    n_sets, len(ds.batch["qstart"]), os.path.getsize(aln) / 1e9),
+                "ok": rc == 0 and small[0] == 0 and all(r_[0] == 0 for r_ in runs),
+                "wall_s": wall, "record_sets_per_s": n_sets / wall,                                    # the whole child process: start-up, loads, pipeline
+                "pipeline_s": tm.get("wall_s"), "pipeline_record_sets_per_s": (n_sets / tm["wall_s"]) if tm.get("wall_s") else None,
+                "stages_s": {"load": tm.get("load_s"), "parse": tm.get("parse_s"), "predict": tm.get("predict_s"), "write": tm.get("write_s")},
+                "bound": "the reader (parse_s ~ pipeline wall): the GPU stage is busy a fraction of the pipeline's time",
+                "gff3_sha1": sha, "gff3_sha1_small_blocks": small[3], "same_output_with_small_blocks": sha == small[3],
+                "files_written_s": t_write}
+    except Exception as e:  # the headline stands whatever happens here
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+
+
 def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_flight, device, profile_tag=None):
     """One of the other BASELINE configurations on this GPU, after the headline has been measured: `steps` steps through
     rpa_submit_batch with `in_flight` of them running (the same timed region as the headline), then `steps` synchronous
@@ -717,6 +777,7 @@ def main():
                     sec[key] = measure_secondary(pkg, synth, torch, c_, sets_, hits_, len_, 3, args.in_flight, local_rank, profile_tag=tag)
                 except Exception as e:  # the headline stands whatever happens here
                     sec[key] = {"error": repr(e)}
+            sec["e2e"] = measure_e2e(synth, ds)
             out["secondary"] = sec
         print(json.dumps(out))
     if use_dist:

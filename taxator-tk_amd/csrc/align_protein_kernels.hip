@@ -214,10 +214,18 @@ constexpr uint32_t kPkScore = 20, kPkMove = 18, kPkMatch = 9;
 constexpr uint32_t kPkMoveMask = 3u << kPkMove;
 constexpr uint32_t kPackedScratchHead = 64;  // words in front of the boundary rows: [0] = the work counter
 
-template <int R>
+// kWide: the SCORE-AND-LENGTH cell for pairs the cell above cannot hold -- `M[i][j] + i + bias` in bits 18-31 (14 bits: la + lb +
+// 11 min(la, lb) + 32 <= 16383, e.g. 1258 x 1258 residues), the move in bits 16-17, the number of diagonal steps in bits
+// 0-15, no match counter.  The placement path only ever uses an alignment's distance and similarity, i.e. its score and its
+// LENGTH = la + lb - #diagonal steps (taxonpredictionmodelsequence.hh:227-233); matches / mismatches are needed by
+// rpa_align_pairs alone, which keeps K3 for such pairs.  Which candidate wins a cell depends on (score, move) only -- the
+// counters sit below them -- so the path, and with it the length, is the one the full cell would have taken.
+template <int R, bool kWide>
 __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
                                                                     uint32_t* __restrict__ scratch, uint32_t col_stride,
                                                                     unsigned long long* prof_acc) {
+  constexpr uint32_t kPkScore = kWide ? 18u : rpa::kPkScore, kPkMove = kWide ? 16u : rpa::kPkMove, kPkMoveMask = 3u << kPkMove;
+  constexpr uint32_t kDiagMask = kWide ? 0xFFFFu : 0x1FFu;
   __shared__ uint32_t tab[kAA * kAA * 32];  // [b][a][bank] -> T(a,b)
   __shared__ int32_t selfdiag[32];
   __shared__ int8_t blosum[kAA * kAA];       // the 729 scores once, then the expansion reads LDS
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2*
   for (int idx = threadIdx.x; idx < kAA * kAA * 32; idx += kPackedBlock) {
     const int bres = idx / (kAA * 32), a = (idx / 32) % kAA;
     const int sc = blosum[a * kAA + bres];
-    tab[idx] = ((uint32_t)(sc + 1) << kPkScore) + (1u << kPkMove) + (a == bres ? 1u << kPkMatch : 0u) + 1u;
+    tab[idx] = ((uint32_t)(sc + 1) << kPkScore) + (1u << kPkMove) + ((!kWide && a == bres) ? 1u << kPkMatch : 0u) + 1u;
   }
   if (threadIdx.x < 32) selfdiag[threadIdx.x] = threadIdx.x < kAA ? blosum[threadIdx.x * kAA + threadIdx.x] : 0;
   __syncthreads();
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2*
       }
     }
     const int32_t mutual = (int32_t)(res >> kPkScore) - (int32_t)(bias + lb);
-    const uint32_t ndiag = res & 0x1FFu, nmatch = (res >> kPkMatch) & 0x1FFu;
+    const uint32_t ndiag = res & kDiagMask, nmatch = kWide ? 0u : (res >> kPkMatch) & 0x1FFu;  // (wide: no match counter; length = gaps + diagonal steps either way)
     const uint32_t gap = (la - ndiag) + (lb - ndiag);
     const uint32_t mismatch = ndiag - nmatch;
     const uint32_t len = gap + nmatch + mismatch;                       // :227
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2*
     const float similarity = (float)(2 * mutual) * normfactor;          // :233
     if (!(selfscore >= mutual) || !(distance >= 0.f)) distance = __builtin_nanf("");
     w.pair_res[res_index(w, dst)] = make_float2(distance, similarity);
-    if (w.pair_ext) w.pair_ext[dst] = make_uint4(nmatch, mismatch, gap, len);
+    if (w.pair_ext) w.pair_ext[dst] = kWide ? make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, gap, len) : make_uint4(nmatch, mismatch, gap, len);  // (wide: matches / mismatches not counted)
   }
 }
 
@@ -622,11 +630,11 @@ hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* lis
 // K3p over a list of pairs that protein_bin() found eligible (protein_fits_packed).  One persistent
 // workgroup per CU; the boundary rows need (max_len + 1) words per resident lane.
 hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
-                                       size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc) {
+                                       size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc, bool wide) {
   if (n == 0) return hipSuccess;
   hipError_t e = upload_blosum();
   if (e != hipSuccess) return e;
-  if (max_len > kPackedMaxLen) return hipErrorInvalidValue;
+  if (max_len > (wide ? kWideMaxLen : kPackedMaxLen)) return hipErrorInvalidValue;
   static int cus[64] = {0};
   int dev = 0;
   e = hipGetDevice(&dev);
@@ -646,7 +654,8 @@ hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32
   if (kPackedScratchHead + (size_t)blocks * kPackedBlock * per_lane_words > scratch_words) return hipErrorOutOfMemory;
   e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch), (int)(blocks * (kPackedBlock / 64) * 64u), 1, st);  // the work counter starts behind the fixed first runs
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_nw_protein_packed<kPackedRows>, dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
+  if (wide) hipLaunchKernelGGL((k_nw_protein_packed<kPackedRows, true>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
+  else hipLaunchKernelGGL((k_nw_protein_packed<kPackedRows, false>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
   return hipGetLastError();
 }
 

@@ -35,6 +35,7 @@
 // exactly where the reference has them (:592,602,659,661); compiled with -ffp-contract=off and IEEE divide/sqrt.
 #include <float.h>
 #include <limits.h>
+#include <stdlib.h>
 
 #include <type_traits>
 #include "rpa_device.h"
@@ -493,7 +494,7 @@ __device__ __forceinline__ int pair_bin(const Params& p, uint32_t la, uint32_t l
   if (p.alphabet == 0) return dna_bin(la < lb ? la : lb);
   (void)la;
   if (p.force_bin >= 0) return p.force_bin;
-  return protein_bin(la, lb, p.protein_lanes != 0);  // protein: B (second segment) is the vertical sequence cut into register strips
+  return protein_bin(la, lb, p.protein_lanes != 0, p.protein_wide != 0);  // protein: B (second segment) is the vertical sequence cut into register strips
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1797,9 +1798,14 @@ __global__ __launch_bounds__(kBlock) void k_bin_pairs(WorkDev w, uint32_t n_pair
   }
 }
 
-hipError_t launch_bin_pairs(hipStream_t st, int alphabet, const WorkDev& w, uint32_t n_pairs) {
+hipError_t launch_bin_pairs(hipStream_t st, const Params& params, const WorkDev& w, uint32_t n_pairs) {
   if (n_pairs == 0) return hipSuccess;
-  Params p{alphabet, 0.f, 0.f, 0u, 0u, -1};
+  Params p = params;
+  // rpa_align_pairs reports matches / mismatches, which the score-and-length cell does not count: K3 for pairs beyond the packed
+  // cell (RPA_PAIRS_WIDE=1, tests: the wide cell here too -- its pairs then report 0xFFFFFFFF matches / mismatches)
+  const char* pw = getenv("RPA_PAIRS_WIDE");
+  const bool pairs_wide = pw && atoi(pw) != 0;
+  p.protein_wide = pairs_wide ? params.protein_wide : 0;
   hipLaunchKernelGGL(k_bin_pairs, dim3((n_pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, st, w, n_pairs, p);
   return hipGetLastError();
 }

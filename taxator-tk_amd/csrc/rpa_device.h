@@ -254,6 +254,8 @@ struct Params {
   uint32_t spec1, spec2;  // speculation chunk (hits per round) of the pass-1 / pass-2 loops; 0 = the whole set at once
   int force_bin;          // >= 0: put every pair into this bin (experiments: RPA_FORCE_BIN); -1 normally
   int protein_lanes;      // 0: packed protein pairs all go to K3p (one lane per pair), none to K3l (A/B: RPA_PROTEIN_LANES=0)
+  int protein_wide;       // 1: pairs beyond the packed cell go to K3p with the score-and-length cell where it holds them (the
+                          //    placement path; A/B: RPA_PROTEIN_WIDE=0 keeps K3); 0 in rpa_align_pairs (match counts wanted)
   int no_combined;        // 1: never ask for pass 0 and the first pass-1 loop in one round (A/B: RPA_NO_COMBINED)
   int filter1;            // >= 1: a pass-1 chunk leaves out the hits that the loop's thresholds at the pause already exclude;
                           // 2 (default) / 3: and ends where the scores fall below the cut-off its first hit would set, for
@@ -312,7 +314,7 @@ hipError_t launch_lca_models(hipStream_t st, const BatchDev& b, const TaxDev& ta
 
 // pair-level entry (rpa_align_pairs): segments straight from an arena-shaped store, explicit pair list
 hipError_t launch_plan_plain_segments(hipStream_t st, int alphabet, const WorkDev& w, const StoreDev& store);
-hipError_t launch_bin_pairs(hipStream_t st, int alphabet, const WorkDev& w, uint32_t n_pairs);
+hipError_t launch_bin_pairs(hipStream_t st, const Params& p, const WorkDev& w, uint32_t n_pairs);
 hipError_t launch_export_alignments(hipStream_t st, const WorkDev& w, uint32_t n_pairs, void* out);
 
 // alignment kernels over one bin list
@@ -338,7 +340,7 @@ hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint2
 hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
-                                       size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
+                                       size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc, bool wide = false);
 hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* work_counter,
                                       unsigned long long* prof_acc);
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
@@ -376,8 +378,13 @@ __device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
 // lanes -- shared twelve bins with the nucleotide kernels: a 200 aa pair, nine strips, ran in the 13-lane class with four
 // pairs per wavefront instead of seven.)
 constexpr uint32_t kPackedMaxLen = 511;
+constexpr uint32_t kWideMaxLen = 16383;  // the score-and-length cell (bin 3): 16-bit step counter, 14-bit score field
 constexpr int kProteinBins = 18;
 constexpr int kProteinPackedBin = 4;
+// Bin 3 (until round 4: K3 with 32-row strips, an experiment's height): pairs beyond the packed cell whose score field fits 14
+// bits -- la + lb + 11 min(la, lb) + 32 <= 16383, e.g. 1258 x 1258 -- when only distance and similarity are wanted (the
+// placement path; rpa_align_pairs also reports matches / mismatches and keeps K3): K3p with the score-and-length cell.
+constexpr int kProteinWideBin = 3;
 #ifndef RPA_LANE_ROWS
 #define RPA_LANE_ROWS 24
 #endif
@@ -388,8 +395,11 @@ __host__ __device__ __forceinline__ int protein_class_lanes(int cls) { return cl
 __host__ __device__ __forceinline__ bool protein_fits_packed(uint32_t la, uint32_t lb) {
   return la <= kPackedMaxLen && lb <= kPackedMaxLen && la + lb + 11u * (la < lb ? la : lb) + 32u <= 4095u;
 }
-__host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb, bool lanes = true) {
-  if (!protein_fits_packed(la, lb)) return 2;
+__host__ __device__ __forceinline__ bool protein_fits_wide(uint32_t la, uint32_t lb) {
+  return la <= kWideMaxLen && lb <= kWideMaxLen && la + lb + 11u * (la < lb ? la : lb) + 32u <= 16383u;
+}
+__host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb, bool lanes = true, bool wide = false) {
+  if (!protein_fits_packed(la, lb)) return (wide && protein_fits_wide(la, lb)) ? kProteinWideBin : 2;
   const uint32_t strips = (lb + kProteinLaneRows - 1u) / kProteinLaneRows;
   if (lanes && strips <= (uint32_t)kProteinMaxLanes) {
     const int cls = strips ? (int)strips - 1 : 0;

@@ -321,6 +321,9 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
       if (bin == kProteinPackedBin)  // every pair of this list passed protein_fits_packed(): no sequence above kPackedMaxLen
         HIP_TRY(e, launch_align_protein_packed(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4,
                                                std::min(max_len, kPackedMaxLen), acc));
+      else if (bin == kProteinWideBin && e->params.protein_wide && e->params.force_bin < 0)  // ... protein_fits_wide(): the score-and-length cell
+        HIP_TRY(e, launch_align_protein_packed(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4,
+                                               std::min(max_len, kWideMaxLen), acc, true));
       else
         HIP_TRY(e, launch_align_protein(e->stream, 8 * (bin + 1), list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
     }
@@ -807,6 +810,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
   e->params.protein_lanes = 1;
   if (const char* v = getenv("RPA_PROTEIN_LANES")) e->params.protein_lanes = atoi(v) != 0;
+  e->params.protein_wide = 1;
+  if (const char* v = getenv("RPA_PROTEIN_WIDE")) e->params.protein_wide = atoi(v) != 0;
   e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
   if (const char* v = getenv("RPA_BAND4_PHASES")) e->band4_wide = atoi(v) == 2 ? -1 : -2;
   e->params.filter1 = 2;
@@ -1525,7 +1530,7 @@ int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, cons
   const StoreDev sv = tmp.view();
   w.store_q = sv.words; w.store_db = sv.words;
   HIP_TRY(e, launch_plan_plain_segments(e->stream, e->params.alphabet, w, sv));
-  HIP_TRY(e, launch_bin_pairs(e->stream, e->params.alphabet, w, n_pairs));
+  HIP_TRY(e, launch_bin_pairs(e->stream, e->params, w, n_pairs));
   HIP_TRY(e, hipMemcpyAsync(e->h_counters, w.counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, e->stream));
   RPA_WHERE("rpa_align_pairs: sync after bin_pairs");
   HIP_TRY(e, hipStreamSynchronize(e->stream));

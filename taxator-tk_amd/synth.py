@@ -425,15 +425,28 @@ def write_files(ds, folder, line_width=80):
                 f.write(seq[i:i + line_width] + b"\n")
             fai.write("ref%d\t%d\t%d\t%d\t%d\n" % (s, len(seq), off, line_width, line_width + 1))
     with open(os.path.join(folder, "query" + ext), "wb") as f:
+        qo = np.asarray(ds.query_offsets).astype(np.int64).tolist()
+        whole = ds.query_letters.tobytes()
+        parts = []
         for s in range(ds.n_sets):
-            seq = ds.query_letters[int(ds.query_offsets[s]):int(ds.query_offsets[s + 1])].tobytes()
-            f.write(b">q%d\n" % s)
-            for i in range(0, len(seq), line_width):
-                f.write(seq[i:i + line_width] + b"\n")
+            seq = whole[qo[s]:qo[s + 1]]
+            parts.append(b">q%d\n" % s)
+            parts.extend(seq[i:i + line_width] + b"\n" for i in range(0, len(seq), line_width))
+            if len(parts) > 200000:
+                f.write(b"".join(parts)); parts = []
+        f.write(b"".join(parts))
     b = ds.batch
+    # (chunks of rows formatted in one go: ~1 us per line instead of ~2.5 with a write per line -- 20 M lines of config 2 in 20 s)
+    so = np.asarray(b["set_offsets"]).astype(np.int64)
+    set_of = np.repeat(np.arange(ds.n_sets, dtype=np.int64), np.diff(so))
+    qlen = np.asarray(b["query_len"])[set_of]
+    star = np.asarray(b["filtered"]).astype(bool) if "filtered" in b and b["filtered"] is not None else np.zeros(len(set_of), bool)
+    fmt = "%sq%d\t%d\t%d\t%d\tref%d\t%d\t%d\t%g\t0\t%d\t%d\n"
     with open(os.path.join(folder, "aln.tsv"), "w") as f:
-        for s in range(ds.n_sets):
-            for r in range(int(b["set_offsets"][s]), int(b["set_offsets"][s + 1])):
-                f.write("%sq%d\t%d\t%d\t%d\tref%d\t%d\t%d\t%g\t0\t%d\t%d\n" % (
-                    "*" if b["filtered"][r] else "", s, b["qstart"][r], b["qstop"][r], b["query_len"][s], b["ref_seq"][r],
-                    b["rstart"][r], b["rstop"][r], b["score"][r], b["identities"][r], b["alnlen"][r]))
+        step = 250000
+        for lo in range(0, len(set_of), step):
+            hi = min(len(set_of), lo + step)
+            cols = [np.where(star[lo:hi], "*", "").tolist(), set_of[lo:hi].tolist(), b["qstart"][lo:hi].tolist(), b["qstop"][lo:hi].tolist(),
+                    qlen[lo:hi].tolist(), b["ref_seq"][lo:hi].tolist(), b["rstart"][lo:hi].tolist(), b["rstop"][lo:hi].tolist(),
+                    np.asarray(b["score"][lo:hi], np.float64).tolist(), b["identities"][lo:hi].tolist(), b["alnlen"][lo:hi].tolist()]
+            f.write("".join([fmt % r for r in zip(*cols)]))

@@ -290,6 +290,63 @@ def test_protein_pairs_golden_and_random(pkg, oracle, golden_dir, lanes, monkeyp
         assert np.float32(got["similarity"]).tobytes() == np.float32(o["similarity"]).tobytes(), k
 
 
+def test_protein_pairs_beyond_the_packed_cell(pkg, oracle, monkeypatch):
+    """Pairs the packed cell cannot hold (from 313 x 313 on) run in the placement path on K3p with the SCORE-AND-LENGTH cell:
+    14 bits of score, 16 bits of diagonal steps, no match counter -- distance and similarity only need the score and the
+    alignment's length.  RPA_PAIRS_WIDE=1 lets rpa_align_pairs take that kernel too (matches / mismatches then read
+    0xFFFFFFFF): distance, similarity, gaps and length must be the oracle's bit for bit, at the field limits (W/W = +11
+    per residue up to the largest score 14 bits hold, nothing in common = all gaps), lopsided pairs, and past the limit
+    (K3 again)."""
+    monkeypatch.setenv("RPA_PAIRS_WIDE", "1")
+    rng = np.random.default_rng(8)
+    w_code = int(np.nonzero(LETTERS_AA == ord("W"))[0][0])
+    c_code, g_code = (int(np.nonzero(LETTERS_AA == ord(ch))[0][0]) for ch in "CG")
+    a_codes, b_codes, wide = [], [], []
+    for la, lb in [(313, 313), (312, 313), (511, 101), (512, 100), (400, 400), (511, 511), (512, 512), (800, 800), (1000, 999), (1257, 1257),
+                   (1258, 1258), (1259, 1259), (1300, 1200), (3000, 300), (300, 3000), (5000, 100), (100, 5000), (16000, 20), (20, 16000), (700, 1)]:
+        fits = la + lb + 11 * min(la, lb) + 32 <= 16383 and not (la <= 511 and lb <= 511 and la + lb + 11 * min(la, lb) + 32 <= 4095)
+        for kind in range(5):
+            if kind == 0: a, b = np.full(la, w_code, np.uint8), np.full(lb, w_code, np.uint8)
+            elif kind == 1: a, b = np.full(la, w_code, np.uint8), np.full(lb, c_code, np.uint8)
+            elif kind == 2: a, b = np.full(la, g_code, np.uint8), np.full(lb, c_code, np.uint8)
+            elif kind == 3: a, b = rng.integers(0, 20, la).astype(np.uint8), rng.integers(0, 20, lb).astype(np.uint8)
+            else:
+                a = rng.integers(0, 20, la).astype(np.uint8)
+                b = np.resize(a, lb).copy()
+                mm = rng.random(lb) < 0.15
+                b[mm] = rng.integers(0, 20, int(mm.sum()))
+                if lb > 40:
+                    b = np.delete(b, rng.integers(0, lb, 5))
+                    b = np.insert(b, rng.integers(0, len(b), 5), rng.integers(0, 20, 5)).astype(np.uint8)
+            a_codes.append(a); b_codes.append(b)
+            wide.append(fits and len(b) == lb)
+    m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.PROTEIN)
+    seqs = [LETTERS_AA[x] for pair in zip(a_codes, b_codes) for x in pair]
+    letters, offsets = _pack(seqs)
+    n = len(a_codes)
+    out = m.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    n_wide = 0
+    for k in range(n):
+        rc, o = oracle.align_protein(a_codes[k], b_codes[k])
+        got = out[k]
+        assert (got["gaps"], got["length"]) == (o["gaps"], o["length"]), (k, len(a_codes[k]), len(b_codes[k]))
+        if got["matches"] == 0xFFFFFFFF:
+            n_wide += 1
+            assert got["mismatches"] == 0xFFFFFFFF
+        else:
+            assert (got["matches"], got["mismatches"]) == (o["matches"], o["mismatches"]), k
+            assert not wide[k], (k, len(a_codes[k]), len(b_codes[k]))  # a pair the wide cell holds went elsewhere
+        if rc == 0:
+            assert np.float32(got["distance"]).tobytes() == np.float32(o["distance"]).tobytes(), k
+        assert np.float32(got["similarity"]).tobytes() == np.float32(o["similarity"]).tobytes(), k
+    assert n_wide >= sum(wide) > 40
+    monkeypatch.setenv("RPA_PROTEIN_WIDE", "0")  # and with the wide cell off: the same bytes for distance / similarity
+    m2 = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.PROTEIN)
+    out2 = m2.align_pairs(letters, offsets, np.arange(n) * 2, np.arange(n) * 2 + 1)
+    assert out2["distance"].tobytes() == out["distance"].tobytes() and out2["similarity"].tobytes() == out["similarity"].tobytes()
+    assert (out2["length"] == out["length"]).all() and (out2["matches"] != 0xFFFFFFFF).all()
+
+
 def _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, speculation=None, exclude_factor=0.5, reeval_bandwidth=0.05):
     model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet, speculation=speculation, exclude_factor=exclude_factor,
                                    reeval_bandwidth=reeval_bandwidth)
@@ -519,6 +576,15 @@ def test_predict_protein(pkg, oracle, synth, lanes, monkeypatch):
     rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 1)
     lens = np.abs(ds.batch["rstop"].astype(np.int64) - ds.batch["rstart"].astype(np.int64)) + 1
     assert (13 * lens + 32 <= 4095).any() and (13 * lens + 32 > 4095).any()
+    # beyond it: 450 and 900 residues (the score-and-length cell up to 1258 x 1258, K3 behind it) -- and the same rows with it off
+    for seg, n_sets in ((450, 40), (900, 16), (1300, 8)):
+        ds = synth.make_dataset(n_sets=n_sets, n_hits=8, seg_len=seg, branching=2, genome_len=2 * seg + 600, seed=7 + seg, alphabet=1,
+                                level_rate=0.06, query_rate=0.08)
+        rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 1)
+        monkeypatch.setenv("RPA_PROTEIN_WIDE", "0")
+        rows0, stats0 = _engine_vs_oracle(pkg, oracle, synth, ds, 1)
+        monkeypatch.delenv("RPA_PROTEIN_WIDE")
+        assert rows.tobytes() == rows0.tobytes() and stats.tobytes() == stats0.tobytes()
 
 
 def test_predict_long_contigs(pkg, oracle, synth):
