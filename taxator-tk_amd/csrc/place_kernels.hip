@@ -108,6 +108,21 @@ struct SetRows {
   __device__ __forceinline__ void store_qd(uint32_t i, float qd) const { reinterpret_cast<float*>(p + (size_t)i * si + sq)[0] = qd; }
   __device__ __forceinline__ float2 result(uint32_t i) const { return res[(size_t)i * sr]; }
 };
+// (t0 = w.tile_base[s >> 6], loaded by the caller: k_decide asks for it together with the set's state, not behind it)
+template <int Q>
+__device__ __forceinline__ SetRows<Q> set_rows(const WorkDev& w, uint32_t s, uint32_t lo, uint32_t tile0) {
+  SetRows<Q> r;
+  uint4* base = reinterpret_cast<uint4*>(w.hits);
+  if (w.tile_base) {
+    const size_t t0 = tile0, l = s & 63u;
+    r.p = base + t0 * Q + l; r.si = 64 * Q; r.sq = 64;
+    r.res = w.pair_res + t0 + l; r.sr = 64;
+  } else {
+    r.p = base + (size_t)lo * Q; r.si = Q; r.sq = 1;
+    r.res = w.pair_res + lo; r.sr = 1;
+  }
+  return r;
+}
 template <int Q>
 __device__ __forceinline__ SetRows<Q> set_rows(const WorkDev& w, uint32_t s, uint32_t lo) {
   SetRows<Q> r;
@@ -823,7 +838,7 @@ __device__ __forceinline__ void state_fill_static(SetState& st, const uint4 info
   st.n = info.x; st.qrstart = info.y; st.qrstop = info.z; st.L = info.z - info.y + 1u;
   st.qseglen = info.w & kLiteLenMask; st.qsegerr = info.w >> 29;
 }
-__device__ __forceinline__ void state_load(const WorkDev& w, uint32_t s, SetState& st) {
+__device__ __forceinline__ void state_load(const WorkDev& w, uint32_t s, SetState& st, const uint4* pre_info = nullptr) {
   const uint4* src = w.state[s].q;
   const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
   st.phase = a.x & 255u; st.loop_live = (a.x >> 8) & 1u; st.combined = (a.x >> 9) & 1u;
@@ -833,7 +848,7 @@ __device__ __forceinline__ void state_load(const WorkDev& w, uint32_t s, SetStat
   st.cnt0 = c.x; st.cnt1 = c.y; st.cnt2 = c.z; st.i_next = c.w; st.chunk_hi = d.x;
   st.nog = 0; st.pad_ = 0; st.d_lnode = 0; st.scut = 0; st.ldist = 0.f; st.udist = 0.f; st.qpid_upper = st.cut_g = st.cut_h = 0.;
   if (st.phase != kDone) {
-    state_fill_static(st, w.set_info[s]);
+    state_fill_static(st, pre_info ? *pre_info : w.set_info[s]);
     if (st.loop_live && st.phase == kPass1Wait) {
       const LoopSave ls = w.loop_save[s];
       st.nog = ls.nog; st.pad_ = ls.pad_; st.d_lnode = ls.d_lnode; st.scut = ls.scut; st.ldist = ls.ldist; st.udist = ls.udist;
@@ -860,6 +875,44 @@ __device__ __forceinline__ void append_live(const WorkDev& w, bool running, uint
   }
   __syncthreads();
   if (running) w.live_out[s_live[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
+}
+
+// The same without making a wavefront wait for its workgroup (k_decide: a wavefront lives for dozens of microseconds and
+// the four of a workgroup finish far apart; with the barriers above each of them also sat out the list reservation's trip
+// to memory -- 15 % of the kernel's wave time, profiles/r04_decide_phases.txt).  Every wavefront leaves its ballot and its
+// sets in LDS and counts itself in; the one that arrives LAST reserves for all four and writes all four's entries (same
+// order inside the workgroup as above).  `arrived` must be zero when the first wavefront gets here (the kernel clears it
+// behind a barrier at its very start, where the wavefronts still run together).
+struct LiveStage {
+  uint32_t arrived;
+  uint32_t pad_;
+  unsigned long long mask[kBlock / 64];
+  uint32_t set[kBlock / 64][64];
+};
+__device__ __forceinline__ void append_live_last_wave(const WorkDev& w, LiveStage& ls, bool running, uint32_t s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(running);
+  ls.set[wave][lane] = s;
+  if (lane == 0) ls.mask[wave] = m;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  uint32_t before = 0;
+  if (lane == 0) before = atomicAdd(&ls.arrived, 1u);
+  before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+  if (before != (uint32_t)(kBlock / 64 - 1)) return;  // (whole wavefront: `before` is uniform)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  uint32_t total = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; ++k) total += (uint32_t)__popcll(ls.mask[k]);
+  if (total == 0) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&w.counters[kCtrActive], total);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; ++k) {
+    const unsigned long long mk = ls.mask[k];
+    if ((mk >> lane) & 1ull) w.live_out[base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = ls.set[k][lane];
+    base += (uint32_t)__popcll(mk);
+  }
 }
 
 // Where a pass-1 chunk ends.  The loop of an anchor stops at the first hit whose score is below its cut-off (:604), and
@@ -1095,21 +1148,34 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
   extern __shared__ float s_band[];
   float* s_fmin = s_band;
   float* s_dmax = s_band + (size_t)w.band_ranks * kBlock;
+  __shared__ LiveStage s_live_stage;
+  if (threadIdx.x == 0) s_live_stage.arrived = 0u;
+  __syncthreads();  // (the only barrier of the kernel: the wavefronts of a workgroup start together and finish far apart)
   // dense rounds: one thread per record set; sparse rounds (few sets still running): one thread per entry of the live list
   const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
   bool live = tid < (w.live_in ? w.n_live_in : b.n_sets);
   const uint32_t s = live ? (w.live_in ? w.live_in[tid] : tid) : 0u;
   SetState st;
   st.phase = kDone;
-  if (live) state_load(w, s, st);
+  // Everything that depends on nothing but the set's number is asked for at once: its state, its static quad, its first row
+  // position and its tile -- a wavefront of this kernel is bound by the number of dependent trips to memory it makes (state
+  // -> offsets -> tile -> rows -> ... : profiles/r04_decide_phases.txt), and these four used to be three trips.
+  uint4 pre_info = make_uint4(0u, 0u, 0u, 0u);
+  uint32_t pre_lo = 0, pre_tile = 0;
+  if (live) {
+    pre_info = w.set_info[s];
+    pre_lo = b.set_offsets[s];
+    if (w.tile_base) pre_tile = w.tile_base[s >> 6];
+    state_load(w, s, st, &pre_info);
+  }
   live = live && st.phase != kDone;
   if (live) {
     EmitInfo em{};
     em.mode = 0; em.n = st.n; em.L = st.L; em.qseglen = st.qseglen;
-    const uint32_t lo = b.set_offsets[s];
+    const uint32_t lo = pre_lo;
     const uint32_t n = st.n, L = st.L;
     const float X = p.exclude_factor;
-    const SetRows<Q> R = set_rows<Q>(w, s, lo);              // rows and alignment results of this set
+    const SetRows<Q> R = set_rows<Q>(w, s, lo, pre_tile);    // rows and alignment results of this set
     const float2* __restrict__ qres_p = w.pair_res + w.P + s;  // result of the anchor <-> query alignment
     const uint32_t nw = (n + 31u) >> 5;
     uint32_t* fq = w.flags + lo;   // qgroup bits
@@ -1603,7 +1669,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     w.emit_lite[s] = emit_desc(em);
     state_store(w, s, st, st.loop_live != 0u && st.phase == kPass1Wait);
   }
-  append_live(w, live && st.phase != kDone, s);  // still running: next round's live list
+  append_live_last_wave(w, s_live_stage, live && st.phase != kDone, s);  // still running: next round's live list
 }
 
 // ---- tiled row layout: per tile of 64 record sets, 64 x (largest record count of the tile) row slots ----

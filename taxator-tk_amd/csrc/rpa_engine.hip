@@ -507,7 +507,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     if (lb_shift < label_shift_for(max_set)) lb_shift = label_shift_for(max_set);
     row_quads = row_quads_for(e->tax.max_depth, lb_shift);
     if (!row_quads)
-      return fail(e, RPA_ERR_UNSUPPORTED, "a record set of %u records on a taxonomy of %u levels: %u levels x %u label bits exceed the widest hit row of this build (832 bits)",
+      return fail(e, RPA_ERR_UNSUPPORTED, "a record set of %u records on a taxonomy of %u levels: %u levels x %u label bits exceed the widest hit row of this build (832 bits: 63 levels for record sets of up to 256 records, 52 up to 65536, 26 beyond) -- prune the taxonomy (taxator -r / -d 1) or split the record set",
                   max_set, e->tax.max_depth, e->tax.max_depth, 1u << lb_shift);
   }
   WorkDev w{};
