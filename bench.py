@@ -771,7 +771,7 @@ def main():
             c4, c5 = CONFIGS["c4"], CONFIGS["c5"]
             for key, c_, sets_, hits_, len_, tag in (("c4", c4, c4["sets"], c4["hits"], c4["seg_len"], "c4"),
                                                      ("c4_200aa", c4, c4["sets"], c4["hits"], 200, None),
-                                                     ("c4_300aa", c4, c4["sets"] // 4, c4["hits"], 300, None),
+                                                     ("c4_450aa", c4, 60_000, c4["hits"], 450, None),  # beyond the packed cell (312 x 312): the score-and-length cell
                                                      ("c5", c5, c5["sets"], c5["hits"], c5["seg_len"], "c5")):
                 try:
                     sec[key] = measure_secondary(pkg, synth, torch, c_, sets_, hits_, len_, 3, args.in_flight, local_rank, profile_tag=tag)
