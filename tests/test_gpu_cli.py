@@ -225,6 +225,30 @@ def test_cli_alignments_sorted_split_and_cutoff_options(oracle, tmp_path, order)
         assert n_sets["-o 1"] == n_sets["default"]
 
 
+def test_cli_taxator_into_binner(oracle, tmp_path):
+    """`taxator | binner` on the GPU box: the GFF3 that taxator prints for queries with several segments goes through the host
+    `binner` (consensus per query: regex group, majority / support, core/binner.cpp:154-340, core/src/predictionranges.hh:
+    117-266) and must come out as the literal Python reading of the reference's binner (tests/test_binner_cpu.py) makes it --
+    the second CLI of the path end to end in the driver's GPU record, not only in the CPU suite."""
+    import subprocess
+    import test_binner_cpu as TB
+    graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    folder = str(tmp_path / "ms")
+    n_queries = _multi_segment_dataset(synth, folder, seed=83, shuffle=True)
+    r = _run(folder, ".fna", extra=["--batch", "500"])
+    assert r.returncode == 0, r.stderr
+    gff3 = r.stdout
+    assert gff3.count("\n") > n_queries
+    tax = R.FlatTaxonomy(os.path.join(folder, "tax"))
+    binner = os.path.join(ROOT, "taxator-tk_amd", "bin", "binner")
+    for extra, kw in (([], {}), (["-j", "0.6", "-s", "40"], dict(majority=0.6, min_support=40)), (["-s", "150", "-j", "0.9"], dict(majority=0.9, min_support=150))):
+        head, body, err = TB.run_binner(binner, os.path.join(folder, "tax"), gff3, extra, cwd=str(tmp_path))
+        exp = TB.naive_binner(gff3.split("\n"), tax, **kw)
+        assert sorted(body) == sorted(exp) and len(body) == n_queries
+        assert len({l.split("\t")[1] for l in body}) > 5
+
+
 @pytest.mark.parametrize("path", [[], ["--record-objects"]])
 def test_cli_errors_like_the_reference(golden_dir, tmp_path, path):
     folder = os.path.join(golden_dir, "survey_edge")
