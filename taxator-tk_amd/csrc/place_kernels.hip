@@ -91,6 +91,7 @@ struct SetRows {
     return c;
   }
   __device__ __forceinline__ float score(uint32_t i) const { return __uint_as_float(reinterpret_cast<const uint32_t*>(p + (size_t)i * si)[0]); }
+  __device__ __forceinline__ uint32_t meta(uint32_t i) const { return reinterpret_cast<const uint32_t*>(p + (size_t)i * si)[3]; }
   __device__ __forceinline__ void path(uint32_t i, uint32_t (&path)[4 * Q - 6]) const {
     const uint4* r = p + (size_t)i * si;
     const uint2 h = reinterpret_cast<const uint2*>(r + sq)[1];
@@ -157,6 +158,24 @@ __device__ __forceinline__ uint32_t meta_err(uint32_t meta) { return (meta >> kM
 // qgroup / outgroup bit sets of one record set (WorkDev::flags)
 __device__ __forceinline__ void bit_clear(uint32_t* words, uint32_t i) { words[i >> 5] &= ~(1u << (i & 31u)); }
 __device__ __forceinline__ void bit_set(uint32_t* words, uint32_t i) { words[i >> 5] |= 1u << (i & 31u); }
+// One of the two bit sets as k_decide sees it: for record sets of up to 32 hits the single word lives in a REGISTER and
+// travels in the set's state record (round 4) -- every read of a group word used to be a trip to memory of its own behind
+// the set's offset, every membership change of the outgroup loop a read-modify-write (profiles/r04_decide_phases.txt: the
+// kernel is bound by the number of such trips); larger sets keep the words in WorkDev::flags.  Indexed like an array.
+struct GroupWords {
+  uint32_t* mem;  // null: the word is `reg`
+  uint32_t reg;
+  struct Ref {
+    GroupWords& g; uint32_t k;
+    __device__ __forceinline__ operator uint32_t() const { return g.mem ? g.mem[k] : g.reg; }
+    __device__ __forceinline__ Ref& operator=(uint32_t v) { if (g.mem) g.mem[k] = v; else g.reg = v; return *this; }
+    __device__ __forceinline__ Ref& operator&=(uint32_t v) { if (g.mem) g.mem[k] &= v; else g.reg &= v; return *this; }
+    __device__ __forceinline__ Ref& operator|=(uint32_t v) { if (g.mem) g.mem[k] |= v; else g.reg |= v; return *this; }
+  };
+  __device__ __forceinline__ Ref operator[](uint32_t k) { return Ref{*this, k}; }
+};
+__device__ __forceinline__ void bit_clear(GroupWords& words, uint32_t i) { words[i >> 5] &= ~(1u << (i & 31u)); }
+__device__ __forceinline__ void bit_set(GroupWords& words, uint32_t i) { words[i >> 5] |= 1u << (i & 31u); }
 
 // length of the common prefix of two label paths = depth of the LCA of the two nodes: the first bit in which the strings
 // differ, in labels (lb_shift = log2 of the label width), never more than either node's own depth
@@ -824,7 +843,7 @@ __device__ __forceinline__ void state_store(const WorkDev& w, uint32_t s, const 
   m.q[1] = make_uint4((st.d_lca_all & 255u) | ((st.d_rtax & 255u) << 8) | ((st.d_lnode_g & 255u) << 16) | (st.d_unode_g << 24), st.lrd_min,
                       __float_as_uint(st.ival_g), __float_as_uint(st.bf_max));
   m.q[2] = make_uint4(st.cnt0, st.cnt1, st.cnt2, st.i_next);
-  m.q[3] = make_uint4(st.chunk_hi, 0u, 0u, 0u);
+  m.q[3] = make_uint4(st.chunk_hi, st.gq, st.go, 0u);
   uint4* dst = w.state[s].q;
   dst[0] = m.q[0]; dst[1] = m.q[1]; dst[2] = m.q[2]; dst[3] = m.q[3];
   if (save_loop) {
@@ -845,7 +864,7 @@ __device__ __forceinline__ void state_load(const WorkDev& w, uint32_t s, SetStat
   st.support = a.y; st.best = a.z; st.anchor = a.w;
   st.d_lca_all = b.x & 255u; st.d_rtax = (b.x >> 8) & 255u; st.d_lnode_g = (b.x >> 16) & 255u; st.d_unode_g = b.x >> 24;
   st.lrd_min = b.y; st.ival_g = __uint_as_float(b.z); st.bf_max = __uint_as_float(b.w);
-  st.cnt0 = c.x; st.cnt1 = c.y; st.cnt2 = c.z; st.i_next = c.w; st.chunk_hi = d.x;
+  st.cnt0 = c.x; st.cnt1 = c.y; st.cnt2 = c.z; st.i_next = c.w; st.chunk_hi = d.x; st.gq = d.y; st.go = d.z;
   st.nog = 0; st.pad_ = 0; st.d_lnode = 0; st.scut = 0; st.ldist = 0.f; st.udist = 0.f; st.qpid_upper = st.cut_g = st.cut_h = 0.;
   if (st.phase != kDone) {
     state_fill_static(st, pre_info ? *pre_info : w.set_info[s]);
@@ -964,7 +983,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
     state_fill_static(st, info);
     st.support = 0; st.best = 0; st.d_lca_all = 0; st.d_rtax = 0; st.d_lnode_g = 0; st.d_unode_g = 0; st.ival_g = 0.f;
     st.bf_max = 1.f; st.lrd_min = 255; st.anchor = 0; st.cnt0 = st.cnt1 = st.cnt2 = 0; st.loop_live = 0; st.chunk_hi = 0; st.i_next = 0;
-    st.combined = 0; st.pad_ = 0;
+    st.combined = 0; st.pad_ = 0; st.gq = 0; st.go = 0;
     OutRow row;
     row.begin = 1; row.end = b.query_len[s];  // initPredictionRecord, core/src/taxonpredictionmodel.hh:42-44
     row.lower = row.upper = row.rtax = kRoot; row.support = 0; row.ival = 0.f; row.flags = 0;
@@ -1178,8 +1197,8 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     const SetRows<Q> R = set_rows<Q>(w, s, lo, pre_tile);    // rows and alignment results of this set
     const float2* __restrict__ qres_p = w.pair_res + w.P + s;  // result of the anchor <-> query alignment
     const uint32_t nw = (n + 31u) >> 5;
-    uint32_t* fq = w.flags + lo;   // qgroup bits
-    uint32_t* fo = fq + nw;        // outgroup bits
+    GroupWords fq{nw == 1u ? nullptr : w.flags + lo, st.gq};        // qgroup bits
+    GroupWords fo{nw == 1u ? nullptr : w.flags + lo + nw, st.go};   // outgroup bits
     bool failed = false;
 
     // Normally one trip: consume the results of the phase the set waited for, then choose what to align next.  A set
@@ -1327,8 +1346,14 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     } else if (st.phase == kPass1Wait) {  // ---- pass 1 for one anchor, :580-728 ----
       const uint32_t a = st.anchor;
       uint32_t pa[PW], pb[PW];
+      // (the loads that depend on the state alone go out together: the anchor's row, the best hit's, the walk's first two)
+      const uint32_t i_first = st.loop_live ? st.i_next : 0u;
       const Row<Q> ra = R.load(a);
       const Row<Q> rb = R.load(st.best);
+      Row<Q> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
+      float2 rn = make_float2(0.f, 0.f), rn2 = rn;
+      if (i_first < n) { nxt = R.load(i_first); rn = R.result(i_first); }
+      if (i_first + 1 < n) { nx2 = R.load(i_first + 1); rn2 = R.result(i_first + 1); }
       const HitCore ha = row_core<Q>(ra);
       row_path<Q>(ra, pa);
       const uint32_t da = meta_depth(ha.meta);
@@ -1361,10 +1386,6 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       unsigned long long ogmask = (small && st.loop_live) ? ((unsigned long long)st.pad_ << 32) | st.nog : 0ull;
       unsigned long long fqclr = 0ull;
       bool paused = false;
-      Row<Q> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
-      float2 rn = make_float2(0.f, 0.f), rn2 = rn;
-      if (i < n) { nxt = R.load(i); rn = R.result(i); }
-      if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
       auto walk = [&](auto small_tag) {
       constexpr bool kSmall = decltype(small_tag)::value;
       for (; d_lnode != 0 && i < n; ++i) {  // :604 (lnode != root)
@@ -1489,25 +1510,52 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           for (uint32_t k = 0; k < nog; ++k) upper((float)ogd[k]);
         }
         uint32_t d_unode = d_lnode;  // unode = lnode, :690 -- (float)INT_MAX != FLT_MAX, so always taken
-        unsigned long long mleft = ogmask;
-        for (uint32_t k = 0; small ? mleft != 0ull : k < nog; ++k) {  // :691-711
-          uint32_t io;
-          float dist;
-          if (small) { io = (uint32_t)__ffsll((long long)mleft) - 1u; mleft &= mleft - 1ull; dist = (float)(int)R.result(io).x; }
-          else { io = ogi[k]; dist = (float)ogd[k]; }
-          if (dist > min_upper_dist) continue;
-          const Row<Q> ri = R.load(io);
-          uint32_t pth[PW];
-          row_path<Q>(ri, pth);
-          const uint32_t cb = common<PW>(pb, db, pth, meta_depth(row_core<Q>(ri).meta), lbs);
+        auto member = [&](uint32_t io, float dist, const uint32_t (&pth)[PW], uint32_t depth) {  // one outgroup_tmp entry, :691-711
+          if (dist > min_upper_dist) return;
+          const uint32_t cb = common<PW>(pb, db, pth, depth, lbs);
           d_unode = min(d_unode, cb);                          // unode = LCA(cnode, unode)
           const uint32_t lca_root_dist = min(st.d_rtax, cb);   // depth(LCA(cnode, rtax))
-          if (lca_root_dist > st.lrd_min) continue;
+          if (lca_root_dist > st.lrd_min) return;
           if (lca_root_dist < st.lrd_min) {
             st.lrd_min = lca_root_dist;
             for (uint32_t kk = 0; kk < nw; ++kk) fo[kk] = 0u;  // outgroup.clear()
           }
           bit_set(fo, io);
+        };
+        if (small) {
+          // members in index order; what a member needs (its distance, its path, its depth) is asked for FOUR members at a time
+          // (narrow rows): a member used to be two dependent trips to memory, its result and then its row
+          constexpr int kBatch = PW <= 2 ? 4 : 1;
+          unsigned long long mleft = ogmask;
+          while (mleft) {
+            uint32_t io[kBatch], depth[kBatch], pth[kBatch][PW];
+            float dd[kBatch];
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+              io[q] = 0u;
+              if (mleft) { io[q] = (uint32_t)__ffsll((long long)mleft) - 1u; mleft &= mleft - 1ull; cnt = q + 1; }
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+              if (q < cnt) {
+                dd[q] = (float)(int)R.result(io[q]).x;  // (float)(int): outgroup_tmp holds int distances
+                R.path(io[q], pth[q]);
+                depth[q] = meta_depth(R.meta(io[q]));
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+              if (q < cnt) member(io[q], dd[q], pth[q], depth[q]);
+          }
+        } else {
+          for (uint32_t k = 0; k < nog; ++k) {
+            const uint32_t io = ogi[k];
+            const Row<Q> ri = R.load(io);
+            uint32_t pth[PW];
+            row_path<Q>(ri, pth);
+            member(io, (float)ogd[k], pth, meta_depth(row_core<Q>(ri).meta));
+          }
         }
         float ival = 0.f;  // :714-719
         if (d_unode != d_lnode && ldist < qdist) ival = (qdist - ldist) / (udist - ldist);
@@ -1521,22 +1569,25 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       }
     } else if (st.phase == kPass2Wait) {  // ---- pass 2 for one anchor, :750-820 ----
       const uint32_t a = st.anchor;
+      // every load that depends on the state alone goes out before anything is looked at: the anchor's and the best hit's
+      // rows, the thresholds of the anchor, the first two rows of the walk, the anchor <-> query result (one trip, not four)
+      uint32_t i = st.loop_live ? st.i_next : 0u;
       const Row<Q> ra = R.load(a);
       const Row<Q> rb = R.load(st.best);
+      const EmitInfo sel = w.emit[s];            // thresholds were fixed when the anchor was selected (:750-754)
+      Row<Q> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
+      float2 rn = make_float2(0.f, 0.f), rn2 = rn;
+      if (i < n) { nxt = R.load(i); rn = R.result(i); }
+      if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
+      const float2 q2_pre = *qres_p;             // (read by the walk only when the anchor was never aligned to the query, :792)
       const HitCore ha = row_core<Q>(ra);
       uint32_t pb[PW];
       row_path<Q>(rb, pb);
       const uint32_t db = meta_depth(row_core<Q>(rb).meta);
       float qd_a = ha.qd, qs_a = ha.qs;
-      const EmitInfo sel = w.emit[s];            // thresholds were fixed when the anchor was selected (:750-754)
       const double qpid_thresh = sel.qpid_thresh;
       const float scut = sel.fcut;
       bool paused = false;
-      uint32_t i = st.loop_live ? st.i_next : 0u;
-      Row<Q> nxt = ra, nx2 = ra;  // rows i+1 and i+2 are in flight while row i is worked on
-      float2 rn = make_float2(0.f, 0.f), rn2 = rn;
-      if (i < n) { nxt = R.load(i); rn = R.result(i); }
-      if (i + 1 < n) { nx2 = R.load(i + 1); rn2 = R.result(i + 1); }
       // (sets of up to 64 hits: the stores of the walk -- querydistance[i], the anchor's pair, outgroup bits to clear -- are
       // noted in registers and done behind it, for the same reason as in pass 1)
       const bool small = n <= 64u;
@@ -1572,7 +1623,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
         } else {
           float qdist_ex;
           if (qd_a == FLT_MAX) {  // :792-808
-            const float2 q2 = *qres_p;
+            const float2 q2 = q2_pre;
             if (!result_ok(w, s, meta_err(ha.meta), st.qsegerr, q2.x)) { failed = true; break; }
             const float d2 = q2.x;
             const float s2 = q2.y < qs_a ? qs_a : q2.y;
@@ -1589,9 +1640,20 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       if (small) walk(std::true_type{}); else walk(std::false_type{});
       if (small && !failed) {
         if (anchor_pair) R.store_qdqs(a, qd_a, qs_a);
-        for (unsigned long long m = qdmask; m; m &= m - 1ull) {
-          const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
-          R.store_qd(k, R.result(k).x);
+        for (unsigned long long m = qdmask; m;) {  // querydistance[i] = dist (:785), four results asked for at a time
+          uint32_t kk[4];
+          float dd[4];
+          int cnt = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            kk[q] = 0u;
+            if (m) { kk[q] = (uint32_t)__ffsll((long long)m) - 1u; m &= m - 1ull; cnt = q + 1; }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dd[q] = q < cnt ? R.result(kk[q]).x : 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < cnt) R.store_qd(kk[q], dd[q]);
         }
         for (uint32_t k = 0; k < nw && foclr; ++k) {
           const uint32_t clr = (uint32_t)(foclr >> (32u * k));
@@ -1667,6 +1729,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     if (failed) { st.phase = kDone; em.mode = 0; }
     if (em.mode == 3u || em.mode == 5u) w.emit[s] = em;  // thresholds that only the full record holds
     w.emit_lite[s] = emit_desc(em);
+    st.gq = fq.reg; st.go = fo.reg;
     state_store(w, s, st, st.loop_live != 0u && st.phase == kPass1Wait);
   }
   append_live_last_wave(w, s_live_stage, live && st.phase != kDone, s);  // still running: next round's live list

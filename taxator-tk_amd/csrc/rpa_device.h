@@ -108,6 +108,7 @@ struct SetState {
   double qpid_upper, cut_g, cut_h;
   uint32_t combined;   // pass 0 and the pass-1 loop of hit 0 were requested together (EmitInfo mode 4)
   uint32_t pad_;       // sets of up to 64 hits: the high word of that bit set
+  uint32_t gq, go;     // sets of up to 32 hits: the query-group / outgroup word (else WorkDev::flags holds the words)
 };
 
 // One hit of a record set at its SortFilter position: Q quads of 16 bytes (Q = WorkDev::row_quads, 2 for taxonomies of up
