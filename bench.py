@@ -365,7 +365,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 = the headline configuration (BASELINE config 2); c3 = config 3's per-GPU share (for --gpus 8), c4 protein, "
                          "c5 long contigs are extra measurements")
-    ap.add_argument("--in-flight", type=int, default=3, help="with --host-buffers / --pipeline: jobs submitted before the oldest is waited for (1..3)")
+    ap.add_argument("--in-flight", type=int, default=4, help="jobs submitted before the oldest is waited for (1 .. RPA_JOBS_IN_FLIGHT = 4; profiles/r04_inflight_sweep.txt)")
     ap.add_argument("--pipeline", action="store_true",
                     help="(the default, kept for old command lines) the steps go through rpa_submit_batch with --in-flight of them "
                          "running at a time on the engine's job slots: the placement rounds of one step under the alignment kernels of "
@@ -492,7 +492,7 @@ def main():
     # RCCL: the gather of step k runs beside the kernels of step k + 1 (rows double-buffered; every step's rows still reach
     # rank 0 inside the timed region).  gloo rehearsals keep the plain blocking gather.
     pipelined = not args.sync and not args.host_buffers
-    args.in_flight = max(1, min(int(os.environ.get("RPA_JOB_SLOTS", "3")), args.in_flight))
+    args.in_flight = max(1, min(int(os.environ.get("RPA_JOB_SLOTS", "4")), args.in_flight))
     overlap_gather = use_dist and not gloo and not args.host_buffers and not pipelined
     rows_buf = [rows, torch.zeros_like(rows)] if overlap_gather else [rows]
     stats_buf = [stats, torch.zeros_like(stats)] if overlap_gather else [stats]

@@ -221,7 +221,7 @@ int rpa_trace_read(rpa_engine* e, rpa_trace_entry* out, uint64_t capacity, uint6
  * you reuse from batch to batch once (page-pinning itself is slow: a few GB/s), unregister before freeing them. */
 int rpa_host_register(rpa_engine* e, void* ptr, size_t bytes);
 int rpa_host_unregister(rpa_engine* e, void* ptr);
-#define RPA_JOBS_IN_FLIGHT 3
+#define RPA_JOBS_IN_FLIGHT 4
 typedef struct rpa_job rpa_job;
 int rpa_submit_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out, rpa_stats* stats, rpa_job** job);
 int rpa_wait(rpa_engine* e, rpa_job* job);

@@ -258,7 +258,7 @@ class RPAPredictionModel:
         self._check(self._L.rpa_host_unregister(self._h, array.ctypes.data))
 
     def submit(self, batch, want_stats=True, out=None, stats=None, mem_kind=MEM_HOST):
-        """Asynchronous predict: returns a job; job.wait() -> (rows, stats).  RPA_JOBS_IN_FLIGHT (3) jobs run at a time.
+        """Asynchronous predict: returns a job; job.wait() -> (rows, stats).  RPA_JOBS_IN_FLIGHT (4) jobs run at a time.
         mem_kind=MEM_DEVICE: batch / out / stats are torch cuda tensors that are complete (synchronise your stream first).
         The job object owns every buffer the engine reads or writes until wait() has returned; a job that is dropped without
         wait() (an exception between submit and wait) waits in its finaliser, so the buffers never go away under the engine."""

@@ -551,6 +551,16 @@ constexpr int kEmitSpan = kEmitBlock * kEmitRows;
 
 // "can the loop the set is about to run reach the alignment of the hit at row `pos`?"  Passes 0 and 1 decide from the
 // row's 4-byte lite word alone; pass 2 (few sets, late rounds) reads the row.  Returns the bin (or -1), fills entry / maxlen.
+// what the emit kernels use of a mode-3 / mode-5 request, from its two quads (emit_desc, emit_ext_quad)
+__device__ __forceinline__ EmitInfo emit_info_from(const uint4 desc, const uint4 ext) {
+  EmitInfo e{};
+  e.mode = desc.x & 7u; e.anchor = desc.x >> 3; e.i_lo = desc.y; e.i_hi = desc.z; e.n = desc.z; e.anchor_len = desc.w;
+  e.fcut = __uint_as_float(ext.x); e.qs_min = __uint_as_float(ext.y);
+  e.best = ext.z & 0x00FFFFFFu; e.d_unode_g = ext.z >> 24;
+  e.qseglen = ext.w & 0x7FFFFFFFu; e.emit_query = ext.w >> 31;
+  return e;
+}
+
 template <int Q>
 __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& w, const Params& p, const EmitInfo& info, uint32_t s,
                                               uint32_t lo, uint32_t pos, const uint32_t lite, uint2& entry, uint32_t& maxlen) {
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
   for (int i = threadIdx.x; i < kNumBins * kVW; i += kEmitBlock) (&s_cnt[0][0])[i] = 0u;  // only bins that occur get a count below
   __syncthreads();
   uint32_t set_of[kEmitRows], lo[kEmitRows], lite[kEmitRows];
-  uint4 desc[kEmitRows];
+  uint4 desc[kEmitRows], ext[kEmitRows];
 #pragma unroll
   for (int k = 0; k < kEmitRows; ++k) {  // level 1: row position -> record set; the row's lite word rides along
     const uint32_t pos = pos0 + k * kEmitBlock;
@@ -610,8 +620,8 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
   }
 #pragma unroll
   for (int k = 0; k < kEmitRows; ++k) {  // level 2: what the set wants (16-byte descriptor)
-    desc[k] = make_uint4(0u, 0u, 0u, 0u); lo[k] = 0;
-    if (set_of[k] != 0xFFFFFFFFu) { desc[k] = w.emit_lite[set_of[k]]; lo[k] = b.set_offsets[set_of[k]]; }
+    desc[k] = make_uint4(0u, 0u, 0u, 0u); ext[k] = desc[k]; lo[k] = 0;
+    if (set_of[k] != 0xFFFFFFFFu) { desc[k] = w.emit_lite[set_of[k]]; ext[k] = w.emit_ext[set_of[k]]; lo[k] = b.set_offsets[set_of[k]]; }
   }
   int bin[kEmitRows];
   uint2 entry[kEmitRows];
@@ -637,12 +647,12 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
             if (bin[k] >= kNumBins) { raise_error(w, kErrUnsupported, set_of[k]); bin[k] = -1; }
           }
         } else {
-          const EmitInfo info = w.emit[set_of[k]];
+          const EmitInfo info = emit_info_from(desc[k], ext[k]);  // (modes 3 and 5: the two quads say it all -- no trip to the 64-byte record)
           bin[k] = emit_predicate<Q>(b, w, p, info, set_of[k], lo[k], pos, lite[k], entry[k], ml);
         }
       }
     } else if (pos < total && mode == 3u) {  // anchor <-> query range (:792-797)
-      const EmitInfo info = w.emit[set_of[k]];
+      const EmitInfo info = emit_info_from(desc[k], ext[k]);
       if (info.emit_query) {
         bin[k] = pair_bin(p, info.anchor_len, info.qseglen);
         ml = p.alphabet == 0 ? max(info.anchor_len, info.qseglen) : info.anchor_len;
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDe
     s = w.live_in[wave_id];
     const uint4 desc = w.emit_lite[s];
     info.mode = desc.x & 7u;
-    if (info.mode == 3u || info.mode == 5u) info = w.emit[s];  // pass 2: thresholds, best hit, depth of unode_global; 5: thresholds
+    if (info.mode == 3u || info.mode == 5u) info = emit_info_from(desc, w.emit_ext[s]);  // pass 2: thresholds, best hit, depth of unode_global; 5: thresholds
     else {                                  // passes 0 and 1: the descriptor says it all (emit_desc)
       info.anchor = desc.x >> 3; info.n = desc.z; info.i_hi = desc.z;
       info.i_lo = info.mode == 4u ? 0u : desc.y;
@@ -1727,7 +1737,11 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     em.mode = 0;                // nothing asked for yet: the second trip decides
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
-    if (em.mode == 3u || em.mode == 5u) w.emit[s] = em;  // thresholds that only the full record holds
+    if (em.mode == 3u || em.mode == 5u) {  // thresholds that only the full record holds (k_decide reads it back), and their 16-byte form for k_emit
+      w.emit[s] = em;
+      w.emit_ext[s] = emit_ext_quad(em);
+      if (em.best > 0x00FFFFFFu) raise_error(w, kErrUnsupported, s);  // (a record set of more than 16 M records)
+    }
     w.emit_lite[s] = emit_desc(em);
     st.gq = fq.reg; st.go = fo.reg;
     state_store(w, s, st, st.loop_live != 0u && st.phase == kPass1Wait);

@@ -174,6 +174,15 @@ __host__ __device__ __forceinline__ uint4 emit_desc(const EmitInfo& e) {
   return uint4{e.mode | (e.anchor << 3), e.mode == 4u ? e.qseglen : e.i_lo, e.i_hi < e.n ? e.i_hi : e.n, e.mode == 1u ? e.qseglen : e.anchor_len};
 }
 
+// ... and the 16 bytes more that a pass-2 request (mode 3) or a pass-1 request with thresholds (mode 5) adds: k_emit reads them
+// beside emit_lite instead of fetching the 64-byte EmitInfo behind it (one dependent load level less per row).
+// x = fcut, y = qs_min (float bits), z = best | d_unode_g << 24, w = qseglen | emit_query << 31
+__host__ __device__ __forceinline__ uint4 emit_ext_quad(const EmitInfo& e) {
+  union { float f; uint32_t u; } a, b;
+  a.f = e.fcut; b.f = e.qs_min;
+  return uint4{a.u, b.u, (e.best & 0x00FFFFFFu) | (e.d_unode_g << 24), (e.qseglen & 0x7FFFFFFFu) | (e.emit_query ? 0x80000000u : 0u)};
+}
+
 // Per-batch working set (all device pointers; sizes in comments; H = n_records, S = n_sets, T = H + S).
 struct WorkDev {
   SetStateMem* state;   // S
@@ -185,6 +194,7 @@ struct WorkDev {
   uint4* set_info;      // S   (n active, qrstart, qrstop, length of the query range segment | its fetch error code << 29)
   EmitInfo* emit;       // S   written for pass 2 only (mode 3): passes 0 and 1 are described completely by emit_lite
   uint4* emit_lite;     // S   emit_desc(emit[s])
+  uint4* emit_ext;      // S   emit_ext_quad(emit[s]): what k_emit needs of a pass-2 / mode-5 request beyond emit_lite (written with emit[s])
   const uint32_t* rec_pre;  // H   record -> preorder number of its taxon (k_validate_batch)
   uint32_t* hit_set;    // H   row position -> record set
   uint32_t* block_first;  // per workgroup of k_rank_records (logical order): record set of its first record

@@ -98,7 +98,7 @@ struct rpa_engine {
   std::string err;
   // batch staging (host batches) and working set
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
-  DevBuf state, loop_save, rec_pre, hits, set_info, emit, emit_lite, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
+  DevBuf state, loop_save, rec_pre, hits, set_info, emit, emit_lite, emit_ext, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
       protein_ws, lanes_counter, retry_list, retry_short;
   uint32_t* h_counters = nullptr;  // pinned
@@ -409,6 +409,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->set_info.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
   HIP_TRY(e, e->emit.ensure((size_t)(S ? S : 1) * sizeof(EmitInfo)));
   HIP_TRY(e, e->emit_lite.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
+  HIP_TRY(e, e->emit_ext.ensure((size_t)(S ? S : 1) * sizeof(uint4)));
   HIP_TRY(e, e->hit_set.ensure((size_t)(H ? H : 1) * 4));
   HIP_TRY(e, e->block_first.ensure(((size_t)H / kBlock + 16) * 4));  // one word per k_rank_records workgroup (grid rounded up to 8)
   HIP_TRY(e, e->flags.ensure((size_t)(H ? H : 1) * 4));
@@ -429,14 +430,14 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   HIP_TRY(e, e->og_idx.ensure((size_t)(T2 ? T2 : 1) * 4));
   HIP_TRY(e, e->og_dist.ensure((size_t)(T2 ? T2 : 1) * 4));
   if (e->poison) {
-    DevBuf* bufs[] = {&e->state, &e->loop_save, &e->hits, &e->res_slot, &e->set_info, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first,
+    DevBuf* bufs[] = {&e->state, &e->loop_save, &e->hits, &e->res_slot, &e->set_info, &e->emit, &e->emit_lite, &e->emit_ext, &e->hit_set, &e->block_first,
                       &e->flags, &e->lite, &e->seg, &e->pair_a, &e->pair_b, &e->pair_res, &e->pair_ext, &e->bin_list, &e->live_a, &e->live_b,
                       &e->band_save, &e->og_idx, &e->og_dist, &e->retry_list, &e->retry_short, &e->protein_ws, &e->out_rows, &e->out_stats};
     for (DevBuf* b : bufs)
       if (b->p) HIP_TRY(e, hipMemsetAsync(b->p, 0xA5, b->cap, e->stream));
   }
   w->state = e->state.as<SetStateMem>(); w->loop_save = e->loop_save.as<LoopSave>(); w->hits = e->hits.as<uint32_t>(); w->set_info = e->set_info.as<uint4>();
-  w->emit = e->emit.as<EmitInfo>(); w->emit_lite = e->emit_lite.as<uint4>(); w->hit_set = e->hit_set.as<uint32_t>(); w->block_first = e->block_first.as<uint32_t>();
+  w->emit = e->emit.as<EmitInfo>(); w->emit_lite = e->emit_lite.as<uint4>(); w->emit_ext = e->emit_ext.as<uint4>(); w->hit_set = e->hit_set.as<uint32_t>(); w->block_first = e->block_first.as<uint32_t>();
   w->rec_pre = e->rec_pre.as<const uint32_t>();
   w->flags = e->flags.as<uint32_t>();
   w->lite = e->lite.as<uint32_t>();
@@ -946,7 +947,7 @@ void rpa_destroy(rpa_engine* e) {
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   DevBuf* bufs[] = {&e->tax_parent, &e->tax_left, &e->tax_right, &e->tax_depth, &e->tax_pre, &e->tax_last, &e->tax_anc, &e->tax_anc_iv, &e->loop_save, &e->rec_pre, &e->trace_buf, &e->trace_count, &e->in_f32, &e->in_u8, &e->in_f64, &e->in_uncl, &e->state, &e->hits,
                     &e->set_info, &e->seg,
-                    &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
+                    &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->emit_ext, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
                     &e->protein_ws, &e->retry_list, &e->retry_short, &e->prof_acc, &e->part_offsets};
   RPA_WHERE("rpa_destroy: hipFree of the buffers");
