@@ -11,66 +11,136 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
+#include <thread>
+
+#include "hostcpus.hh"
 
 namespace taxator {
 
-// Line-wise over 4 MiB reads: a header line opens a record, every other line is appended minus blanks.  memchr finds
-// the line ends and whole lines are copied at once (the usual 60-80 column FASTA has no blanks inside lines), so loading
-// runs at a few GB/s instead of one branch per byte.
+// The whole FASTA, by all host threads (round 4: one thread loaded config 2's 200 MB of queries, a million records, in
+// 0.45 s -- more than the pipeline then needs for the alignments themselves).  The file is mapped and cut into chunks at
+// line starts; pass 1 counts, per chunk, the header lines and the residues (every byte of a non-header line that is not a
+// blank; bytes in front of the file's first header belong to no record); prefix sums give every chunk its first record and
+// its place in the letters; pass 2 copies whole lines (memchr finds the line ends; the usual 60-80 column FASTA has no blanks
+// inside lines) and writes identifiers and offsets where they belong.  The identifier -> index map is built on the first
+// getIndex(): the columnar reader has a table of its own and never asks.
+namespace {
+inline bool is_blank(char c) { return c == '\r' || c == ' ' || c == '\t'; }
+struct FastaChunk {
+  const char* begin; const char* end;
+  size_t records = 0, residues = 0;
+  size_t first_record = 0, first_residue = 0;
+};
+// calls header(s, e) / residues(s, e) per line of [begin, end); lines are '\n'-separated, the last may lack its '\n'
+template <class H, class R>
+inline void for_fasta_lines(const char* begin, const char* end, H&& header, R&& residues) {
+  for (const char* s = begin; s < end;) {
+    const char* nl = (const char*)memchr(s, '\n', (size_t)(end - s));
+    const char* e = nl ? nl : end;
+    if (s != e) { if (*s == '>') header(s + 1, e); else residues(s, e); }
+    s = nl ? nl + 1 : end;
+  }
+}
+}  // namespace
+
 SequenceStore::SequenceStore(const std::string& fasta_filename) {
-  FILE* f = fopen(fasta_filename.c_str(), "rb");
-  if (!f) throw FileNotFound(fasta_filename);
-  if (fseek(f, 0, SEEK_END) == 0) {
-    const long sz = ftell(f);
-    if (sz > 0) letters_.reserve((size_t)sz);
-    fseek(f, 0, SEEK_SET);
-  }
+  const int fd = open(fasta_filename.c_str(), O_RDONLY);
+  if (fd < 0) throw FileNotFound(fasta_filename);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); throw FileNotFound(fasta_filename); }
+  const size_t len = (size_t)sb.st_size;
   offsets_.push_back(0);
-  bool have_record = false;
-  auto add_header = [&](const char* s, const char* e) {  // s points behind '>'
-    if (have_record) offsets_.push_back(letters_.size());
-    have_record = true;
-    std::string id;
-    for (; s < e; ++s) {
-      if (*s == '\r') continue;
-      if (isspace((unsigned char)*s)) break;
-      id.push_back(*s);
-    }
-    add_id(id);
-  };
-  auto add_line = [&](const char* s, const char* e) {
-    if (s == e) return;
-    if (*s == '>') { add_header(s + 1, e); return; }
-    if (!have_record) return;
-    const size_t n = (size_t)(e - s);
-    if (!memchr(s, '\r', n) && !memchr(s, ' ', n) && !memchr(s, '\t', n)) { letters_.insert(letters_.end(), s, e); return; }
-    for (; s < e; ++s)
-      if (*s != '\r' && *s != ' ' && *s != '\t') letters_.push_back((uint8_t)*s);  // readRegion skips whitespace (faidx.h:340-347)
-  };
-  std::vector<char> buf((size_t)4 << 20);
-  size_t fill = 0;
-  for (;;) {
-    if (fill == buf.size()) buf.resize(buf.size() * 2);  // a single line longer than the buffer
-    const size_t got = fread(buf.data() + fill, 1, buf.size() - fill, f);
-    fill += got;
-    const bool eof = got == 0;
-    const char* s = buf.data();
-    const char* end = buf.data() + fill;
-    while (s < end) {
-      const char* nl = (const char*)memchr(s, '\n', (size_t)(end - s));
-      if (!nl) {
-        if (!eof) break;
-        nl = end;
-      }
-      add_line(s, nl);
-      s = nl < end ? nl + 1 : end;
-    }
-    fill = (size_t)(end - s);
-    memmove(buf.data(), s, fill);
-    if (eof) break;
+  if (len == 0) { close(fd); return; }
+  void* m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) throw FileNotFound(fasta_filename + " (mmap failed)");
+  (void)madvise(m, len, MADV_SEQUENTIAL);
+  const char* base = (const char*)m;
+  const char* file_end = base + len;
+  size_t per_chunk = (size_t)4 << 20;  // (TAXATOR_FASTA_CHUNK=bytes: tests cut small files into many chunks)
+  if (const char* v = getenv("TAXATOR_FASTA_CHUNK")) per_chunk = (size_t)std::max(1ll, atoll(v));
+  const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(per_chunk < ((size_t)4 << 20) ? 64 : usable_cpus(), len / per_chunk + 1));
+  std::vector<FastaChunk> chunks(T);
+  const char* p = base;
+  for (unsigned t = 0; t < T; ++t) {
+    chunks[t].begin = p;
+    const char* q = t + 1 == T ? file_end : base + len * (t + 1) / T;
+    if (q < p) q = p;
+    if (q < file_end) { const char* nl = (const char*)memchr(q, '\n', (size_t)(file_end - q)); q = nl ? nl + 1 : file_end; }
+    chunks[t].end = q;
+    p = q;
   }
-  fclose(f);
-  if (have_record) offsets_.push_back(letters_.size());
+  auto run = [&](auto&& fn) {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([&, t] { fn(chunks[t], t); });
+    fn(chunks[0], 0u);
+    for (auto& x : th) x.join();
+  };
+  // ---- pass 1: records and residues per chunk (residues in front of the chunk's first header apart: they belong to a record
+  // only if an earlier chunk opened one) ----
+  std::vector<size_t> lead(T, 0);
+  run([&](FastaChunk& c, unsigned t) {
+    size_t before = 0, after = 0;
+    bool own_header = false;
+    for_fasta_lines(c.begin, c.end,
+                    [&](const char*, const char*) { ++c.records; own_header = true; },
+                    [&](const char* s, const char* e) {
+                      size_t n = (size_t)(e - s);
+                      if (memchr(s, '\r', n) || memchr(s, ' ', n) || memchr(s, '\t', n)) { size_t k = 0; for (; s < e; ++s) k += is_blank(*s) ? 0 : 1; n = k; }
+                      (own_header ? after : before) += n;
+                    });
+    lead[t] = before; c.residues = after;
+  });
+  size_t n_rec = 0, n_res = 0;
+  bool seen_header = false;
+  for (unsigned t = 0; t < T; ++t) {
+    FastaChunk& c = chunks[t];
+    if (seen_header) c.residues += lead[t];  // (else: bytes in front of the file's first header, dropped)
+    seen_header = seen_header || c.records != 0;
+    c.first_record = n_rec; c.first_residue = n_res;
+    n_rec += c.records; n_res += c.residues;
+  }
+  letters_.resize(n_res);
+  offsets_.assign(n_rec + 1, 0);
+  ids_.resize(n_rec);
+  // ---- pass 2: identifiers, offsets, letters ----
+  std::vector<uint8_t> headerless(T, 0);
+  for (unsigned t = 0, before = 1; t < T; ++t) { headerless[t] = (uint8_t)before; if (chunks[t].records) before = 0; }
+  run([&](FastaChunk& c, unsigned t) {
+    size_t rec = c.first_record, pos = c.first_residue;
+    bool open_record = !headerless[t];
+    uint8_t* out = letters_.data();
+    for_fasta_lines(c.begin, c.end,
+                    [&](const char* s, const char* e) {  // s points behind '>': the identifier ends at the first whitespace (faidx.h:590)
+                      offsets_[rec] = pos;
+                      std::string& id = ids_[rec++];
+                      for (; s < e; ++s) {
+                        if (*s == '\r') continue;
+                        if (isspace((unsigned char)*s)) break;
+                        id.push_back(*s);
+                      }
+                      open_record = true;
+                    },
+                    [&](const char* s, const char* e) {
+                      if (!open_record) return;
+                      const size_t n = (size_t)(e - s);
+                      if (!memchr(s, '\r', n) && !memchr(s, ' ', n) && !memchr(s, '\t', n)) { memcpy(out + pos, s, n); pos += n; return; }
+                      for (; s < e; ++s)
+                        if (!is_blank(*s)) out[pos++] = (uint8_t)*s;  // readRegion skips whitespace (faidx.h:340-347)
+                    });
+  });
+  offsets_[n_rec] = n_res;
+  munmap(m, len);
+  index_built_ = false;  // (built by the first getIndex)
+}
+
+void SequenceStore::build_index() const {
+  std::lock_guard<std::mutex> lk(index_mu_);
+  if (index_built_) return;
+  index_.reserve(ids_.size());
+  for (size_t i = 0; i < ids_.size(); ++i) index_.emplace(ids_[i], (uint32_t)i);  // first occurrence wins, like the .fai name lookup
+  index_built_ = true;
 }
 
 SequenceStore::~SequenceStore() {

@@ -14,7 +14,9 @@
 // "could not build fasta index" there because it takes the success return of its index builder for a failure,
 // sequencestorage.hh:322-326); nothing is written next to the FASTA.
 #pragma once
+#include <atomic>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -32,6 +34,7 @@ class SequenceStore {
   SequenceStore& operator=(const SequenceStore&) = delete;
 
   uint32_t getIndex(const std::string& id) const {  // SequenceNotFound as in sequencestorage.hh:348-351
+    if (!index_built_) build_index();
     auto it = index_.find(id);
     if (it == index_.end()) throw SequenceNotFound("seqid " + id);
     return it->second;
@@ -59,7 +62,10 @@ class SequenceStore {
   std::vector<uint8_t> letters_;
   std::vector<uint64_t> offsets_;
   std::vector<std::string> ids_;
-  std::unordered_map<std::string, uint32_t> index_;
+  mutable std::unordered_map<std::string, uint32_t> index_;  // in-memory stores: built by the first getIndex() (build_index)
+  mutable std::atomic<bool> index_built_{true};
+  mutable std::mutex index_mu_;
+  void build_index() const;
   std::vector<FaiEntry> entries_;
   const char* map_ = nullptr;  // the memory-mapped FASTA
   size_t map_len_ = 0;

@@ -22,6 +22,7 @@
 #include <deque>
 #include <exception>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -445,8 +446,10 @@ static int run(int argc, char** argv) {
       std::cerr << "the taxonomy keeps " << (int)tax->getMaxDepth() << " levels below the root; this build supports 63" << std::endl;
       return EXIT_FAILURE;
     }
+    const Clock::time_point t_tax = Clock::now();
     stage("seqid->taxid mapping");
     std::unique_ptr<StrIDConverter> seqid2taxid(loadStrIDConverterFromFile(o.mapping, 1000));
+    const Clock::time_point t_map = Clock::now();
     std::ofstream logsink(o.logfile.c_str(), std::ios_base::app);
     if (alignment_free) {  // taxator.cpp:346-361; doPredictionsSerial (:50-77) in batches
       std::unique_ptr<TaxonPredictionModel> model;
@@ -484,6 +487,12 @@ static int run(int argc, char** argv) {
     SequenceStore& db_storage = *db_ptr;
     const unsigned host_threads = o.processors ? o.processors : usable_cpus();
     std::vector<std::unique_ptr<RPAPredictionModel>> engines;
+    const Clock::time_point t_stores = Clock::now();
+    // the reader's identifier tables (a hash probe per reference / query identifier: ~0.1 s for a million queries) are built on a
+    // thread of their own while the engines come up (runtime start-up, taxonomy tables, stores to HBM)
+    std::future<std::shared_ptr<const ReaderTables>> tables_future;
+    if (!o.record_objects)
+      tables_future = std::async(std::launch::async, [&] { return std::make_shared<const ReaderTables>(*seqid2taxid, tax.get(), &db_storage, &query_storage); });
     stage("engines (rpa_create + stores to HBM)");
     for (int dev : o.devices) {
       engines.emplace_back(new RPAPredictionModel(tax.get(), query_storage, db_storage, o.filterout, o.toppercent, o.dataformat == "protein", dev));
@@ -495,6 +504,9 @@ static int run(int argc, char** argv) {
     const bool logging_on = o.logfile != "/dev/null";
     if (logging_on) rpa.setTrace(true);
     const Clock::time_point t_loaded = Clock::now();
+    if (o.timing)  // where the loading goes: taxonomy dump | mapping | FASTA files on the host | engines (runtime start-up, tables, stores to HBM)
+      std::cerr << "LOAD\ttaxonomy_s=" << secs(t_start, t_tax) << "\tmapping_s=" << secs(t_tax, t_map) << "\tfasta_s=" << secs(t_map, t_stores)
+                << "\tengines_s=" << secs(t_stores, t_loaded) << std::endl;
     auto store_report = [&]() {  // what is resident in HBM (per engine; the engines hold the same sequences)
       if (!o.timing) return;
       for (int which = 0; which < 2; ++which) {
@@ -517,7 +529,7 @@ static int run(int argc, char** argv) {
       }
       const unsigned reader_threads_total = o.processors ? o.processors : usable_cpus();
       std::vector<std::unique_ptr<ColumnarReader>> readers;
-      std::shared_ptr<const ReaderTables> tables;
+      std::shared_ptr<const ReaderTables> tables = tables_future.get();
       for (size_t t = 0; t < teams; ++t) {
         const unsigned th = teams == 1 ? o.processors : std::max(1u, (unsigned)((reader_threads_total + teams - 1 - t) / teams));
         readers.emplace_back(new ColumnarReader(stdin, *seqid2taxid, tax.get(), &db_storage, &query_storage, o.split_alignments, th, block_bytes,

@@ -108,3 +108,38 @@ def test_alignments_sorted_option(parsecheck, golden_dir):
     assert o == c and o != run("objects", unsorted, False)
     # input order: (5,40) (1,30) (35,60) | (100,140) (90,99: 90 <= 140 joins) | (141,150)
     assert [int(l.split(b"\t")[4]) for l in o.split(b"\n") if l.startswith(b"SET")] == [3, 2, 1]
+
+
+@pytest.mark.parametrize("chunk", ["1", "37", "500", "100000"])
+def test_in_memory_store_loaded_by_many_threads(parsecheck, tmp_path, chunk, monkeypatch):
+    """The in-memory store is read by all host threads: the mapped file cut into chunks at line starts, records and residues
+    counted per chunk, then copied to their places (host/sequencestorage.cpp).  TAXATOR_FASTA_CHUNK makes the chunks a few
+    bytes long, so that every kind of line sits at a chunk seam: headers, irregular lines with blanks and CRLF, empty lines,
+    a record that spans dozens of chunks, chunks without any line start of their own -- and text in front of the first
+    header (dropped, as by the reference's reader).  The indexed store (its index rebuilt by a scan) must hold the same."""
+    monkeypatch.setenv("TAXATOR_FASTA_CHUNK", chunk)
+    rng = random.Random(5)
+    seqs = [(b"r%d" % k, bytes(rng.choice(b"ACGTNacgtn") for _ in range(rng.choice([0, 1, 2, 59, 60, 61, 200, 3000]))))
+            for k in range(60)]
+    total = sum(len(s) for _, s in seqs)
+    path = str(tmp_path / "odd.fna")
+    with open(path, "wb") as f:
+        for name, seq in seqs:
+            f.write(b">" + name + rng.choice([b"", b" description with > inside", b"\tx"]) + rng.choice([b"\n", b"\r\n"]))
+            i = 0
+            while i < len(seq):
+                n = rng.randint(1, 120)
+                piece = seq[i:i + n]
+                if rng.random() < 0.2 and len(piece) > 2:
+                    piece = piece[:1] + b" " + piece[1:2] + b"\t" + piece[2:]
+                f.write(piece + rng.choice([b"\n", b"\r\n", b"\n\n"]))
+                i += n
+    assert _check(parsecheck, path, "-") == (0, "OK 60 %d" % total)
+    # text in front of the first header belongs to no record
+    body = open(path, "rb").read()
+    lead = str(tmp_path / "lead.fna")
+    with open(lead, "wb") as f:
+        f.write(b"ACGTACGT\nthis is not a record\n\n" + body)
+    out = subprocess.run([parsecheck, "--fasta", lead, "-"], capture_output=True, text=True)
+    # the scanned index of the indexed store starts at the first header too: both stores agree on 60 sequences
+    assert out.returncode == 0 and out.stdout.strip() == "OK 60 %d" % total, out.stdout

@@ -46,7 +46,7 @@ for rep in range(2):
     r = subprocess.run(cmd, stdin=open(aln), stdout=open(folder + "/out.gff3", "w"), stderr=subprocess.PIPE, text=True, env=env)
     dt = time.time() - t0
     lines = r.stderr.strip().splitlines()
-    print("run %d: rc=%d wall %.2f s  %.0f record sets/s  %s" % (rep, r.returncode, dt, n_sets * repeat / dt, " | ".join(l for l in lines if l.startswith(("TIMING", "STORE", "READERS")))), flush=True)
+    print("run %d: rc=%d wall %.2f s  %.0f record sets/s  %s" % (rep, r.returncode, dt, n_sets * repeat / dt, " | ".join(l for l in lines if l.startswith(("TIMING", "LOAD", "READERS")))), flush=True)
     if r.returncode:
         print(r.stderr[-2000:])
 h = hashlib.sha1()
