@@ -499,6 +499,7 @@ static int run(int argc, char** argv) {
       engines.back()->setHostThreads(std::max(1u, host_threads / (unsigned)o.devices.size()));
       if (o.store_tile) engines.back()->setTile(o.store_tile);
       if (o.store_gb > 0) engines.back()->setStoreBudget((uint64_t)(o.store_gb * 1073741824.0));
+      if (const char* v = getenv("TAXATOR_STORE_GARBAGE")) engines.back()->setGarbageSlack((uint64_t)atoll(v));  // (tests: residues of swallowed windows tolerated)
     }
     RPAPredictionModel& rpa = *engines[0];
     const bool logging_on = o.logfile != "/dev/null";

@@ -210,13 +210,18 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
       }
     }
     const uint64_t total = fetch_offsets_.back();
-    if (store_budget_ && !emptied) {
+    if (!emptied) {
       const rpa_store_info info = storeInfo(which);
       const uint64_t half_bytes = rpa_store_bits_ / 4;  // per residue: 4-bit DNA = 1 half byte, 8-bit protein = 2
-      if ((info.residues + total) * half_bytes / 2 > store_budget_ && info.residues) {
-        // The store would outgrow its budget: drop everything resident and start over with what this batch needs -- once no
-        // batch that was made resident earlier is still running on what is there (the wait lets go of the lock: another
-        // thread may come through here meanwhile, so the scan above is stale afterwards and is done again either way).
+      const bool over_budget = store_budget_ && (info.residues + total) * half_bytes / 2 > store_budget_ && info.residues;
+      // Windows are only ever added: a new window that swallows resident ones leaves their residues behind in the arena.  When
+      // more than half of the arena (and more than garbage_slack_ residues) is such garbage, emptying the store and fetching
+      // what this batch needs again is the compaction (the regions come from the mapped FASTA).
+      const bool garbage = info.residues > 2 * info.live_residues && info.residues - info.live_residues > garbage_slack_;
+      if (over_budget || garbage) {
+        // Drop everything resident and start over with what this batch needs -- once no batch that was made resident earlier
+        // is still running on what is there (the wait lets go of the lock: another thread may come through here meanwhile, so
+        // the scan above is stale afterwards and is done again either way).
         if (in_flight_) { resident_cv_.wait(lk, [&] { return in_flight_ == 0; }); continue; }
         check(engine_, rpa_store_reset(engine_, which));
         std::fill(res.begin(), res.end(), 0);

@@ -66,6 +66,7 @@ class RPAPredictionModel : public TaxonPredictionModel {
   void setHostThreads(unsigned t) { threads_ = t ? t : 1; }
   void setTile(uint64_t residues) { tile_ = residues ? residues : 65536; }       // before the first batch
   void setStoreBudget(uint64_t bytes) { store_budget_ = bytes; }                  // 0 = no limit; per store
+  void setGarbageSlack(uint64_t residues) { garbage_slack_ = residues; }
   rpa_store_info storeInfo(int which) const;
   // page-lock / release host arrays that are handed to predictColumns() again and again (rpa_host_register)
   void pinHost(void* p, size_t bytes) const;
@@ -78,6 +79,7 @@ class RPAPredictionModel : public TaxonPredictionModel {
   std::vector<uint64_t> tile_base_[2];
   std::vector<uint64_t> resident_[2];
   uint64_t tile_ = 65536, store_budget_ = 0;
+  uint64_t garbage_slack_ = (uint64_t)1 << 30;  // residues of swallowed windows an indexed store may carry before it is emptied and refilled (setGarbageSlack)
   unsigned rpa_store_bits_ = 4;  // packed bits per residue in the engine (DNA 4, protein 8): what a residue costs against the budget
   size_t makeResidentStore(int which, const rpa_batch& b, const std::vector<uint32_t>& span, std::unique_lock<std::mutex>& lk);
   std::atomic<bool> reverse_noted_{false};

@@ -457,6 +457,19 @@ def test_cli_region_granular_reads_of_long_references(tmp_path):
     assert s_fine["live_residues"] <= touched * 4 * 2048 and s_fine["live_residues"] < total // 100 and s_fine["device_bytes"] < s_mem["device_bytes"] // 50
     kind, s_tight = store(tight.stderr)
     assert s_tight["residues"] * 0.5 <= 0.0001 * 2 ** 30 * 1.5 and s_tight["residues"] < s_fine["residues"]                                        # emptied and refilled along the stream
+    # Without a budget: a window that swallows resident ones leaves their residues behind in the arena; when more than half of
+    # the arena is such garbage the driver empties the store and fetches what the block at hand needs again (the compaction).
+    # TAXATOR_STORE_GARBAGE=0: no slack -- many small blocks, many merges, same output, and the arena stays within twice what is live.
+    garb = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "512", "--block-mb", "0.004", "-p", "4"],
+                     timeout=CHILD_LIMIT_S, stdin_path=aln, env=dict(env, TAXATOR_STORE_GARBAGE="0"))
+    assert garb.returncode == 0, garb.stderr[-2000:]
+    assert garb.stdout == mem.stdout
+    kind, s_garb = store(garb.stderr)
+    plain = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "512", "--block-mb", "0.004", "-p", "4"],
+                      timeout=CHILD_LIMIT_S, stdin_path=aln, env=env)
+    kind, s_plain = store(plain.stderr)
+    assert plain.stdout == mem.stdout and s_plain["residues"] >= s_plain["live_residues"]
+    assert s_garb["residues"] <= 2 * s_garb["live_residues"] + 64 * 512 and s_garb["residues"] <= s_plain["residues"]
 
 
 @pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])
