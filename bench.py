@@ -365,7 +365,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 = the headline configuration (BASELINE config 2); c3 = config 3's per-GPU share (for --gpus 8), c4 protein, "
                          "c5 long contigs are extra measurements")
-    ap.add_argument("--in-flight", type=int, default=4, help="jobs submitted before the oldest is waited for (1 .. RPA_JOBS_IN_FLIGHT = 4; profiles/r04_inflight_sweep.txt)")
+    ap.add_argument("--in-flight", type=int, default=None, help="jobs submitted before the oldest is waited for (1 .. RPA_JOBS_IN_FLIGHT = 4); default: 4 for the nucleotide configurations (profiles/r04_inflight_sweep.txt), 3 for protein (its lanes kernel holds a 91 KB table per CU: a fourth job costs it 8 %)")
     ap.add_argument("--pipeline", action="store_true",
                     help="(the default, kept for old command lines) the steps go through rpa_submit_batch with --in-flight of them "
                          "running at a time on the engine's job slots: the placement rounds of one step under the alignment kernels of "
@@ -492,6 +492,8 @@ def main():
     # RCCL: the gather of step k runs beside the kernels of step k + 1 (rows double-buffered; every step's rows still reach
     # rank 0 inside the timed region).  gloo rehearsals keep the plain blocking gather.
     pipelined = not args.sync and not args.host_buffers
+    if args.in_flight is None:
+        args.in_flight = 3 if cfg["alphabet"] == 1 else 4
     args.in_flight = max(1, min(int(os.environ.get("RPA_JOB_SLOTS", "4")), args.in_flight))
     overlap_gather = use_dist and not gloo and not args.host_buffers and not pipelined
     rows_buf = [rows, torch.zeros_like(rows)] if overlap_gather else [rows]
@@ -774,7 +776,7 @@ def main():
                                                      ("c4_450aa", c4, 60_000, c4["hits"], 450, None),  # beyond the packed cell (312 x 312): the score-and-length cell
                                                      ("c5", c5, c5["sets"], c5["hits"], c5["seg_len"], "c5")):
                 try:
-                    sec[key] = measure_secondary(pkg, synth, torch, c_, sets_, hits_, len_, 3, args.in_flight, local_rank, profile_tag=tag)
+                    sec[key] = measure_secondary(pkg, synth, torch, c_, sets_, hits_, len_, 3, 3 if c_["alphabet"] == 1 else args.in_flight, local_rank, profile_tag=tag)
                 except Exception as e:  # the headline stands whatever happens here
                     sec[key] = {"error": repr(e)}
             sec["e2e"] = measure_e2e(synth, ds)
