@@ -282,9 +282,13 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
   for (uint32_t k = threadIdx.x; k < kWin; k += kBlock) {
     const uint32_t rr = w0 + k;
     if (rr < b.n_records) {
-      s_rec[k] = make_uint4(__float_as_uint(b.score[rr]), b.identities[rr], b.qstart[rr], b.qstop[rr]);
+      // (a masked record sits in the window with values that change nothing in the scan of a staged set below: a NaN score --
+      // never "before" anybody, skipped by the maximum -- and an empty query range)
+      const bool filt = rec_filtered(b, rr);
+      s_rec[k] = filt ? make_uint4(0x7FC00000u, b.identities[rr], 0xFFFFFFFFu, 0u)
+                      : make_uint4(__float_as_uint(b.score[rr]), b.identities[rr], b.qstart[rr], b.qstop[rr]);
       s_pre[k] = w.rec_pre[rr];  // preorder number of the record's taxon, left by k_validate_batch
-      s_filt[k] = rec_filtered(b, rr) ? 1 : 0;
+      s_filt[k] = filt ? 1 : 0;
     }
   }
   const uint32_t first = w.block_first[lblock];
@@ -335,20 +339,41 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
     n += act ? 1u : 0u;
     qrstart = act ? min(qrstart, v.z) : qrstart;
     qrstop = act ? max(qrstop, v.w) : qrstop;
-    const bool before = (sj > sc) || (sj == sc && (ij > id || (ij == id && j < r)));
+    // (bitwise, not short-circuit: the nested branches of `||` / `&&` cost ~14 scalar instructions per record)
+    const bool before = (sj > sc) | ((sj == sc) & ((((uint64_t)ij << 32) | (uint32_t)~j) > (((uint64_t)id << 32) | (uint32_t)~r)));
     rank += (act && before) ? 1u : 0u;
   };
   if (beg >= w0 && end <= w0 + kWin) {
-    // the whole set is staged (the usual case): a tight loop over LDS, four records in flight (the loop is bound by the
-    // LDS round trip of each record, not by the compares)
+    // the whole set is staged (the usual case): a tight loop over LDS, four records in flight.  Per record: the two ends of the
+    // query range, the largest score that is not a NaN, the first unmasked record, the count of masked ones, and three compares
+    // for "before me" -- 12 instructions (27 with the running values of `take`, whose compound conditions had become branches:
+    // the kernel is bound by instruction issue, 1.21 -> 1.12 ms on config 2).
+    // The best score of :391-404 starts from the first unmasked record and a NaN there stays; any other NaN is passed over.
+    const uint64_t my_key = ((uint64_t)id << 32) | (uint32_t)~r;
+    uint32_t n_filt = 0, first_act = 0xFFFFFFFFu;
+    float smax_nn = -INFINITY;
+    auto scan = [&](uint32_t j, const uint4 v, uint32_t filt) {
+      const float sj = __uint_as_float(v.x);
+      n_filt += filt;
+      qrstart = min(qrstart, v.z);
+      qrstop = max(qrstop, v.w);
+      smax_nn = __builtin_fmaxf(smax_nn, sj);
+      first_act = min(first_act, filt ? 0xFFFFFFFFu : j);
+      rank += (uint32_t)((sj > sc) | ((sj == sc) & ((((uint64_t)v.y << 32) | (uint32_t)~j) > my_key)));
+    };
     uint32_t j = beg;
     for (; j + 4u <= end; j += 4u) {
       const uint32_t jl = j - w0;
       const uint4 v0 = s_rec[jl], v1 = s_rec[jl + 1], v2 = s_rec[jl + 2], v3 = s_rec[jl + 3];
-      const bool f0 = s_filt[jl] != 0, f1 = s_filt[jl + 1] != 0, f2 = s_filt[jl + 2] != 0, f3 = s_filt[jl + 3] != 0;
-      take(j, v0, f0); take(j + 1, v1, f1); take(j + 2, v2, f2); take(j + 3, v3, f3);
+      const uint32_t f0 = s_filt[jl], f1 = s_filt[jl + 1], f2 = s_filt[jl + 2], f3 = s_filt[jl + 3];
+      scan(j, v0, f0); scan(j + 1, v1, f1); scan(j + 2, v2, f2); scan(j + 3, v3, f3);
     }
-    for (; j < end; ++j) take(j, s_rec[j - w0], s_filt[j - w0] != 0);
+    for (; j < end; ++j) scan(j, s_rec[j - w0], s_filt[j - w0]);
+    n = (end - beg) - n_filt;
+    if (n) {
+      const float s_first = __uint_as_float(s_rec[first_act - w0].x);
+      smax = isnan(s_first) ? s_first : smax_nn;
+    }
   } else {
     for (uint32_t j = beg; j < end; ++j) {
       const uint32_t jl = j - w0;  // wraps for j < w0
@@ -734,7 +759,7 @@ __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDe
   __shared__ uint32_t s_cnt[kNumBins][kSparseBlock / 64];
   const uint32_t wave_id = (blockIdx.x * kSparseBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool have = wave_id < w.counters[kCtrActive];  // exact list length (the grid is sized by an upper bound)
+  const bool have = wave_id < w.counters[w.ctr_live_in];  // exact list length (the grid is sized by an upper bound)
   const uint32_t H = b.n_records;
   uint32_t s = 0, lo = 0, i_hi = 0, i_lo = 0;
   EmitInfo info{};
@@ -898,7 +923,7 @@ __device__ __forceinline__ void append_live(const WorkDev& w, bool running, uint
     uint32_t total = 0;
 #pragma unroll
     for (int k = 0; k < kBlock / 64; ++k) { const uint32_t c = s_live[k]; s_live[k] = total; total += c; }
-    const uint32_t base = total ? atomicAdd(&w.counters[kCtrActive], total) : 0u;
+    const uint32_t base = total ? atomicAdd(&w.counters[w.ctr_live_out], total) : 0u;
 #pragma unroll
     for (int k = 0; k < kBlock / 64; ++k) s_live[k] += base;
   }
@@ -934,7 +959,7 @@ __device__ __forceinline__ void append_live_last_wave(const WorkDev& w, LiveStag
   for (int k = 0; k < kBlock / 64; ++k) total += (uint32_t)__popcll(ls.mask[k]);
   if (total == 0) return;
   uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(&w.counters[kCtrActive], total);
+  if (lane == 0) base = atomicAdd(&w.counters[w.ctr_live_out], total);
   base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
   for (int k = 0; k < kBlock / 64; ++k) {
@@ -1179,6 +1204,12 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
   float* s_dmax = s_band + (size_t)w.band_ranks * kBlock;
   __shared__ LiveStage s_live_stage;
   if (threadIdx.x == 0) s_live_stage.arrived = 0u;
+  // the round's counters are spent (the alignment launches in front of this kernel were their last readers; this kernel counts
+  // in ctr_live_out only): cleared here for the next round's k_emit instead of by a fill between the launches
+  if (blockIdx.x == 0 && threadIdx.x < (uint32_t)kNumRoundCounters) {
+    if (threadIdx.x != (uint32_t)kCtrActive) w.counters[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) w.counters[w.ctr_live_in] = 0u;
+  }
   __syncthreads();  // (the only barrier of the kernel: the wavefronts of a workgroup start together and finish far apart)
   // dense rounds: one thread per record set; sparse rounds (few sets still running): one thread per entry of the live list
   const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;

@@ -217,6 +217,7 @@ struct WorkDev {
   uint4* pair_ext;      // optional (rpa_align_pairs only): matches, mismatches, gaps, length; indexed like pair_res
   uint2* bin_list;      // kNumBins * T2 entries (segment A, segment B | kDstIsB)
   uint32_t* counters;   // kNumCounters words, layout below
+  uint32_t ctr_live_in, ctr_live_out;  // kCtrActive / kCtrActiveB: the word that counts the live list a round reads / appends to
   // pass-1 scratch (per set region like the pair slots)
   float* band_save;     // S * 2*band_ranks: BandFactor accumulators of paused pass-1 loops
   uint32_t band_ranks;  // deepest taxonomy level + 1: rows of the LDS accumulators of k_decide
@@ -242,9 +243,13 @@ struct WorkDev {
 // retry lists (banded alignments whose distance turned out to lie outside their band;
 // (kCtrRetry: the strip kernel's, kCtrRetryShort: the one-strip kernels') | error code | error set/pair
 // | retried pairs so far in this batch (long, short: added up by the retry launches; the host reads them a round later)
+// | the live count of every other round.  The first kNumRoundCounters are reset every round -- by k_decide itself (its first
+// thread; nobody else touches them while it runs), not by a fill between the launches: the list a round's k_decide appends to
+// is counted in the OTHER live word (WorkDev::ctr_live_out) than the one the round's k_emit and the host read (ctr_live_in),
+// and the two swap every round (round 4: a memset per round was ~10 us of a synchronous step's ~130 us per sparse round).
 constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNumBins + 2, kCtrRetryShort = kNumBins + 3, kCtrErr = kNumBins + 4,
-              kCtrErrSet = kNumBins + 5, kCtrRetryTotal = kNumBins + 6, kCtrRetryShortTotal = kNumBins + 7, kNumCounters = kNumBins + 8,
-              kNumRoundCounters = kNumBins + 4;  // the first kNumRoundCounters are reset every round
+              kCtrErrSet = kNumBins + 5, kCtrRetryTotal = kNumBins + 6, kCtrRetryShortTotal = kNumBins + 7, kCtrActiveB = kNumBins + 8,
+              kNumCounters = kNumBins + 9, kNumRoundCounters = kNumBins + 4;
 
 // Row shapes the placement kernels are built for.  A row holds 4Q - 6 path words = (4Q - 6) * 32 / label bits levels.
 constexpr int kRowQuadChoices[] = {2, 3, 4, 6, 8};

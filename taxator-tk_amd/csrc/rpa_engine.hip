@@ -449,6 +449,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   w->res_slot = (want_ext || !tiled) ? nullptr : e->res_slot.as<uint32_t>();  // linear layout: result slot = row position (P = H)
   w->pair_res = e->pair_res.as<float2>(); w->pair_ext = want_ext ? e->pair_ext.as<uint4>() : nullptr;
   w->bin_list = e->bin_list.as<uint2>(); w->counters = e->counters.as<uint32_t>();
+  w->ctr_live_in = kCtrActive; w->ctr_live_out = kCtrActive;  // (k_plan_sets counts the first live list here; predict_part alternates from then on)
   w->og_idx = e->og_idx.as<uint32_t>(); w->band_save = e->band_save.as<float>();
   w->live_in = nullptr; w->n_live_in = 0; w->live_out = e->live_a.as<uint32_t>();
   w->band_ranks = e->tax.max_depth + 1;
@@ -533,14 +534,16 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     uint32_t* next_list = list_in_a ? e->live_b.as<uint32_t>() : e->live_a.as<uint32_t>();
     const bool sparse_emit = rounds > 0 && (uint64_t)prev_live * e->sparse_div_emit <= S;
     w.live_in = sparse_emit ? cur_list : nullptr;
-    w.n_live_in = prev_live;  // grid bound only: the kernel reads the exact length from counters[kCtrActive]
+    w.n_live_in = prev_live;  // grid bound only: the kernel reads the exact length from counters[ctr_live_in]
+    w.ctr_live_in = (rounds & 1) ? kCtrActiveB : kCtrActive;   // (plan counted the first list in kCtrActive)
+    w.ctr_live_out = (rounds & 1) ? kCtrActive : kCtrActiveB;
     HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, e->params));
     HIP_TRY(e, launch_publish_words(e->stream, w.counters, e->h_counters, kNumCounters));  // (a kernel, not a copy: see k_publish_words)
     RPA_WHERE("predict_part: sync after emit (round)");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     rc = check_device_error(e, e->h_counters);
     if (rc) return rc;
-    const uint32_t live_now = e->h_counters[kCtrActive];
+    const uint32_t live_now = e->h_counters[w.ctr_live_in];
     if (live_now == 0) {  // the batch is done: what did the bands cost? (totals added up by the retry launches)
       if (e->banded_short_batch >= 65536 && (uint64_t)e->h_counters[kCtrRetryShortTotal] * 4 > e->banded_short_batch) e->band_short_pause = 16;
       else if (e->band_short_pause) --e->band_short_pause;
@@ -580,7 +583,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
       if (retried || retried_short) fprintf(stderr, "[rpa]   banded alignments that left their band and were re-run wide open: %u long, %u short\n", retried, retried_short);
     }
     if (rounds == 1) gate.open();  // the long pass-1 alignment launch is queued: the next part may start underneath it
-    HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kNumRoundCounters, e->stream));  // keep the error words
+    // (no fill of the round's counters here: k_decide clears them, rpa_device.h)
     const bool sparse_decide = rounds > 0 && (uint64_t)live_now * e->sparse_div_decide <= S;
     w.live_in = sparse_decide ? cur_list : nullptr;
     w.n_live_in = live_now;   // exact
