@@ -512,6 +512,45 @@ def test_cutoff_settings_on_coarse_scores_and_big_sets(pkg, oracle, synth, x, t,
     _engine_vs_oracle(pkg, oracle, synth, dp, 1, exclude_factor=x, reeval_bandwidth=t)
 
 
+def test_scores_of_any_sign_and_masked_records(pkg, oracle, synth):
+    """What k_rank_records gathers per record set in one scan -- the rank of every record (score, identities, input order), the
+    number of unmasked records, their query range, the best score (whose fraction is the pass-0 threshold, :499) -- on scores
+    the parsers let through but no aligner writes: negative ones, zeros of either sign, runs of ties; a third of
+    the records masked (a masked record must count for nothing: its score, range and position in the set)."""
+    rng = np.random.default_rng(77)
+    for k, n_hits in enumerate((20, 7, 70)):
+        ds = synth.make_dataset(n_sets=300, n_hits=n_hits, seg_len=120, branching=3, genome_len=2000, seed=170 + k, variety=True)
+        b = ds.batch
+        sc = b["score"].astype(np.float32).copy()
+        H = len(sc)
+        kind = rng.integers(0, 8, H)
+        sc[kind == 0] = -sc[kind == 0]
+        sc[kind == 1] = 0.0
+        sc[kind == 2] = -0.0
+        sc[kind == 3] = np.round(sc[kind == 3] / 64.0) * 64.0
+        sc[(kind == 4) & (rng.random(H) < 0.1)] = np.float32(3e9)  # (infinite scores are left out: the reference's `int cut-off = X * score`,
+        #  :657-659, is undefined behaviour beyond the int range -- x86 gives INT_MIN, the GPU's conversion saturates)
+        b["score"] = sc
+        filt = b["filtered"].copy()
+        filt[rng.random(H) < 0.3] = 1
+        b["filtered"] = filt
+        # (masked records with ranges and scores that would dominate the set if they counted)
+        m = filt != 0
+        b["qstart"] = np.where(m & (rng.random(H) < 0.5), 1, b["qstart"]).astype(np.uint32)
+        b["score"] = np.where(m & (rng.random(H) < 0.5), np.float32(1e9), b["score"]).astype(np.float32)
+        # (a set whose best unmasked score is negative has an empty best-reference group -- the score is below its own 95 % --
+        # and the reference asserts: those sets get their scores' absolute values)
+        so = b["set_offsets"].astype(np.int64)
+        sc = b["score"].copy()
+        for lo, hi in zip(so[:-1], so[1:]):
+            act = b["filtered"][lo:hi] == 0
+            if act.any() and sc[lo:hi][act].max() < 0:
+                sc[lo:hi] = np.abs(sc[lo:hi])
+        b["score"] = sc
+        for x, t in ((0.5, 0.05), (0.0, 0.3)):
+            _engine_vs_oracle(pkg, oracle, synth, ds, 0, exclude_factor=x, reeval_bandwidth=t)
+
+
 def test_band_widens_when_too_many_pairs_leave_it(pkg, oracle, synth, monkeypatch, capfd):
     """The one-strip band has a three-word middle (exact up to 80 - |delta| edits); a batch in which more than one banded
     pair in sixteen lies beyond that makes the engine use four words all the way (96 - |delta|) for the following batches.
