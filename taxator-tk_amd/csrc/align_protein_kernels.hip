@@ -223,6 +223,7 @@ constexpr uint32_t kPackedScratchHead = 64;  // words in front of the boundary r
 template <int R, bool kWide>
 __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
                                                                     uint32_t* __restrict__ scratch, uint32_t col_stride,
+                                                                    uint32_t* __restrict__ work_counter, uint32_t counter_first,
                                                                     unsigned long long* prof_acc) {
   constexpr uint32_t kPkScore = kWide ? 18u : rpa::kPkScore, kPkMove = kWide ? 16u : rpa::kPkMove, kPkMoveMask = 3u << kPkMove;
   constexpr uint32_t kDiagMask = kWide ? 0xFFFFu : 0x1FFu;
@@ -250,13 +251,14 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_packed(const uint2*
   asm volatile("" : "+v"(c_horiz), "+v"(c_keep), "+v"(c_one));
 
   // The first run of a wavefront is fixed -- wavefront v of workgroup g takes run v * gridDim.x + g, so a short list is
-  // dealt one run per CU before any CU gets a second -- the following ones come from the counter (which starts behind
-  // the fixed runs).  Every wavefront leaves through the break: the counter only grows.
+  // dealt one run per CU before any CU gets a second -- the following ones come from the counter (a word that is ZERO when
+  // the launch begins -- a fresh one of the engine's pool per launch, cleared once per batch, instead of a fill in front of
+  // every launch -- plus counter_first: the pairs of the fixed runs).  Every wavefront leaves through the break: the counter only grows.
   uint32_t base = ((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64u;
   for (;; ) {
     if (base >= n_list) break;
     const uint32_t run = base;
-    if (lane == 0) base = atomicAdd(scratch, 64u);
+    if (lane == 0) base = atomicAdd(work_counter, 64u) + counter_first;
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     const uint32_t t = run + lane;
     const bool active = t < n_list;
@@ -560,7 +562,8 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
 // dominant class 15 % -- config 4: 4.1 -> 4.8 ms of alignment per step).
 template <int R, int G>
 __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_lanes(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
-                                                                   uint32_t* __restrict__ work_counter, unsigned long long* prof_acc) {
+                                                                   uint32_t* __restrict__ work_counter, uint32_t counter_first,
+                                                                   unsigned long long* prof_acc) {
   __shared__ uint32_t tab[kAX * kAX * 32];  // [b][a][bank] -> T(a,b) as in K3p; T(null,b) = 0; T(a,padding) = "score - 1, move 0"
   __shared__ int32_t selfdiag[64];          // s(x,x); [27..31] = 0 (null residue), [32..63] = 0 (lanes that do not count A)
   __shared__ int8_t blosum[kAA * kAA];
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_lanes(const uint2* 
   for (;;) {
     if (base >= n_list) break;
     const uint32_t run = base;
-    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(work_counter, kPairs);
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(work_counter, kPairs) + counter_first;  // (the word is zero when the launch begins, see K3p)
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     protein_lanes_run<R, G>(list, n_list, run, w, tabb, selfdiag, c_horiz, c_keep, c_one, prof_acc);
   }
@@ -630,7 +633,7 @@ hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* lis
 // K3p over a list of pairs that protein_bin() found eligible (protein_fits_packed).  One persistent
 // workgroup per CU; the boundary rows need (max_len + 1) words per resident lane.
 hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
-                                       size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc, bool wide) {
+                                       size_t scratch_words, uint32_t max_len, uint32_t* work_counter, unsigned long long* prof_acc, bool wide) {
   if (n == 0) return hipSuccess;
   hipError_t e = upload_blosum();
   if (e != hipSuccess) return e;
@@ -652,15 +655,14 @@ hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32
   const size_t per_lane_words = ((size_t)max_len + 3) / 4 * 4;  // whole groups of four columns
   while (blocks > 1 && kPackedScratchHead + (size_t)blocks * kPackedBlock * per_lane_words > scratch_words) --blocks;
   if (kPackedScratchHead + (size_t)blocks * kPackedBlock * per_lane_words > scratch_words) return hipErrorOutOfMemory;
-  e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch), (int)(blocks * (kPackedBlock / 64) * 64u), 1, st);  // the work counter starts behind the fixed first runs
-  if (e != hipSuccess) return e;
-  if (wide) hipLaunchKernelGGL((k_nw_protein_packed<kPackedRows, true>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
-  else hipLaunchKernelGGL((k_nw_protein_packed<kPackedRows, false>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, prof_acc);
+  const uint32_t first = blocks * (kPackedBlock / 64) * 64u;  // the counter's runs start behind the fixed first ones
+  if (wide) hipLaunchKernelGGL((k_nw_protein_packed<kPackedRows, true>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, work_counter, first, prof_acc);
+  else hipLaunchKernelGGL((k_nw_protein_packed<kPackedRows, false>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, scratch, blocks * kPackedBlock, work_counter, first, prof_acc);
   return hipGetLastError();
 }
 
 // K3l over the list of a lanes-per-pair class (protein_bin(): the vertical sequence needs `lanes` strips of
-// kProteinLaneRows).  Persistent workgroups as in K3p; `work_counter` is one word of device memory.
+// kProteinLaneRows).  Persistent workgroups as in K3p; `work_counter` is one word of device memory that is zero when the launch begins.
 hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* work_counter,
                                       unsigned long long* prof_acc) {
   if (n == 0) return hipSuccess;
@@ -680,10 +682,9 @@ hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* li
   const uint32_t per_wave = 64u / (uint32_t)lanes;
   uint32_t blocks = (n + per_wave - 1u) / per_wave;
   if (blocks > (uint32_t)n_cu) blocks = (uint32_t)n_cu;
-  e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(work_counter), (int)(blocks * (kPackedBlock / 64) * per_wave), 1, st);  // behind the fixed first runs
-  if (e != hipSuccess) return e;
+  const uint32_t first = blocks * (kPackedBlock / 64) * per_wave;  // behind the fixed first runs
 #define RPA_LAUNCH_LANES(GV) \
-  case GV: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, GV>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, prof_acc); break;
+  case GV: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, GV>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, first, prof_acc); break;
   switch (lanes) {
     RPA_LAUNCH_LANES(1) RPA_LAUNCH_LANES(2) RPA_LAUNCH_LANES(3) RPA_LAUNCH_LANES(4) RPA_LAUNCH_LANES(5) RPA_LAUNCH_LANES(6) RPA_LAUNCH_LANES(7)
     RPA_LAUNCH_LANES(8) RPA_LAUNCH_LANES(9) RPA_LAUNCH_LANES(10) RPA_LAUNCH_LANES(11) RPA_LAUNCH_LANES(12) RPA_LAUNCH_LANES(13)

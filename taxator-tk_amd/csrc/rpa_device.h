@@ -356,7 +356,7 @@ hipError_t launch_align_dna_long(hipStream_t st, int words_per_lane, const uint2
 hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                 size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc);
 hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
-                                       size_t scratch_words, uint32_t max_len, unsigned long long* prof_acc, bool wide = false);
+                                       size_t scratch_words, uint32_t max_len, uint32_t* work_counter, unsigned long long* prof_acc, bool wide = false);
 hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* work_counter,
                                       unsigned long long* prof_acc);
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);

@@ -105,6 +105,7 @@ struct rpa_engine {
   // profiling
   bool profiling = false;
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
+  uint32_t counter_next = 0;  // next free word of the work-counter pool (lanes_counter), see next_work_counter
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
   // alignment trace (rpa_trace_begin / rpa_trace_read): synchronous calls on the owner engine only
@@ -237,6 +238,25 @@ struct LaunchTimer {
   }
 };
 
+// A zero word for the work counter of a persistent protein launch (K3p, K3l): the pool is cleared once per batch and every
+// launch takes the next word -- until round 4 a fill in front of every launch, i.e. a second packet and a gap on the
+// stream per launch (the nucleotide rounds lost theirs the same way: rpa_device.h, kNumRoundCounters).
+constexpr uint32_t kCounterPoolWords = 4096;
+int counter_pool_reset(rpa_engine* e) {
+  HIP_TRY(e, e->lanes_counter.ensure((size_t)kCounterPoolWords * 4));
+  HIP_TRY(e, hipMemsetAsync(e->lanes_counter.p, 0, (size_t)kCounterPoolWords * 4, e->stream));
+  e->counter_next = 0;
+  return RPA_OK;
+}
+int next_work_counter(rpa_engine* e, uint32_t** out) {
+  if (!e->lanes_counter.p || e->counter_next >= kCounterPoolWords) {  // (a batch of more launches than words: clear behind the ones in flight on this stream)
+    const int rc = counter_pool_reset(e);
+    if (rc) return rc;
+  }
+  *out = e->lanes_counter.as<uint32_t>() + e->counter_next++;
+  return RPA_OK;
+}
+
 int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
   unsigned long long* acc = e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr;
   const uint32_t* counts = counts_in;
@@ -311,19 +331,26 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
     } else {
       const uint32_t max_len = counts[kCtrMaxLen];
       if (bin > kProteinPackedBin) {  // K3l: the strips of a pair in adjacent lanes, nothing but the work counter in memory
-        HIP_TRY(e, e->lanes_counter.ensure(256));
-        HIP_TRY(e, launch_align_protein_lanes(e->stream, protein_class_lanes(bin - kProteinPackedBin - 1), list, n, w, e->lanes_counter.as<uint32_t>(), acc));
+        uint32_t* ctr = nullptr;
+        trc = next_work_counter(e, &ctr);
+        if (trc) return trc;
+        HIP_TRY(e, launch_align_protein_lanes(e->stream, protein_class_lanes(bin - kProteinPackedBin - 1), list, n, w, ctr, acc));
         trc = timer.end();
         if (trc) return trc;
         continue;
       }
       HIP_TRY(e, e->protein_ws.ensure(protein_scratch_words(n, max_len) * 4));
+      uint32_t* ctr = nullptr;
+      if (bin == kProteinPackedBin || (bin == kProteinWideBin && e->params.protein_wide && e->params.force_bin < 0)) {
+        trc = next_work_counter(e, &ctr);
+        if (trc) return trc;
+      }
       if (bin == kProteinPackedBin)  // every pair of this list passed protein_fits_packed(): no sequence above kPackedMaxLen
         HIP_TRY(e, launch_align_protein_packed(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4,
-                                               std::min(max_len, kPackedMaxLen), acc));
+                                               std::min(max_len, kPackedMaxLen), ctr, acc));
       else if (bin == kProteinWideBin && e->params.protein_wide && e->params.force_bin < 0)  // ... protein_fits_wide(): the score-and-length cell
         HIP_TRY(e, launch_align_protein_packed(e->stream, list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4,
-                                               std::min(max_len, kWideMaxLen), acc, true));
+                                               std::min(max_len, kWideMaxLen), ctr, acc, true));
       else
         HIP_TRY(e, launch_align_protein(e->stream, 8 * (bin + 1), list, n, w, e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, acc));
     }
@@ -519,6 +546,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   rc = profile_begin(e);
   if (rc) return rc;
   HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * (kNumCounters + 1), e->stream));
+  if (e->params.alphabet != RPA_DNA) { const int crc = counter_pool_reset(e); if (crc) return crc; }
   // (w.seg needs no clearing: k_rank_records writes the descriptor of every row position and query range a list entry can name)
   w.set_offsets = b.set_offsets;
   w.store_q = q.words; w.store_db = db.words;
@@ -1529,6 +1557,7 @@ int rpa_align_pairs(rpa_engine* e, uint32_t n_seqs, const uint8_t* letters, cons
   HIP_TRY(e, hipMemcpyAsync(w.pair_a, pair_a, (size_t)n_pairs * 4, kind, e->stream));
   HIP_TRY(e, hipMemcpyAsync(w.pair_b, pair_b, (size_t)n_pairs * 4, kind, e->stream));
   HIP_TRY(e, hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * (kNumCounters + 1), e->stream));
+  if (e->params.alphabet != RPA_DNA) { const int crc = counter_pool_reset(e); if (crc) return crc; }
   rc = profile_begin(e);
   if (rc) return rc;
   const StoreDev sv = tmp.view();
