@@ -110,6 +110,7 @@ struct Work {
   uint64_t seq = 0;             // position in the input: the writer prints in this order
   std::vector<std::pair<void*, size_t>> pinned;       // the arrays below that are page-locked
   std::vector<std::pair<void*, size_t>> pinned_want;  // ... and what was asked for last (some may have been refused)
+  unsigned uses = 0;            // blocks this object has carried to a GPU (pin_work)
 };
 
 // The columns of a Work object are reused from block to block: page-lock them (once per growth of a vector) so that the
@@ -131,6 +132,10 @@ void room_for_rows(Work& w, size_t S, const RPAPredictionModel& rpa) {
   w.stats.resize(S);
 }
 void pin_work(Work& w, const RPAPredictionModel& rpa) {
+  // Page-locking ~100 MB (the columns of a 128 MB block) costs 30-40 ms, a copy from pageable memory ~10 ms more than one
+  // from locked memory: an object is locked when it carries its THIRD block (1 M record sets are 8 blocks on 3-6 objects:
+  // locking them all was 0.25 s of a 0.6 s run; 10 M record sets reuse every object a dozen times).
+  if (++w.uses < 3) return;
   std::vector<std::pair<void*, size_t>> now;
   ColumnarBatch& b = w.batch;
   add_range(now, b.set_offsets); add_range(now, b.query_seq); add_range(now, b.query_len);
@@ -519,10 +524,15 @@ static int run(int argc, char** argv) {
     };
     if (!o.record_objects) {
       std::cout << GFF3Header() << std::flush;
-      // one reader team per engine when stdin is a regular file and there is more than one engine (--readers N forces N);
-      // a pipe, one engine or --readers 1: ONE reader on all host threads
+      // Reader teams when stdin is a regular file (--readers N forces N): at least one per engine, and four (two on fewer than
+      // eight host threads) even for ONE engine -- a team parses its slice of the mapped file in place, while the single
+      // reader of a stream copies every block out of the page cache first (4 M record sets, one engine: 0.99 s with one
+      // reader, 0.78 with two teams, 0.73 with four; profiles/r04_cli_teams_one_engine.txt).  A pipe or --readers 1: ONE
+      // reader on all host threads.
       const size_t block_bytes = (size_t)std::max(4096.0, o.block_mb * 1048576.0);
-      size_t teams = o.readers ? o.readers : (engines.size() > 1 ? engines.size() : 1);
+      const unsigned host_cpus = o.processors ? o.processors : usable_cpus();
+      const size_t default_teams = host_cpus >= 8 ? 4 : (host_cpus >= 4 ? 2 : 1);
+      size_t teams = o.readers ? o.readers : std::max(engines.size(), default_teams);
       std::unique_ptr<SliceCutter> cutter;
       if (teams > 1) {
         cutter.reset(new SliceCutter(stdin, block_bytes));

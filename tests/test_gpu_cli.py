@@ -460,16 +460,22 @@ def test_cli_region_granular_reads_of_long_references(tmp_path):
     # Without a budget: a window that swallows resident ones leaves their residues behind in the arena; when more than half of
     # the arena is such garbage the driver empties the store and fetches what the block at hand needs again (the compaction).
     # TAXATOR_STORE_GARBAGE=0: no slack -- many small blocks, many merges, same output, and the arena stays within twice what is live.
-    garb = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "512", "--block-mb", "0.004", "-p", "4"],
+    # (one reader: with reader teams the order in which the blocks reach the store, and with it the arena's final size, depends on timing)
+    garb = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "512", "--block-mb", "0.004", "-p", "4", "--readers", "1"],
                      timeout=CHILD_LIMIT_S, stdin_path=aln, env=dict(env, TAXATOR_STORE_GARBAGE="0"))
     assert garb.returncode == 0, garb.stderr[-2000:]
     assert garb.stdout == mem.stdout
     kind, s_garb = store(garb.stderr)
-    plain = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "512", "--block-mb", "0.004", "-p", "4"],
+    plain = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "512", "--block-mb", "0.004", "-p", "4", "--readers", "1"],
                       timeout=CHILD_LIMIT_S, stdin_path=aln, env=env)
     kind, s_plain = store(plain.stderr)
     assert plain.stdout == mem.stdout and s_plain["residues"] >= s_plain["live_residues"]
     assert s_garb["residues"] <= 2 * s_garb["live_residues"] + 64 * 512 and s_garb["residues"] <= s_plain["residues"]
+    teams = run_child(base + ["-i", os.path.join(folder, "ref.fna.fai"), "--store-tile", "512", "--block-mb", "0.004", "-p", "4"],   # the default: reader teams
+                      timeout=CHILD_LIMIT_S, stdin_path=aln, env=dict(env, TAXATOR_STORE_GARBAGE="0"))
+    assert teams.returncode == 0 and teams.stdout == mem.stdout
+    kind, s_teams = store(teams.stderr)
+    assert s_teams["residues"] <= 2 * s_teams["live_residues"] + 64 * 512
 
 
 @pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])
