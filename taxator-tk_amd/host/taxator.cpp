@@ -54,7 +54,7 @@ struct Options {
   std::vector<std::string> ranks;
   bool split_alignments = true, alignments_sorted = false, delete_unmarked = true;
   float filterout = 0.5f, toppercent = 0.05f, minscore = 0.0f;
-  size_t readers = 0;  // --readers N: reader teams over a regular input file (0: one per engine when there are several engines)
+  size_t readers = 0;  // --readers N: reader teams over a regular input file (0: four, two on few host threads, at least one per engine)
   double maxevalue = 1000.0;
   unsigned minsupport = 1, nbest = 1;
   bool ignore_unclassified = false;
@@ -93,7 +93,7 @@ static void usage(std::ostream& o) {
        "            emptied and refilled with what the block at hand needs; 0 = no limit), --store-tile N (=65536 residues: the\n"
        "            granularity at which regions of a sequence become resident), --readers N (reader teams over a regular input file:\n"
        "            the file is cut into slices where the query identifier changes and the teams parse slices side by side;\n"
-       "            0 = one team per engine when --devices names several, else one reader)\n";
+       "            0 = four teams, two on fewer than eight host threads, and at least one per engine; a pipe has one reader)\n";
 }
 
 namespace {
