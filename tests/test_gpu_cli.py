@@ -35,10 +35,12 @@ def _unpack(golden_dir, name, ext, tmp_path):
 
 
 @pytest.mark.parametrize("name,ext,extra", [("survey_dna", ".fna", []), ("survey_protein", ".faa", ["-b", "protein"])])
-@pytest.mark.parametrize("path", [[], ["--record-objects"], ["--block-mb", "0.004", "-p", "3"]])
+@pytest.mark.parametrize("path", [[], ["--record-objects"], ["--block-mb", "0.004", "-p", "3"], ["--block-mb", "0.004", "--readers", "1"],
+                                  ["--block-mb", "0.004", "--readers", "4"]])
 def test_cli_reproduces_reference_gff3(golden_dir, tmp_path, name, ext, extra, path):
-    """Default = columnar pipeline (reader / GPU / writer threads); --record-objects = the per-record object loop; tiny
-    blocks = many batches with groups straddling block boundaries.  Same bytes as the reference printed."""
+    """Default = columnar pipeline (reader teams over the mapped input / GPU / writer threads); --record-objects = the
+    per-record object loop; tiny blocks = many batches, with ONE reader (-p 3, --readers 1: groups straddle block boundaries
+    and are carried) and with four teams (slices cut where the query identifier changes).  Same bytes as the reference printed."""
     folder = _unpack(golden_dir, name, ext, tmp_path)
     r = _run(folder, ext, extra + path + ["--batch", "97"])  # several GPU calls: the stale-ival state must carry across them
     assert r.returncode == 0, r.stderr
