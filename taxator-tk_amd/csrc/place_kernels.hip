@@ -864,7 +864,19 @@ __global__ __launch_bounds__(kSparseBlock) void k_emit_sparse(BatchDev b, WorkDe
       }
     }
   }
-  wave_max_to(&w.counters[kCtrMaxLen], maxlen);
+  // the longest sequence of any emitted pair: ONE atomic per workgroup (one per wavefront was 6 k atomics on one address in the
+  // first sparse round of a config-2 step, ~11 ns each: 66 of the kernel's 80 us)
+  __shared__ uint32_t s_maxlen[kSparseBlock / 64];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor(maxlen, d, 64));
+  if (lane == 0) s_maxlen[wave] = maxlen;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t m = lane < kSparseBlock / 64 ? s_maxlen[lane] : 0u;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, 64));
+    if (lane == 0 && m) atomicMax(&w.counters[kCtrMaxLen], m);
+  }
 }
 
 // ---- a set's state between rounds --------------------------------------------------------------------------------
@@ -1217,6 +1229,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
   const uint32_t s = live ? (w.live_in ? w.live_in[tid] : tid) : 0u;
   SetState st;
   st.phase = kDone;
+  uint32_t prof_done = 0;
   // Everything that depends on nothing but the set's number is asked for at once: its state, its static quad, its first row
   // position and its tile -- a wavefront of this kernel is bound by the number of dependent trips to memory it makes (state
   // -> offsets -> tile -> rows -> ... : profiles/r04_decide_phases.txt), and these four used to be three trips.
@@ -1756,7 +1769,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
         row.rtax = anc_node(tax, nb, st.d_rtax); row.flags = 0;
         rows[s] = row;
         if (stats) stats[s] = OutStats{n, st.cnt0, st.cnt1, st.cnt2};
-        if (prof_acc) atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * kProfSlots + 3], (unsigned long long)(st.cnt0 + st.cnt1 + st.cnt2));
+        prof_done = st.cnt0 + st.cnt1 + st.cnt2;  // (demanded alignments of a finished set: added up per wavefront below)
         if (st.d_unode_g > st.d_lnode_g) raise_error(w, kErrAssert, s);  // setNodeRange assert, predictionrecord.hh:153
         st.phase = kDone;
       }
@@ -1776,6 +1789,12 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     w.emit_lite[s] = emit_desc(em);
     st.gq = fq.reg; st.go = fo.reg;
     state_store(w, s, st, st.loop_live != 0u && st.phase == kPass1Wait);
+  }
+  if (prof_acc) {  // (uniform; one atomic per wavefront, not one per finished record set: a million on 64 addresses per config-2 step)
+    uint32_t v = prof_done;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * kProfSlots + 3], (unsigned long long)v);
   }
   append_live_last_wave(w, s_live_stage, live && st.phase != kDone, s);  // still running: next round's live list
 }
