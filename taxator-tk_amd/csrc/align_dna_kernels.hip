@@ -270,11 +270,12 @@ __device__ __forceinline__ void store_dna_result(const WorkDev& w, uint32_t dst,
 // n_list_dev != null: `list` is a retry list whose length only the device knows (n_list bounds it) and the grid strides.
 template <int NW>
 __global__ __launch_bounds__(kBlock) void k_myers_short(const uint2* __restrict__ list, uint32_t n_list, const uint32_t* __restrict__ n_list_dev,
-                                                         const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
+                                                         uint32_t dev_split, const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
                                                          unsigned long long* prof_acc) {
   extern __shared__ uint32_t peq[];  // [5][NW][kBlock]
   const int tid = threadIdx.x;
   if (n_list_dev) {
+    if (*n_list_dev <= dev_split) return;  // (a list of up to dev_split pairs is k_myers_short_wave's, launched in front of this kernel; 0: all mine)
     n_list = *n_list_dev < n_list ? *n_list_dev : n_list;
     if (blockIdx.x == 0 && tid == 0 && n_list) atomicAdd(&w.counters[kCtrRetryShortTotal], n_list);  // what the band cost this batch
   }
@@ -581,8 +582,124 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
   else retry[atomicAdd(retry_n, 1u)] = entry;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K1w: the same alignment with a pattern WORD per lane -- eight lanes per pair, eight pairs per wavefront -- for launches of a
+// few thousand pairs (the sparse rounds at the end of a batch, the retry lists of the later dense rounds).  With a pair per
+// lane such a launch takes what ONE lane takes, ~45 us for 200 columns x 8 words, however few pairs it carries; here lane l
+// owns word l (VP, VN, its five match masks in LDS) and runs l + 1 columns behind lane 0, so a column's add carry and the top
+// bits of HP / HN reach the word above one step later through ONE `v_mov_b32 ... row_shr:1` (DPP, no LDS, no memory), and so
+// does the column's symbol -- a step ahead of the carries, so that the match mask of the next column is already on its way
+// from LDS while the current one is computed.  n + 8 steps of one word update instead of n x 8: ~9 us.  Exact for any pattern
+// of up to 256 residues, like k_myers_short<8>.  A retry list's length is known to the device only: both kernels are launched
+// on it and `dev_split` decides which of them works (this one up to dev_split pairs, k_myers_short above).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kWaveWords = 8;  // lanes per pair = words of the widest pattern
+__device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+__global__ __launch_bounds__(kBlock) void k_myers_short_wave(const uint2* __restrict__ list, uint32_t n_list, const uint32_t* __restrict__ n_list_dev,
+                                                              uint32_t dev_split, const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
+                                                              unsigned long long* prof_acc) {
+  __shared__ uint32_t peq[6 * kBlock];  // [symbol][thread]; row 5 = no match (the symbol of the steps before and behind the text)
+  const int tid = threadIdx.x;
+  const uint32_t sub = (uint32_t)tid & (kWaveWords - 1), group = (uint32_t)tid / kWaveWords;
+  constexpr uint32_t kPairs = kBlock / kWaveWords;  // pairs per workgroup and trip
+  if (n_list_dev) {
+    const uint32_t cnt = *n_list_dev;
+    if (cnt > dev_split) return;  // (whole grid: the pair-per-lane kernel behind this launch takes the list)
+    n_list = cnt < n_list ? cnt : n_list;
+    if (blockIdx.x == 0 && tid == 0 && n_list) atomicAdd(&w.counters[kCtrRetryShortTotal], n_list);  // what the band cost this batch
+  }
+  const uint32_t total = n_list + n_list2;
+  peq[5 * kBlock + tid] = 0u;
+  for (uint32_t base = blockIdx.x * kPairs; base < total; base += gridDim.x * kPairs) {
+    const uint32_t t = base + group;
+    const bool active = t < total;
+    uint32_t dst = 0, m = 0, n = 0;
+    SegView pat{}, txt{};
+    if (active) {
+      uint32_t a, b;
+      resolve_pair(w, t < n_list ? list[t] : list2[t - n_list], a, b, dst);
+      SegView va = seg_view(w, a), vb = seg_view(w, b);
+      const bool a_pat = (va.len + 31u) / 32u == (vb.len + 31u) / 32u ? va.len >= vb.len : va.len < vb.len;  // as in k_myers_short
+      if (a_pat) { txt = vb; pat = va; } else { txt = va; pat = vb; }
+      n = txt.len; m = pat.len;
+    }
+    if (prof_acc) profile_add(prof_acc, active && sub == 0u, n, m, (unsigned long long)n * (kWaveWords * 32u));
+    {
+      uint32_t mask[5] = {0u, 0u, 0u, 0u, 0u};
+      if (active && sub * 32u < m) {
+        NtStream ps;
+        ps.init(pat, sub * 32u);
+        peq_word(ps, sub, m, mask);
+      }
+#pragma unroll
+      for (int c = 0; c < 5; ++c) peq[c * kBlock + tid] = mask[c];
+    }
+    // (no barrier: a lane only ever reads its own LDS column)
+    uint32_t VP = 0xFFFFFFFFu, VN = 0u;
+    uint32_t sym_now = 5u, eq_now = 0u, out_bits = 0u;  // out_bits: add carry | HP's top bit << 1 | HN's top bit << 2 of my last column
+    uint32_t step = 0;
+    auto advance = [&](uint32_t c_next) {  // c_next: the symbol of column `step` (lane 0 computes it in the NEXT step), 5 behind the text
+      // the symbol of my next column is the one the word below computes in this step: its match mask is asked for first and
+      // arrives from LDS while this step's column is computed
+      uint32_t sym_next = row_shr1(sym_now);
+      sym_next = sub == 0u ? c_next : sym_next;
+      const uint32_t eq_next = peq[sym_next * kBlock + tid];
+      // the carries of the word below for the column I compute now (lane 0: +1 enters row 0 of a global alignment)
+      uint32_t in_bits = row_shr1(out_bits);
+      in_bits = sub == 0u ? 2u : in_bits;
+      const uint32_t X = eq_now | VN;
+      const uint64_t s64 = (uint64_t)VP + (uint64_t)(X & VP) + (uint64_t)(in_bits & 1u);
+      const uint32_t sum = (uint32_t)s64;
+      const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, VP, X, 0xBE);   // (sum ^ VP) | X
+      const uint32_t HN = VP & D0;
+      const uint32_t HP = __builtin_amdgcn_bitop3_b32(VN, VP, D0, 0xF1);   // VN | ~(VP | D0)
+      const uint32_t Xs = (HP << 1) | ((in_bits >> 1) & 1u), Hs = (HN << 1) | (in_bits >> 2);
+      const bool on = step - sub - 1u < n;  // my column this step: step - sub - 1 (unsigned: not before the text, not behind it)
+      VN = on ? (Xs & D0) : VN;
+      VP = on ? __builtin_amdgcn_bitop3_b32(Hs, Xs, D0, 0xF1) : VP;       // Hs | ~(Xs | D0)
+      out_bits = (uint32_t)(s64 >> 32) | ((HP >> 31) << 1) | ((HN >> 31) << 2);
+      sym_now = sym_next;
+      eq_now = eq_next;
+      ++step;
+    };
+    if (active) walk_text(txt, [&](uint32_t c) { advance(c); });
+    // (every lane of a wavefront must take every step: the text lengths of its eight pairs differ -- the shorter ones idle
+    // through no-match columns; an inactive group has n = 0)
+    {
+      uint32_t longest = n;
+#pragma unroll
+      for (int d = 32; d >= kWaveWords; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, d, 64));
+      while (step < longest + kWaveWords) advance(5u);
+    }
+    int32_t part = 0;
+    {
+      const uint32_t pos = sub * 32u;
+      const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
+      part = (int32_t)__popc(VP & vm) - (int32_t)__popc(VN & vm);
+    }
+#pragma unroll
+    for (int d = 1; d < kWaveWords; d <<= 1) part += __shfl_xor(part, d, 64);
+    if (active && sub == 0u) store_dna_result(w, dst, (int32_t)n + part, n, m);
+  }
+}
+
+hipError_t launch_align_dna_short_wave(hipStream_t st, const uint2* list, uint32_t n, const uint32_t* n_dev, uint32_t dev_split,
+                                       const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc) {
+  if ((uint64_t)n + n2 == 0) return hipSuccess;
+  if ((uint64_t)n + n2 > 0xFFFFFF00ull) return hipErrorInvalidValue;
+  const uint64_t bound = n_dev ? (uint64_t)(n < dev_split ? n : dev_split) + n2 : (uint64_t)n + n2;
+  constexpr uint32_t kPairs = kBlock / kWaveWords;
+  uint32_t blocks = (uint32_t)((bound + kPairs - 1) / kPairs);
+  if (blocks > 8192u) blocks = 8192u;  // (the grid strides)
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_myers_short_wave, dim3(blocks), dim3(kBlock), 0, st, list, n, n_dev, dev_split, list2, n2, w, prof_acc);
+  return hipGetLastError();
+}
+
 hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint32_t* n_dev, uint32_t grid_blocks,
-                                  const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc) {
+                                  const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc, uint32_t dev_split) {
   if ((uint64_t)n + n2 == 0) return hipSuccess;
   if ((uint64_t)n + n2 > 0xFFFFFF00ull) return hipErrorInvalidValue;
   uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
@@ -591,7 +708,7 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
   static const size_t lds_pad = getenv("RPA_LDS_PAD") ? (size_t)atoi(getenv("RPA_LDS_PAD")) : 0;  // occupancy experiments only
   lds += lds_pad;
 #define RPA_LAUNCH_MYERS(NWV) \
-  case NWV: hipLaunchKernelGGL(k_myers_short<NWV>, dim3(blocks), dim3(kBlock), lds, st, list, n, n_dev, list2, n2, w, prof_acc); break;
+  case NWV: hipLaunchKernelGGL(k_myers_short<NWV>, dim3(blocks), dim3(kBlock), lds, st, list, n, n_dev, dev_split, list2, n2, w, prof_acc); break;
   switch (words) {
     RPA_LAUNCH_MYERS(1) RPA_LAUNCH_MYERS(2) RPA_LAUNCH_MYERS(3) RPA_LAUNCH_MYERS(4)
     RPA_LAUNCH_MYERS(5) RPA_LAUNCH_MYERS(6) RPA_LAUNCH_MYERS(7) RPA_LAUNCH_MYERS(8)

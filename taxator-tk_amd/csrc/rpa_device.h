@@ -337,7 +337,10 @@ hipError_t launch_export_alignments(hipStream_t st, const WorkDev& w, uint32_t n
 // walks `list` then `list2` (n2 may be 0): pairs of a narrower class may ride along, the kernel is exact for any pattern <= 32*words
 // n_dev != null: `list` is a retry list whose length is read on the device (bounded by n); grid_blocks workgroups stride over it
 hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, uint32_t n, const uint32_t* n_dev, uint32_t grid_blocks,
-                                  const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc);
+                                  const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc, uint32_t dev_split = 0);
+// K1w (a pattern word per lane: launches of few pairs); with n_dev: works only when the list holds up to dev_split pairs
+hipError_t launch_align_dna_short_wave(hipStream_t st, const uint2* list, uint32_t n, const uint32_t* n_dev, uint32_t dev_split,
+                                       const uint2* list2, uint32_t n2, const WorkDev& w, unsigned long long* prof_acc);
 // the same inside a band of 2 words either side of the diagonal (patterns of 5..8 words); pairs whose distance lies
 // outside it are appended to retry[*retry_n] instead of being answered
 bool dna_short_band_available(int words);

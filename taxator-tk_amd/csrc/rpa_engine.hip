@@ -106,6 +106,7 @@ struct rpa_engine {
   bool profiling = false;
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   uint32_t counter_next = 0;  // next free word of the work-counter pool (lanes_counter), see next_work_counter
+  uint32_t short_wave_max = 16384;  // one-strip launches of up to this many pairs run on K1w (RPA_SHORT_WAVE_MAX; 0: never; tools/short_wave_bench.py)
   bool trace_rounds = false;  // RPA_TRACE_ROUNDS=1: print live sets / alignments per round to stderr
   bool linear_rows = false;   // RPA_ROW_LAYOUT=linear: never tile the hit rows (tests, A/B)
   // alignment trace (rpa_trace_begin / rpa_trace_read): synchronous calls on the owner engine only
@@ -300,7 +301,9 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
                                                  e->band4_wide > 0 || e->band4_wide == -1, acc));
           banded_short += (uint64_t)n + n2;
           widest_short = bin + 1;
-        } else HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, nullptr, 0, list2, n2, w, acc));
+        } else if (e->short_wave_max && (uint64_t)n + n2 <= e->short_wave_max)  // few pairs: a pattern word per lane (K1w), any one-strip class
+          HIP_TRY(e, launch_align_dna_short_wave(e->stream, list, n, nullptr, 0, list2, n2, w, acc));
+        else HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, nullptr, 0, list2, n2, w, acc));
       } else {
         // Patterns of more than 256 nt.  Many pairs: one per lane, register strips inside Ukkonen's band (K1s).  Few pairs
         // (not enough to give every SIMD a few waves of lanes): one per wavefront (K2, every cell), as long as the pattern
@@ -364,8 +367,15 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
     LaunchTimer timer{e};
     int trc = timer.begin();
     if (trc) return trc;
-    HIP_TRY(e, launch_align_dna_short(e->stream, widest_short, e->retry_short.as<uint2>(), bound, w.counters + kCtrRetryShort, 2048u,
-                                      nullptr, 0, w, nullptr));
+    // (how many pairs the list holds only the device knows; when even the banded launches were few pairs, K1w takes it.  Both
+    // kernels on every list, each working on its side of a device-side threshold, was measured: the retry lists of config 2's
+    // dense rounds hold 13 k - 100 k pairs, K1w's 41 us + an empty launch against 49 us -- not worth a second launch)
+    if (e->short_wave_max && bound <= e->short_wave_max)
+      HIP_TRY(e, launch_align_dna_short_wave(e->stream, e->retry_short.as<uint2>(), bound, w.counters + kCtrRetryShort, bound,
+                                             nullptr, 0, w, nullptr));
+    else
+      HIP_TRY(e, launch_align_dna_short(e->stream, widest_short, e->retry_short.as<uint2>(), bound, w.counters + kCtrRetryShort, 2048u,
+                                        nullptr, 0, w, nullptr));
     trc = timer.end();
     if (trc) return trc;
   }
@@ -679,7 +689,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift;
+  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = make_stream(w->device, &w->own_stream);
@@ -838,6 +848,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_POISON")) e->poison = atoi(v) != 0;
   if (const char* v = getenv("RPA_LABEL_BITS")) e->force_label_shift = atoi(v) == 32 ? 5u : atoi(v) == 16 ? 4u : atoi(v) == 8 ? 3u : 0u;
   if (const char* v = getenv("RPA_PARTS")) e->parts_override = atoi(v);
+  if (const char* v = getenv("RPA_SHORT_WAVE_MAX")) e->short_wave_max = (uint32_t)strtoul(v, nullptr, 10);
   e->params.force_bin = -1;
   if (const char* v = getenv("RPA_FORCE_BIN")) e->params.force_bin = atoi(v);
   e->params.protein_lanes = 1;

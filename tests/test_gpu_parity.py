@@ -53,7 +53,11 @@ def _check_dna(oracle, out, a_codes, b_codes):
         assert np.float32(got["similarity"]).tobytes() == np.float32(o["similarity"]).tobytes(), k
 
 
-def test_dna_pairs_golden(pkg, oracle, golden_dir):
+@pytest.mark.parametrize("short_kernel", ["word-per-lane", "pair-per-lane"])
+def test_dna_pairs_golden(pkg, oracle, golden_dir, short_kernel, monkeypatch):
+    """The reference's own SeqAn vectors through both one-strip kernels for launches of few pairs: K1w (a pattern word per lane,
+    eight lanes per pair: the default below 16 384 pairs) and k_myers_short (a pair per lane)."""
+    monkeypatch.setenv("RPA_SHORT_WAVE_MAX", "1000000" if short_kernel == "word-per-lane" else "0")
     vec = json.load(open(os.path.join(golden_dir, "pairs_dna.json")))
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
     seqs, pa, pb = [], [], []
@@ -68,13 +72,15 @@ def test_dna_pairs_golden(pkg, oracle, golden_dir):
             v["dist"], v["match"], v["mismatch"], v["gap"], v["length"]), (len(v["a"]), len(v["b"]))
 
 
-@pytest.mark.parametrize("long_kernel", ["wave", "lane", None, "short-band"])
+@pytest.mark.parametrize("long_kernel", ["wave", "lane", None, "short-band", "short-pair-per-lane"])
 def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
     """Every length bin of the nucleotide kernels against the oracle.  Patterns above 256 nt have two kernels (one pair
     per wavefront for few pairs, register strips per lane for many, chosen by a cost model): both are forced in turn;
     above 16384 nt only the strip kernel applies."""
     monkeypatch.delenv("RPA_LONG_KERNEL", raising=False)
+    monkeypatch.delenv("RPA_SHORT_WAVE_MAX", raising=False)
     if long_kernel == "short-band": monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")  # banded one-strip kernel for launches of any size
+    elif long_kernel == "short-pair-per-lane": monkeypatch.setenv("RPA_SHORT_WAVE_MAX", "0")  # (the default for these few pairs is K1w, a pattern word per lane)
     elif long_kernel: monkeypatch.setenv("RPA_LONG_KERNEL", long_kernel)
     rng = np.random.default_rng(42)
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
@@ -108,13 +114,15 @@ def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
     assert out.tobytes() == out2.tobytes()
 
 
-@pytest.mark.parametrize("band", ["forced", "four-words", "five-words", "off"])
+@pytest.mark.parametrize("band", ["forced", "forced-retries-pair-per-lane", "four-words", "five-words", "off"])
 def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     """Patterns of 5..8 words (129..256 nt) go through a one-strip kernel that only updates the pattern words within two
     words of the diagonal; pairs whose distance lies outside that band (or whose lengths differ by 64 and more) are
     re-run by the full kernel.  Forced on for launches of any size / switched off: the same bytes either way, and both
     equal to the oracle -- from identical pairs to unrelated ones, with N's, and every length difference class."""
     monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")
+    monkeypatch.delenv("RPA_SHORT_WAVE_MAX", raising=False)
+    if band == "forced-retries-pair-per-lane": monkeypatch.setenv("RPA_SHORT_WAVE_MAX", "0")  # (a short retry list is K1w's by default)
     if band == "off": monkeypatch.setenv("RPA_BAND_SHORT", "0")
     if band == "five-words": monkeypatch.setenv("RPA_BAND_WORDS", "5")  # the in-phase window (k = 128 - |delta|)
     if band == "four-words": monkeypatch.setenv("RPA_BAND4_PHASES", "2")  # four words all the way, out of phase (96); default: a three-word middle (80)
