@@ -604,7 +604,7 @@ def main():
             pending_gather[k_] = None
     if ring is not None:
         ring.drain()
-    model.profile(enable=True, reset=True)
+    model.profile(enable=True, reset=True)  # (on in the timed region as well: 8.26 / 8.35 / 8.34 ms per step without it against 8.46 / 8.44 / 8.35 with it, the spread of repeated runs)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -629,10 +629,20 @@ def main():
     prof = model.profile()
     prof_steps = args.steps
     sync_ms = None
+    sync_plain_ms = None
     if pipelined:
         # The same steps once more as synchronous calls, for the profile only (launch durations by HIP events on the
         # engine's stream, cells, demanded / computed alignments, rounds): jobs that overlap inflate each other's launches.
         prof_steps = max(1, min(args.steps, 10))
+        # (first without the profile: its event pairs around every alignment launch cost a synchronous step ~0.1 ms; this is
+        # the call a synchronous caller makes -- then with it, for the roofline)
+        model.profile(enable=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
+        torch.cuda.synchronize()
+        sync_plain_ms = (time.perf_counter() - t1) / prof_steps * 1e3
         model.profile(enable=True, reset=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -741,7 +751,8 @@ def main():
             "submission": ("rpa_submit_batch / rpa_wait, %d steps in flight on the engine's job slots (the timed region); `roofline`, device_ms_per_step, "
                            "align_ms_per_step and rounds_per_step come from %d synchronous rpa_predict_batch calls on the same batch after it"
                            % (args.in_flight, prof_steps)) if pipelined else "one synchronous call per step",
-            "sync_ms_per_step": sync_ms,
+            "sync_ms_per_step": sync_ms,   # one rpa_predict_batch per step WITH the profile on (the leg `roofline` comes from)
+            "sync_unprofiled_ms_per_step": sync_plain_ms,  # ... the same call as a caller makes it (no event pairs around the launches)
             "datagen_s": t_gen,
             "hbm_in_use_gb": (lambda fr_to: round((fr_to[1] - fr_to[0]) / 1e9, 2))(torch.cuda.mem_get_info()),  # this rank's device, everything resident
             "reference_store": {"replicas": args.store_replicas, "packed_bytes": store_bytes,
