@@ -195,7 +195,7 @@ struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, recor
 typedef std::chrono::steady_clock Clock;
 double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
 
-// reader thread -> one GPU thread per engine -> writer thread; 2 x engines + 1 Work objects in circulation.  The
+// reader thread(s) -> two GPU threads per engine -> writer thread; 4 x engines + teams Work objects in circulation.  The
 // reference's doPredictionsParallel (core/taxator.cpp:181-210) has N consumer threads call predict() on one model and
 // prints in whatever order they finish; here a parsed block goes to whichever GPU is free and the writer puts the
 // blocks back into input order (what the reference's serial loop prints, :69-74).
@@ -210,10 +210,12 @@ void run_columnar(std::vector<std::unique_ptr<ColumnarReader>>& readers, SliceCu
   for (Work& w : works) free_q.push(&w);
   std::atomic<bool> stop(false);
   std::mutex tm_mu;
-  // ONE reader (a pipe, or a single engine): blocks in stream order, the open group at a block's end carried to the next.
-  // SEVERAL reader teams (a regular file on stdin and more than one engine): the file is cut into slices at query-identifier
+  // ONE reader (a pipe, --readers 1, few host threads): blocks in stream order, the open group at a block's end carried to the next.
+  // SEVERAL reader teams (a regular file on stdin: four by default, at least one per engine): the file is cut into slices at query-identifier
   // boundaries (SliceCutter), every team parses whole slices with its share of the host threads, the slice index is the
-  // block's place in the output -- the feed scales with the host's cores instead of ending at one team's ~50 M lines/s.
+  // block's place in the output -- the feed scales with the host's cores instead of ending at one reader's ~100 M lines/s.
+  // (A team takes a Work object BEFORE it asks for a slice, so the earliest slice not yet printed always owns one: the writer,
+  // which holds finished blocks until their turn, cannot starve it.)
   std::vector<std::thread> reader_threads;
   std::atomic<bool> last_sent(false);
   auto reader_loop = [&](size_t team) {
