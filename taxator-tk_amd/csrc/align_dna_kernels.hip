@@ -730,8 +730,10 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
   const bool five = bw && atoi(bw) == 5;
   // Occupancy of the ring kernel: 20 KB of LDS and 73-79 VGPRs per wavefront give six wavefronts per SIMD, which is worth
   // 2 % to a batch that has the GPU to itself and leaves no registers for anybody else.  A job slot (several batches in
-  // flight) asks for 20 KB more: four wavefronts per SIMD, and the memory-bound placement kernels of the other jobs find
-  // room beside them (config 2, three steps in flight: 10.17 -> 9.76 ms per step; one synchronous batch: 11.5 -> 11.7).
+  // flight) asks for 20 KB more: four wavefronts per SIMD (config 2, three steps in flight, round 2: 10.17 -> 9.76 ms per step;
+  // one synchronous batch: 11.5 -> 11.7).  Not because the other jobs' placement kernels then sit beside them -- four workgroups
+  // of 40 KB fill a CU's LDS -- and on round 4's engine 8, 14.5 (LDS left for k_rank_records), 20 and 26 KB (three wavefronts,
+  // room for k_decide / k_emit) all give the same step: profiles/r04_ab_decide_occupancy.txt.
   const char* padv = getenv("RPA_BAND4_LDS_PAD");  // (experiments: extra dynamic LDS per workgroup in bytes, whoever launches)
   const size_t pad4 = padv ? (size_t)atoi(padv) : (shared_gpu ? 20000u : 0u);
 #define RPA_LAUNCH_MYERS_BAND(NWV) \
