@@ -1439,6 +1439,12 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       const bool small = n <= 64u;
       unsigned long long ogmask = (small && st.loop_live) ? ((unsigned long long)st.pad_ << 32) | st.nog : 0ull;
       unsigned long long fqclr = 0ull;
+      // ... and, for sets of up to 32 hits on trees of up to 15 levels in a loop that starts in this call, the depth of
+      // LCA(member, best hit) of every outgroup member as a nibble (the walk has the member's path in registers; the member
+      // loop behind it then re-reads the members' RESULTS only, not their rows: in a first pass-1 round nearly every hit is a
+      // member, and the rows were fetched twice -- 1.9 KB per record set where the walk needs 0.9)
+      const bool cb_packed = small && n <= 32u && w.band_ranks <= 16u && !st.loop_live;
+      unsigned long long cb_lo = 0ull, cb_hi = 0ull;
       bool paused = false;
       auto walk = [&](auto small_tag) {
       constexpr bool kSmall = decltype(small_tag)::value;
@@ -1487,8 +1493,13 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
             }
             if (!scut) scut = (int)(h.score * X);
           }
-          if constexpr (kSmall) ogmask |= 1ull << i;
-          else { ogi[nog] = i; ogd[nog] = (int)dist; ++nog; }
+          if constexpr (kSmall) {
+            ogmask |= 1ull << i;
+            if (cb_packed) {
+              const unsigned long long cbn = (unsigned long long)common<PW>(pb, db, pth, dh, lbs) << ((i & 15u) * 4u);
+              if (i < 16u) cb_lo |= cbn; else cb_hi |= cbn;
+            }
+          } else { ogi[nog] = i; ogd[nog] = (int)dist; ++nog; }
         }
       }
       };
@@ -1564,9 +1575,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           for (uint32_t k = 0; k < nog; ++k) upper((float)ogd[k]);
         }
         uint32_t d_unode = d_lnode;  // unode = lnode, :690 -- (float)INT_MAX != FLT_MAX, so always taken
-        auto member = [&](uint32_t io, float dist, const uint32_t (&pth)[PW], uint32_t depth) {  // one outgroup_tmp entry, :691-711
-          if (dist > min_upper_dist) return;
-          const uint32_t cb = common<PW>(pb, db, pth, depth, lbs);
+        auto member_cb = [&](uint32_t io, uint32_t cb) {  // an outgroup_tmp entry within min_upper_dist, :691-711; cb = depth of LCA(cnode, best hit)
           d_unode = min(d_unode, cb);                          // unode = LCA(cnode, unode)
           const uint32_t lca_root_dist = min(st.d_rtax, cb);   // depth(LCA(cnode, rtax))
           if (lca_root_dist > st.lrd_min) return;
@@ -1576,7 +1585,29 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
           }
           bit_set(fo, io);
         };
-        if (small) {
+        auto member = [&](uint32_t io, float dist, const uint32_t (&pth)[PW], uint32_t depth) {
+          if (dist > min_upper_dist) return;
+          member_cb(io, common<PW>(pb, db, pth, depth, lbs));
+        };
+        if (cb_packed) {  // (the nibbles of the walk above: a member is its result slot)
+          unsigned long long mleft = ogmask;
+          while (mleft) {
+            uint32_t io[4];
+            float dd[4];
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              io[q] = 0u;
+              if (mleft) { io[q] = (uint32_t)__ffsll((long long)mleft) - 1u; mleft &= mleft - 1ull; cnt = q + 1; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dd[q] = q < cnt ? (float)(int)R.result(io[q]).x : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (q < cnt && !(dd[q] > min_upper_dist))
+                member_cb(io[q], (uint32_t)(((io[q] < 16u ? cb_lo : cb_hi) >> ((io[q] & 15u) * 4u)) & 15ull));
+          }
+        } else if (small) {
           // members in index order; what a member needs (its distance, its path, its depth) is asked for FOUR members at a time
           // (narrow rows): a member used to be two dependent trips to memory, its result and then its row
           constexpr int kBatch = PW <= 2 ? 4 : 1;
