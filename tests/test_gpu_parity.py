@@ -559,6 +559,28 @@ def test_scores_of_any_sign_and_masked_records(pkg, oracle, synth):
             _engine_vs_oracle(pkg, oracle, synth, ds, 0, exclude_factor=x, reeval_bandwidth=t)
 
 
+def test_one_engine_across_batches_of_different_shapes(pkg, oracle, synth):
+    """One engine, batches whose row shape and size change from call to call -- 20 hits per set (8-bit path labels, rows of two
+    quads), 300 hits per set (16-bit labels, wider rows; a tree of 7^6 species), a handful of sets, many sets, and back: the working set is resized
+    and re-tiled between the calls (as the `taxator` driver's blocks do) and every batch equals the oracle."""
+    model = None
+    for k, (n_sets, n_hits) in enumerate([(300, 20), (12, 300), (2000, 20), (3, 2), (40, 300), (300, 33)]):
+        ds = synth.make_dataset(n_sets=n_sets, n_hits=n_hits, seg_len=60, branching=7, genome_len=400, seed=301 + k, variety=(k % 2 == 0))
+        if model is None:
+            model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+        # (every data set brings its own sequences: the stores are reloaded, the engine and its working set stay)
+        model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+        model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+        rows, stats = model.predict(ds.batch)
+        tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+        q = oracle.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+        db = oracle.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+        rc, exp, est = oracle.predict_batch(tax, q, db, 0, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
+                                            synth.records_aos(ds.batch, oracle.RECORD_DTYPE))
+        assert rc == 0
+        assert rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes(), (k, n_sets, n_hits)
+
+
 def test_band_widens_when_too_many_pairs_leave_it(pkg, oracle, synth, monkeypatch, capfd):
     """The one-strip band has a three-word middle (exact up to 80 - |delta| edits); a batch in which more than one banded
     pair in sixteen lies beyond that makes the engine use four words all the way (96 - |delta|) for the following batches.
