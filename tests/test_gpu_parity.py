@@ -526,8 +526,10 @@ def test_scores_of_any_sign_and_masked_records(pkg, oracle, synth):
     the parsers let through but no aligner writes: negative ones, zeros of either sign, runs of ties; a third of
     the records masked (a masked record must count for nothing: its score, range and position in the set)."""
     rng = np.random.default_rng(77)
-    for k, n_hits in enumerate((20, 7, 70)):
-        ds = synth.make_dataset(n_sets=300, n_hits=n_hits, seg_len=120, branching=3, genome_len=2000, seed=170 + k, variety=True)
+    for k, (n_hits, alphabet) in enumerate(((20, 0), (7, 0), (70, 0), (20, 1))):
+        kw = dict(alphabet=1, level_rate=0.06, query_rate=0.08) if alphabet else {}
+        ds = synth.make_dataset(n_sets=300, n_hits=n_hits, seg_len=120 if alphabet == 0 else 67, branching=3, genome_len=2000 if alphabet == 0 else 1200,
+                                seed=170 + k, variety=True, **kw)
         b = ds.batch
         sc = b["score"].astype(np.float32).copy()
         H = len(sc)
@@ -556,7 +558,7 @@ def test_scores_of_any_sign_and_masked_records(pkg, oracle, synth):
                 sc[lo:hi] = np.abs(sc[lo:hi])
         b["score"] = sc
         for x, t in ((0.5, 0.05), (0.0, 0.3)):
-            _engine_vs_oracle(pkg, oracle, synth, ds, 0, exclude_factor=x, reeval_bandwidth=t)
+            _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, exclude_factor=x, reeval_bandwidth=t)
 
 
 def test_one_engine_across_batches_of_different_shapes(pkg, oracle, synth):
