@@ -333,6 +333,14 @@ def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_fli
         torch.cuda.synchronize()
         sync_ms = (time.perf_counter() - t1) / steps * 1e3
         prof = model.profile()
+        model.profile(enable=pkg.PROFILE_TIMING, reset=True)  # the launch durations without the kernels' counters (see the headline's leg)
+        torch.cuda.synchronize()
+        for _ in range(steps):
+            model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=outs[0][0], stats=outs[0][1])
+        torch.cuda.synchronize()
+        prof_t = model.profile()
+        if prof_t["launches"] == prof["launches"]:
+            prof = dict(prof, align_ms=prof_t["align_ms"], total_ms=prof_t["total_ms"])
     demanded = int(outs[0][1][:, 1:].to(torch.int64).sum().item())
     align_s = max(prof["align_ms"] / 1e3, 1e-12)
     traffic, traffic_src, valu_pl, valu_src = committed_profile(profile_tag) if profile_tag else (None, None, None, None)
@@ -630,6 +638,8 @@ def main():
     prof_steps = args.steps
     sync_ms = None
     sync_plain_ms = None
+    sync_timing_ms = None
+    prof_t = None
     if pipelined:
         # The same steps once more as synchronous calls, for the profile only (launch durations by HIP events on the
         # engine's stream, cells, demanded / computed alignments, rounds): jobs that overlap inflate each other's launches.
@@ -651,6 +661,17 @@ def main():
         torch.cuda.synchronize()
         sync_ms = (time.perf_counter() - t1) / prof_steps * 1e3
         prof = model.profile()
+        # ... and once more with the launch timing alone: the counters are reductions inside the alignment kernels (a shuffle
+        # reduction of four 64-bit sums per wavefront: ~4 % of K1's time), the launch durations `roofline` is quoted on should
+        # not contain the instrument
+        model.profile(enable=pkg.PROFILE_TIMING, reset=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
+        torch.cuda.synchronize()
+        sync_timing_ms = (time.perf_counter() - t1) / prof_steps * 1e3
+        prof_t = model.profile()
 
     # What each rank saw, for the first multi-GPU run to be diagnosable from its one JSON line: per rank the time its own K
     # steps took, the time until its share of the exchanges was done, and the cost of ONE gather of a step's rows on an
@@ -710,8 +731,9 @@ def main():
             tcfg = "c2" if args.config == "c3" else args.config  # config 3 runs config 2's kernels on config 2's shapes
             traffic, traffic_src, valu_per_launch, valu_src = committed_profile(tcfg)
         value = demanded_all * args.steps / elapsed
+        tprof = prof_t if prof_t is not None and prof_t["launches"] == prof["launches"] else prof  # launch timing without the counters (same launches)
         n_launch = max(prof["launches"], 1)
-        align_s = prof["align_ms"] / 1e3
+        align_s = tprof["align_ms"] / 1e3
         achieved = prof["residue_bytes"] / max(align_s, 1e-12) / 1e9
         out = {
             "metric": "query-segment realignments/sec",
@@ -734,7 +756,8 @@ def main():
                          "traffic_source": traffic_src,
                          "kernel": cfg["kernel"],
                          "bytes_per_launch": prof["residue_bytes"] / n_launch,
-                         "avg_launch_ms": prof["align_ms"] / n_launch, "launches": prof["launches"],
+                         "avg_launch_ms": tprof["align_ms"] / n_launch, "launches": prof["launches"],
+                         "timing": "HIP events around every alignment launch of %d synchronous calls with the kernels' counters OFF (rpa_profile_enable(RPA_PROFILE_TIMING)); bytes / pairs / cells from the same calls with the counters on (avg launch %.4f ms there)" % (prof_steps, prof["align_ms"] / n_launch) if tprof is not prof else "HIP events around every alignment launch, counters on",
                          "computed_alignments_per_s_in_kernel": prof["pairs"] / max(align_s, 1e-12),
                          "cell_updates_per_s_in_kernel": prof["cells"] / max(align_s, 1e-12),
                          "cell_updates_note": "cell-EQUIVALENTS: len_a x len_b per computed alignment, whatever part of the matrix the kernel swept",
@@ -745,14 +768,16 @@ def main():
                          # vector-instruction issue: wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of the committed profile)
                          # over the live launch duration, per SIMD (1024 of them); a wave64 instruction takes a SIMD-32 two cycles
                          # (MI355X_MICROARCH.md) = 1.2 per ns at 2.4 GHz; plain and/or/add measured ~1.0, shifts and carry ops ~0.57
-                         "valu_issue": valu_issue(valu_per_launch, valu_src, prof["align_ms"], n_launch)},
-            "device_ms_per_step": prof["total_ms"] / prof_steps, "align_ms_per_step": prof["align_ms"] / prof_steps,
+                         "valu_issue": valu_issue(valu_per_launch, valu_src, tprof["align_ms"], n_launch)},
+            "device_ms_per_step": tprof["total_ms"] / prof_steps, "align_ms_per_step": tprof["align_ms"] / prof_steps,
+            "align_ms_with_counters_per_step": prof["align_ms"] / prof_steps,
             "computed_over_demanded": prof["pairs"] / max(prof["demanded"], 1), "rounds_per_step": prof["rounds"] / prof_steps,
             "submission": ("rpa_submit_batch / rpa_wait, %d steps in flight on the engine's job slots (the timed region); `roofline`, device_ms_per_step, "
                            "align_ms_per_step and rounds_per_step come from %d synchronous rpa_predict_batch calls on the same batch after it"
                            % (args.in_flight, prof_steps)) if pipelined else "one synchronous call per step",
             "sync_ms_per_step": sync_ms,   # one rpa_predict_batch per step WITH the profile on (the leg `roofline` comes from)
             "sync_unprofiled_ms_per_step": sync_plain_ms,  # ... the same call as a caller makes it (no event pairs around the launches)
+            "sync_timing_only_ms_per_step": sync_timing_ms,  # ... with the event pairs but without the kernels' counters
             "datagen_s": t_gen,
             "hbm_in_use_gb": (lambda fr_to: round((fr_to[1] - fr_to[0]) / 1e9, 2))(torch.cuda.mem_get_info()),  # this rank's device, everything resident
             "reference_store": {"replicas": args.store_replicas, "packed_bytes": store_bytes,

@@ -275,6 +275,10 @@ typedef struct {
                               protein: every cell of the register strips, padding rows included (ABI 4) */
 } rpa_profile;
 
+/* on: 0 = off; 1 = launch timing + the counters (pairs, residue_bytes, cells, cells_updated, demanded: reductions inside the
+ * alignment kernels, which cost the dominant nucleotide kernel ~4 % of its time); RPA_PROFILE_TIMING = launch timing only
+ * (launches, align_ms, total_ms, rounds advance; the counters keep the values of the last counting pass). */
+#define RPA_PROFILE_TIMING 2
 int rpa_profile_enable(rpa_engine* e, int on);
 int rpa_profile_get(rpa_engine* e, rpa_profile* out);
 int rpa_profile_reset(rpa_engine* e);

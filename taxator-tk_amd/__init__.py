@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("RPA_LIB_PATH") or os.path.join(_HERE, "librpa_hip.so"
 DNA, PROTEIN = 0, 1
 STORE_QUERY, STORE_DB = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
+PROFILE_TIMING = 2  # RPAPredictionModel.profile(enable=PROFILE_TIMING): launch timing without the in-kernel counters
 FLAG_IVAL_UNTOUCHED, FLAG_SHORTCUT, FLAG_SINGLE = 1, 2, 4
 
 PRED_DTYPE = np.dtype([("lower", "<u4"), ("upper", "<u4"), ("rtax", "<u4"), ("support", "<u4"), ("begin", "<u4"),
@@ -395,7 +396,7 @@ class RPAPredictionModel:
 
     def profile(self, enable=None, reset=False):
         if enable is not None:
-            self._check(self._L.rpa_profile_enable(self._h, 1 if enable else 0))
+            self._check(self._L.rpa_profile_enable(self._h, PROFILE_TIMING if enable == PROFILE_TIMING and enable is not True else (1 if enable else 0)))
         if reset:
             self._check(self._L.rpa_profile_reset(self._h))
         p = _Profile()

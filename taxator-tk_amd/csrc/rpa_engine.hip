@@ -104,6 +104,7 @@ struct rpa_engine {
   uint32_t* h_counters = nullptr;  // pinned
   // profiling
   bool profiling = false;
+  bool prof_counters = true;   // rpa_profile_enable(2): events only -- the kernels carry no counters (their reductions cost K1 4 %)
   int long_kernel = 0;        // RPA_LONG_KERNEL=wave|lane: force K2 / K1s for patterns > 256 nt (tests, A/B); 0 = cost model
   uint32_t counter_next = 0;  // next free word of the work-counter pool (lanes_counter), see next_work_counter
   uint32_t short_wave_max = 16384;  // one-strip launches of up to this many pairs run on K1w (RPA_SHORT_WAVE_MAX; 0: never; tools/short_wave_bench.py)
@@ -259,7 +260,7 @@ int next_work_counter(rpa_engine* e, uint32_t** out) {
 }
 
 int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
-  unsigned long long* acc = e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr;
+  unsigned long long* acc = (e->profiling && e->prof_counters) ? e->prof_acc.as<unsigned long long>() : nullptr;
   const uint32_t* counts = counts_in;
   int rider = -1;  // a narrower one-strip class waiting for the next launch
   uint64_t banded_pairs = 0;  // pairs that went through the banded strip kernel this round: the retry list's bound
@@ -427,6 +428,7 @@ int profile_end(rpa_engine* e) {
     HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_pool[pr.first], e->ev_pool[pr.second]));
     e->prof.align_ms += ms;
   }
+  if (!e->prof_counters) return RPA_OK;  // (timing only: pairs / bytes / cells / demanded stay what the last counting pass left)
   unsigned long long parts[kProfParts * kProfSlots], acc[kProfSlots] = {};
   HIP_TRY(e, hipMemcpy(parts, e->prof_acc.p, sizeof(parts), hipMemcpyDeviceToHost));
   for (int k = 0; k < kProfParts; ++k)
@@ -644,7 +646,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
       }
     }
     HIP_TRY(e, launch_decide(e->stream, b, w, e->tax, pr, rows_dev, stats_dev,
-                             e->profiling ? e->prof_acc.as<unsigned long long>() : nullptr));
+                             (e->profiling && e->prof_counters) ? e->prof_acc.as<unsigned long long>() : nullptr));
     prev_live = live_now;
     list_in_a = !list_in_a;
     ++rounds;
@@ -689,7 +691,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
+  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = make_stream(w->device, &w->own_stream);
@@ -762,7 +764,7 @@ int run_parts(rpa_engine* e, const BatchDev& b, const uint32_t* h_offsets, void*
     pe->trace_view = e->trace_view; pe->trace_view_n = e->trace_view_n; pe->trace_view_cap = e->trace_view_cap; pe->trace_set_base = s_lo[k];
     if (k) {
       pe->err.clear();
-      pe->profiling = e->profiling;
+      pe->profiling = e->profiling; pe->prof_counters = e->prof_counters;
       HIP_TRY(pe, hipSetDevice(pe->device));
       HIP_TRY(pe, hipStreamWaitEvent(pe->stream, e->ev_inputs, 0));
       gates[k - 1].wait();  // start underneath the previous part's long alignment launch
@@ -1680,7 +1682,8 @@ int rpa_profile_enable(rpa_engine* e, int on) {
   if (!e) return RPA_ERR_INVALID;
   std::lock_guard<std::mutex> lk(e->mu);
   e->profiling = on != 0;
-  for (rpa_engine* w : e->workers) w->profiling = e->profiling;
+  e->prof_counters = on != RPA_PROFILE_TIMING;
+  for (rpa_engine* w : e->workers) { w->profiling = e->profiling; w->prof_counters = e->prof_counters; }
   return RPA_OK;
 }
 

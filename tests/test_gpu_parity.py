@@ -762,6 +762,15 @@ def test_device_resident_batch_and_profile(pkg, oracle, synth):
     assert prof["demanded"] == demanded and prof["pairs"] >= demanded and prof["launches"] >= 3
     assert 0 < prof["align_ms"] <= prof["total_ms"]
     assert prof["residue_bytes"] > prof["pairs"] * 300 and prof["cells"] > prof["pairs"] * 150 * 150
+    # launch timing alone (RPA_PROFILE_TIMING): the kernels carry no counters, the launches are timed as before, same rows
+    model.profile(enable=pkg.PROFILE_TIMING, reset=True)
+    model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=out, stats=st)
+    torch.cuda.synchronize()
+    t_only = model.profile()
+    assert out.cpu().numpy().tobytes() == host_rows.tobytes()
+    assert t_only["launches"] == prof["launches"] and 0 < t_only["align_ms"] <= t_only["total_ms"] and t_only["rounds"] == prof["rounds"]
+    assert t_only["pairs"] == 0 and t_only["cells"] == 0 and t_only["demanded"] == 0
+    model.profile(enable=False)
 
 
 def test_reverse_strand_at_store_edges_and_tiny_segments(pkg, oracle):
