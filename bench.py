@@ -612,7 +612,11 @@ def main():
             pending_gather[k_] = None
     if ring is not None:
         ring.drain()
-    model.profile(enable=True, reset=True)  # (on in the timed region as well: 8.26 / 8.35 / 8.34 ms per step without it against 8.46 / 8.44 / 8.35 with it, the spread of repeated runs)
+    # The profile in the timed region: job slots (steps in flight, host buffers) never profile; synchronous steps (--sync,
+    # multi-rank runs with a blocking gather) time their launches WITHOUT the kernels' counters here and count in a short pass
+    # behind the timed region (RPA_PROFILE_TIMING: the counters are reductions inside the alignment kernels, ~4 % of K1).
+    sync_steps = not pipelined and not args.host_buffers
+    model.profile(enable=pkg.PROFILE_TIMING if sync_steps else True, reset=True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -636,14 +640,24 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = model.profile()
     prof_steps = args.steps
+    count_steps = args.steps  # steps the counters (pairs, bytes, cells, demanded) of `prof` cover
     sync_ms = None
     sync_plain_ms = None
     sync_timing_ms = None
     prof_t = None
+    if sync_steps:
+        prof_t = prof
+        count_steps = max(1, min(args.steps, 2))
+        model.profile(enable=True, reset=True)
+        for _ in range(count_steps):
+            model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=rows, stats=stats)
+        torch.cuda.synchronize()
+        prof = model.profile()
     if pipelined:
         # The same steps once more as synchronous calls, for the profile only (launch durations by HIP events on the
         # engine's stream, cells, demanded / computed alignments, rounds): jobs that overlap inflate each other's launches.
         prof_steps = max(1, min(args.steps, 10))
+        count_steps = prof_steps
         # (first without the profile: its event pairs around every alignment launch cost a synchronous step ~0.1 ms; this is
         # the call a synchronous caller makes -- then with it, for the roofline)
         model.profile(enable=False)
@@ -731,9 +745,13 @@ def main():
             tcfg = "c2" if args.config == "c3" else args.config  # config 3 runs config 2's kernels on config 2's shapes
             traffic, traffic_src, valu_per_launch, valu_src = committed_profile(tcfg)
         value = demanded_all * args.steps / elapsed
-        tprof = prof_t if prof_t is not None and prof_t["launches"] == prof["launches"] else prof  # launch timing without the counters (same launches)
-        n_launch = max(prof["launches"], 1)
-        align_s = tprof["align_ms"] / 1e3
+        # launch timing without the counters (prof_t: prof_steps steps) beside the counting pass (prof: count_steps steps of the same
+        # batch, i.e. the same launches per step); everything below is per step
+        same = prof_t is not None and prof_t["launches"] * count_steps == prof["launches"] * prof_steps
+        tprof = prof_t if same else prof
+        t_steps = prof_steps if same else count_steps
+        n_launch = max(tprof["launches"], 1)                       # launches of the timing pass
+        align_s = tprof["align_ms"] / 1e3 * count_steps / t_steps  # ... its alignment time, scaled to the steps the counters cover
         achieved = prof["residue_bytes"] / max(align_s, 1e-12) / 1e9
         out = {
             "metric": "query-segment realignments/sec",
@@ -755,9 +773,9 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC)",
                          "traffic_source": traffic_src,
                          "kernel": cfg["kernel"],
-                         "bytes_per_launch": prof["residue_bytes"] / n_launch,
-                         "avg_launch_ms": tprof["align_ms"] / n_launch, "launches": prof["launches"],
-                         "timing": "HIP events around every alignment launch of %d synchronous calls with the kernels' counters OFF (rpa_profile_enable(RPA_PROFILE_TIMING)); bytes / pairs / cells from the same calls with the counters on (avg launch %.4f ms there)" % (prof_steps, prof["align_ms"] / n_launch) if tprof is not prof else "HIP events around every alignment launch, counters on",
+                         "bytes_per_launch": prof["residue_bytes"] / max(prof["launches"], 1),
+                         "avg_launch_ms": tprof["align_ms"] / n_launch, "launches": tprof["launches"],
+                         "timing": "HIP events around every alignment launch of %d synchronous calls with the kernels' counters OFF (rpa_profile_enable(RPA_PROFILE_TIMING)); bytes / pairs / cells from the same calls with the counters on (avg launch %.4f ms there)" % (t_steps, prof["align_ms"] / max(prof["launches"], 1)) if tprof is not prof else "HIP events around every alignment launch, counters on",
                          "computed_alignments_per_s_in_kernel": prof["pairs"] / max(align_s, 1e-12),
                          "cell_updates_per_s_in_kernel": prof["cells"] / max(align_s, 1e-12),
                          "cell_updates_note": "cell-EQUIVALENTS: len_a x len_b per computed alignment, whatever part of the matrix the kernel swept",
@@ -769,9 +787,9 @@ def main():
                          # over the live launch duration, per SIMD (1024 of them); a wave64 instruction takes a SIMD-32 two cycles
                          # (MI355X_MICROARCH.md) = 1.2 per ns at 2.4 GHz; plain and/or/add measured ~1.0, shifts and carry ops ~0.57
                          "valu_issue": valu_issue(valu_per_launch, valu_src, tprof["align_ms"], n_launch)},
-            "device_ms_per_step": tprof["total_ms"] / prof_steps, "align_ms_per_step": tprof["align_ms"] / prof_steps,
-            "align_ms_with_counters_per_step": prof["align_ms"] / prof_steps,
-            "computed_over_demanded": prof["pairs"] / max(prof["demanded"], 1), "rounds_per_step": prof["rounds"] / prof_steps,
+            "device_ms_per_step": tprof["total_ms"] / t_steps, "align_ms_per_step": tprof["align_ms"] / t_steps,
+            "align_ms_with_counters_per_step": prof["align_ms"] / count_steps,
+            "computed_over_demanded": prof["pairs"] / max(prof["demanded"], 1), "rounds_per_step": prof["rounds"] / count_steps,
             "submission": ("rpa_submit_batch / rpa_wait, %d steps in flight on the engine's job slots (the timed region); `roofline`, device_ms_per_step, "
                            "align_ms_per_step and rounds_per_step come from %d synchronous rpa_predict_batch calls on the same batch after it"
                            % (args.in_flight, prof_steps)) if pipelined else "one synchronous call per step",
