@@ -42,6 +42,12 @@ def test_bench_one_rank_over_rccl(config, extra):
     assert len(d["per_rank_ms"]) == 1 and 0 < d["per_rank_ms"][0] <= d["per_rank_exchange_done_ms"][0] <= d["per_rank_barrier_ms"][0] * 1.001
     assert d["gather_ms"] > 0 and d["gather_bytes"] == 32 * sum(out["config"]["shard_sets"])
     assert out["roofline"]["achieved"] > 0 and out["roofline"]["launches"] > 0
+    # the three synchronous legs behind the timed region: plain <= launch timing only <= timing + the kernels' counters (within noise),
+    # and the roofline quoted on the launch durations of the timing-only leg
+    assert 0 < out["sync_unprofiled_ms_per_step"] and 0 < out["sync_timing_only_ms_per_step"] and 0 < out["sync_ms_per_step"]
+    assert "counters OFF" in out["roofline"]["timing"]
+    assert 0.5 < out["align_ms_per_step"] / out["align_ms_with_counters_per_step"] < 1.5   # (tiny workloads here: the two passes differ by noise)
+    assert abs(out["roofline"]["avg_launch_ms"] * out["roofline"]["launches"] / 2 - out["align_ms_per_step"]) < 1e-6 * out["align_ms_per_step"] + 1e-9
 
 
 RANKS = 4  # the GPU box allows six processes on its card: the test runner + four ranks (eight ranks: tests/test_distributed_cpu.py)
