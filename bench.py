@@ -272,19 +272,54 @@ def measure_e2e(synth, ds):
         small = run(["--block-mb", "8", "--batch", "50000"], "out_small.gff3")
         rc, wall, tm, sha = min(runs, key=lambda x: x[1])
         n_sets = int(ds.n_sets)
+        # which stage bounds the pipeline, from the stage times the run reported: parse_s = the busiest reader team's seconds, predict_s =
+        # seconds the GPU threads (two per engine, each submits a block and waits for it) spent in their calls, write_s = the writer's
+        wall_p = tm.get("wall_s") or 0.0
+        busy = {"reader": (tm.get("parse_s") or 0.0) / wall_p, "gpu": (tm.get("predict_s") or 0.0) / 2.0 / max(1.0, tm.get("gpus") or 1.0) / wall_p,
+                "writer": (tm.get("write_s") or 0.0) / wall_p} if wall_p > 0 else None
+        bound = None
+        if busy:
+            top = max(busy, key=busy.get)
+            bound = "%s (busy %.0f %% of the pipeline's wall time; reader %.0f %%, GPU threads %.0f %%, writer %.0f %%)" % (
+                top, 100 * busy[top], 100 * busy["reader"], 100 * busy["gpu"], 100 * busy["writer"])
         return {"workload": "taxator < aln.tsv > out.gff3: %d record sets, %d alignment lines, %.2f GB of TSV, in-memory FASTA stores" % (
                     n_sets, len(ds.batch["qstart"]), os.path.getsize(aln) / 1e9),
                 "ok": rc == 0 and small[0] == 0 and all(r_[0] == 0 for r_ in runs),
                 "wall_s": wall, "record_sets_per_s": n_sets / wall,                                    # the whole child process: start-up, loads, pipeline
                 "pipeline_s": tm.get("wall_s"), "pipeline_record_sets_per_s": (n_sets / tm["wall_s"]) if tm.get("wall_s") else None,
-                "stages_s": {"load": tm.get("load_s"), "parse": tm.get("parse_s"), "predict": tm.get("predict_s"), "write": tm.get("write_s")},
-                "bound": "the reader (parse_s ~ pipeline wall): the GPU stage is busy a fraction of the pipeline's time",
+                "stages_s": {"load": tm.get("load_s"), "parse": tm.get("parse_s"), "parse_all_teams": tm.get("parse_sum_s"), "predict": tm.get("predict_s"),
+                             "write": tm.get("write_s"), "reader_teams": tm.get("reader_teams")},
+                "stage_busy_over_pipeline_wall": busy, "bound": bound,
                 "gff3_sha1": sha, "gff3_sha1_small_blocks": small[3], "same_output_with_small_blocks": sha == small[3],
                 "files_written_s": t_write}
     except Exception as e:  # the headline stands whatever happens here
         return {"error": repr(e)}
     finally:
         shutil.rmtree(folder, ignore_errors=True)
+
+
+def measure_hbm_store(replicas, headline_ms, headline_sync_ms):
+    """The headline once more against a reference store that is really spread over HBM (config 2's own 8 MB collection sits in
+    L2 / Infinity Cache): `--store-replicas R` lays it out R times and points every alignment row at a random replica.  A child
+    process of its own (the 64 GB of letters it packs and the engine's job slots are gone when it ends); after the headline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--store-replicas", str(replicas), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+           "--no-secondary"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
+        o = json.loads(lines[-1])
+        return {"workload": o["config"]["workload"] + " -- reference store laid out %d times (%.1f GB packed), every row at a random replica" % (
+                    replicas, o["reference_store"]["packed_bytes"] / 1e9),
+                "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "sync_unprofiled_ms_per_step": o["sync_unprofiled_ms_per_step"],
+                "align_ms_per_step": o["align_ms_per_step"], "hbm_in_use_gb": o["hbm_in_use_gb"], "store_packed_bytes": o["reference_store"]["packed_bytes"],
+                "roofline_frac": o["roofline"]["frac"],
+                "over_cache_resident_store": {"ms_per_step": o["ms_per_step"] / headline_ms if headline_ms else None,
+                                              "sync_unprofiled_ms_per_step": (o["sync_unprofiled_ms_per_step"] / headline_sync_ms) if headline_sync_ms else None}}
+    except Exception as e:  # the headline stands whatever happens here
+        return {"error": repr(e)}
 
 
 def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_flight, device, profile_tag=None):
@@ -365,7 +400,48 @@ def measure_secondary(pkg, synth, torch, cfg, sets, hits, seg_len, steps, in_fli
     return res
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves, the way the
+    reference's parallel mode is ONE command (`taxator -p N`, core/taxator.cpp:181-210).  Decided before this process has
+    imported torch or touched the GPU in any way: the ranks are fresh children of `python -m torch.distributed.run` (never
+    an exec of a process that initialised HIP), this process only relays their output and the launcher's exit code.
+    RPA_BENCH_RANK_SCRIPT replaces the script the ranks run (tests/test_distributed_cpu.py: a stub that needs no GPU)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.environ.get("RPA_BENCH_RANK_SCRIPT") or os.path.abspath(__file__)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks' processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %d ranks (%s)\n" % (n, n, " ".join(cmd)))
+    sys.stderr.flush()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        for line in p.stdout:   # rank 0's JSON line (and anything else the ranks print) as it comes
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        rc = p.wait()
+    except BaseException:
+        p.terminate()
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+        raise
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    n_gpus = pre.parse_known_args()[0].gpus
+    if n_gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(n_gpus, sys.argv[1:]))  # (before torch is imported: this process never sees the GPU)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -770,6 +846,13 @@ def main():
                        "unit_counted": "alignments demanded by the reference control flow (STATS gcounter), not speculative ones"},
             "record_sets_per_s": int(n_sets_all.item()) * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         # SURVEY 8(d) defines achieved = realignments/s x bytes on DEMANDED alignments: `frac` above counts every
+                         # alignment the kernels computed (speculative ones included) over the kernels' own time; frac_demanded
+                         # the demanded ones only over the same time; frac_step the demanded ones over the whole driver-timed step
+                         # (placement kernels, host round trips and all), per GPU
+                         "frac_demanded": achieved / 8000.0 * prof["demanded"] / max(prof["pairs"], 1),
+                         "frac_step": (value / world) * (prof["residue_bytes"] / max(prof["pairs"], 1)) / 8e12,
+                         "bytes_per_alignment": prof["residue_bytes"] / max(prof["pairs"], 1),
                          "traffic": traffic, "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC)",
                          "traffic_source": traffic_src,
                          "kernel": cfg["kernel"],
@@ -834,6 +917,8 @@ def main():
                 except Exception as e:  # the headline stands whatever happens here
                     sec[key] = {"error": repr(e)}
             sec["e2e"] = measure_e2e(synth, ds)
+            del ds
+            sec["c2_hbm_store"] = measure_hbm_store(4000, out["ms_per_step"], out["sync_unprofiled_ms_per_step"])
             out["secondary"] = sec
         print(json.dumps(out))
     if use_dist:

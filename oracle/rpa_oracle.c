@@ -365,6 +365,11 @@ static int rec_less(const orc_record* x, const orc_record* y) {
   return x->identities < y->identities;
 }
 
+/* `int x = <float>` as the reference's platform (x86-64) computes it: cvttss2si truncates and answers the "integer indefinite"
+ * 0x80000000 for a NaN and for anything outside the int range (:602,657-659: `qsearchscore_thresh_heuristic = score * X`).  In C
+ * that conversion is undefined behaviour, so the oracle spells the platform's answer out instead of relying on the compiler. */
+static int orc_float_to_int(float v) { return (v >= -2147483648.f && v < 2147483648.f) ? (int)v : INT_MIN; }
+
 void orc_sort_records(const orc_record* recs, uint32_t n, uint32_t* order) {
   for (uint32_t i = 0; i < n; ++i) order[i] = i;
   for (uint32_t i = 1; i < n; ++i) { /* stable insertion sort: move left only past strictly smaller elements */
@@ -456,6 +461,8 @@ int orc_predict(const orc_taxonomy* tax, const orc_store* qstore, const orc_stor
     if (act[i].qstop > qrstop) qrstop = act[i].qstop;
   }
   const uint32_t qrlength = qrstop - qrstart + 1;
+  for (uint32_t i = 0; i < n; ++i)
+    if (act[i].score != act[i].score) { free(act); free(order); return ORC_ERR_NAN_SCORE; } /* no ordering to restate: see the header */
   orc_sort_records(act, n, order); /* :412 */
 
   pctx c;
@@ -623,7 +630,7 @@ int orc_predict(const orc_taxonomy* tax, const orc_store* qstore, const orc_stor
                 qpid_thresh_guarantee = qsearchpid * 2. - 1.;
                 qpid_thresh_heuristic = qsearchpid * exclude_alignments_factor_;
               }
-              if (!qsearchscore_thresh_heuristic) qsearchscore_thresh_heuristic = (int)(REC(i)->score * exclude_alignments_factor_);
+              if (!qsearchscore_thresh_heuristic) qsearchscore_thresh_heuristic = orc_float_to_int(REC(i)->score * exclude_alignments_factor_);
             }
             og_idx[nog] = i; og_dist[nog] = (int)dist; ++nog; /* tuple<uint,int>: truncation, :661 */
           }

@@ -27,7 +27,8 @@ enum {
   ORC_ERR_RANGE = 1,      /* SequenceRangeError / assert(length(seq)==stop-start+1), sequencestorage.hh:341-362 */
   ORC_ERR_SEQ_ID = 2,     /* SequenceNotFound, sequencestorage.hh:348-351 */
   ORC_ERR_ASSERT = 3,     /* a live assert of the reference build would abort (core/CMakeLists.txt:38 has no -DNDEBUG) */
-  ORC_ERR_NOMEM = 4
+  ORC_ERR_NOMEM = 4,
+  ORC_ERR_NAN_SCORE = 5   /* a NaN score among >= 2 active records: list::sort (:412) on an inconsistent comparator -- refused */
 };
 
 /* Flattened pruned taxonomy (core/src/taxontree.hh:45-70): node 0 is the root, parent[0]==0. */

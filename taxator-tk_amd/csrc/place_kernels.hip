@@ -54,6 +54,11 @@ constexpr uint32_t kFlagIvalUntouched = 1u, kFlagShortcut = 2u, kFlagSingle = 4u
 
 __device__ __forceinline__ bool rec_filtered(const BatchDev& b, uint32_t r) { return b.filtered && b.filtered[r]; }
 
+// `int x = <float expression>` as the reference's platform computes it (:602,657-659 `qsearchscore_thresh_heuristic = score * X`):
+// x86-64's cvttss2si truncates and answers the "integer indefinite" 0x80000000 for a NaN and for anything outside the int range;
+// v_cvt_i32_f32 would saturate (INT_MAX for 3e9, 0 for a NaN).  oracle/rpa_oracle.c: orc_float_to_int.
+__device__ __forceinline__ int float_to_int_x86(float v) { return (v >= -2147483648.f && v < 2147483648.f) ? (int)v : INT_MIN; }
+
 __device__ __forceinline__ void raise_error(const WorkDev& w, uint32_t code, uint32_t set) {
   if (atomicCAS(&w.counters[kCtrErr], 0u, code) == 0u) w.counters[kCtrErrSet] = set;
 }
@@ -381,6 +386,10 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
       else take(j, make_uint4(__float_as_uint(b.score[j]), b.identities[j], b.qstart[j], b.qstop[j]), rec_filtered(b, j));
     }
   }
+  // A NaN score among the records that are sorted (n >= 2): the reference's list::sort (:412) then runs on a comparator that is
+  // no ordering at all, and the order it leaves is an accident of libstdc++'s merge tree -- refused (as the oracle refuses it)
+  // instead of ranked into a row that another record owns.
+  if (!me_filtered && n >= 2 && sc != sc) raise_error(w, kErrNanScore, s);
   // Every load of this thread comes before its first store: loads and stores share one counter on gfx9 and may complete
   // out of order with each other, so a load behind a store waits for the store as well.
   const bool set_head = r == beg;
@@ -996,7 +1005,7 @@ __device__ __forceinline__ bool assume_first_hit_cutoff(const Params& p) { retur
 template <int Q>
 __device__ __forceinline__ uint32_t chunk_end_by_score(const SetRows<Q>& R, uint32_t first, uint32_t hi, int scut_now, float X) {
   if (first + 1u >= hi) return hi;
-  const int scut = scut_now ? scut_now : (int)(R.score(first) * X);
+  const int scut = scut_now ? scut_now : float_to_int_x86(R.score(first) * X);
   const float fcut = (float)scut;
   if (R.score(hi - 1u) >= fcut) return hi;  // (scores within a factor X of each other: the usual DNA case, one probe)
   uint32_t a = first + 1u, b = hi - 1u;  // smallest r in (first, hi) with !(score_r >= fcut)
@@ -1491,7 +1500,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
               cut_g = qsearchpid * 2. - 1.;
               cut_h = qsearchpid * X;
             }
-            if (!scut) scut = (int)(h.score * X);
+            if (!scut) scut = float_to_int_x86(h.score * X);
           }
           if constexpr (kSmall) {
             ogmask |= 1ull << i;

@@ -22,7 +22,8 @@ constexpr int kMaxDepth = 63;         // deepest taxonomy level: the BandFactor 
 
 // error codes mirror include/taxator_rpa.h
 enum { kOk = 0, kErrInvalid = 1, kErrDevice = 2, kErrRange = 3, kErrSeqId = 4, kErrAssert = 5, kErrUnsupported = 6,
-       kErrNotResident = 7 };  // device-only: a segment outside the resident windows of its sequence (reported as RPA_ERR_INVALID)
+       kErrNotResident = 7,    // device-only: a segment outside the resident windows of its sequence (reported as RPA_ERR_INVALID)
+       kErrNanScore = 8 };     // device-only: a NaN score in a record set of two or more unmasked records (reported as RPA_ERR_INVALID)
 
 // Flattened taxonomy (reference: Taxon::leftvalue/rightvalue/root_pathlength, core/src/taxontree.hh:64-66).
 struct TaxDev {

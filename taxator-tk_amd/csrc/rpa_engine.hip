@@ -208,6 +208,7 @@ const char* kernel_error_text(uint32_t code) {
     case kErrAssert: return "a reference assert would abort here (reverse reference coordinates in protein mode, empty best-reference group or inconsistent node range)";
     case kErrUnsupported: return "sequence pair not supported by this build";
     case kErrNotResident: return "a segment reaches outside the resident windows of its sequence (rpa_store_append_windows must cover every region a batch refers to)";
+    case kErrNanScore: return "a score that is not a number in a record set of two or more unmasked alignments: the reference sorts such a set with a comparator that is no ordering (core/src/alignmentrecord.hh:89-93) and what it then does is an accident of the sort";
     default: return "inconsistent batch";
   }
 }
@@ -1516,15 +1517,25 @@ int rpa_submit_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out,
   if (batch->mem_kind != RPA_MEM_HOST && batch->mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch: bad mem_kind");
   HIP_TRY(e, hipSetDevice(e->device));
   static const size_t n_slots = [] { const char* v = getenv("RPA_JOB_SLOTS"); const long n = v ? atol(v) : 0; return (size_t)(n >= 1 && n <= 8 ? n : RPA_JOBS_IN_FLIGHT); }();  // (experiments)
-  while (e->slots.size() < n_slots) {
+  // The lowest-numbered idle slot takes the job; a new slot is made only when every existing one is busy (a slot sizes a whole
+  // working set -- rows, pair lists, bin lists: several GB for a 128 MB block -- at its first job, so a caller that keeps k jobs
+  // in flight touches k slots, not RPA_JOBS_IN_FLIGHT of them: the CLI keeps two per engine).  All busy and no room for another:
+  // wait for the slots in turn, as before.
+  rpa_engine* slot = nullptr;
+  for (rpa_engine* s : e->slots) {
+    std::lock_guard<std::mutex> sl(s->job_mu);
+    if (!s->job_busy) { slot = s; break; }  // (only this thread, under e->mu, ever sets job_busy: the slot stays idle until it does)
+  }
+  if (!slot && e->slots.size() < n_slots) {
     rpa_engine* s = make_worker(e);
     if (!s) return RPA_ERR_DEVICE;
     s->owner = e;
     s->profiling = false;
     s->job_thread = std::thread(slot_main, s);
     e->slots.push_back(s);
+    slot = s;
   }
-  rpa_engine* slot = e->slots[e->next_slot++ % e->slots.size()];
+  if (!slot) slot = e->slots[e->next_slot++ % e->slots.size()];
   rpa_job* job = new (std::nothrow) rpa_job();
   if (!job) return fail(e, RPA_ERR_DEVICE, "out of host memory");
   job->batch = *batch; job->out = out; job->stats = stats; job->slot = slot;

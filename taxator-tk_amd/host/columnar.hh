@@ -127,6 +127,7 @@ class ColumnarReader {
   void parse_block(const char* begin, const char* end, bool eof, ColumnarBatch& out);
   void emit_groups(ColumnarBatch& out);
   [[noreturn]] void raise_failure();  // the deferred error of parse_block, as the reference's generator words it
+  bool fast_path_accepts(const char* s, const char* limit) const;  // parse_block's own test of one data line (nothing is stored)
 
   FILE* in_;
   AlignmentRecordFactory legacy_;  // error texts

@@ -70,8 +70,36 @@ static int fasta_check(const char* fasta, const char* fai) {
   }
 }
 
+// parsecheck --taxonomy DELETE_UNMARKED [rank ...]: the taxonomy the driver would hand to the engine ($TAXATORTK_TAXONOMY_NCBI, the
+// ranks of `-r` or the default ones, `-d`), one node per line in index order: taxid, parent's taxid, depth, left, right, rank;
+// further arguments after "--" are taxids to look up ("NODE taxid index" or "MISSING taxid": the reference's TaxonNotFound)
+static int taxonomy_check(int argc, char** argv) {
+  const bool delete_unmarked = atoi(argv[2]) != 0;
+  std::vector<std::string> ranks, lookups;
+  int i = 3;
+  for (; i < argc && strcmp(argv[i], "--"); ++i) ranks.push_back(argv[i]);
+  for (++i; i < argc; ++i) lookups.push_back(argv[i]);
+  if (ranks.empty()) ranks = default_ranks;  // core/taxator.cpp:324-326
+  try {
+    std::unique_ptr<Taxonomy> tax(loadTaxonomyFromEnvironment(&ranks, delete_unmarked));
+    if (!tax) return 2;
+    for (size_t k = 0; k < tax->size(); ++k)
+      printf("%s\t%s\t%u\t%u\t%u\t%s\n", tax->taxid[k].c_str(), tax->taxid[tax->parent[k]].c_str(), (unsigned)tax->depth[k], tax->left[k], tax->right[k],
+             tax->rank[k].c_str());
+    for (const std::string& t : lookups) {
+      try { printf("NODE %s %u\n", t.c_str(), tax->getNode(t)); }
+      catch (Exception& e) { printf("MISSING %s (%s)\n", t.c_str(), e.what()); }
+    }
+    return 0;
+  } catch (Exception& e) {
+    printf("ERROR %s\n", e.what());
+    return 1;
+  }
+}
+
 int main(int argc, char** argv) {
   if (argc == 4 && !strcmp(argv[1], "--fasta")) return fasta_check(argv[2], argv[3]);
+  if (argc >= 3 && !strcmp(argv[1], "--taxonomy")) return taxonomy_check(argc, argv);
   if (argc < 6) { fprintf(stderr, "usage: parsecheck mapping query.fasta ref.fasta objects|columnar split [threads] [block_bytes]\n"); return 2; }
   const std::string mode = argv[4];
   const bool split = atoi(argv[5]) != 0;

@@ -54,7 +54,7 @@ struct Options {
   std::vector<std::string> ranks;
   bool split_alignments = true, alignments_sorted = false, delete_unmarked = true;
   float filterout = 0.5f, toppercent = 0.05f, minscore = 0.0f;
-  size_t readers = 0;  // --readers N: reader teams over a regular input file (0: four, two on few host threads, at least one per engine)
+  size_t readers = 0;  // --readers N: reader teams over a regular input file (0: four / two / one by the number of host threads, at least one per engine)
   double maxevalue = 1000.0;
   unsigned minsupport = 1, nbest = 1;
   bool ignore_unclassified = false;
@@ -93,7 +93,8 @@ static void usage(std::ostream& o) {
        "            emptied and refilled with what the block at hand needs; 0 = no limit), --store-tile N (=65536 residues: the\n"
        "            granularity at which regions of a sequence become resident), --readers N (reader teams over a regular input file:\n"
        "            the file is cut into slices where the query identifier changes and the teams parse slices side by side;\n"
-       "            0 = four teams, two on fewer than eight host threads, and at least one per engine; a pipe has one reader)\n";
+       "            0 = four teams on eight or more host threads, two on four to seven, one below that, and at least one per engine;\n"
+       "            at most one team per host thread, 64 at most; a pipe has one reader)\n";
 }
 
 namespace {
@@ -190,7 +191,9 @@ inline void append_log_set(std::string& lg, const char* qid, size_t qid_len, con
   lg.append("\n\n");
 }
 
-struct Timing { double parse = 0, predict = 0, write = 0; size_t sets = 0, records = 0; };
+// parse: the busiest reader's seconds (with several teams parsing side by side the SUM of their seconds can exceed the wall time and
+// says nothing about what bounds the pipeline); parse_sum: all teams' thread-seconds
+struct Timing { double parse = 0, parse_sum = 0, predict = 0, write = 0; size_t sets = 0, records = 0; };
 
 typedef std::chrono::steady_clock Clock;
 double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
@@ -221,6 +224,7 @@ void run_columnar(std::vector<std::unique_ptr<ColumnarReader>>& readers, SliceCu
   auto reader_loop = [&](size_t team) {
     ColumnarReader& reader = *readers[team];
     uint64_t seq = 0;
+    double busy = 0;  // this team's parse seconds
     for (;;) {
       Work* w = free_q.pop();
       if (!w) break;
@@ -244,10 +248,19 @@ void run_columnar(std::vector<std::unique_ptr<ColumnarReader>>& readers, SliceCu
           break;
         }
         w->seq = index;
-        reader.parse_slice(*cutter, b, e, w->batch, w->err);
+        // (an exception out of the parser itself -- std::bad_alloc from the column buffers, a failing unregistration -- must take the
+        // same ordered way out as a bad line: what precedes this slice is printed, the engines are destroyed, never std::terminate)
+        try { reader.parse_slice(*cutter, b, e, w->batch, w->err); }
+        catch (...) { w->err = std::current_exception(); w->batch.clear(); }
         if (w->err) { w->err_after = true; stop.store(true); cutter->close(); }  // what precedes the bad line is printed; no further slice is taken
       }
-      { std::lock_guard<std::mutex> lk(tm_mu); tm.parse += secs(t0, Clock::now()); }
+      {
+        const double dt = secs(t0, Clock::now());
+        busy += dt;
+        std::lock_guard<std::mutex> lk(tm_mu);
+        tm.parse_sum += dt;
+        tm.parse = std::max(tm.parse, busy);
+      }
       parsed_q.push(w);
       if (w->last) break;
     }
@@ -420,7 +433,11 @@ static int run(int argc, char** argv) {
     else if (a == "--block-mb") o.block_mb = atof(val("--block-mb").c_str());
     else if (a == "--store-gb") o.store_gb = atof(val("--store-gb").c_str());
     else if (a == "--store-tile") o.store_tile = (uint64_t)atoll(val("--store-tile").c_str());
-    else if (a == "--readers") o.readers = (size_t)atoll(val("--readers").c_str());
+    else if (a == "--readers") {
+      const long long n = atoll(val("--readers").c_str());
+      if (n < 0) { std::cerr << "--readers takes a number of reader teams >= 0 (0 = chosen by the number of host threads)" << std::endl; return EXIT_FAILURE; }
+      o.readers = (size_t)std::min<long long>(n, 64);  // (capped again by the host's threads below: a team is a thread, a reader and ~100 MB of page-locked columns)
+    }
     else if (a == "--batch") o.batch = (size_t)atoll(val("--batch").c_str());
     else if (a == "-r" || a == "--ranks") { while (i + 1 < argc && argv[i + 1][0] != '-') o.ranks.push_back(argv[++i]); }
     else { std::cerr << "unrecognised option '" << a << "'" << std::endl; return EXIT_FAILURE; }
@@ -534,7 +551,7 @@ static int run(int argc, char** argv) {
       const size_t block_bytes = (size_t)std::max(4096.0, o.block_mb * 1048576.0);
       const unsigned host_cpus = o.processors ? o.processors : usable_cpus();
       const size_t default_teams = host_cpus >= 8 ? 4 : (host_cpus >= 4 ? 2 : 1);
-      size_t teams = o.readers ? o.readers : std::max(engines.size(), default_teams);
+      size_t teams = o.readers ? std::min<size_t>(o.readers, std::max<size_t>(1, host_cpus)) : std::max(engines.size(), default_teams);
       std::unique_ptr<SliceCutter> cutter;
       if (teams > 1) {
         cutter.reset(new SliceCutter(stdin, block_bytes));
@@ -566,7 +583,8 @@ static int run(int argc, char** argv) {
       if (o.timing)
         std::cerr << "TIMING\tload_s=" << secs(t_start, t_loaded) << "\tparse_s=" << tm.parse << "\tpredict_s=" << tm.predict << "\twrite_s="
                   << tm.write << "\twall_s=" << secs(t_loaded, Clock::now()) << "\trecord_sets=" << tm.sets << "\trecords=" << tm.records
-                  << "\tgpus=" << o.devices.size() << "\t(columnar pipeline: the three stages overlap)" << std::endl;
+                  << "\tgpus=" << o.devices.size() << "\tparse_sum_s=" << tm.parse_sum << "\treader_teams=" << teams
+                  << "\t(columnar pipeline: the three stages overlap; parse_s = the busiest reader team, parse_sum_s = all teams; predict_s = GPU-thread seconds, two threads per engine)" << std::endl;
       return EXIT_SUCCESS;
     }
     stage("record-object loop: first record");

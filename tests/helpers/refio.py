@@ -259,10 +259,11 @@ def gff3_line(qid, qlen, pred, tax, prev_ival):
 class Dataset:
     """A directory with tax/{nodes,names}.dmp, mapping.tax, a reference FASTA, a query FASTA and an alignments TSV."""
 
-    def __init__(self, folder, alphabet=0, ref_name=None, query_name=None, aln_name="aln.tsv", split=True, presorted=False):
+    def __init__(self, folder, alphabet=0, ref_name=None, query_name=None, aln_name="aln.tsv", split=True, presorted=False,
+                 ranks=DEFAULT_RANKS, prune=True):
         ext = ".fna" if alphabet == 0 else ".faa"
         self.alphabet = alphabet
-        self.tax = FlatTaxonomy(os.path.join(folder, "tax"))
+        self.tax = FlatTaxonomy(os.path.join(folder, "tax"), ranks=ranks, prune=prune)  # taxator -r ... / -d 0 (core/taxator.cpp:324-340)
         self.mapping = read_mapping(os.path.join(folder, "mapping.tax"))
         self.ref = Fasta(os.path.join(folder, ref_name or ("ref" + ext)), alphabet)
         self.query = Fasta(os.path.join(folder, query_name or ("query" + ext)), alphabet)

@@ -164,3 +164,33 @@ def test_shard_bounds_by_cost():
     batch = dict(set_offsets=np.array([0, 2, 3], np.uint32), qstart=np.array([1, 1, 5], np.uint32), qstop=np.array([10, 20, 14], np.uint32),
                  rstart=np.array([100, 50, 9], np.uint32), rstop=np.array([91, 69, 18], np.uint32))
     assert list(sharding.set_costs(batch)) == [10 * 10 + 20 * 20, 10 * 10]
+
+
+# ---- `python bench.py --gpus N` with no launcher around it (the shape of the driver's 1-GPU command): the reference's parallel
+# mode is one command (`taxator -p N`, core/taxator.cpp:181-210), so bench.py starts its N ranks itself -- before it imports
+# torch or touches the GPU -- and relays rank 0's line and the launcher's exit code.  Here the ranks run a stub (no GPU).
+def _run_launcherless(tmp_path, n, extra=()):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RPA_BENCH_RANK_SCRIPT"] = os.path.join(ROOT, "tests", "helpers", "rank_stub.py")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--mark-dir", str(tmp_path)] + list(extra)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=240, cwd=ROOT)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks(tmp_path):
+    n = 4
+    p, lines = _run_launcherless(tmp_path, n)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == n and lines[0]["dist"]["world_size"] == n and lines[0]["sum_of_ranks"] == n * (n + 1) // 2
+    marks = sorted(os.listdir(tmp_path))
+    assert [m.split(".")[0] for m in marks] == ["rank%d" % r for r in range(n)]                 # N children ...
+    assert len({m.split(".pid")[1] for m in marks}) == n                                        # ... N different processes
+    assert "starting %d ranks" % n in p.stderr
+
+
+def test_bench_without_a_launcher_reports_a_failing_rank(tmp_path):
+    p, lines = _run_launcherless(tmp_path, 2, ["--fail-rank", "1"])
+    assert p.returncode != 0 and not lines

@@ -227,6 +227,63 @@ def test_cli_alignments_sorted_split_and_cutoff_options(oracle, tmp_path, order)
         assert n_sets["-o 1"] == n_sets["default"]
 
 
+@pytest.mark.parametrize("path", [[], ["--record-objects"]])
+def test_cli_prunes_a_real_shaped_taxonomy(oracle, tmp_path, path):
+    """What the driver does to every real NCBI dump before the engine sees a node index (core/taxator.cpp:324-340: mark the ranks
+    of `-r`, default = the seven major ranks, then TaxonTree::deleteUnmarkedNodes, core/src/taxontree.cpp:55-70: an unmarked node
+    goes, its children move to its parent, depths shrink :169-178).  The dump here has chains of "no rank" nodes inside its
+    edges, as NCBI's has; through `taxator` with the default ranks, with `-r species genus family`, with `-d 0` (nothing deleted:
+    deeper rows) -- GFF3 byte for byte what the oracle gives on a literal reading of the pruning (tests/helpers/refio.py) -- and
+    with a reference sequence mapped onto a taxid that pruning deletes: the reference then dies on the first alignment line that
+    names it (core/src/alignmentrecord.hh:222-227, TaxonNotFound) after printing the record sets in front."""
+    graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    ds = synth.make_dataset(n_sets=160, n_hits=12, seg_len=150, branching=3, genome_len=1500, seed=911, variety=True)
+    synth.stretch_dataset(ds, lambda i: (i * 7 + 3) % 4)  # 0-3 "no rank" nodes in the edge above every node
+    assert "no rank" in ds.tax.rank[1:] and int(ds.tax.depth.max()) > 12
+    folder = str(tmp_path / "pr")
+    synth.write_files(ds, folder)
+    outs = {}
+    for name, extra, kw in (("default", [], {}), ("three ranks", ["-r", "species", "genus", "family"], dict(ranks=("species", "genus", "family"))),
+                            ("whole tree", ["-d", "0"], dict(prune=False)),
+                            ("whole tree, ranks named", ["-r", "species", "-d", "0"], dict(prune=False))):
+        r = _run(folder, ".fna", extra=extra + path)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        fds = R.Dataset(folder, 0, **kw)
+        b = fds.batch()
+        tax = oracle.TaxArrays(fds.tax.parent, fds.tax.left, fds.tax.right, fds.tax.depth)
+        q = oracle.StoreArrays(fds.query.residues, fds.query.offsets)
+        db = oracle.StoreArrays(fds.ref.residues, fds.ref.offsets)
+        rc, out, st = oracle.predict_batch(tax, q, db, 0, b["offsets"], b["qseq"], b["qlen"], b["recs"])
+        assert rc == 0
+        assert r.stdout == fds.gff3(out, b["qids"], b["qlen"]), name
+        outs[name] = (r.stdout, int(fds.tax.depth.max()), len(fds.tax.parent))
+    assert outs["default"][1] == 7 and outs["three ranks"][1] == 3 and outs["whole tree"][1] > 12           # levels below the root
+    assert outs["three ranks"][2] < outs["default"][2] < outs["whole tree"][2]                                  # nodes kept
+    assert len({v[0] for v in outs.values()}) == 3 and outs["whole tree"][0] == outs["whole tree, ranks named"][0]
+    # a reference sequence on a taxid that the default pruning deletes (a "no rank" node): fine with -d 0, fatal without
+    deleted = next(t for t, rk in zip(ds.tax.taxid[1:], ds.tax.rank[1:]) if rk == "no rank")
+    lines = open(os.path.join(folder, "mapping.tax")).read().split("\n")
+    recs = R.parse_alignments(os.path.join(folder, "aln.tsv"))
+    victim_row = len(recs) // 2
+    victim = recs[victim_row].rid
+    with open(os.path.join(folder, "mapping.tax"), "w") as f:
+        f.write("\n".join((l.split("\t")[0] + "\t" + deleted) if l.split("\t")[0] == victim else l for l in lines))
+    r = _run(folder, ".fna", extra=["-d", "0"] + path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = _run(folder, ".fna", extra=path)
+    assert r.returncode != 0 and "An unrecoverable error occurred" in r.stderr and ("taxid " + deleted) in r.stderr
+    first_bad = next(k for k, rec in enumerate(recs) if rec.rid == victim)
+    qid_bad = recs[first_bad].qid
+    printed = [l.split("\t")[0] for l in r.stdout.split("\n")[1:] if l]
+    before = []
+    for rec in recs[:first_bad]:
+        if rec.qid != qid_bad and (not before or before[-1] != rec.qid):
+            before.append(rec.qid)
+    assert qid_bad not in printed and [q_ for k, q_ in enumerate(printed) if k == 0 or printed[k - 1] != q_] == before
+    assert r.stdout == "".join(l + "\n" for l in outs["default"][0].split("\n")[:1 + len(printed)])          # ... the same lines as the good run's
+
+
 def test_cli_taxator_into_binner(oracle, tmp_path):
     """`taxator | binner` on the GPU box: the GFF3 that taxator prints for queries with several segments goes through the host
     `binner` (consensus per query: regex group, majority / support, core/binner.cpp:154-340, core/src/predictionranges.hh:

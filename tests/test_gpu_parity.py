@@ -538,8 +538,11 @@ def test_scores_of_any_sign_and_masked_records(pkg, oracle, synth):
         sc[kind == 1] = 0.0
         sc[kind == 2] = -0.0
         sc[kind == 3] = np.round(sc[kind == 3] / 64.0) * 64.0
-        sc[(kind == 4) & (rng.random(H) < 0.1)] = np.float32(3e9)  # (infinite scores are left out: the reference's `int cut-off = X * score`,
-        #  :657-659, is undefined behaviour beyond the int range -- x86 gives INT_MIN, the GPU's conversion saturates)
+        # scores whose `int cut-off = X * score` (:657-659) leaves the int range: 3e9 (with X = 1 below), +-infinity (X = 0: inf * 0 is a
+        # NaN) -- the reference's platform answers INT_MIN there (cvttss2si), and so do the oracle and the device (float_to_int_x86)
+        sc[(kind == 4) & (rng.random(H) < 0.1)] = np.float32(3e9)
+        sc[(kind == 5) & (rng.random(H) < 0.1)] = np.float32(np.inf)
+        sc[(kind == 6) & (rng.random(H) < 0.05)] = np.float32(-np.inf)
         b["score"] = sc
         filt = b["filtered"].copy()
         filt[rng.random(H) < 0.3] = 1
@@ -557,8 +560,51 @@ def test_scores_of_any_sign_and_masked_records(pkg, oracle, synth):
             if act.any() and sc[lo:hi][act].max() < 0:
                 sc[lo:hi] = np.abs(sc[lo:hi])
         b["score"] = sc
-        for x, t in ((0.5, 0.05), (0.0, 0.3)):
+        for x, t in ((0.5, 0.05), (0.0, 0.3), (1.0, 0.05)):
             _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, exclude_factor=x, reeval_bandwidth=t)
+
+
+def test_nan_scores_are_refused_where_the_reference_would_sort_them(pkg, oracle, synth):
+    """A score that is not a number.  In a record set of ONE unmasked record, or on a masked record, it is never compared and the
+    result is the reference's.  Among two or more unmasked records the reference's list::sort (:412) runs on a comparator that
+    is no ordering (core/src/alignmentrecord.hh:89-93: every comparison with a NaN is false) and what it leaves is an accident of
+    libstdc++'s merge tree: engine and oracle both refuse the batch, naming the record set, instead of inventing an order."""
+    ds = synth.make_dataset(n_sets=200, n_hits=6, seg_len=100, branching=3, genome_len=1500, seed=411, variety=True)
+    b = ds.batch
+    so = b["set_offsets"].astype(np.int64)
+    sc = b["score"].astype(np.float32).copy()
+    filt = b["filtered"].copy()
+    # harmless NaNs: on masked records, and on the only unmasked record of a set
+    for s_ in range(0, 60, 3):
+        lo, hi = so[s_], so[s_ + 1]
+        if hi - lo >= 2:
+            filt[lo + 1] = 1
+            sc[lo + 1] = np.nan
+    for s_ in range(60, 80, 4):
+        lo, hi = so[s_], so[s_ + 1]
+        if hi - lo >= 1:
+            filt[lo:hi] = 1
+            filt[lo] = 0
+            sc[lo] = np.nan
+    b["score"], b["filtered"] = sc, filt
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    # ... and one in a set that is sorted
+    victim = next(s_ for s_ in range(100, 200) if (filt[so[s_]:so[s_ + 1]] == 0).sum() >= 3)
+    act = np.nonzero(filt[so[victim]:so[victim + 1]] == 0)[0]
+    sc2 = sc.copy()
+    sc2[so[victim] + act[1]] = np.nan
+    b["score"] = sc2
+    tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+    q = oracle.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+    db = oracle.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+    rc, _, _ = oracle.predict_batch(tax, q, db, 0, b["set_offsets"], b["query_seq"], b["query_len"], synth.records_aos(b, oracle.RECORD_DTYPE))
+    assert rc == 5                                            # ORC_ERR_NAN_SCORE
+    model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+    model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+    model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+    with pytest.raises(pkg.RpaError) as ei:
+        model.predict(b)
+    assert ei.value.code == 1 and "not a number" in str(ei.value) and ("set / pair %d)" % victim) in str(ei.value)   # RPA_ERR_INVALID
 
 
 def test_one_engine_across_batches_of_different_shapes(pkg, oracle, synth):

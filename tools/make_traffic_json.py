@@ -18,11 +18,16 @@ ker = sorted(k for k in f if "k_myers" in k or "k_nw_protein" in k)
 fetch = sum(f[k]["sum_kb"] for k in ker); write = sum(w[k]["sum_kb"] for k in ker if k in w)
 disp = sum(f[k]["dispatches"] for k in ker)
 pk = [k for k in f if "k_pack_letters" in k]
+# what k_pack_letters reads / writes ONCE per process in each configuration of bench.py (letters in: query + reference store, one
+# byte per residue; packed words out: 4 bit per nucleotide, 8 bit per amino acid) -- the counters above are sums over the run
+expected = ("config 4: 33.5 MB of query + 6.1 MB of reference letters in, the same 39.6 MB out (8 bit per residue)" if "_c4" in tag else
+            "config 5: 125 MB of query + 164 MB of reference letters in, 144 MB of packed words out (4 bit per nucleotide)" if "_c5" in tag else
+            "config 2: 200 MB of query + 16 MB of reference letters in, 108 MB of packed words out (4 bit per nucleotide)")
 total = (2 * fetch + write) * 1024.0
 json.dump({"kernels": ker, "dispatches": disp, "predict_calls": calls, "FETCH_SIZE_KB_sum": fetch, "WRITE_SIZE_KB_sum": write,
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is. "
-                         "Calibration in the same run: k_pack_letters FETCH_SIZE %.1f MB / WRITE_SIZE %.1f MB (config 2 reads 216 MB of letters and writes 108 MB of packed words there)." %
-                         (sum(f[k]["sum_kb"] for k in pk) / 1024, sum(w[k]["sum_kb"] for k in pk if k in w) / 1024),
+                         "Calibration in the same run: k_pack_letters FETCH_SIZE %.1f MB / WRITE_SIZE %.1f MB over %d predict call(s)' worth of store loads (%s)." %
+                         (sum(f[k]["sum_kb"] for k in pk) / 1024, sum(w[k]["sum_kb"] for k in pk if k in w) / 1024, calls, expected),
            "traffic_bytes_per_launch": total / disp, "traffic_bytes_per_predict_call": total / calls,
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-include-regex rpa:: -- python3 bench.py [--config cN] --steps 2 --warmup 1 --no-cpu-baseline"},
           open("profiles/%s_traffic.json" % tag, "w"), indent=1)
