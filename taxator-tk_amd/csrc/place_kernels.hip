@@ -56,7 +56,7 @@ __device__ __forceinline__ bool rec_filtered(const BatchDev& b, uint32_t r) { re
 
 // `int x = <float expression>` as the reference's platform computes it (:602,657-659 `qsearchscore_thresh_heuristic = score * X`):
 // x86-64's cvttss2si truncates and answers the "integer indefinite" 0x80000000 for a NaN and for anything outside the int range;
-// v_cvt_i32_f32 would saturate (INT_MAX for 3e9, 0 for a NaN).  oracle/rpa_oracle.c: orc_float_to_int.
+// v_cvt_i32_f32 would saturate (INT_MAX for 3e9, 0 for a NaN).
 __device__ __forceinline__ int float_to_int_x86(float v) { return (v >= -2147483648.f && v < 2147483648.f) ? (int)v : INT_MIN; }
 
 __device__ __forceinline__ void raise_error(const WorkDev& w, uint32_t code, uint32_t set) {
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
     }
   }
   // A NaN score among the records that are sorted (n >= 2): the reference's list::sort (:412) then runs on a comparator that is
-  // no ordering at all, and the order it leaves is an accident of libstdc++'s merge tree -- refused (as the oracle refuses it)
+  // no ordering at all, and the order it leaves is an accident of libstdc++'s merge tree -- refused
   // instead of ranked into a row that another record owns.
   if (!me_filtered && n >= 2 && sc != sc) raise_error(w, kErrNanScore, s);
   // Every load of this thread comes before its first store: loads and stores share one counter on gfx9 and may complete
