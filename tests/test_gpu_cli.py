@@ -240,7 +240,10 @@ def test_cli_prunes_a_real_shaped_taxonomy(oracle, tmp_path, path):
     synth = importlib.import_module("taxator_tk_amd.synth")
     ds = synth.make_dataset(n_sets=160, n_hits=12, seg_len=150, branching=3, genome_len=1500, seed=911, variety=True)
     synth.stretch_dataset(ds, lambda i: (i * 7 + 3) % 4)  # 0-3 "no rank" nodes in the edge above every node
-    assert "no rank" in ds.tax.rank[1:] and int(ds.tax.depth.max()) > 12
+    # ... and BRANCHING nodes that pruning deletes too (a chain node is never an LCA; NCBI's "no rank" clades and sub-ranks are): every
+    # order becomes a "no rank" clade, every other class a "subclass" -- by default their children move up to the class / phylum
+    ds.tax.rank = ["no rank" if rk == "order" else ("subclass" if rk == "class" and k % 2 else rk) for k, rk in enumerate(ds.tax.rank)]
+    assert "no rank" in ds.tax.rank[1:] and "subclass" in ds.tax.rank and int(ds.tax.depth.max()) > 12
     folder = str(tmp_path / "pr")
     synth.write_files(ds, folder)
     outs = {}
@@ -258,7 +261,7 @@ def test_cli_prunes_a_real_shaped_taxonomy(oracle, tmp_path, path):
         assert rc == 0
         assert r.stdout == fds.gff3(out, b["qids"], b["qlen"]), name
         outs[name] = (r.stdout, int(fds.tax.depth.max()), len(fds.tax.parent))
-    assert outs["default"][1] == 7 and outs["three ranks"][1] == 3 and outs["whole tree"][1] > 12           # levels below the root
+    assert outs["default"][1] == 6 and outs["three ranks"][1] == 3 and outs["whole tree"][1] > 12           # levels below the root (no order left)
     assert outs["three ranks"][2] < outs["default"][2] < outs["whole tree"][2]                                  # nodes kept
     assert len({v[0] for v in outs.values()}) == 3 and outs["whole tree"][0] == outs["whole tree, ranks named"][0]
     # a reference sequence on a taxid that the default pruning deletes (a "no rank" node): fine with -d 0, fatal without
