@@ -283,6 +283,11 @@ def test_cli_prunes_a_real_shaped_taxonomy(oracle, tmp_path, path):
     for rec in recs[:first_bad]:
         if rec.qid != qid_bad and (not before or before[-1] != rec.qid):
             before.append(rec.qid)
+    # the generator closes a group by reading the line BEHIND it (core/src/alignmentrecord.hh:464-479): when the bad line is the
+    # first of its own group, the exception leaves while the group in front is still open and takes it along
+    if first_bad > 0 and recs[first_bad - 1].qid != qid_bad:
+        before.pop()
+    assert len(before) > 20
     assert qid_bad not in printed and [q_ for k, q_ in enumerate(printed) if k == 0 or printed[k - 1] != q_] == before
     assert r.stdout == "".join(l + "\n" for l in outs["default"][0].split("\n")[:1 + len(printed)])          # ... the same lines as the good run's
 

@@ -35,6 +35,7 @@ CONFIGS = {
 LIFT_STATS = {}
 P2_FIRST = 0  # pass 2: size of an anchor's first chunk (0: S2)
 P2_GROUP = 0  # pass 2: hits per chunk and lift target (0: no limit)
+P2_DEFER = 0  # pass 2: hits that an earlier hit of their chunk may take out of the loop wait for a second launch of the same round
 F32 = np.float32
 FLT_MAX = F32(np.finfo(np.float32).max)
 
@@ -46,6 +47,7 @@ class Loop:
         self.rows = []      # (i, what, state) what in {"align", "free", "skip"}; state = thresholds BEFORE the row was looked at
         self.end = None     # first row index the loop did not look at (n if it ran out of rows)
         self.extra = False  # pass 2: the anchor <-> query alignment happened inside this loop
+        self.lift = {}      # pass 2: row -> True where the row's alignment lifted unode_global
 
 
 def replay(tax, recs, qrlength, D, X=F32(0.5), reeval=0.05):
@@ -204,7 +206,9 @@ def replay(tax, recs, qrlength, D, X=F32(0.5), reeval=0.05):
                     if i != a:
                         di = int(tax.depth[tax.lca(int(node[i]), rtax)]); da = int(tax.depth[tax.lca(rtax, int(node[a]))])
                         LIFT_STATS.setdefault(di - da, [0, 0])[0 if lifted else 1] += 1
-                    if lifted: unode_g = tax.lca(unode_g, int(node[i]))
+                    if lifted:
+                        unode_g = tax.lca(unode_g, int(node[i]))
+                        L.lift[i] = True
             else:
                 L.rows.append((i, "skip", unode_g))
             i += 1
@@ -229,10 +233,12 @@ def play(tax, recs, loops, qd0, qrlength, S1, S2, mode):
     for L in loops:
         n_chunk = 0
         emitted = {}
+        dropped = set()
         for (i, what, st) in L.rows:
             if what != "align":
                 continue
             demanded += 1
+            assert i not in dropped, "a dropped hit was consumed"
             if i not in emitted:  # pause: a new chunk from row i
                 n_chunk += 1
                 key = ("p1 " if L.kind == 1 else "p2 ") + ("first chunk" if n_chunk == 1 else "later chunks")
@@ -255,6 +261,7 @@ def play(tax, recs, loops, qd0, qrlength, S1, S2, mode):
                 else:
                     un = st
                     groups = {}
+                    first_launch = []
                     for r in range(lo, hi):
                         if r == L.anchor: continue
                         if score[r] < L.fcut: break
@@ -267,6 +274,20 @@ def play(tax, recs, loops, qd0, qrlength, S1, S2, mode):
                             covered = sum(c for (t, c) in groups.items() if t == tgt or tax.is_parent_of(t, tgt))
                             if covered >= P2_GROUP: continue
                             groups[tgt] = groups.get(tgt, 0) + 1
+                        if P2_DEFER:
+                            # Two launches inside ONE round: a hit that an earlier hit of the same chunk would take out of the loop by
+                            # lifting unode_global (depth of LCA(hit, best) not above the earlier hit's) waits for the first launch's
+                            # results and is dropped when such an earlier hit of the first launch did lift
+                            cb = int(tax.depth[tax.lca(cn, st)])
+                            cover = [j for (j, cj) in first_launch if cj <= cb]
+                            if cover:
+                                play.deferred += 1
+                                if any(L.lift.get(j) for j in cover):
+                                    emitted[r] = key; play.dropped += 1   # never consumed: the loop steps over it (asserted below)
+                                    dropped.add(r)
+                                    continue
+                            else:
+                                first_launch.append((r, cb))
                         computed += 1; cat[key][0] += 1; emitted[r] = key
                         if mode == "cautious": un = tax.lca(un, cn)
             cat[emitted[i]][1] += 1
@@ -300,7 +321,7 @@ def main():
                [("filtered", S1, S2) for (S1, S2) in ((0, 10), (4, 10))] + \
                [("cautious", S1, S2) for (S1, S2) in ((0, 10),)] + \
                [("first", S1, S2) for (S1, S2) in ((0, 10), (4, 10), (8, 10))] + [("first-score", 0, 10), ("first-pid", 0, 10)] + \
-               [("first-score+p2first", 0, 10, k) for k in (3, 6)] + [("first-score+p2group", 0, S2, k) for S2 in (10, 20) for k in (1, 2, 3)]
+               [("first-score+p2defer", 0, S2, 1) for S2 in (10, 20, 0)] + [("first-score+p2first", 0, 10, k) for k in (3, 6)] + [("first-score+p2group", 0, S2, k) for S2 in (10, 20) for k in (1, 2, 3)]
     totals = {p: [0, 0, 0] for p in policies}
     cats = {p: {} for p in policies}
     pass0 = 0
@@ -332,7 +353,9 @@ def main():
         act2["_qs"] = qs
         pass0 += len(pass0_rows)
         for p in policies:
-            global P2_FIRST, P2_GROUP
+            global P2_FIRST, P2_GROUP, P2_DEFER
+            P2_DEFER = 1 if "p2defer" in p[0] else 0
+            play.deferred = getattr(play, "deferred", 0); play.dropped = getattr(play, "dropped", 0)
             P2_FIRST = p[3] if len(p) > 3 and "p2first" in p[0] else 0
             P2_GROUP = p[3] if len(p) > 3 and "p2group" in p[0] else 0
             c, d, r = play(tax, act2, loops, qd0, qrlength, p[1], p[2], p[0].split("+")[0])
@@ -348,6 +371,7 @@ def main():
         print("  %-9s" % (p[0] + (str(p[3]) if len(p) > 3 else "")) + " S1=%d S2=%-2d  computed/demanded %.3f  (pass 1+2: asked %d, used %d = %.0f %%)  request rounds after pass 0 per set %.2f"
               % (p[1], p[2], (pass0 + c) / dem_all, c, d, 100.0 * d / max(1, c), r / max(1, n_done)))
         print("            " + ";  ".join("%s asked %d used %d" % (k, v[0], v[1]) for k, v in cats[p].items()))
+    print("p2defer (all three settings together): %d hits waited for a second launch, %d of them were dropped" % (getattr(play, "deferred", 0), getattr(play, "dropped", 0)))
 
 
 if __name__ == "__main__":
