@@ -918,6 +918,12 @@ def main():
                     sec[key] = {"error": repr(e)}
             sec["e2e"] = measure_e2e(synth, ds)
             del ds
+            try:  # record sets of mixed shape (1 ... 500 hits, 50 ... 1500 nt, 500 k-node taxonomy pruned and whole): tools/ragged_bench.py
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import ragged_bench
+                sec["c2_ragged"] = ragged_bench.run(pkg, synth, torch, steps=5, in_flight=args.in_flight)
+            except Exception as e:
+                sec["c2_ragged"] = {"error": repr(e)}
             sec["c2_hbm_store"] = measure_hbm_store(4000, out["ms_per_step"], out["sync_unprofiled_ms_per_step"])
             out["secondary"] = sec
         print(json.dumps(out))

@@ -198,7 +198,10 @@ def make_dataset(n_sets, n_hits, seg_len=200, branching=4, genome_len=4000, seed
     # --- choose species + locus per record set ---
     W = seg_len
     p = rng.integers(0, genome_len - W, n_sets)
-    sp = rng.integers(0, n_species, (n_sets, n_hits))
+    if n_hits > 64:  # (redrawing whole rows until they hold no duplicate never ends for hundreds of hits out of thousands of species)
+        sp = np.argsort(rng.random((n_sets, n_species)), axis=1)[:, :n_hits].astype(np.int64)
+    else:
+        sp = rng.integers(0, n_species, (n_sets, n_hits))
     for _ in range(64):  # make the species of a set distinct
         srt = np.sort(sp, axis=1)
         dup_rows = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
@@ -450,3 +453,105 @@ def write_files(ds, folder, line_width=80):
                     qlen[lo:hi].tolist(), b["ref_seq"][lo:hi].tolist(), b["rstart"][lo:hi].tolist(), b["rstop"][lo:hi].tolist(),
                     np.asarray(b["score"][lo:hi], np.float64).tolist(), b["identities"][lo:hi].tolist(), b["alnlen"][lo:hi].tolist()]
             f.write("".join([fmt % r for r in zip(*cols)]))
+
+
+def embed_in_big_tree(tax, n_total, max_depth, seed=7):
+    """`tax` (nodes 0 .. n0-1 keep their indices) inside a tree of n_total nodes of NCBI shape: the other n_total - n0 nodes are
+    clades no record refers to, hung under random earlier nodes whose depth is below max_depth (four of five under a node of
+    the previous batch, so the tree grows level by level).  What the engine sees of a real taxonomy: most of its tables are
+    about taxa the batch never names.  Returns an object with parent / depth / left / right (fresh nested-set numbers)."""
+    rng = np.random.default_rng(seed)
+    n0 = len(tax.parent)
+    n = max(n_total, n0)
+    parent = np.zeros(n, np.uint32)
+    depth = np.zeros(n, np.uint8)
+    parent[:n0] = np.asarray(tax.parent)
+    depth[:n0] = np.asarray(tax.depth)
+    lo, prev_lo = n0, 0
+    while lo < n:
+        hi = min(n, int(lo * 1.22) + 1)
+        deep = rng.random(hi - lo) < 0.8
+        cand = np.where(deep, rng.integers(prev_lo, lo, hi - lo), rng.integers(0, lo, hi - lo))
+        cand[depth[cand] >= max_depth] = 0
+        parent[lo:hi] = cand
+        depth[lo:hi] = depth[cand] + 1
+        prev_lo, lo = lo, hi
+    order = np.argsort(parent[1:], kind="stable") + 1
+    start = np.searchsorted(parent[order], np.arange(n + 1))
+    left = np.zeros(n, np.uint32)
+    right = np.zeros(n, np.uint32)
+    nxt = start[:-1].copy()
+    stack, ctr = [0], 1
+    left[0] = 1
+    while stack:
+        v = stack[-1]
+        if nxt[v] < start[v + 1]:
+            c = int(order[nxt[v]]); nxt[v] += 1
+            ctr += 1; left[c] = ctr
+            stack.append(c)
+        else:
+            ctr += 1; right[v] = ctr
+            stack.pop()
+
+    class Tree:
+        pass
+    t = Tree()
+    t.parent, t.depth, t.left, t.right = parent, depth, left, right
+    return t
+
+
+def make_ragged_dataset(classes, seed=1, device="cpu", branching=4, shuffle=True, level_rate=0.03, query_rate=0.05):
+    """Record sets of MIXED shape in one batch: `classes` = [(n_sets, n_hits, seg_len), ...]; every class is a make_dataset()
+    workload of its own (own genomes, same mock taxonomy), the classes' reference and query collections laid out back to back
+    in one store each, the record sets of all classes shuffled into one stream.  Sets of 1 ... hundreds of hits and segments
+    of 50 ... 1500 nt side by side is what a real alignment stream looks like (core/USAGE.md:90-96) and what the uniform
+    BASELINE configurations never show the engine: ragged tiles, several length bins per round, wide path labels."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for k, (n_sets, n_hits, seg_len) in enumerate(classes):
+        parts.append(make_dataset(n_sets=n_sets, n_hits=n_hits, seg_len=seg_len, branching=branching, genome_len=max(2000, 4 * seg_len),
+                                  seed=seed * 1000 + k, device=device, level_rate=level_rate, query_rate=query_rate))
+    ds = Dataset()
+    ds.alphabet = 0
+    ds.tax = parts[0].tax
+    ds.n_sets = sum(p.n_sets for p in parts)
+    ds.n_hits = None
+    ds.classes = list(classes)
+    ds.query_letters = np.concatenate([p.query_letters for p in parts])
+    ds.ref_letters = np.concatenate([p.ref_letters for p in parts])
+    q_off, r_off, q_base, r_base, qseq_base, rseq_base = [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)], 0, 0, [], []
+    nq = nr = 0
+    for p in parts:
+        q_off.append(p.query_offsets[1:] + np.uint64(q_base)); r_off.append(p.ref_offsets[1:] + np.uint64(r_base))
+        q_base += int(p.query_offsets[-1]); r_base += int(p.ref_offsets[-1])
+        qseq_base.append(nq); rseq_base.append(nr)
+        nq += len(p.query_offsets) - 1; nr += len(p.ref_offsets) - 1
+    ds.query_offsets = np.concatenate(q_off)
+    ds.ref_offsets = np.concatenate(r_off)
+    # per set: (class, set inside the class); shuffled
+    cls = np.concatenate([np.full(p.n_sets, k, np.int64) for k, p in enumerate(parts)])
+    loc = np.concatenate([np.arange(p.n_sets, dtype=np.int64) for p in parts])
+    perm = rng.permutation(len(cls)) if shuffle else np.arange(len(cls))
+    cls, loc = cls[perm], loc[perm]
+    hits = np.array([c[1] for c in classes], np.int64)[cls]
+    so = np.zeros(len(cls) + 1, np.int64)
+    so[1:] = np.cumsum(hits)
+    H = int(so[-1])
+    # records: position of every record of the stream inside its class's arrays
+    rec_cls = np.repeat(cls, hits)
+    rec_in = np.repeat(loc * hits, hits) + (np.arange(H) - np.repeat(so[:-1], hits))
+    batch = {"set_offsets": so.astype(np.uint32)}
+    batch["query_seq"] = (np.array(qseq_base, np.int64)[cls] + loc).astype(np.uint32)
+    batch["query_len"] = np.zeros(len(cls), np.uint32)
+    for f in ("qstart", "qstop", "rstart", "rstop", "score", "identities", "alnlen", "ref_seq", "node", "filtered"):
+        batch[f] = np.zeros(H, parts[0].batch[f].dtype)
+    for k, p in enumerate(parts):
+        m = cls == k
+        batch["query_len"][m] = p.batch["query_len"][loc[m]]
+        mr = rec_cls == k
+        for f in ("qstart", "qstop", "rstart", "rstop", "score", "identities", "alnlen", "node", "filtered"):
+            batch[f][mr] = p.batch[f][rec_in[mr]]
+        batch["ref_seq"][mr] = (p.batch["ref_seq"][rec_in[mr]].astype(np.int64) + rseq_base[k]).astype(np.uint32)
+    ds.batch = batch
+    ds.set_class = cls
+    return ds
