@@ -490,10 +490,13 @@ static int run(int argc, char** argv) {
       std::cout << GFF3Header();
       std::ostringstream outbuf;
       const size_t batch_sets = o.batch ? o.batch : (size_t)1 << 16;
-      while (recgen.notEmpty()) {
+      std::exception_ptr input_failure;  // the reference predicts and prints set by set (:69-74): what was read before a bad line is still printed
+      while (recgen.notEmpty() && !input_failure) {
         stage("alignment-free model: reading record sets");
         sets.clear();
-        while (recgen.notEmpty() && sets.size() < batch_sets) { sets.emplace_back(); recgen.getNext(sets.back()); }
+        try {
+          while (recgen.notEmpty() && sets.size() < batch_sets) { sets.emplace_back(); recgen.getNext(sets.back()); }
+        } catch (...) { input_failure = std::current_exception(); sets.pop_back(); }
         stage("alignment-free model: predict");
         model->predict(sets, precs, logsink);
         stage("alignment-free model: output");
@@ -501,6 +504,7 @@ static int run(int argc, char** argv) {
         for (size_t s = 0; s < sets.size(); ++s) outbuf << precs[s];
         std::cout << outbuf.str();
       }
+      if (input_failure) { std::cout.flush(); std::rethrow_exception(input_failure); }
       return EXIT_SUCCESS;
     }
     // in memory unless an index file is named (core/taxator.cpp:232-249); an indexed store loads nothing here
@@ -539,6 +543,13 @@ static int run(int argc, char** argv) {
         std::cerr << "STORE\t" << (which == 0 ? "query" : "ref") << "\t" << ((which == 0 ? query_storage : db_storage).indexed() ? "indexed" : "in-memory")
                   << "\tsequences=" << si.n_seqs << "\tresident=" << si.n_resident << "\tresidues=" << si.residues << "\tdevice_bytes=" << si.device_bytes
                   << "\twindows=" << si.windows << "\tlive_residues=" << si.live_residues << std::endl;
+        if ((which == 0 ? query_storage : db_storage).indexed()) {  // engine 0's share of making regions resident (every engine fetches for itself)
+          const RPAPredictionModel::ResidentStats rs = rpa.residentStats(which == 0 ? RPA_STORE_QUERY : RPA_STORE_DB);
+          std::cerr << "RESIDENT\t" << (which == 0 ? "query" : "ref") << "\tscan_s=" << rs.scan_s << "\tfetch_s=" << rs.fetch_s << "\tappend_s=" << rs.append_s
+                    << "\twait_s=" << rs.wait_s << "\tfetched_residues=" << rs.residues << "\twindows_appended=" << rs.windows << "\tblocks_that_fetched=" << rs.blocks
+                    << "\tstore_emptied=" << rs.resets << "\tfetch_MB_per_s=" << (rs.fetch_s > 0 ? rs.residues / rs.fetch_s / 1e6 : 0.0)
+                    << "\tappend_MB_per_s=" << (rs.append_s > 0 ? rs.residues / rs.append_s / 1e6 : 0.0) << std::endl;
+        }
       }
     };
     if (!o.record_objects) {
@@ -595,15 +606,18 @@ static int run(int argc, char** argv) {
     std::cout << GFF3Header();
     std::ostringstream outbuf;
     const size_t batch_sets = o.batch ? o.batch : (size_t)1 << 16;
-    while (recgen.notEmpty()) {
+    std::exception_ptr input_failure;  // the reference predicts and prints set by set (:69-74): what was read before a bad line is still printed
+    while (recgen.notEmpty() && !input_failure) {
       stage("record-object loop: reading record sets");
       const Clock::time_point t0 = Clock::now();
       sets.clear();
-      while (recgen.notEmpty() && sets.size() < batch_sets) {
-        sets.emplace_back();
-        recgen.getNext(sets.back());
-        n_records += sets.back().size();
-      }
+      try {
+        while (recgen.notEmpty() && sets.size() < batch_sets) {
+          sets.emplace_back();
+          recgen.getNext(sets.back());
+          n_records += sets.back().size();
+        }
+      } catch (...) { input_failure = std::current_exception(); sets.pop_back(); }
       n_sets += sets.size();
       const Clock::time_point t1 = Clock::now();
       stage("record-object loop: predict");
@@ -630,6 +644,7 @@ static int run(int argc, char** argv) {
       const Clock::time_point t3 = Clock::now();
       t_parse += secs(t0, t1); t_predict += secs(t1, t2); t_write += secs(t2, t3);
     }
+    if (input_failure) { std::cout.flush(); std::rethrow_exception(input_failure); }
     if (o.timing)
       std::cerr << "TIMING\tload_s=" << secs(t_start, t_loaded) << "\tparse_s=" << t_parse << "\tpredict_s=" << t_predict << "\twrite_s="
                 << t_write << "\trecord_sets=" << n_sets << "\trecords=" << n_records << std::endl;

@@ -2,6 +2,7 @@
 #include "taxonpredictionmodel.hh"
 
 #include <algorithm>
+#include <chrono>
 #include <iostream>
 #include <memory>
 #include <mutex>
@@ -133,7 +134,11 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
   const uint64_t n_tiles = base.back();
   const size_t n_units = which == RPA_STORE_QUERY ? b.n_sets : b.n_records;
   bool emptied = false;  // the store was emptied for this batch: what it needs now is all there will be
+  typedef std::chrono::steady_clock Clock;
+  auto since = [](Clock::time_point a) { return std::chrono::duration<double>(Clock::now() - a).count(); };
+  ResidentStats& rs = resident_stats_[which == RPA_STORE_QUERY ? 0 : 1];
   for (;;) {
+    const Clock::time_point t_scan = Clock::now();
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, n_units / 65536 + 1));
     std::vector<std::vector<uint64_t>> need(T);
     std::vector<uint8_t> out_of_range(T, 0), any(T, 0);
@@ -186,7 +191,7 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
       if (want.empty()) want.swap(need[t]);
       else for (size_t k = 0; k < want.size(); ++k) want[k] |= need[t][k];
     }
-    if (want.empty()) return 0;
+    if (want.empty()) { rs.scan_s += since(t_scan); return 0; }
     // runs of (resident | wanted) tiles that hold a wanted tile, sequence by sequence
     std::vector<rpa_window> wins;
     fetch_offsets_.assign(1, 0);
@@ -210,6 +215,7 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
       }
     }
     const uint64_t total = fetch_offsets_.back();
+    rs.scan_s += since(t_scan);
     if (!emptied) {
       const rpa_store_info info = storeInfo(which);
       const uint64_t half_bytes = rpa_store_bits_ / 4;  // per residue: 4-bit DNA = 1 half byte, 8-bit protein = 2
@@ -222,8 +228,9 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
         // Drop everything resident and start over with what this batch needs -- once no batch that was made resident earlier
         // is still running on what is there (the wait lets go of the lock: another thread may come through here meanwhile, so
         // the scan above is stale afterwards and is done again either way).
-        if (in_flight_) { resident_cv_.wait(lk, [&] { return in_flight_ == 0; }); continue; }
+        if (in_flight_) { const Clock::time_point t_w = Clock::now(); resident_cv_.wait(lk, [&] { return in_flight_ == 0; }); rs.wait_s += since(t_w); continue; }
         check(engine_, rpa_store_reset(engine_, which));
+        ++rs.resets;
         std::fill(res.begin(), res.end(), 0);
         emptied = true;
         continue;
@@ -231,6 +238,7 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
     }
     if (store_budget_ && total * (rpa_store_bits_ / 4) / 2 > store_budget_)
       throw GeneralError("one block of the alignment stream needs more sequence than --store-gb allows: use smaller blocks (--block-mb) or a larger budget");
+    const Clock::time_point t_fetch = Clock::now();
     fetch_letters_.resize((size_t)total + 8);
     const unsigned F = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, wins.size()));
     std::exception_ptr err;
@@ -248,7 +256,11 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
       for (auto& x : th) x.join();
     }
     if (err) std::rethrow_exception(err);
+    rs.fetch_s += since(t_fetch);
+    const Clock::time_point t_app = Clock::now();
     check(engine_, rpa_store_append_windows(engine_, which, (uint32_t)wins.size(), wins.data(), fetch_letters_.data(), fetch_offsets_.data()));
+    rs.append_s += since(t_app);
+    rs.residues += total; rs.windows += wins.size(); ++rs.blocks;
     for (size_t k = 0; k < want.size(); ++k) res[k] |= want[k];  // marked resident only now that the engine has them
     return wins.size();
   }

@@ -68,6 +68,12 @@ class RPAPredictionModel : public TaxonPredictionModel {
   void setStoreBudget(uint64_t bytes) { store_budget_ = bytes; }                  // 0 = no limit; per store
   void setGarbageSlack(uint64_t residues) { garbage_slack_ = residues; }
   rpa_store_info storeInfo(int which) const;
+  // where the time of making regions resident went (taxator --timing: RESIDENT lines), per indexed store, summed over the blocks:
+  // scanning the block's columns for tiles that are not resident | reading the regions out of the mapped FASTA (all host threads)
+  // | rpa_store_append_windows (waits for the jobs in flight, copies the letters to the device, packs) | waiting for earlier
+  // batches before the store may be emptied; residues fetched, windows appended, blocks that fetched anything, times the store was emptied
+  struct ResidentStats { double scan_s = 0, fetch_s = 0, append_s = 0, wait_s = 0; uint64_t residues = 0, windows = 0, blocks = 0, resets = 0; };
+  ResidentStats residentStats(int which) const { return resident_stats_[which == RPA_STORE_QUERY ? 0 : 1]; }
   // page-lock / release host arrays that are handed to predictColumns() again and again (rpa_host_register)
   void pinHost(void* p, size_t bytes) const;
   void unpinHost(void* p) const;
@@ -80,6 +86,7 @@ class RPAPredictionModel : public TaxonPredictionModel {
   std::vector<uint64_t> resident_[2];
   uint64_t tile_ = 65536, store_budget_ = 0;
   uint64_t garbage_slack_ = (uint64_t)1 << 30;  // residues of swallowed windows an indexed store may carry before it is emptied and refilled (setGarbageSlack)
+  ResidentStats resident_stats_[2];
   unsigned rpa_store_bits_ = 4;  // packed bits per residue in the engine (DNA 4, protein 8): what a residue costs against the budget
   size_t makeResidentStore(int which, const rpa_batch& b, const std::vector<uint32_t>& span, std::unique_lock<std::mutex>& lk);
   std::atomic<bool> reverse_noted_{false};
