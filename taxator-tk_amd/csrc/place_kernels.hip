@@ -597,7 +597,7 @@ __device__ __forceinline__ EmitInfo emit_info_from(const uint4 desc, const uint4
 
 template <int Q>
 __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& w, const Params& p, const EmitInfo& info, uint32_t s,
-                                              uint32_t lo, uint32_t pos, const uint32_t lite, uint2& entry, uint32_t& maxlen) {
+                                              uint32_t lo, uint32_t pos, const uint32_t lite, uint2& entry, uint32_t& maxlen, uint32_t* cb_out = nullptr) {
   const uint32_t H = b.n_records;
   const uint32_t seglen = lite & kLiteLenMask;
   bool want = false;
@@ -618,7 +618,9 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
       uint32_t pb[4 * Q - 6], pth[4 * Q - 6];
       R.path(info.best, pb);
       R.path(i, pth);
-      want = !(common<4 * Q - 6>(pb, meta_depth(R.core(info.best).meta), pth, meta_depth(h.meta), w.lb_shift) >= info.d_unode_g);
+      const uint32_t cb = common<4 * Q - 6>(pb, meta_depth(R.core(info.best).meta), pth, meta_depth(h.meta), w.lb_shift);
+      want = !(cb >= info.d_unode_g);
+      if (cb_out) *cb_out = cb;
     }
   }
   if (!want) return -1;
@@ -634,12 +636,19 @@ __device__ __forceinline__ int emit_predicate(const BatchDev& b, const WorkDev& 
 #ifndef RPA_EMIT_WAVES
 #define RPA_EMIT_WAVES 8  // (A/B: tools/build_variant.sh)
 #endif
+// (rows of four and more quads -- deep taxonomies, 16- / 32-bit labels: the two paths a pass-2 candidate compares do not fit 64
+// registers beside the rest, the kernel spilled 50 / 64 / 232 of them; those shapes get the registers of ONE resident block per CU)
 template <int Q>
-__global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b, WorkDev w, Params p) {  // two resident blocks per CU: one computes while the other waits on its loads
+__global__ __launch_bounds__(kEmitBlock, (Q <= 3 ? RPA_EMIT_WAVES : 4)) void k_emit(BatchDev b, WorkDev w, Params p) {  // two resident blocks per CU: one computes while the other waits on its loads
   constexpr int kVW = kEmitSpan / 64;  // "virtual waves": runs of 64 consecutive row positions
   static_assert(kVW == 64, "the prefix over virtual waves is done by one wavefront");
   __shared__ uint32_t s_cnt[kNumBins][kVW];  // per bin, per virtual wave: number of active lanes, then its list offset
   __shared__ uint32_t s_maxlen[kVW];
+  // pass-2 requests (mode 3): depth of LCA(hit, best hit) per row position of the block, 0xFF = not a pass-2 request -- what decides
+  // whether a hit waits for the round's second launch (kDeferredMark, rpa_device.h)
+  __shared__ uint8_t s_cb[kEmitSpan];
+  __shared__ uint32_t s_deferred;
+  if (threadIdx.x == 0) s_deferred = 0u;
   const uint32_t H = b.n_records, total = H + b.n_sets;
   const uint32_t pos0 = blockIdx.x * kEmitSpan + threadIdx.x;
   for (int i = threadIdx.x; i < kNumBins * kVW; i += kEmitBlock) (&s_cnt[0][0])[i] = 0u;  // only bins that occur get a count below
@@ -660,6 +669,7 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
   int bin[kEmitRows];
   uint2 entry[kEmitRows];
   uint32_t maxlen = 0;
+  uint32_t pass2_rows = 0;  // bit k: row k of this thread is a pass-2 request
 #pragma unroll
   for (int k = 0; k < kEmitRows; ++k) {
     const uint32_t pos = pos0 + k * kEmitBlock;
@@ -668,6 +678,7 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
     bin[k] = -1;
     entry[k] = make_uint2(0u, 0u);
     uint32_t ml = 0;
+    uint32_t cb = 0xFFu;
     if (pos < H) {
       if (mode != 0u && (mode == 4u || i >= desc[k].y) && i < desc[k].z && (mode == 1u || mode == 4u || i != anchor)) {
         if (mode != 3u && mode != 5u) {  // passes 0 and 1: the lite word decides
@@ -682,7 +693,9 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
           }
         } else {
           const EmitInfo info = emit_info_from(desc[k], ext[k]);  // (modes 3 and 5: the two quads say it all -- no trip to the 64-byte record)
-          bin[k] = emit_predicate<Q>(b, w, p, info, set_of[k], lo[k], pos, lite[k], entry[k], ml);
+          uint32_t cbv = 0xFFu;
+          bin[k] = emit_predicate<Q>(b, w, p, info, set_of[k], lo[k], pos, lite[k], entry[k], ml, &cbv);
+          if (mode == 3u && bin[k] >= 0 && p.defer2) { cb = cbv < 0xFFu ? cbv : 0xFEu; pass2_rows |= 1u << k; }
         }
       }
     } else if (pos < total && mode == 3u) {  // anchor <-> query range (:792-797)
@@ -695,6 +708,29 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
       }
     }
     maxlen = max(maxlen, ml);
+    s_cb[k * kEmitBlock + threadIdx.x] = (uint8_t)cb;
+  }
+  // Which pass-2 requests wait for the round's second launch: those that an EARLIER request of the same chunk could take out of
+  // the loop by lifting unode_global -- an earlier row of my set, inside the chunk, whose LCA with the best hit is no deeper than
+  // mine.  Rows of a set are consecutive row positions = consecutive threads of one of the block's four runs of 1024; what lies
+  // in front of a run is not seen (the hit then simply goes with the first launch, which is always allowed).
+  __syncthreads();
+  if (pass2_rows) {
+#pragma unroll
+    for (int k = 0; k < kEmitRows; ++k) {
+      if (!((pass2_rows >> k) & 1u)) continue;
+      const uint32_t pos = pos0 + k * kEmitBlock, i = pos - lo[k], i_lo = desc[k].y;
+      const uint32_t back = min(min(i - i_lo, (uint32_t)threadIdx.x), kDeferSpan - 1u);  // rows of my chunk in front of me that this run holds
+      if (i - i_lo >= kDeferSpan) continue;  // (the filter keeps a chunk's held-back hits as one 64-bit set)
+      const uint32_t mine = s_cb[k * kEmitBlock + threadIdx.x];
+      bool covered = false;
+      for (uint32_t j = 1; j <= back; ++j) covered = covered || s_cb[k * kEmitBlock + threadIdx.x - j] <= mine;
+      if (covered) {
+        w.pair_res[res_index(w, pos)] = make_float2(kDeferredMark, 0.f);
+        bin[k] = -1;
+        atomicAdd(&s_deferred, 1u);
+      }
+    }
   }
   // block-level compaction: wave ballots -> LDS -> one atomic per non-empty bin per block
   // (per row position of a thread: one ballot per bin PRESENT in the wavefront -- usually one or none -- instead of one
@@ -740,12 +776,97 @@ __global__ __launch_bounds__(kEmitBlock, RPA_EMIT_WAVES) void k_emit(BatchDev b,
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, 64));
     if (lane == 0 && m) atomicMax(&w.counters[kCtrMaxLen], m);
+    if (lane == 0 && s_deferred) atomicAdd(&w.counters[kCtrDeferred], s_deferred);
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kEmitRows; ++k)
     if (bin[k] >= 0)
       w.bin_list[(size_t)bin[k] * w.T2 + s_cnt[bin[k]][k * (kEmitBlock / 64) + wave] + (uint32_t)__popcll(my_mask[k] & ((1ull << lane) - 1ull))] = entry[k];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Between the two launches of a pass-2 round (kDeferredMark, rpa_device.h): one thread per record set whose request is a pass-2
+// chunk.  It walks the chunk the way k_decide's pass-2 loop will (:757-813) with the results the first launch left: `d` follows
+// unode_global wherever a result that is there lifts it.  d never lies below the value the real loop will have at the same row --
+// every lift applied here happens there too, or the hit is stepped over there because unode_global is already at or above it
+// -- so a held-back hit with LCA depth >= d is one the real loop steps over: it stays unaligned.  Every other held-back hit goes
+// onto the bin lists of the second launch (counted in counters[kCtrSurvivor + bin]).  Nothing else changes: k_decide consumes
+// exactly what it always did, and a mark it should ever consume is a failed assert, not a distance.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kFilterBlock = 1024;  // one list reservation per bin per workgroup
+template <int Q>
+__global__ __launch_bounds__(kFilterBlock) void k_defer_filter(BatchDev b, WorkDev w, Params p) {
+  constexpr int PW = 4 * Q - 6;
+  __shared__ uint32_t s_count[kNumBins], s_base[kNumBins];
+  if (threadIdx.x < (uint32_t)kNumBins) s_count[threadIdx.x] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { w.counters[kCtrRetry] = 0u; w.counters[kCtrRetryShort] = 0u; }  // the retry lists start over for the second launch
+  __syncthreads();
+  const uint32_t s = blockIdx.x * kFilterBlock + threadIdx.x;
+  unsigned long long survivors = 0ull;  // bit k: hit i_lo + k of my chunk goes into the second launch
+  uint32_t lo = 0, i_lo = 0, anchor = 0, anchor_len = 0;
+  if (s < b.n_sets) {
+    const uint4 desc = w.emit_lite[s];
+    if ((desc.x & 7u) == 3u) {
+      const EmitInfo info = emit_info_from(desc, w.emit_ext[s]);
+      const double qpid_thresh = w.emit[s].qpid_thresh;
+      const uint4 sinfo = w.set_info[s];
+      const uint32_t L = sinfo.z - sinfo.y + 1u;
+      const float bf_max = __uint_as_float(w.state[s].q[1].w);
+      lo = b.set_offsets[s];
+      i_lo = info.i_lo; anchor = info.anchor; anchor_len = info.anchor_len;
+      const SetRows<Q> R = set_rows<Q>(w, s, lo);
+      uint32_t pb[PW];
+      R.path(info.best, pb);
+      const uint32_t db = meta_depth(R.meta(info.best));
+      float qd_a = R.core(anchor).qd;
+      uint32_t d = info.d_unode_g;
+      const uint32_t i_hi = min(info.i_hi, sinfo.x);
+      for (uint32_t i = i_lo; i < i_hi; ++i) {
+        const HitCore h = R.core(i);
+        if (!(h.score >= info.fcut)) break;   // :757
+        if (i == anchor) continue;           // distance 0: lifts nothing, is never held back
+        if (!((double)h.qs / L >= qpid_thresh)) continue;  // :765 (the real test; k_emit's float threshold is a superset)
+        uint32_t pth[PW];
+        R.path(i, pth);
+        const uint32_t cb = common<PW>(pb, db, pth, meta_depth(h.meta), w.lb_shift);
+        if (cb >= d) continue;               // :771 with d >= the real unode_global: stepped over there too
+        const float2 r2 = R.result(i);
+        if (r2.x == kDeferredMark) {         // held back and still reachable
+          if (i - i_lo < kDeferSpan) survivors |= 1ull << (i - i_lo);
+          continue;
+        }
+        if (r2.x != 0.f) {                   // :789-813
+          if (qd_a == FLT_MAX) qd_a = w.pair_res[w.P + s].x;  // the anchor <-> query alignment (:792-797): asked for with the anchor's first chunk
+          if (r2.x <= qd_a * bf_max) d = min(d, cb);
+        }
+      }
+    }
+  }
+  // survivors -> bin lists: count per bin in LDS, one reservation per bin and workgroup, then write
+  uint32_t my_bins = 0;  // (a set's held-back hits nearly always share one bin; the general case walks the bits twice)
+  for (unsigned long long m = survivors; m; m &= m - 1ull) {
+    const uint32_t i = i_lo + (uint32_t)__ffsll((long long)m) - 1u;
+    int bin = pair_bin(p, w.lite[lo + i] & kLiteLenMask, anchor_len);
+    if (bin >= kNumBins) { raise_error(w, kErrUnsupported, s); bin = 0; }
+    atomicAdd(&s_count[bin], 1u);
+    ++my_bins;
+  }
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)kNumBins) {
+    const uint32_t c = s_count[threadIdx.x];
+    s_base[threadIdx.x] = c ? atomicAdd(&w.counters[kCtrSurvivor + threadIdx.x], c) : 0u;
+    s_count[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  for (unsigned long long m = survivors; m; m &= m - 1ull) {
+    const uint32_t i = i_lo + (uint32_t)__ffsll((long long)m) - 1u;
+    int bin = pair_bin(p, w.lite[lo + i] & kLiteLenMask, anchor_len);
+    if (bin >= kNumBins) bin = 0;
+    const uint32_t at = s_base[bin] + atomicAdd(&s_count[bin], 1u);
+    w.bin_list[(size_t)bin * w.T2 + at] = make_uint2(lo + i, lo + anchor);
+  }
+  (void)my_bins;
 }
 
 // In a sparse round every launch is latency-bound (a few thousand lanes at most), so all patterns of up to 256 nt go
@@ -1178,7 +1299,7 @@ struct BandAcc {
 // selfscore >= mutual / distance >= 0 (:205,:240), which the kernel flags by a NaN distance.
 __device__ __forceinline__ bool result_ok(const WorkDev& w, uint32_t s, uint32_t err_a, uint32_t err_b, float dist) {
   if (err_a | err_b) { raise_error(w, err_a ? err_a : err_b, s); return false; }
-  if (dist != dist) { raise_error(w, kErrAssert, s); return false; }
+  if (dist != dist || dist < 0.f) { raise_error(w, kErrAssert, s); return false; }  // (negative: a kDeferredMark nobody replaced -- never consumed by design)
   return true;
 }
 
@@ -1231,6 +1352,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     if (threadIdx.x != (uint32_t)kCtrActive) w.counters[threadIdx.x] = 0u;
     if (threadIdx.x == 0) w.counters[w.ctr_live_in] = 0u;
   }
+  if (blockIdx.x == 0 && threadIdx.x >= 64u && threadIdx.x <= 64u + (uint32_t)kNumBins) w.counters[kCtrDeferred + (threadIdx.x - 64u)] = 0u;  // kCtrDeferred, kCtrSurvivor ..
   __syncthreads();  // (the only barrier of the kernel: the wavefronts of a workgroup start together and finish far apart)
   // dense rounds: one thread per record set; sparse rounds (few sets still running): one thread per entry of the live list
   const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
@@ -1975,6 +2097,13 @@ hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, cons
   if (total == 0) return hipSuccess;
   const dim3 grid((total + kEmitSpan - 1) / kEmitSpan);
   RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_emit<Q>, grid, dim3(kEmitBlock), 0, st, b, w, p));
+  return hipGetLastError();
+}
+
+hipError_t launch_defer_filter(hipStream_t st, const BatchDev& b, const WorkDev& w, const Params& p) {
+  if (b.n_sets == 0) return hipSuccess;
+  const dim3 grid((b.n_sets + kFilterBlock - 1) / kFilterBlock);
+  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_defer_filter<Q>, grid, dim3(kFilterBlock), 0, st, b, w, p));
   return hipGetLastError();
 }
 

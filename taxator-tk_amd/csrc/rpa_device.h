@@ -250,7 +250,21 @@ struct WorkDev {
 // and the two swap every round (round 4: a memset per round was ~10 us of a synchronous step's ~130 us per sparse round).
 constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNumBins + 2, kCtrRetryShort = kNumBins + 3, kCtrErr = kNumBins + 4,
               kCtrErrSet = kNumBins + 5, kCtrRetryTotal = kNumBins + 6, kCtrRetryShortTotal = kNumBins + 7, kCtrActiveB = kNumBins + 8,
-              kNumCounters = kNumBins + 9, kNumRoundCounters = kNumBins + 4;
+              kCtrDeferred = kNumBins + 9,   // pass-2 hits of this round that wait for the round's second launch (k_emit; see kDeferredMark)
+              kCtrSurvivor = kNumBins + 10,  // [kNumBins words] pairs per bin of that second launch (k_defer_filter)
+              kNumCounters = 2 * kNumBins + 10, kNumRoundCounters = kNumBins + 4;
+static_assert(kNumCounters <= 64, "launch_publish_words moves up to 64 words");
+
+// Two launches inside ONE pass-2 round.  A pass-2 loop steps over every hit whose taxon lies at or below unode_global (:771), and
+// unode_global is lifted by the hits in front of it (:811-813): of the hits a first pass-2 chunk asks for, half are never consumed
+// because an earlier hit of the same chunk lifted unode_global over them (tools/spec_waste.py).  So k_emit holds back every hit
+// that an EARLIER requested hit of its chunk could take out that way (the depth of its LCA with the best hit is not above the
+// earlier one's) -- it leaves kDeferredMark in the hit's result slot instead of a list entry --, the round's first launch runs
+// without them, k_defer_filter replays the chunk with the results that are there and lists the held-back hits the loop can still
+// reach, and a second launch of the same round computes those.  Consumption (k_decide) is unchanged and exact: a hit that was
+// dropped is one the reference's loop steps over; config 2 computes 1.03 alignments per demanded one instead of 1.13.
+constexpr float kDeferredMark = -1.f;  // (a distance is never negative; k_decide treats a consumed mark as a failed assert)
+constexpr uint32_t kDeferSpan = 64;    // only the first 64 rows of a chunk can be held back (the filter keeps them as one bit set)
 
 // Row shapes the placement kernels are built for.  A row holds 4Q - 6 path words = (4Q - 6) * 32 / label bits levels.
 constexpr int kRowQuadChoices[] = {2, 3, 4, 6, 8};
@@ -280,6 +294,8 @@ struct Params {
                           //    (chunk_end_by_score; A/B: RPA_PASS1_FILTER=0|1|3)
   int grow;               // 1: a loop that pauses asks for as many hits again as it has already walked (chunks 2,2,4,8,...):
                           //    a loop that has not stopped early so far probably will not; log2(n) rounds instead of n/chunk
+  int defer2;             // 1: pass-2 hits that an earlier hit of their chunk may take out of the loop wait for the round's second launch
+                          //    (kDeferredMark; A/B: RPA_DEFER2=0)
   uint32_t spec2_first;   // pass 2: the FIRST chunk of an anchor's loop (0: spec2).  The hits that lift unode_global come early
                           // in a loop and take most of the hits behind them out of it: a short first chunk, then spec2
 };
@@ -318,6 +334,8 @@ hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w,
 hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p);
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc);
+// between the two launches of a round (kDeferredMark): the held-back pass-2 hits that are still needed -> bin lists, counters[kCtrSurvivor ..]
+hipError_t launch_defer_filter(hipStream_t st, const BatchDev& b, const WorkDev& w, const Params& p);
 
 // alignment-free models (lca_kernels.hip): model 0 dummy, 1 simple-lca, 2 megan-lca, 3 n-best-lca
 struct LcaParamsDev {

@@ -614,6 +614,27 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     }
     rc = run_align_bins(e, w, counts);
     if (rc) return rc;
+    if (e->h_counters[kCtrDeferred]) {
+      // The round's second launch (kDeferredMark, rpa_device.h): pass-2 hits that an earlier hit of their chunk may have taken out
+      // of the loop.  The filter replays the chunks with the first launch's results; what is still reachable comes back as bin
+      // lists with their lengths in counters[kCtrSurvivor ..].
+      const uint32_t held_back = e->h_counters[kCtrDeferred];
+      HIP_TRY(e, launch_defer_filter(e->stream, b, w, e->params));
+      HIP_TRY(e, launch_publish_words(e->stream, w.counters, e->h_counters, kNumCounters));
+      RPA_WHERE("predict_part: sync after the deferred-hit filter (round)");
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      rc = check_device_error(e, e->h_counters);
+      if (rc) return rc;
+      uint32_t counts2[kNumRoundCounters];
+      memcpy(counts2, counts, sizeof(counts2));
+      uint64_t again = 0;
+      for (int k = 0; k < kNumBins; ++k) { counts2[k] = e->h_counters[kCtrSurvivor + k]; again += counts2[k]; }
+      if (e->trace_rounds) fprintf(stderr, "[rpa]   second launch: %u pass-2 alignments were held back, %llu of them are still reachable\n", held_back, (unsigned long long)again);
+      if (again) {
+        rc = run_align_bins(e, w, counts2);
+        if (rc) return rc;
+      }
+    }
     if (e->trace_rounds) {  // (a synchronisation the normal path does not have)
       uint32_t retried = 0;
       HIP_TRY(e, hipMemcpyAsync(&retried, w.counters + kCtrRetry, 4, hipMemcpyDeviceToHost, e->stream));
@@ -875,6 +896,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_SPEC2")) { e->params.spec2 = (uint32_t)atoi(v); e->fixed_speculation = true; }
   e->params.spec2_first = 0;
   if (const char* v = getenv("RPA_SPEC2_FIRST")) e->params.spec2_first = (uint32_t)atoi(v);
+  e->params.defer2 = 1;
+  if (const char* v = getenv("RPA_DEFER2")) e->params.defer2 = atoi(v) != 0;
   e->fill_lanes = 3u * kResidentLanes;  // RPA_FILL_LANES sweep: config 5 1174 / 1137 / 1053 ms at 1x / 2x / 3x, configs 2 and 4 indifferent
   if (const char* v = getenv("RPA_FILL_LANES")) e->fill_lanes = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SPARSE_EMIT")) e->sparse_div_emit = (uint32_t)atoi(v);

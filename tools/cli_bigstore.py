@@ -63,7 +63,7 @@ def main():
     synth = importlib.import_module("taxator_tk_amd.synth")
     base = args.dir or tempfile.mkdtemp(prefix="bigstore_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     os.makedirs(base, exist_ok=True)
-    gen = os.path.join(base, "bigstore_gen")
+    gen = os.path.join(tempfile.mkdtemp(prefix="bigstore_gen_"), "bigstore_gen")  # (not under /dev/shm: mounted noexec on the GPU boxes)
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", gen, os.path.join(ROOT, "tools", "bigstore_gen.cpp")])
     tax = synth.MockTaxonomy(4)
     tax.write_ncbi_dump(os.path.join(base, "tax"))
