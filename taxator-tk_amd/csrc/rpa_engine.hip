@@ -102,6 +102,15 @@ struct rpa_engine {
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
       protein_ws, lanes_counter, retry_list, retry_short;
   uint32_t* h_counters = nullptr;  // pinned
+  // The alignment launches of ONE round that do not depend on each other (one per length class: the strip-height classes of long
+  // nucleotide pairs, the lanes-per-pair classes of protein pairs) go to side streams, forked from and joined to the engine's stream
+  // by events: on batches of mixed segment lengths most of them fill a fraction of the chip and last as long as their longest pair
+  // (tools/ragged_bench.py: 43 launches per step one after the other).  Uniform batches have one launch per round and never fork.
+  static constexpr int kSideStreams = 4;
+  hipStream_t side_stream[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+  DevBuf side_ws[kSideStreams];  // the strip kernel's boundary-plane scratch, one per side stream
+  bool side_streams_on = true;   // RPA_SIDE_STREAMS=0: every launch on the engine's stream (A/B)
   // profiling
   bool profiling = false;
   bool prof_counters = true;   // rpa_profile_enable(2): events only -- the kernels carry no counters (their reductions cost K1 4 %)
@@ -263,6 +272,43 @@ int next_work_counter(rpa_engine* e, uint32_t** out) {
 int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
   unsigned long long* acc = (e->profiling && e->prof_counters) ? e->prof_acc.as<unsigned long long>() : nullptr;
   const uint32_t* counts = counts_in;
+  // Side streams for the launches that have one: only when the round has several launches to make, and never under the profile
+  // (its event pairs time one launch after the other on the engine's stream).
+  int n_side_candidates = 0, n_launch_groups = 0;
+  for (int bin = 0; bin < kNumBins; ++bin) {
+    if (!counts[bin]) continue;
+    const bool side_ok = e->params.alphabet == RPA_DNA ? bin >= kShortWords : bin > kProteinPackedBin;
+    n_side_candidates += side_ok ? 1 : 0;
+    ++n_launch_groups;
+  }
+  const bool fork = e->side_streams_on && !e->profiling && n_side_candidates >= 1 && n_launch_groups >= 2;
+  bool side_used[rpa_engine::kSideStreams] = {false, false, false, false};
+  int side_next = 0;
+  if (fork) {
+    if (!e->ev_fork) {
+      HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+      for (int k = 0; k < rpa_engine::kSideStreams; ++k) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->side_stream[k], hipStreamNonBlocking));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
+      }
+    }
+    HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
+  }
+  auto take_side = [&](int* which) -> hipStream_t {  // the next side stream (it waits for everything queued on the engine's stream so far)
+    const int k = side_next++ % rpa_engine::kSideStreams;
+    if (!side_used[k]) { side_used[k] = true; (void)hipStreamWaitEvent(e->side_stream[k], e->ev_fork, 0); }
+    *which = k;
+    return e->side_stream[k];
+  };
+  auto join_sides = [&]() -> int {
+    for (int k = 0; k < rpa_engine::kSideStreams; ++k)
+      if (side_used[k]) {
+        HIP_TRY(e, hipEventRecord(e->ev_join[k], e->side_stream[k]));
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join[k], 0));
+        side_used[k] = false;
+      }
+    return RPA_OK;
+  };
   int rider = -1;  // a narrower one-strip class waiting for the next launch
   uint64_t banded_pairs = 0;  // pairs that went through the banded strip kernel this round: the retry list's bound
   uint64_t banded_short = 0;  // ... through the banded one-strip kernel (its own retry list and counter)
@@ -324,11 +370,17 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
         bool wave = max_len <= kWaveMaxPattern && tp_wave > tp_lane;
         if (e->long_kernel == 1 && max_len <= kWaveMaxPattern) wave = true;
         if (e->long_kernel == 2) wave = false;
-        if (wave) HIP_TRY(e, launch_align_dna_long(e->stream, (int)wpl, list, n, nullptr, 0, w, acc));
+        int sk = -1;
+        hipStream_t st = fork ? take_side(&sk) : e->stream;
+        if (wave) HIP_TRY(e, launch_align_dna_long(st, (int)wpl, list, n, nullptr, 0, w, acc));
         else {
-          HIP_TRY(e, e->protein_ws.ensure(dna_strip_scratch_words(n, max_len) * 4));
-          HIP_TRY(e, launch_align_dna_strips(e->stream, bin - kShortWords + kStripMinWords, list, n, nullptr, 0, w, e->protein_ws.as<uint32_t>(),
-                                             e->protein_ws.cap / 4, max_len, !use_band_long, e->band_margin, e->retry_list.as<uint2>(),
+          DevBuf& ws = sk >= 0 ? e->side_ws[sk] : e->protein_ws;  // (a scratch per stream: the launches of a round run side by side)
+          if (dna_strip_scratch_words(n, max_len) * 4 > ws.cap) {
+            if (sk >= 0) HIP_TRY(e, hipStreamSynchronize(st));  // (growing frees the old buffer: nothing of an earlier round may still use it -- rounds are joined, this is for safety)
+            HIP_TRY(e, ws.ensure(dna_strip_scratch_words(n, max_len) * 4));
+          }
+          HIP_TRY(e, launch_align_dna_strips(st, bin - kShortWords + kStripMinWords, list, n, nullptr, 0, w, ws.as<uint32_t>(),
+                                             ws.cap / 4, max_len, !use_band_long, e->band_margin, e->retry_list.as<uint2>(),
                                              w.counters + kCtrRetry, acc));
           if (use_band_long) banded_pairs += n;
         }
@@ -339,7 +391,9 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
         uint32_t* ctr = nullptr;
         trc = next_work_counter(e, &ctr);
         if (trc) return trc;
-        HIP_TRY(e, launch_align_protein_lanes(e->stream, protein_class_lanes(bin - kProteinPackedBin - 1), list, n, w, ctr, acc));
+        int sk = -1;
+        hipStream_t st = fork ? take_side(&sk) : e->stream;
+        HIP_TRY(e, launch_align_protein_lanes(st, protein_class_lanes(bin - kProteinPackedBin - 1), list, n, w, ctr, acc));
         trc = timer.end();
         if (trc) return trc;
         continue;
@@ -381,6 +435,7 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
     trc = timer.end();
     if (trc) return trc;
   }
+  { const int jrc = join_sides(); if (jrc) return jrc; }  // (the one-strip launches and their retries above ran beside the side streams' launches)
   if (banded_pairs) {
     // The pairs whose distance lies outside their band, with the band wide open.  How many there are only the device
     // knows (counters[kCtrRetry]): the launch is sized for "a few" and strides over the list.  One pair per wavefront
@@ -715,6 +770,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   w->device = e->device; w->params = e->params; w->tax = e->tax;
   w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
+  w->side_streams_on = e->side_streams_on;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = make_stream(w->device, &w->own_stream);
   if (err == hipSuccess) err = hipHostMalloc((void**)&w->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault);
@@ -896,6 +952,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_SPEC2")) { e->params.spec2 = (uint32_t)atoi(v); e->fixed_speculation = true; }
   e->params.spec2_first = 0;
   if (const char* v = getenv("RPA_SPEC2_FIRST")) e->params.spec2_first = (uint32_t)atoi(v);
+  if (const char* v = getenv("RPA_SIDE_STREAMS")) e->side_streams_on = atoi(v) != 0;
   e->params.defer2 = 1;
   if (const char* v = getenv("RPA_DEFER2")) e->params.defer2 = atoi(v) != 0;
   e->fill_lanes = 3u * kResidentLanes;  // RPA_FILL_LANES sweep: config 5 1174 / 1137 / 1053 ms at 1x / 2x / 3x, configs 2 and 4 indifferent
@@ -1028,6 +1085,12 @@ void rpa_destroy(rpa_engine* e) {
   if (e->ev_total0) (void)hipEventDestroy(e->ev_total0);
   if (e->ev_total1) (void)hipEventDestroy(e->ev_total1);
   if (e->ev_inputs) (void)hipEventDestroy(e->ev_inputs);
+  for (int k = 0; k < rpa_engine::kSideStreams; ++k) {
+    if (e->side_stream[k]) { (void)hipStreamSynchronize(e->side_stream[k]); (void)hipStreamDestroy(e->side_stream[k]); }
+    if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+    e->side_ws[k].release();
+  }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   RPA_WHERE("rpa_destroy: hipHostFree");
   if (e->h_counters) (void)hipHostFree(e->h_counters);
   RPA_WHERE("rpa_destroy: hipStreamDestroy");
