@@ -212,7 +212,7 @@ __device__ __forceinline__ SegDesc plan_segment_desc(const StoreDev& store, bool
   if (seq >= store.n_seqs) err = kErrSeqId;
   else {
     const ulonglong2 ex = store.extent[seq];
-    const uint64_t off = ex.x, slen = ex.y;
+    const uint64_t off = store.windows ? (ex.x & ((1ull << kWinFirstBits) - 1ull)) : ex.x, slen = ex.y;
     if (start > stop) err = kErrAssert;
     else {
       if ((uint64_t)stop > slen) stop = (uint32_t)slen;
@@ -221,7 +221,7 @@ __device__ __forceinline__ SegDesc plan_segment_desc(const StoreDev& store, bool
       else {
         // windowed store (the region-granular reads of the reference's indexed store, sequencestorage.hh:341-362): the
         // window that holds residue start-1 must hold the whole segment
-        const uint32_t nw = store.win_count[seq], a = start - 1u, n_seg = stop - start + 1u;
+        const uint32_t nw = (uint32_t)(ex.x >> kWinFirstBits), a = start - 1u, n_seg = stop - start + 1u;
         const uint4* __restrict__ wv = store.windows + off;
         uint32_t lo = 0, hi = nw;  // largest k with wv[k].x <= a
         while (hi - lo > 1u) {

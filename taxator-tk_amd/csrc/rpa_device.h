@@ -59,8 +59,10 @@ struct StoreDev {
   const ulonglong2* extent;
   uint32_t n_seqs;
   const uint4* windows;       // null: whole-sequence store
-  const uint32_t* win_count;
+  const uint32_t* win_count;  // (host-side bookkeeping mirror; the kernels read the count out of extent[i].x, below)
 };
+// windowed stores: extent[i].x = first entry of sequence i's window list (low kWinFirstBits bits) | its number of entries << kWinFirstBits
+constexpr int kWinFirstBits = 40;
 
 // Batch (device pointers), same meaning as rpa_batch in include/taxator_rpa.h.
 struct BatchDev {

@@ -1293,7 +1293,9 @@ int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_win
   }
   // bookkeeping first, on copies: a window may sit beside the resident windows of its sequence or cover some of them
   // entirely (those are dropped: the new window is their hull), never overlap one partly -- a segment is only readable
-  // from ONE window, so overlapping windows are the caller's mistake
+  // from ONE window, so overlapping windows are the caller's mistake.  One merge of two sorted lists per sequence (round 5:
+  // until then every new window rebuilt its sequence's whole list -- quadratic for a sequence that collects thousands of small
+  // windows, which is what a 10 Mbp chromosome does under `taxator --store-tile 2048`).
   struct WinRec { uint4 w; int64_t k; };  // k >= 0: window number k of THIS call (its arena offset is filled in below); -1: resident
   std::vector<uint32_t> changed;
   std::vector<std::vector<WinRec>> lists;
@@ -1301,37 +1303,49 @@ int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_win
   std::vector<uint32_t> order(n);
   for (uint32_t k = 0; k < n; ++k) order[k] = k;
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return win[a].seq_index != win[b].seq_index ? win[a].seq_index < win[b].seq_index : win[a].first < win[b].first; });
-  uint32_t cur_seq = 0xFFFFFFFFu;
-  std::vector<WinRec>* cur = nullptr;
-  for (uint32_t oi = 0; oi < n; ++oi) {
-    const uint32_t k = order[oi];
-    if (win[k].seq_index != cur_seq) {  // (windows of one sequence are consecutive in `order`: one lookup per sequence)
-      cur_seq = win[k].seq_index;
-      changed.push_back(cur_seq);
-      lists.emplace_back();
-      cur = &lists.back();
-      cur->reserve(st->seq_windows[cur_seq].size() + 1);
-      for (const uint4& x : st->seq_windows[cur_seq]) cur->push_back(WinRec{x, -1});
-    }
-    const uint64_t a = win[k].first, b = a + win[k].n;
-    std::vector<WinRec> kept;
-    kept.reserve(cur->size() + 1);
-    for (const WinRec& r : *cur) {
-      const uint4& x = r.w;
+  for (uint32_t oi = 0; oi < n;) {
+    const uint32_t seq = win[order[oi]].seq_index;
+    uint32_t oj = oi;
+    while (oj < n && win[order[oj]].seq_index == seq) ++oj;  // the new windows [oi, oj) of this sequence, by first residue
+    for (uint32_t t = oi + 1; t < oj; ++t)
+      if (win[order[t - 1]].first + win[order[t - 1]].n > win[order[t]].first)
+        return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: windows %u and %u of this call overlap", order[t - 1], order[t]);
+    changed.push_back(seq);
+    lists.emplace_back();
+    std::vector<WinRec>& out = lists.back();
+    const std::vector<uint4>& have = st->seq_windows[seq];
+    out.reserve(have.size() + (oj - oi));
+    uint32_t t = oi;  // next new window that has not been put out
+    for (const uint4& x : have) {
       const uint64_t xa = x.x, xb = (uint64_t)x.x + x.y;
-      if (xb <= a || xa >= b) kept.push_back(r);
-      else if (xa >= a && xb <= b) {  // swallowed by the new window: its residues stay behind in the arena (two windows of one call that overlap are the caller's mistake)
-        if (r.k >= 0) return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: windows %u and %lld of this call overlap", k, (long long)r.k);
-        dropped_residues += x.y; ++dropped_windows;
-      } else return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: window %u (sequence %u, residues %llu..%llu) overlaps a resident window partly", k, cur_seq, (unsigned long long)a, (unsigned long long)b);
+      while (t < oj && win[order[t]].first + win[order[t]].n <= xa) {  // new windows that end in front of x
+        out.push_back(WinRec{make_uint4((uint32_t)win[order[t]].first, (uint32_t)win[order[t]].n, 0u, 0u), (int64_t)order[t]});
+        ++t;
+      }
+      if (t < oj && win[order[t]].first < xb) {  // x and the next new window share residues: x must lie inside it
+        const uint64_t a = win[order[t]].first, b = a + win[order[t]].n;
+        if (xa >= a && xb <= b) { dropped_residues += x.y; ++dropped_windows; continue; }  // swallowed: its residues stay behind in the arena
+        return fail(e, RPA_ERR_INVALID, "rpa_store_append_windows: window %u (sequence %u, residues %llu..%llu) overlaps a resident window partly", order[t], seq,
+                    (unsigned long long)a, (unsigned long long)b);
+      }
+      out.push_back(WinRec{x, -1});
     }
-    kept.push_back(WinRec{make_uint4((uint32_t)a, (uint32_t)win[k].n, 0u, 0u), (int64_t)k});
-    std::sort(kept.begin(), kept.end(), [](const WinRec& p, const WinRec& q) { return p.w.x < q.w.x; });
-    cur->swap(kept);
+    for (; t < oj; ++t) out.push_back(WinRec{make_uint4((uint32_t)win[order[t]].first, (uint32_t)win[order[t]].n, 0u, 0u), (int64_t)order[t]});
+    if (out.size() >= (1u << 24)) return fail(e, RPA_ERR_UNSUPPORTED, "rpa_store_append_windows: more than 16 M resident windows in one sequence");
+    oi = oj;
   }
   HIP_TRY(e, hipSetDevice(e->device));
-  quiesce_slots(e);  // the arena and the pool may move: no job may be reading them
   const uint64_t total = offsets[n];
+  uint64_t need = 0;
+  for (auto& l : lists) need += l.size();
+  // Jobs in flight read the arena, the pool and the extent table.  An append only ever writes BEHIND what is resident (new residues,
+  // new list copies at the pool's end) and then switches a sequence to its new list with ONE 64-bit store (first entry | count,
+  // k_store_window_lists) -- a running job sees the old list or the new one, and both hold every window it was made resident
+  // for.  So the jobs only have to be waited for when something MOVES: the arena or the pool outgrows its allocation.
+  const int bits_now = e->params.alphabet == RPA_DNA ? 4 : 8;
+  const bool arena_moves = !st->words.p || ((((st->n_residues + 7u) & ~7ull) + total) * bits_now + 31) / 32 > st->cap_words;  // (store_grow's own test)
+  const bool pool_moves = st->pool_used + need > st->pool_cap;
+  if (arena_moves || pool_moves) quiesce_slots(e);
   uint64_t first = 0;
   int rc = store_grow(e, st, total, &first);
   if (rc) return rc;
@@ -1340,8 +1354,6 @@ int rpa_store_append_windows(rpa_engine* e, int which, uint32_t n, const rpa_win
   HIP_TRY(e, hipMemcpyAsync(e->tmp_letters.p, letters, (size_t)total, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, launch_pack_letters(e->stream, e->params.alphabet, e->tmp_letters.as<const uint8_t>(), total, st->words.as<uint32_t>() + kLeadWords + first * bits / 32));
   // the changed lists go to the end of the pool
-  uint64_t need = 0;
-  for (auto& l : lists) need += l.size();
   if (st->pool_used + need > st->pool_cap) {
     uint64_t cap = st->pool_cap ? st->pool_cap : 1024;
     while (cap < st->pool_used + need) cap *= 2;
@@ -1406,7 +1418,10 @@ int rpa_store_reset(rpa_engine* e, int which) {
   st->n_residues = 0; st->n_resident = 0; st->pool_used = 0; st->n_windows = 0; st->live_residues = 0;
   if (st->windowed) {
     for (auto& l : st->seq_windows) l.clear();
-    HIP_TRY(e, hipMemsetAsync(st->win_count.p, 0, (size_t)(st->n_seqs ? st->n_seqs : 1) * 4, e->stream));
+    // every sequence back to "length known, no window": extent = (0, length), count 0 (the kernels read the count out of extent.x)
+    HIP_TRY(e, st->tmp_offsets.ensure((size_t)(st->n_seqs ? st->n_seqs : 1) * 8));
+    if (st->n_seqs) HIP_TRY(e, hipMemcpyAsync(st->tmp_offsets.p, st->seq_length.data(), (size_t)st->n_seqs * 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, launch_store_lengths(e->stream, st->tmp_offsets.as<const uint64_t>(), st->n_seqs, st->extent.as<ulonglong2>(), st->win_count.as<uint32_t>()));
   } else {
     HIP_TRY(e, hipMemsetAsync(st->extent.p, 0, (size_t)(st->n_seqs ? st->n_seqs : 1) * sizeof(ulonglong2), e->stream));
   }

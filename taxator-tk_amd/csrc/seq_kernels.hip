@@ -107,7 +107,9 @@ __global__ __launch_bounds__(kBlock) void k_store_window_lists(const uint32_t* _
   const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
   const uint32_t i = index[k];
-  extent[i].x = first[k];
+  // first entry | entries << 40 in ONE 64-bit store: a job that is running while a later block's windows are appended reads the
+  // sequence's old list or its new one, never the first entry of one with the length of the other (kWinFirstBits, rpa_device.h)
+  extent[i].x = (unsigned long long)first[k] | ((unsigned long long)count[k] << kWinFirstBits);
   win_count[i] = count[k];
 }
 hipError_t launch_store_window_lists(hipStream_t st, const uint32_t* index, const uint32_t* first, const uint32_t* count, uint32_t n,
