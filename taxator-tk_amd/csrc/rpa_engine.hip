@@ -111,6 +111,7 @@ struct rpa_engine {
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf side_ws[kSideStreams];  // the strip kernel's boundary-plane scratch, one per side stream
   bool side_streams_on = true;   // RPA_SIDE_STREAMS=0: every launch on the engine's stream (A/B)
+  int defer_mode = 2;            // RPA_DEFER2=0 | 1 | auto: two launches per pass-2 round never | always | where alignments are expensive (predict_part)
   // profiling
   bool profiling = false;
   bool prof_counters = true;   // rpa_profile_enable(2): events only -- the kernels carry no counters (their reductions cost K1 4 %)
@@ -281,7 +282,10 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
     n_side_candidates += side_ok ? 1 : 0;
     ++n_launch_groups;
   }
-  const bool fork = e->side_streams_on && !e->profiling && n_side_candidates >= 1 && n_launch_groups >= 2;
+  // ... and not on a job slot: several batches in flight already fill each other's gaps, and four slots x five streams are more
+  // streams than hardware queues (make_stream): tools/ragged_bench.py, mixed shapes: a synchronous step 28.0 -> 23.1 ms with the
+  // side streams, four steps in flight 15.7 -> 17.3 ms per step.
+  const bool fork = e->side_streams_on && !e->profiling && e->owner == nullptr && n_side_candidates >= 1 && n_launch_groups >= 2;
   bool side_used[rpa_engine::kSideStreams] = {false, false, false, false};
   int side_next = 0;
   if (fork) {
@@ -621,6 +625,11 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
   HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev));
   uint64_t rounds = 0;
+  // Two launches per pass-2 round (kDeferredMark) cost a replay kernel, a host round trip and a second set of launches per round:
+  // ~0.3 ms on a million record sets.  What they save is alignments -- 8 % of them on the BASELINE shapes -- which pays when an
+  // alignment is expensive: decided per batch from round 0's own work lists, "most pairs have patterns of more than 256 nt" (the
+  // strip kernels' bins; config 5: -4 % per step, configs 2 and 4: +0 ... +4 %, mixed shapes with a launch per bin: +30 %).
+  bool defer_pays = false;
   uint32_t prev_live = S;     // upper bound of the current live list's length (its exact length is counters[kCtrActive])
   bool list_in_a = true;      // plan wrote the first live list into live_a
   for (;;) {
@@ -633,7 +642,9 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     w.n_live_in = prev_live;  // grid bound only: the kernel reads the exact length from counters[ctr_live_in]
     w.ctr_live_in = (rounds & 1) ? kCtrActiveB : kCtrActive;   // (plan counted the first list in kCtrActive)
     w.ctr_live_out = (rounds & 1) ? kCtrActive : kCtrActiveB;
-    HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, e->params));
+    Params pe = e->params;
+    pe.defer2 = (e->defer_mode == 1 || (e->defer_mode == 2 && defer_pays)) && !sparse_emit ? 1 : 0;
+    HIP_TRY(e, launch_emit(e->stream, b, w, e->tax, pe));
     HIP_TRY(e, launch_publish_words(e->stream, w.counters, e->h_counters, kNumCounters));  // (a kernel, not a copy: see k_publish_words)
     RPA_WHERE("predict_part: sync after emit (round)");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -659,6 +670,11 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     }
     uint32_t counts[kNumRoundCounters];
     memcpy(counts, e->h_counters, sizeof(counts));
+    if (rounds == 0 && e->params.alphabet == RPA_DNA) {
+      uint64_t all = 0, strips = 0;
+      for (int k = 0; k < kNumBins; ++k) { all += counts[k]; if (k >= kShortWords) strips += counts[k]; }
+      defer_pays = all > 0 && strips * 2 >= all;
+    }
     if (e->trace_rounds) {
       uint64_t pairs = 0;
       for (int k = 0; k < kNumBins; ++k) pairs += counts[k];
@@ -771,6 +787,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->side_streams_on = e->side_streams_on;
+  w->defer_mode = e->defer_mode;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = make_stream(w->device, &w->own_stream);
   if (err == hipSuccess) err = hipHostMalloc((void**)&w->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault);
@@ -953,8 +970,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.spec2_first = 0;
   if (const char* v = getenv("RPA_SPEC2_FIRST")) e->params.spec2_first = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SIDE_STREAMS")) e->side_streams_on = atoi(v) != 0;
-  e->params.defer2 = 1;
-  if (const char* v = getenv("RPA_DEFER2")) e->params.defer2 = atoi(v) != 0;
+  e->params.defer2 = 0;
+  if (const char* v = getenv("RPA_DEFER2")) e->defer_mode = !strcmp(v, "auto") ? 2 : (atoi(v) != 0 ? 1 : 0);
   e->fill_lanes = 3u * kResidentLanes;  // RPA_FILL_LANES sweep: config 5 1174 / 1137 / 1053 ms at 1x / 2x / 3x, configs 2 and 4 indifferent
   if (const char* v = getenv("RPA_FILL_LANES")) e->fill_lanes = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SPARSE_EMIT")) e->sparse_div_emit = (uint32_t)atoi(v);

@@ -564,6 +564,42 @@ def test_scores_of_any_sign_and_masked_records(pkg, oracle, synth):
             _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, exclude_factor=x, reeval_bandwidth=t)
 
 
+@pytest.mark.parametrize("mode", ["1", "0", "auto"])
+def test_two_launches_per_pass2_round(pkg, oracle, synth, mode, monkeypatch):
+    """Round 5: pass-2 hits that an earlier hit of their chunk may take out of the loop (by lifting unode_global over them, :771,
+    :811-813) wait for the round's second launch; k_defer_filter replays the chunk with the first launch's results and lists the
+    ones the loop can still reach (kDeferredMark, rpa_device.h).  Rows, STATS counters and the consumed-alignment trace must be the
+    reference's whatever the setting (RPA_DEFER2 = 1: always, 0: never, auto: by pattern length), the chunk sizes (whole loops,
+    chunks of 10 / 3 / 1 hits), the cut-off settings, the row layout and the alphabet -- and the setting must really change what is
+    computed: fewer alignments with it than without."""
+    monkeypatch.setenv("RPA_DEFER2", mode)
+    computed = {}
+    for alphabet, kw in ((0, dict(seg_len=150, genome_len=3000)), (1, dict(seg_len=60, genome_len=1500, alphabet=1, level_rate=0.06, query_rate=0.08)),
+                         (0, dict(seg_len=700, genome_len=4000))):
+        ds = synth.make_dataset(n_sets=1200 if kw["seg_len"] < 500 else 150, n_hits=24, branching=4, seed=520 + alphabet + kw["seg_len"], variety=True, **kw)
+        for speculation, x, t in ((None, 0.5, 0.05), ((0, 0), 0.5, 0.05), ((0, 0), 0.2, 0.2), ((0, 10), 0.5, 0.05), ((5, 3), 0.5, 0.05), ((1, 1), 0.8, 0.0)):
+            _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, speculation=speculation, exclude_factor=x, reeval_bandwidth=t)
+        # the trace of consumed alignments, and how many were computed
+        model = pkg.RPAPredictionModel(ds.tax, alphabet=alphabet, speculation=(0, 0))
+        model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+        model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+        model.profile(enable=True, reset=True)
+        rows, stats = model.predict(ds.batch)
+        prof = model.profile()
+        assert prof["demanded"] == int(stats["pass0"].sum() + stats["pass1"].sum() + stats["pass2"].sum())
+        computed[(alphabet, kw["seg_len"])] = prof["pairs"] / max(prof["demanded"], 1)
+    if mode == "1":
+        monkeypatch.setenv("RPA_DEFER2", "0")
+        ds = synth.make_dataset(n_sets=1200, n_hits=24, seg_len=150, genome_len=3000, branching=4, seed=520 + 0 + 150, variety=True)
+        model = pkg.RPAPredictionModel(ds.tax, alphabet=0, speculation=(0, 0))
+        model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+        model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+        model.profile(enable=True, reset=True)
+        model.predict(ds.batch)
+        prof = model.profile()
+        assert computed[(0, 150)] < prof["pairs"] / max(prof["demanded"], 1) - 0.02, (computed, prof)
+
+
 def test_nan_scores_are_refused_where_the_reference_would_sort_them(pkg, oracle, synth):
     """A score that is not a number.  In a record set of ONE unmasked record, or on a masked record, it is never compared and the
     result is the reference's.  Among two or more unmasked records the reference's list::sort (:412) runs on a comparator that
