@@ -918,6 +918,17 @@ def main():
                     sec[key] = {"error": repr(e)}
             sec["e2e"] = measure_e2e(synth, ds)
             del ds
+            try:  # N1 against an indexed reference that is not the toy collection (small variant of tools/cli_bigstore.py: 2 Gbases, 250 k record sets)
+                import types
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import cli_bigstore
+                r_ = cli_bigstore.measure(types.SimpleNamespace(gbases=2.0, sets=250_000, hits=20, dir=None, runs="default,turnover:0.5,inmemory", keep=False, json=None), quiet=True)
+                sec["e2e_indexed"] = {"workload": "taxator -i ref.fna.fai -v query.fna.fai < aln.tsv: a %.1f GB reference FASTA in %d sequences of 10 kbp ... 10 Mbp, %d record sets x %d hits at random loci (tools/bigstore_gen.cpp); the full-size run (32 Gbases, 10 M record sets) is profiles/r05_cli_bigstore.txt"
+                                                  % (r_["files"]["ref.fna"] / 1e9, r_["files"]["sequences"], r_["files"]["record_sets"], r_["files"]["hits"]),
+                                      "runs": {k: {kk: v[kk] for kk in ("args", "rc", "wall_s", "record_sets_per_s", "pipeline_s", "pipeline_record_sets_per_s", "load_s", "stages_s", "resident",
+                                                                        "same_gff3_as_first_run")} for k, v in r_["runs"].items()}}
+            except Exception as e:
+                sec["e2e_indexed"] = {"error": repr(e)}
             try:  # record sets of mixed shape (1 ... 500 hits, 50 ... 1500 nt, 500 k-node taxonomy pruned and whole): tools/ragged_bench.py
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import ragged_bench

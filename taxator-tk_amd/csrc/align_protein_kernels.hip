@@ -211,7 +211,6 @@ __global__ __launch_bounds__(kBlock) void k_nw_protein(const uint2* __restrict__
 constexpr int kPackedBlock = RPA_PACKED_BLOCK;
 constexpr int kPackedRows = RPA_PACKED_ROWS;
 constexpr uint32_t kPkScore = 20, kPkMove = 18, kPkMatch = 9;
-constexpr uint32_t kPkMoveMask = 3u << kPkMove;
 constexpr uint32_t kPackedScratchHead = 64;  // words in front of the boundary rows: [0] = the work counter
 
 // kWide: the SCORE-AND-LENGTH cell for pairs the cell above cannot hold -- `M[i][j] + i + bias` in bits 18-31 (14 bits: la + lb +
@@ -412,10 +411,12 @@ __device__ __forceinline__ uint32_t from_lane_below(uint32_t v) {  // lane i rec
 }
 
 // One run of 64 / G pairs of a G-lanes-per-pair list, starting at pair `run` (the whole wavefront calls it together).
-template <int R, int G>
+template <int R, int G, bool kWide>
 __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list, uint32_t n_list, uint32_t run, const WorkDev& w,
                                                   const uint8_t* __restrict__ tabb, const int32_t* __restrict__ selfdiag,
                                                   uint32_t c_horiz, uint32_t c_keep, uint32_t c_one, unsigned long long* prof_acc) {
+  constexpr uint32_t kPkScore = kWide ? 18u : rpa::kPkScore, kPkMatch = rpa::kPkMatch;  // (kWide: the score-and-length cell of K3p)
+  constexpr uint32_t kDiagMask = kWide ? 0xFFFFu : 0x1FFu;
   constexpr uint32_t kPairs = 64u / G;  // pairs per wavefront
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t sub = lane % G, slot = lane / G;  // my strip, my pair of the run (slot == kPairs: the spare lane of G = 3)
@@ -544,7 +545,7 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
     if (have && (nstrips ? sub + 1u == nstrips : sub == 0u)) {
       const int32_t selfscore_all = self_all;
       const int32_t mutual = (int32_t)(res >> kPkScore) - (int32_t)(bias + lb);
-      const uint32_t ndiag = res & 0x1FFu, nmatch = (res >> kPkMatch) & 0x1FFu;
+      const uint32_t ndiag = res & kDiagMask, nmatch = kWide ? 0u : (res >> kPkMatch) & 0x1FFu;
       const uint32_t gap = (la - ndiag) + (lb - ndiag);
       const uint32_t mismatch = ndiag - nmatch;
       const uint32_t len = gap + nmatch + mismatch;                           // :227
@@ -553,17 +554,18 @@ __device__ __forceinline__ void protein_lanes_run(const uint2* __restrict__ list
       const float similarity = (float)(2 * mutual) * normfactor;              // :233
       if (!(selfscore_all >= mutual) || !(distance >= 0.f)) distance = __builtin_nanf("");
       w.pair_res[res_index(w, dst)] = make_float2(distance, similarity);
-      if (w.pair_ext) w.pair_ext[dst] = make_uint4(nmatch, mismatch, gap, len);
+      if (w.pair_ext) w.pair_ext[dst] = kWide ? make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, gap, len) : make_uint4(nmatch, mismatch, gap, len);
     }
   }
 }
 
 // One kernel per class (one launch that dispatched on the class of each run was tried: the four inlined bodies cost the
 // dominant class 15 % -- config 4: 4.1 -> 4.8 ms of alignment per step).
-template <int R, int G>
+template <int R, int G, bool kWide>
 __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_lanes(const uint2* __restrict__ list, uint32_t n_list, WorkDev w,
                                                                    uint32_t* __restrict__ work_counter, uint32_t counter_first,
                                                                    unsigned long long* prof_acc) {
+  constexpr uint32_t kPkScore = kWide ? 18u : rpa::kPkScore, kPkMove = kWide ? 16u : rpa::kPkMove, kPkMoveMask = 3u << kPkMove, kPkMatch = rpa::kPkMatch;
   __shared__ uint32_t tab[kAX * kAX * 32];  // [b][a][bank] -> T(a,b) as in K3p; T(null,b) = 0; T(a,padding) = "score - 1, move 0"
   __shared__ int32_t selfdiag[64];          // s(x,x); [27..31] = 0 (null residue), [32..63] = 0 (lanes that do not count A)
   __shared__ int8_t blosum[kAA * kAA];
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_lanes(const uint2* 
     const int bres = idx / (kAX * 32), a = (idx / 32) % kAX;
     const int sc = a < kAA && bres < kAA ? blosum[a * kAA + bres] : 0;
     tab[idx] = bres == kAA ? 0u - (1u << kPkScore) - (1u << kPkMove)
-               : a < kAA ? ((uint32_t)(sc + 1) << kPkScore) + (1u << kPkMove) + (a == bres ? 1u << kPkMatch : 0u) + 1u : 0u;
+               : a < kAA ? ((uint32_t)(sc + 1) << kPkScore) + (1u << kPkMove) + ((!kWide && a == bres) ? 1u << kPkMatch : 0u) + 1u : 0u;
   }
   if (threadIdx.x < 64) selfdiag[threadIdx.x] = threadIdx.x < kAA ? blosum[threadIdx.x * kAA + threadIdx.x] : 0;
   __syncthreads();
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(kPackedBlock) void k_nw_protein_lanes(const uint2* 
     const uint32_t run = base;
     if ((threadIdx.x & 63u) == 0u) base = atomicAdd(work_counter, kPairs) + counter_first;  // (the word is zero when the launch begins, see K3p)
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    protein_lanes_run<R, G>(list, n_list, run, w, tabb, selfdiag, c_horiz, c_keep, c_one, prof_acc);
+    protein_lanes_run<R, G, kWide>(list, n_list, run, w, tabb, selfdiag, c_horiz, c_keep, c_one, prof_acc);
   }
 }
 
@@ -664,11 +666,11 @@ hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32
 // K3l over the list of a lanes-per-pair class (protein_bin(): the vertical sequence needs `lanes` strips of
 // kProteinLaneRows).  Persistent workgroups as in K3p; `work_counter` is one word of device memory that is zero when the launch begins.
 hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* work_counter,
-                                      unsigned long long* prof_acc) {
+                                      unsigned long long* prof_acc, bool wide) {
   if (n == 0) return hipSuccess;
   hipError_t e = upload_blosum();
   if (e != hipSuccess) return e;
-  if (lanes < 1 || lanes > kProteinMaxLanes) return hipErrorInvalidValue;
+  if (wide ? !(lanes == 16 || lanes == 21 || lanes == 32 || lanes == 64) : (lanes < 1 || lanes > kProteinMaxLanes)) return hipErrorInvalidValue;
   static int cus[64] = {0};
   int dev = 0;
   e = hipGetDevice(&dev);
@@ -683,8 +685,18 @@ hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* li
   uint32_t blocks = (n + per_wave - 1u) / per_wave;
   if (blocks > (uint32_t)n_cu) blocks = (uint32_t)n_cu;
   const uint32_t first = blocks * (kPackedBlock / 64) * per_wave;  // behind the fixed first runs
+  if (wide) {
+#define RPA_LAUNCH_WIDE_LANES(GV) \
+  case GV: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, GV, true>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, first, prof_acc); break;
+    switch (lanes) {
+      RPA_LAUNCH_WIDE_LANES(16) RPA_LAUNCH_WIDE_LANES(21) RPA_LAUNCH_WIDE_LANES(32) RPA_LAUNCH_WIDE_LANES(64)
+      default: return hipErrorInvalidValue;
+    }
+#undef RPA_LAUNCH_WIDE_LANES
+    return hipGetLastError();
+  }
 #define RPA_LAUNCH_LANES(GV) \
-  case GV: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, GV>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, first, prof_acc); break;
+  case GV: hipLaunchKernelGGL((k_nw_protein_lanes<kProteinLaneRows, GV, false>), dim3(blocks), dim3(kPackedBlock), 0, st, list, n, w, work_counter, first, prof_acc); break;
   switch (lanes) {
     RPA_LAUNCH_LANES(1) RPA_LAUNCH_LANES(2) RPA_LAUNCH_LANES(3) RPA_LAUNCH_LANES(4) RPA_LAUNCH_LANES(5) RPA_LAUNCH_LANES(6) RPA_LAUNCH_LANES(7)
     RPA_LAUNCH_LANES(8) RPA_LAUNCH_LANES(9) RPA_LAUNCH_LANES(10) RPA_LAUNCH_LANES(11) RPA_LAUNCH_LANES(12) RPA_LAUNCH_LANES(13)

@@ -12,7 +12,7 @@ constexpr int kShortWords = 8;       // per-lane Myers kernel: pattern <= 8*32 =
 constexpr int kStripMinWords = 5;    // longer patterns: register strips of 5..8 words, whichever wastes the fewest rows
 constexpr int kStripBins = kShortWords - kStripMinWords + 1;
 constexpr int kDnaBins = kShortWords + kStripBins;  // bins 0..7: one strip of bin+1 words ; bins 8..11: strips of bin-3 words
-constexpr int kNumBins = 18;         // work lists per round: the nucleotide bins above, or the 18 protein bins below
+constexpr int kNumBins = 22;         // work lists per round: the nucleotide bins above, or the 22 protein bins below
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
 constexpr int kProfParts = 64;        // profiling accumulators are split 64 ways (block index & 63) and summed on the host
@@ -382,7 +382,7 @@ hipError_t launch_align_protein(hipStream_t st, int strip_rows, const uint2* lis
 hipError_t launch_align_protein_packed(hipStream_t st, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* scratch,
                                        size_t scratch_words, uint32_t max_len, uint32_t* work_counter, unsigned long long* prof_acc, bool wide = false);
 hipError_t launch_align_protein_lanes(hipStream_t st, int lanes, const uint2* list, uint32_t n, const WorkDev& w, uint32_t* work_counter,
-                                      unsigned long long* prof_acc);
+                                      unsigned long long* prof_acc, bool wide = false);
 size_t protein_scratch_words(uint32_t n_pairs, uint32_t max_len);
 
 // Work-list entry -> (segment A, segment B, result index).  Order matters for protein (A is the horizontal sequence):
@@ -419,7 +419,7 @@ __device__ __forceinline__ uint32_t res_index(const WorkDev& w, uint32_t dst) {
 // pairs per wavefront instead of seven.)
 constexpr uint32_t kPackedMaxLen = 511;
 constexpr uint32_t kWideMaxLen = 16383;  // the score-and-length cell (bin 3): 16-bit step counter, 14-bit score field
-constexpr int kProteinBins = 18;
+constexpr int kProteinBins = 22;
 constexpr int kProteinPackedBin = 4;
 // Bin 3 (until round 4: K3 with 32-row strips, an experiment's height): pairs beyond the packed cell whose score field fits 14
 // bits -- la + lb + 11 min(la, lb) + 32 <= 16383, e.g. 1258 x 1258 -- when only distance and similarity are wanted (the
@@ -432,6 +432,12 @@ constexpr int kProteinLaneRows = RPA_LANE_ROWS;
 constexpr int kProteinLaneClasses = 13;
 constexpr int kProteinMaxLanes = 13;
 __host__ __device__ __forceinline__ int protein_class_lanes(int cls) { return cls + 1; }  // lanes per pair of a class
+// Bins 18..21 (round 5): K3l with the SCORE-AND-LENGTH cell (kWideMaxLen) for pairs whose vertical sequence needs 14 ... 64 strips
+// (313 ... 1536 residues; the placement path only: no match counter) -- 16, 21, 32 or 64 lanes per pair (4, 3, 2, 1 pairs per
+// wavefront), a pair takes the narrowest class that holds its strips.  Until then such pairs ran one lane per pair with every strip
+// boundary through an HBM scratch (K3p wide, bin 3): 450 aa segments at 0.43 of the cell rate K3l reaches at 200 aa.
+constexpr int kProteinWideLaneBin = 18, kProteinWideLaneClasses = 4;
+__host__ __device__ __forceinline__ int protein_wide_class_lanes(int cls) { return cls == 0 ? 16 : cls == 1 ? 21 : cls == 2 ? 32 : 64; }
 __host__ __device__ __forceinline__ bool protein_fits_packed(uint32_t la, uint32_t lb) {
   return la <= kPackedMaxLen && lb <= kPackedMaxLen && la + lb + 11u * (la < lb ? la : lb) + 32u <= 4095u;
 }
@@ -439,15 +445,19 @@ __host__ __device__ __forceinline__ bool protein_fits_wide(uint32_t la, uint32_t
   return la <= kWideMaxLen && lb <= kWideMaxLen && la + lb + 11u * (la < lb ? la : lb) + 32u <= 16383u;
 }
 __host__ __device__ __forceinline__ int protein_bin(uint32_t la, uint32_t lb, bool lanes = true, bool wide = false) {
-  if (!protein_fits_packed(la, lb)) return (wide && protein_fits_wide(la, lb)) ? kProteinWideBin : 2;
   const uint32_t strips = (lb + kProteinLaneRows - 1u) / kProteinLaneRows;
-  if (lanes && strips <= (uint32_t)kProteinMaxLanes) {
+  const bool packed = protein_fits_packed(la, lb);
+  if (packed && lanes && strips <= (uint32_t)kProteinMaxLanes) {
     const int cls = strips ? (int)strips - 1 : 0;
     return kProteinPackedBin + 1 + cls;
   }
-  return kProteinPackedBin;
+  if (wide && lanes && strips <= 64u && (packed || protein_fits_wide(la, lb)))  // more strips than a packed class has lanes for: the wide-cell lanes classes
+    return kProteinWideLaneBin + (strips <= 16u ? 0 : strips <= 21u ? 1 : strips <= 32u ? 2 : 3);
+  if (packed) return kProteinPackedBin;
+  return (wide && protein_fits_wide(la, lb)) ? kProteinWideBin : 2;
 }
-static_assert(kProteinPackedBin + 1 + kProteinLaneClasses <= kProteinBins && kProteinBins <= kNumBins && kDnaBins <= kNumBins, "bins");
+static_assert(kProteinPackedBin + 1 + kProteinLaneClasses <= kProteinWideLaneBin && kProteinWideLaneBin + kProteinWideLaneClasses <= kProteinBins &&
+              kProteinBins <= kNumBins && kDnaBins <= kNumBins, "bins");
 
 // ---- reading a segment out of the packed store --------------------------------------------------------------
 __device__ __forceinline__ uint32_t revcomp8(uint32_t x) {  // 8 packed nt: reverse the nibble order, A<->T, C<->G, N stays

@@ -397,7 +397,8 @@ int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
         if (trc) return trc;
         int sk = -1;
         hipStream_t st = fork ? take_side(&sk) : e->stream;
-        HIP_TRY(e, launch_align_protein_lanes(st, protein_class_lanes(bin - kProteinPackedBin - 1), list, n, w, ctr, acc));
+        if (bin >= kProteinWideLaneBin) HIP_TRY(e, launch_align_protein_lanes(st, protein_wide_class_lanes(bin - kProteinWideLaneBin), list, n, w, ctr, acc, true));
+        else HIP_TRY(e, launch_align_protein_lanes(st, protein_class_lanes(bin - kProteinPackedBin - 1), list, n, w, ctr, acc));
         trc = timer.end();
         if (trc) return trc;
         continue;

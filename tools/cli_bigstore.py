@@ -58,6 +58,12 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--json", default=None, help="also write the results as JSON here")
     args = ap.parse_args()
+    return measure(args)
+
+
+def measure(args, quiet=False):
+    """args: an object with gbases, sets, hits, dir, runs, keep, json (bench.py calls this for secondary.e2e_indexed)"""
+    say = (lambda *a, **k: None) if quiet else print
     import __graft_entry__ as graft
     graft.load_package()
     synth = importlib.import_module("taxator_tk_amd.synth")
@@ -70,10 +76,11 @@ def main():
     with open(os.path.join(base, "species.txt"), "w") as f:
         f.write("\n".join(tax.taxid[int(i)] for i in tax.species) + "\n")
     t0 = time.time()
-    subprocess.check_call([gen, base, str(args.gbases), str(args.sets), str(args.hits), os.path.join(base, "species.txt")])
+    subprocess.check_call([gen, base, str(args.gbases), str(args.sets), str(args.hits), os.path.join(base, "species.txt")],
+                          stderr=subprocess.DEVNULL if quiet else None)
     sizes = {n: os.path.getsize(os.path.join(base, n)) for n in ("ref.fna", "query.fna", "aln.tsv")}
     n_seqs = sum(1 for _ in open(os.path.join(base, "ref.fna.fai")))
-    print("files: reference %.1f GB in %d sequences, queries %.2f GB, alignments %.2f GB (%d record sets x %d hits), written to %s in %.0f s"
+    say("files: reference %.1f GB in %d sequences, queries %.2f GB, alignments %.2f GB (%d record sets x %d hits), written to %s in %.0f s"
           % (sizes["ref.fna"] / 1e9, n_seqs, sizes["query.fna"] / 1e9, sizes["aln.tsv"] / 1e9, args.sets, args.hits, base, time.time() - t0), flush=True)
     exe = os.path.join(ROOT, "taxator-tk_amd", "bin", "taxator")
     env = dict(os.environ, TAXATORTK_TAXONOMY_NCBI=os.path.join(base, "tax"))
@@ -90,6 +97,11 @@ def main():
         elif run == "budget":
             gb = max(0.05, (resident_bytes or 4e9) / 5 / 1073741824.0)
             extra = idx + ["--store-tile", "2048", "--store-gb", "%.3f" % gb]
+        elif run.startswith("turnover"):
+            # a budget far below what the stream touches: every block of the stream (16 MB of TSV, ~15 k record sets) brings a few kbp
+            # per hit into an HBM budget of turnover:G GB (default 2) and the store is emptied again and again
+            gb = float(run.split(":")[1]) if ":" in run else 2.0
+            extra = idx + ["--store-tile", "1024", "--store-gb", "%.3f" % gb, "--block-mb", "16"]
         elif run == "inmemory":
             extra = []
         else:
@@ -115,13 +127,13 @@ def main():
         first_sha = first_sha or digest
         res["same_gff3_as_first_run"] = digest == first_sha
         results["runs"][run] = res
-        print("run %-9s rc=%d wall %.2f s = %.0f record sets/s (pipeline %.2f s = %.0f/s)  sha1 %s %s" % (
+        say("run %-9s rc=%d wall %.2f s = %.0f record sets/s (pipeline %.2f s = %.0f/s)  sha1 %s %s" % (
             run, r.returncode, wall, args.sets / wall, tm.get("wall_s") or 0, (args.sets / tm["wall_s"]) if tm.get("wall_s") else 0, digest[:12],
             "" if digest == first_sha else "DIFFERENT OUTPUT"), flush=True)
         for l in lines:
-            print("    " + l, flush=True)
+            say("    " + l, flush=True)
         if r.returncode:
-            print(r.stderr[-1500:], flush=True)
+            say(r.stderr[-1500:], flush=True)
     if args.json:
         with open(args.json, "w") as f:
             json.dump(results, f, indent=1)
