@@ -730,7 +730,8 @@ def test_predict_protein(pkg, oracle, synth, lanes, monkeypatch):
     lens = np.abs(ds.batch["rstop"].astype(np.int64) - ds.batch["rstart"].astype(np.int64)) + 1
     assert (13 * lens + 32 <= 4095).any() and (13 * lens + 32 > 4095).any()
     # beyond it: 450 and 900 residues (the score-and-length cell up to 1258 x 1258, K3 behind it) -- and the same rows with it off
-    for seg, n_sets in ((450, 40), (900, 16), (1300, 8)):
+    # (round 5: with the lanes-per-pair kernel the strips of such a pair sit in 16 / 21 / 32 / 64 adjacent lanes -- 330, 450, 600, 900 aa)
+    for seg, n_sets in ((330, 40), (450, 40), (600, 24), (900, 16), (1300, 8)):
         ds = synth.make_dataset(n_sets=n_sets, n_hits=8, seg_len=seg, branching=2, genome_len=2 * seg + 600, seed=7 + seg, alphabet=1,
                                 level_rate=0.06, query_rate=0.08)
         rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 1)
