@@ -111,6 +111,9 @@ struct rpa_engine {
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf side_ws[kSideStreams];  // the strip kernel's boundary-plane scratch, one per side stream
   bool side_streams_on = true;   // RPA_SIDE_STREAMS=0: every launch on the engine's stream (A/B)
+  bool align_low_priority = false;  // RPA_ALIGN_PRIORITY=1: a job slot's alignment launches on a stream of the lowest priority (run_align_bins)
+  hipStream_t lo_stream = nullptr;
+  hipEvent_t ev_lo_begin = nullptr, ev_lo_end = nullptr;
   int defer_mode = 2;            // RPA_DEFER2=0 | 1 | auto: two launches per pass-2 round never | always | where alignments are expensive (predict_part)
   // profiling
   bool profiling = false;
@@ -270,7 +273,34 @@ int next_work_counter(rpa_engine* e, uint32_t** out) {
   return RPA_OK;
 }
 
+int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in);
+
+// The alignment launches of a JOB SLOT go to a stream of the lowest priority, everything else of the job (rank, plan, emit, decide:
+// short kernels that wait on memory) stays on the slot's own stream: with several batches in flight the placement kernels of one
+// batch are then dispatched ahead of the next workgroups of another batch's long alignment launch instead of queueing behind them
+// (RPA_ALIGN_PRIORITY=0: one stream per slot, as until round 5).  The two streams hand over with events.
 int run_align_bins(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
+  if (!e->owner || !e->align_low_priority || e->profiling) return run_align_bins_on_stream(e, w, counts_in);
+  if (!e->lo_stream) {
+    int least = 0, greatest = 0;
+    HIP_TRY(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(e, hipStreamCreateWithPriority(&e->lo_stream, hipStreamNonBlocking, least));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_lo_begin, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_lo_end, hipEventDisableTiming));
+  }
+  HIP_TRY(e, hipEventRecord(e->ev_lo_begin, e->stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->lo_stream, e->ev_lo_begin, 0));
+  hipStream_t own = e->stream;
+  e->stream = e->lo_stream;  // (everything run_align_bins_on_stream queues -- launches, retries, side-stream forks -- hangs off this stream)
+  const int rc = run_align_bins_on_stream(e, w, counts_in);
+  e->stream = own;
+  if (rc) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev_lo_end, e->lo_stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_lo_end, 0));
+  return RPA_OK;
+}
+
+int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* counts_in) {
   unsigned long long* acc = (e->profiling && e->prof_counters) ? e->prof_acc.as<unsigned long long>() : nullptr;
   const uint32_t* counts = counts_in;
   // Side streams for the launches that have one: only when the round has several launches to make, and never under the profile
@@ -789,6 +819,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   w->fixed_speculation = e->fixed_speculation;
   w->side_streams_on = e->side_streams_on;
   w->defer_mode = e->defer_mode;
+  w->align_low_priority = e->align_low_priority;
   w->sparse_div_emit = e->sparse_div_emit; w->sparse_div_decide = e->sparse_div_decide; w->fill_lanes = e->fill_lanes;
   hipError_t err = make_stream(w->device, &w->own_stream);
   if (err == hipSuccess) err = hipHostMalloc((void**)&w->h_counters, sizeof(uint32_t) * (kNumCounters + 1), hipHostMallocDefault);
@@ -971,6 +1002,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.spec2_first = 0;
   if (const char* v = getenv("RPA_SPEC2_FIRST")) e->params.spec2_first = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SIDE_STREAMS")) e->side_streams_on = atoi(v) != 0;
+  if (const char* v = getenv("RPA_ALIGN_PRIORITY")) e->align_low_priority = atoi(v) != 0;
   e->params.defer2 = 0;
   if (const char* v = getenv("RPA_DEFER2")) e->defer_mode = !strcmp(v, "auto") ? 2 : (atoi(v) != 0 ? 1 : 0);
   e->fill_lanes = 3u * kResidentLanes;  // RPA_FILL_LANES sweep: config 5 1174 / 1137 / 1053 ms at 1x / 2x / 3x, configs 2 and 4 indifferent
@@ -1109,6 +1141,9 @@ void rpa_destroy(rpa_engine* e) {
     e->side_ws[k].release();
   }
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->lo_stream) { (void)hipStreamSynchronize(e->lo_stream); (void)hipStreamDestroy(e->lo_stream); }
+  if (e->ev_lo_begin) (void)hipEventDestroy(e->ev_lo_begin);
+  if (e->ev_lo_end) (void)hipEventDestroy(e->ev_lo_end);
   RPA_WHERE("rpa_destroy: hipHostFree");
   if (e->h_counters) (void)hipHostFree(e->h_counters);
   RPA_WHERE("rpa_destroy: hipStreamDestroy");

@@ -169,24 +169,86 @@ SequenceStore::SequenceStore(const std::string& fasta_filename, const std::strin
     madvise(m, map_len_, MADV_RANDOM);  // regions are read where the alignment stream points, not front to back
   }
   close(fd);
-  std::ifstream fai(fai_filename.c_str());
-  if (!fai_filename.empty() && fai) {
-    std::string line;
-    while (std::getline(fai, line)) {
-      if (line.empty()) continue;
-      const size_t t1 = line.find('\t');
-      if (t1 == std::string::npos) throw ParsingError("fasta index line without columns: " + line);
-      FaiEntry e{0, 0, 0, 0};
-      unsigned long long len = 0, off = 0, lb = 0, lw = 0;
-      if (sscanf(line.c_str() + t1 + 1, "%llu\t%llu\t%llu\t%llu", &len, &off, &lb, &lw) != 4)
-        throw ParsingError("fasta index line is not name, length, offset, line bases, line width: " + line);
-      e.length = len; e.offset = off; e.linebases = (uint32_t)lb; e.linewidth = (uint32_t)lw;
-      if (e.offset > map_len_ || (e.length && (e.linebases == 0 || e.linewidth < e.linebases)))
-        throw ParsingError("fasta index does not fit the fasta file: " + line);
-      add_id(line.substr(0, t1));
-      entries_.push_back(e);
+  // The index file, by all host threads (round 5: `std::getline` + `sscanf` + a hash-map insertion per line took 6 s for the ten
+  // million queries of a 10 M-record-set run, more than the stream itself): mapped, cut into chunks at line starts, lines counted
+  // per chunk, then parsed in place into their slots.  The name -> index map is built by the first getIndex() (the columnar reader
+  // has tables of its own and never asks), as for the in-memory store.
+  const int ffd = fai_filename.empty() ? -1 : open(fai_filename.c_str(), O_RDONLY);
+  struct stat fsb;
+  if (ffd >= 0 && fstat(ffd, &fsb) == 0) {
+    const size_t flen = (size_t)fsb.st_size;
+    const char* fbase = nullptr;
+    if (flen) {
+      void* fm = mmap(nullptr, flen, PROT_READ, MAP_PRIVATE, ffd, 0);
+      if (fm == MAP_FAILED) { close(ffd); throw FileNotFound(fai_filename + " (mmap failed)"); }
+      fbase = (const char*)fm;
     }
+    close(ffd);
+    const char* fend = fbase + flen;
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(usable_cpus(), flen / ((size_t)1 << 20) + 1));
+    struct Piece { const char* b; const char* e; size_t lines = 0, first = 0; std::string err; };
+    std::vector<Piece> pieces(T);
+    const char* p = fbase;
+    for (unsigned t = 0; t < T; ++t) {
+      pieces[t].b = p;
+      const char* q = t + 1 == T ? fend : fbase + flen * (t + 1) / T;
+      if (q < p) q = p;
+      if (q < fend) { const char* nl = (const char*)memchr(q, '\n', (size_t)(fend - q)); q = nl ? nl + 1 : fend; }
+      pieces[t].e = q;
+      p = q;
+    }
+    auto for_pieces = [&](auto&& fn) {
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < T; ++t) th.emplace_back([&, t] { fn(pieces[t]); });
+      fn(pieces[0]);
+      for (auto& x : th) x.join();
+    };
+    auto for_lines = [](const char* b, const char* e, auto&& fn) {  // non-empty lines of [b, e)
+      for (const char* s = b; s < e;) {
+        const char* nl = (const char*)memchr(s, '\n', (size_t)(e - s));
+        const char* le = nl ? nl : e;
+        const char* trimmed = le;
+        if (trimmed > s && trimmed[-1] == '\r') --trimmed;
+        if (trimmed != s) fn(s, trimmed);
+        s = nl ? nl + 1 : e;
+      }
+    };
+    for_pieces([&](Piece& pc) { for_lines(pc.b, pc.e, [&](const char*, const char*) { ++pc.lines; }); });
+    size_t n_lines = 0;
+    for (Piece& pc : pieces) { pc.first = n_lines; n_lines += pc.lines; }
+    ids_.resize(n_lines);
+    entries_.resize(n_lines);
+    index_built_ = false;  // (built by the first getIndex)
+    const size_t map_len = map_len_;
+    for_pieces([&](Piece& pc) {
+      size_t k = pc.first;
+      for_lines(pc.b, pc.e, [&](const char* s, const char* e) {
+        if (!pc.err.empty()) return;
+        const char* t1 = (const char*)memchr(s, '\t', (size_t)(e - s));
+        if (!t1) { pc.err = "fasta index line without columns: " + std::string(s, e); return; }
+        unsigned long long v[4] = {0, 0, 0, 0};
+        const char* q = t1 + 1;
+        bool ok = true;
+        for (int f = 0; f < 4 && ok; ++f) {  // four unsigned decimal columns separated by tabs (anything behind the fourth is ignored, as sscanf did)
+          if (q >= e || *q < '0' || *q > '9') { ok = false; break; }
+          unsigned long long x = 0;
+          while (q < e && *q >= '0' && *q <= '9') { x = x * 10 + (unsigned long long)(*q - '0'); ++q; }
+          v[f] = x;
+          if (f < 3) { if (q < e && *q == '\t') ++q; else ok = false; }
+        }
+        if (!ok) { pc.err = "fasta index line is not name, length, offset, line bases, line width: " + std::string(s, e); return; }
+        FaiEntry en{v[0], v[1], (uint32_t)v[2], (uint32_t)v[3]};
+        if (en.offset > map_len || (en.length && (en.linebases == 0 || en.linewidth < en.linebases))) { pc.err = "fasta index does not fit the fasta file: " + std::string(s, e); return; }
+        ids_[k].assign(s, t1);
+        entries_[k] = en;
+        ++k;
+      });
+    });
+    if (fbase) munmap((void*)fbase, flen);
+    for (const Piece& pc : pieces)
+      if (!pc.err.empty()) throw ParsingError(pc.err);
   } else {
+    if (ffd >= 0) close(ffd);
     build_index_by_scan();
   }
 }

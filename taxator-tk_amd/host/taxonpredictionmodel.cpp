@@ -238,30 +238,46 @@ size_t RPAPredictionModel::makeResidentStore(int which, const rpa_batch& b, cons
     }
     if (store_budget_ && total * (rpa_store_bits_ / 4) / 2 > store_budget_)
       throw GeneralError("one block of the alignment stream needs more sequence than --store-gb allows: use smaller blocks (--block-mb) or a larger budget");
-    const Clock::time_point t_fetch = Clock::now();
-    fetch_letters_.resize((size_t)total + 8);
-    const unsigned F = (unsigned)std::max<size_t>(1, std::min<size_t>(threads_, wins.size()));
+    // Fetch and append in pieces of about a GiB of letters (whole windows): the staging buffer keeps its pages from block to block --
+    // the first blocks of a stream over a large collection want tens of GB at once (round 5, 32 Gbases: a fresh 48 GB buffer was
+    // mostly page faults) -- and what is resident in the engine is marked resident here piece by piece.
+    const uint64_t piece_residues = (uint64_t)1 << 30;
+    const unsigned F0 = threads_;
     std::exception_ptr err;
     std::mutex err_mu;
-    auto fetch = [&](unsigned t) {  // slices of equal residue count, not of equal window count
-      const size_t lo = std::lower_bound(fetch_offsets_.begin(), fetch_offsets_.end() - 1, total * t / F) - fetch_offsets_.begin();
-      const size_t hi = t + 1 == F ? wins.size() : std::lower_bound(fetch_offsets_.begin(), fetch_offsets_.end() - 1, total * (t + 1) / F) - fetch_offsets_.begin();
-      try { for (size_t k = lo; k < hi; ++k) st.fetch_region(wins[k].seq_index, wins[k].first, wins[k].n, fetch_letters_.data() + fetch_offsets_[k]); }
-      catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
-    };
-    {
-      std::vector<std::thread> th;
-      for (unsigned t = 1; t < F; ++t) th.emplace_back(fetch, t);
-      fetch(0);
-      for (auto& x : th) x.join();
+    for (size_t w0 = 0; w0 < wins.size();) {
+      size_t w1 = w0 + 1;
+      while (w1 < wins.size() && fetch_offsets_[w1 + 1] - fetch_offsets_[w0] <= piece_residues) ++w1;
+      const uint64_t base_off = fetch_offsets_[w0], piece_total = fetch_offsets_[w1] - base_off;
+      const Clock::time_point t_fetch = Clock::now();
+      if (fetch_letters_.size() < (size_t)piece_total + 8) fetch_letters_.resize((size_t)piece_total + 8);
+      piece_offsets_.resize(w1 - w0 + 1);
+      for (size_t k = w0; k <= w1; ++k) piece_offsets_[k - w0] = fetch_offsets_[k] - base_off;
+      const unsigned F = (unsigned)std::max<size_t>(1, std::min<size_t>(F0, w1 - w0));
+      auto fetch = [&](unsigned t) {  // slices of equal residue count, not of equal window count
+        const size_t lo = std::lower_bound(piece_offsets_.begin(), piece_offsets_.end() - 1, piece_total * t / F) - piece_offsets_.begin();
+        const size_t hi = t + 1 == F ? w1 - w0 : std::lower_bound(piece_offsets_.begin(), piece_offsets_.end() - 1, piece_total * (t + 1) / F) - piece_offsets_.begin();
+        try { for (size_t k = lo; k < hi; ++k) st.fetch_region(wins[w0 + k].seq_index, wins[w0 + k].first, wins[w0 + k].n, fetch_letters_.data() + piece_offsets_[k]); }
+        catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+      };
+      {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < F; ++t) th.emplace_back(fetch, t);
+        fetch(0);
+        for (auto& x : th) x.join();
+      }
+      if (err) std::rethrow_exception(err);
+      rs.fetch_s += since(t_fetch);
+      const Clock::time_point t_app = Clock::now();
+      check(engine_, rpa_store_append_windows(engine_, which, (uint32_t)(w1 - w0), wins.data() + w0, fetch_letters_.data(), piece_offsets_.data()));
+      rs.append_s += since(t_app);
+      for (size_t k = w0; k < w1; ++k) {  // these windows' tiles are resident now
+        const uint64_t t0 = base[wins[k].seq_index] + wins[k].first / tile_, t1 = base[wins[k].seq_index] + (wins[k].first + wins[k].n - 1) / tile_;
+        for (uint64_t t = t0; t <= t1; ++t) set_bit(res, t);
+      }
+      w0 = w1;
     }
-    if (err) std::rethrow_exception(err);
-    rs.fetch_s += since(t_fetch);
-    const Clock::time_point t_app = Clock::now();
-    check(engine_, rpa_store_append_windows(engine_, which, (uint32_t)wins.size(), wins.data(), fetch_letters_.data(), fetch_offsets_.data()));
-    rs.append_s += since(t_app);
     rs.residues += total; rs.windows += wins.size(); ++rs.blocks;
-    for (size_t k = 0; k < want.size(); ++k) res[k] |= want[k];  // marked resident only now that the engine has them
     return wins.size();
   }
   return 0;

@@ -93,7 +93,7 @@ class RPAPredictionModel : public TaxonPredictionModel {
   unsigned in_flight_ = 0;             // batches between makeResident(hold) and releaseResident(); guarded by resident_mu_
   std::condition_variable resident_cv_;
   std::vector<uint8_t> fetch_letters_;
-  std::vector<uint64_t> fetch_offsets_;
+  std::vector<uint64_t> fetch_offsets_, piece_offsets_;
   unsigned threads_ = 1;
   std::mutex resident_mu_;
   rpa_engine* engine_ = nullptr;
