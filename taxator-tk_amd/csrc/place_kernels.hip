@@ -1373,8 +1373,9 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     state_load(w, s, st, &pre_info);
   }
   live = live && st.phase != kDone;
+  EmitInfo em{};
+  bool write_back = false;  // this thread decided something: its request and its state go back to memory at the very end
   if (live) {
-    EmitInfo em{};
     em.mode = 0; em.n = st.n; em.L = st.L; em.qseglen = st.qseglen;
     const uint32_t lo = pre_lo;
     const uint32_t n = st.n, L = st.L;
@@ -1943,14 +1944,8 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     em.mode = 0;                // nothing asked for yet: the second trip decides
     }
     if (failed) { st.phase = kDone; em.mode = 0; }
-    if (em.mode == 3u || em.mode == 5u) {  // thresholds that only the full record holds (k_decide reads it back), and their 16-byte form for k_emit
-      w.emit[s] = em;
-      w.emit_ext[s] = emit_ext_quad(em);
-      if (em.best > 0x00FFFFFFu) raise_error(w, kErrUnsupported, s);  // (a record set of more than 16 M records)
-    }
-    w.emit_lite[s] = emit_desc(em);
     st.gq = fq.reg; st.go = fo.reg;
-    state_store(w, s, st, st.loop_live != 0u && st.phase == kPass1Wait);
+    write_back = true;
   }
   if (prof_acc) {  // (uniform; one atomic per wavefront, not one per finished record set: a million on 64 addresses per config-2 step)
     uint32_t v = prof_done;
@@ -1958,7 +1953,20 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor(v, d, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&prof_acc[(blockIdx.x & (kProfParts - 1)) * kProfSlots + 3], (unsigned long long)v);
   }
+  // The live-list hand-over comes BEFORE the thread's last stores (round 5): its release fence waits for every store the
+  // wavefront has in flight, and with the 80-byte state record and the request quads just issued that wait was most of the
+  // epilogue's 28 % of a wavefront's life (profiles/r04_decide_phases.txt); now the stores are the last thing a wavefront does
+  // and it ends without waiting for them.
   append_live_last_wave(w, s_live_stage, live && st.phase != kDone, s);  // still running: next round's live list
+  if (write_back) {
+    if (em.mode == 3u || em.mode == 5u) {  // thresholds that only the full record holds (k_decide reads it back), and their 16-byte form for k_emit
+      w.emit[s] = em;
+      w.emit_ext[s] = emit_ext_quad(em);
+      if (em.best > 0x00FFFFFFu) raise_error(w, kErrUnsupported, s);  // (a record set of more than 16 M records)
+    }
+    w.emit_lite[s] = emit_desc(em);
+    state_store(w, s, st, st.loop_live != 0u && st.phase == kPass1Wait);
+  }
 }
 
 // ---- tiled row layout: per tile of 64 record sets, 64 x (largest record count of the tile) row slots ----
