@@ -708,14 +708,14 @@ __global__ __launch_bounds__(kEmitBlock, (Q <= 3 ? RPA_EMIT_WAVES : 4)) void k_e
       }
     }
     maxlen = max(maxlen, ml);
-    s_cb[k * kEmitBlock + threadIdx.x] = (uint8_t)cb;
+    if (p.defer2) s_cb[k * kEmitBlock + threadIdx.x] = (uint8_t)cb;  // (uniform: a launch parameter)
   }
   // Which pass-2 requests wait for the round's second launch: those that an EARLIER request of the same chunk could take out of
   // the loop by lifting unode_global -- an earlier row of my set, inside the chunk, whose LCA with the best hit is no deeper than
   // mine.  Rows of a set are consecutive row positions = consecutive threads of one of the block's four runs of 1024; what lies
   // in front of a run is not seen (the hit then simply goes with the first launch, which is always allowed).
-  __syncthreads();
-  if (pass2_rows) {
+  if (p.defer2) __syncthreads();
+  if (p.defer2 && pass2_rows) {
 #pragma unroll
     for (int k = 0; k < kEmitRows; ++k) {
       if (!((pass2_rows >> k) & 1u)) continue;

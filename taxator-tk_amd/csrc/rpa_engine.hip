@@ -174,6 +174,7 @@ struct rpa_engine {
   struct rpa_job* job_pending = nullptr;
   bool job_busy = false, job_quit = false;
   unsigned next_slot = 0;               // owner: jobs go to the slots in turn
+  unsigned peak_in_flight = 0;          // owner: most jobs the caller has had in flight at once (rpa_submit_batch: the ring of slots is one larger)
   std::mutex copy_mu;                   // owner: one job copies its batch to the device at a time (see predict_on)
 };
 
@@ -1671,25 +1672,28 @@ int rpa_submit_batch(rpa_engine* e, const rpa_batch* batch, rpa_prediction* out,
   if (batch->mem_kind != RPA_MEM_HOST && batch->mem_kind != RPA_MEM_DEVICE) return fail(e, RPA_ERR_INVALID, "rpa_submit_batch: bad mem_kind");
   HIP_TRY(e, hipSetDevice(e->device));
   static const size_t n_slots = [] { const char* v = getenv("RPA_JOB_SLOTS"); const long n = v ? atol(v) : 0; return (size_t)(n >= 1 && n <= 8 ? n : RPA_JOBS_IN_FLIGHT); }();  // (experiments)
-  // The lowest-numbered idle slot takes the job; a new slot is made only when every existing one is busy (a slot sizes a whole
-  // working set -- rows, pair lists, bin lists: several GB for a 128 MB block -- at its first job, so a caller that keeps k jobs
-  // in flight touches k slots, not RPA_JOBS_IN_FLIGHT of them: the CLI keeps two per engine).  All busy and no room for another:
-  // wait for the slots in turn, as before.
-  rpa_engine* slot = nullptr;
+  // The slots take the jobs in turn, over a ring of ONE MORE slot than the caller has ever had in flight (a slot sizes a whole
+  // working set -- rows, pair lists, bin lists: several GB for a 128 MB block -- at its first job, so a caller that keeps k jobs in
+  // flight touches k + 1 slots, not RPA_JOBS_IN_FLIGHT of them: the CLI, two per engine, three).  Why one more and not "the lowest
+  // idle slot": measured on config 4, three jobs in flight -- 4.29 ms per step when a job goes to the slot that has just finished,
+  // 4.08 in turn over four (profiles/r05_ab_slot_choice.txt); the spare slot's stream and thread are ready while the finished one
+  // still winds down.
+  unsigned busy_now = 0;
   for (rpa_engine* s : e->slots) {
     std::lock_guard<std::mutex> sl(s->job_mu);
-    if (!s->job_busy) { slot = s; break; }  // (only this thread, under e->mu, ever sets job_busy: the slot stays idle until it does)
+    busy_now += s->job_busy ? 1u : 0u;
   }
-  if (!slot && e->slots.size() < n_slots) {
+  e->peak_in_flight = std::max(e->peak_in_flight, busy_now + 1u);
+  const size_t ring = std::min<size_t>(n_slots, (size_t)e->peak_in_flight + 1u);
+  while (e->slots.size() < ring) {
     rpa_engine* s = make_worker(e);
     if (!s) return RPA_ERR_DEVICE;
     s->owner = e;
     s->profiling = false;
     s->job_thread = std::thread(slot_main, s);
     e->slots.push_back(s);
-    slot = s;
   }
-  if (!slot) slot = e->slots[e->next_slot++ % e->slots.size()];
+  rpa_engine* slot = e->slots[e->next_slot++ % e->slots.size()];
   rpa_job* job = new (std::nothrow) rpa_job();
   if (!job) return fail(e, RPA_ERR_DEVICE, "out of host memory");
   job->batch = *batch; job->out = out; job->stats = stats; job->slot = slot;
