@@ -206,7 +206,7 @@ def committed_profile(tcfg):
     if os.path.exists(sq):
         cur, instr, disp = None, 0.0, 0
         for line in open(sq):
-            m = re.match(r"(?:void )?(rpa::.+?)\s+dispatches=(\d+)", line)
+            m = re.search(r"(rpa::.+?)\s+dispatches=(\d+)", line)
             if m:
                 cur = m.group(1) if ("k_myers" in m.group(1) or "k_nw_protein" in m.group(1)) else None
                 disp += int(m.group(2)) if cur else 0

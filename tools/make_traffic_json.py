@@ -7,7 +7,7 @@ tag, calls = sys.argv[1], int(sys.argv[2])
 def read(path, counter):
     out, cur = {}, None
     for line in open(path):
-        m = re.match(r"void (rpa::.+?)\s+dispatches=(\d+)", line) or re.match(r"(rpa::.+?)\s+dispatches=(\d+)", line)
+        m = re.search(r"(rpa::.+?)\s+dispatches=(\d+)", line)  # (pmc_summary.py keeps the last 42 characters of a kernel's name: "void " may be cut)
         if m: cur = m.group(1); out[cur] = {"dispatches": int(m.group(2))}
         m = re.search(counter + r"\s+sum=(\S+)", line)
         if m and cur: out[cur]["sum_kb"] = float(m.group(1))
