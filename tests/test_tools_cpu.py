@@ -52,4 +52,4 @@ def test_bigstore_generator_writes_what_its_alignments_say(tmp_path):
             assert len(rseq) == len(qseq) == al and sum(a == b for a, b in zip(qseq, rseq)) == idn and int(sc) == 2 * idn - al
             assert idn > 0.7 * al   # (a copy of the same ancestral stretch: 5 % + 2-15 % substitutions)
             n += 1
-    assert n > 1500 and rev > n // 30 and len(sets) == 3000
+    assert n > 500 and rev > n // 30 and len(sets) == 3000   # (0.25 Gbases over 20 k ancestral blocks: one to three copies, i.e. hits, per set)
