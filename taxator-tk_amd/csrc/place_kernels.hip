@@ -646,7 +646,8 @@ __global__ __launch_bounds__(kEmitBlock, (Q <= 3 ? RPA_EMIT_WAVES : 4)) void k_e
   __shared__ uint32_t s_maxlen[kVW];
   // pass-2 requests (mode 3): depth of LCA(hit, best hit) per row position of the block, 0xFF = not a pass-2 request -- what decides
   // whether a hit waits for the round's second launch (kDeferredMark, rpa_device.h)
-  __shared__ uint8_t s_cb[kEmitSpan];
+  extern __shared__ uint8_t s_cb[];  // kEmitSpan bytes when the round defers (p.defer2), none otherwise: static LDS of this kernel is what it
+                                     // takes from the other jobs' kernels on the same CU (config 4 in flight: +4 % per step with 4 KB more)
   __shared__ uint32_t s_deferred;
   if (threadIdx.x == 0) s_deferred = 0u;
   const uint32_t H = b.n_records, total = H + b.n_sets;
@@ -2104,7 +2105,7 @@ hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, cons
   const uint32_t total = b.n_records + b.n_sets;
   if (total == 0) return hipSuccess;
   const dim3 grid((total + kEmitSpan - 1) / kEmitSpan);
-  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_emit<Q>, grid, dim3(kEmitBlock), 0, st, b, w, p));
+  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL(k_emit<Q>, grid, dim3(kEmitBlock), p.defer2 ? (size_t)kEmitSpan : 0, st, b, w, p));
   return hipGetLastError();
 }
 
