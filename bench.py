@@ -24,7 +24,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP comes up (torch): a hardware queue per engine stream (rpa_engine.hip: make_stream)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before HIP comes up (torch): a hardware queue per engine stream (rpa_engine.hip: make_stream)
 
 import numpy as np
 

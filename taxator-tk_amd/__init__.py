@@ -90,7 +90,7 @@ def load_library(path=None):
     # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  If
     # torch is going to be used in this process (bench.py, torch.distributed) it has to be loaded FIRST so that this
     # library binds to the runtime that is already resident; two runtimes in one process fight over the device.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP comes up: a hardware queue per engine stream (rpa_engine.hip: make_stream)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before HIP comes up: a hardware queue per engine stream (rpa_engine.hip: make_stream)
     try:
         import torch  # noqa: F401
     except ImportError:

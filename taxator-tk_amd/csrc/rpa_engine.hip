@@ -791,6 +791,8 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
 // stream is never pooled) -- and that turned out to be what makes the runtime's exit handler spin for ever in a process
 // that leaves within milliseconds of creating one (15 of 850 short-lived drivers, none of 2200 with plain
 // streams).  Since round 3 the streams are plain non-blocking ones and the pool is made large enough instead:
+// (round 5: 16, not 8 -- the owner's four side streams for the launches of a round, created by a synchronous call, moved the job
+// slots' streams onto shared queues: config 4 with three jobs in flight 4.09 against 3.99 ms per step, profiles/r05_ab_hw_queues.txt)
 // rpa_create puts GPU_MAX_HW_QUEUES=8 into the environment if nobody set it and the runtime has not been initialised yet
 // (taxator, any ctypes caller; a process that initialises HIP first -- PyTorch -- sets it itself, bench.py does): 14.3 ms
 // again (profiles/r03_ab_hostbuf.txt); device-resident batches never cared (9.5-9.6 ms either way).
@@ -958,7 +960,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
     if (i && !(tax->left[tax->parent[i]] < tax->left[i] && tax->right[tax->parent[i]] > tax->right[i]))
       return fail(nullptr, RPA_ERR_INVALID, "rpa_create: nested-set values of node %u are not inside its parent's", i);
   }
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);  // a hardware queue per stream of the jobs in flight (make_stream); no effect once HIP is up
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);  // a hardware queue per stream of the jobs in flight (make_stream); no effect once HIP is up
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(nullptr, RPA_ERR_DEVICE, "rpa_create: no HIP device visible (this engine has no CPU path)");

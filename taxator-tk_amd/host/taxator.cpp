@@ -672,7 +672,7 @@ static int run(int argc, char** argv) {
 // test run.  So the driver flushes its streams and leaves with _exit: no handler of anybody's runs, the exit code is the
 // same.  TAXATOR_RUN_EXIT_HANDLERS=1 restores the plain return (the hunt's control arm).
 int main(int argc, char** argv) {
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);  // before the HIP runtime comes up: a hardware queue per stream of the jobs in flight (rpa_engine.hip: make_stream)
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);  // before the HIP runtime comes up: a hardware queue per stream of the jobs in flight (rpa_engine.hip: make_stream)
   install_stage_reporter();  // SIGUSR1 / SIGTERM / TAXATOR_WATCHDOG_S: say where the process is (stage.hh)
   atexit([] { stage("exit handlers (runtime teardown)"); });
   const int rc = run(argc, argv);

@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--oracle-cells", type=float, default=2.5e10)
     args = ap.parse_args()
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import __graft_entry__ as graft
     pkg = graft.load_package()
