@@ -367,6 +367,9 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
       rank += (uint32_t)((sj > sc) | ((sj == sc) & ((((uint64_t)v.y << 32) | (uint32_t)~j) > my_key)));
     };
     uint32_t j = beg;
+#ifdef RPA_STUB_RANK
+    j = end;
+#endif
     for (; j + 4u <= end; j += 4u) {
       const uint32_t jl = j - w0;
       const uint4 v0 = s_rec[jl], v1 = s_rec[jl + 1], v2 = s_rec[jl + 2], v3 = s_rec[jl + 3];
@@ -400,7 +403,11 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
   const uint32_t pos = beg + rank;  // row position = segment id = result slot of this hit
   uint2 sp = make_uint2(0u, 0u);
   SegDesc sdesc{0u, 0u, 0u, 0u};
+#ifdef RPA_STUB_SEG
+  if (false) {
+#else
   if (n >= 2) {
+#endif
     const uint32_t left_ext = b.qstart[r] - qrstart, right_ext = qrstop - b.qstop[r];  // :523
     const uint32_t start = b.rstart[r], stop = b.rstop[r];
     if (start <= stop) {
@@ -443,7 +450,11 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
       // back to front, so that the record nearest the front of the set has the last word: three vector instructions per
       // level and record (subtract, compare, select).  (Four records per trip, their LDS reads in flight together, measured
       // slower: 1.45 against 1.27 ms on config 2 -- the extra registers cost a resident wave.)
+#ifdef RPA_STUB_LABELS
+      for (uint32_t j = beg; j-- > beg;) {
+#else
       for (uint32_t j = r; j-- > beg;) {
+#endif
         const uint32_t pj = staged ? s_pre[j - w0] : w.rec_pre[j];
         const uint32_t idx = j - beg;
 #pragma unroll
@@ -511,7 +522,11 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
   const uint32_t ns = s_lim[0] - first + 1u, maxrank = s_lim[1];
   const uint64_t total = (uint64_t)maxrank * Q * ns;
   uint4* __restrict__ hits4 = reinterpret_cast<uint4*>(w.hits);
+#ifdef RPA_STUB_WRITEOUT
+  if (false) {} else if (false) {
+#else
   if (tiled && s_lim[2] == 0u && ns <= (uint32_t)kBlock && total <= 24ull * kBlock) {
+#endif
     // idx / ns by one multiply: exact for idx < 2^32 / ns (here idx < 6144, ns <= 256); a 32-bit division is ~35 instructions
     const uint32_t ns_magic = ns == 1u ? 0u : (uint32_t)(0x100000000ull / ns) + 1u;
     for (uint32_t idx = tid; idx < (uint32_t)total; idx += kBlock) {

@@ -110,6 +110,7 @@ struct rpa_engine {
   hipStream_t side_stream[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf side_ws[kSideStreams];  // the strip kernel's boundary-plane scratch, one per side stream
+  bool rank_only = false;        // RPA_DEBUG_RANK_ONLY=1
   bool side_streams_on = true;   // RPA_SIDE_STREAMS=0: every launch on the engine's stream (A/B)
   bool align_low_priority = false;  // RPA_ALIGN_PRIORITY=1: a job slot's alignment launches on a stream of the lowest priority (run_align_bins)
   hipStream_t lo_stream = nullptr;
@@ -655,6 +656,10 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   w.set_offsets = b.set_offsets;
   w.store_q = q.words; w.store_db = db.words;
   HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
+  if (e->rank_only) {  // RPA_DEBUG_RANK_ONLY=1 (tools/rank_parts.sh: timing builds of k_rank_records whose rows are not usable): stop here
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return fail(e, RPA_ERR_UNSUPPORTED, "RPA_DEBUG_RANK_ONLY: stopped behind k_rank_records");
+  }
   HIP_TRY(e, launch_plan_sets(e->stream, b, w, e->tax, e->params, rows_dev, stats_dev));
   uint64_t rounds = 0;
   // Two launches per pass-2 round (kDeferredMark) cost a replay kernel, a host round trip and a second set of launches per round:
@@ -1005,6 +1010,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   e->params.spec2_first = 0;
   if (const char* v = getenv("RPA_SPEC2_FIRST")) e->params.spec2_first = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SIDE_STREAMS")) e->side_streams_on = atoi(v) != 0;
+  if (const char* v = getenv("RPA_DEBUG_RANK_ONLY")) e->rank_only = atoi(v) != 0;
   if (const char* v = getenv("RPA_ALIGN_PRIORITY")) e->align_low_priority = atoi(v) != 0;
   e->params.defer2 = 0;
   if (const char* v = getenv("RPA_DEFER2")) e->defer_mode = !strcmp(v, "auto") ? 2 : (atoi(v) != 0 ? 1 : 0);

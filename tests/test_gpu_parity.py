@@ -713,6 +713,26 @@ def test_predict_dna_group_bit_sets(pkg, oracle, synth, n_hits):
     _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(5, 3))
 
 
+@pytest.mark.parametrize("n_hits", [100, 300, 530])
+def test_predict_dna_large_record_sets(pkg, oracle, synth, n_hits):
+    """Record sets of hundreds of hits (k_decide keeps their outgroup as lists in memory, path labels of 8 and 16 bits), with
+    loops that pause at several chunk sizes and without: the same rows and counters whatever the chunks."""
+    ds = synth.make_dataset(n_sets=24, n_hits=n_hits, seg_len=70, branching=3, genome_len=1500, seed=700 + n_hits, variety=True)
+    rows, stats = _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    for spec in ((5, 3), (40, 70)):
+        rows_p, stats_p = _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=spec)
+        assert rows_p.tobytes() == rows.tobytes() and stats_p.tobytes() == stats.tobytes()
+
+
+def test_predict_dna_mixed_set_sizes_one_batch(pkg, oracle, synth):
+    """One batch with record sets on every path of k_decide at once: <= 32 hits (packed LCA depths), <= 64 (register bit sets),
+    beyond (lists in memory) -- as a real alignment stream mixes them (tools/ragged_bench.py)."""
+    ds = synth.make_ragged_dataset([(200, 12, 150), (60, 40, 100), (40, 64, 90), (24, 65, 90), (16, 150, 70), (8, 400, 60), (3, 600, 60)],
+                                   seed=5, branching=3)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(6, 4))
+
+
 @pytest.mark.parametrize("lanes", ["lanes-per-pair", "one-lane"])
 def test_predict_protein(pkg, oracle, synth, lanes, monkeypatch):
     if lanes == "one-lane":

@@ -162,7 +162,9 @@ def run(pkg, synth, torch, variants=("pruned256", "pruned", "deep"), steps=5, in
     big = synth.embed_in_big_tree(ds.tax, 500_000, 7)
     for v in variants:
         try:
-            if v == "pruned256":
+            if v == "pruned64":  # (not in the default list: every set inside k_decide's register-resident path, the yardstick for the larger ones)
+                out["variants"][v] = run_variant(pkg, synth, torch, v, big, subset(ds, nrec <= 64), ds, steps, in_flight, oracle_cells)
+            elif v == "pruned256":
                 out["variants"][v] = run_variant(pkg, synth, torch, v, big, subset(ds, nrec <= 256), ds, steps, in_flight, oracle_cells)
             elif v == "pruned":
                 out["variants"][v] = run_variant(pkg, synth, torch, v, big, ds.batch, ds, steps, in_flight, oracle_cells)
