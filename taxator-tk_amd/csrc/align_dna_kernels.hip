@@ -712,6 +712,7 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
   switch (words) {
     RPA_LAUNCH_MYERS(1) RPA_LAUNCH_MYERS(2) RPA_LAUNCH_MYERS(3) RPA_LAUNCH_MYERS(4)
     RPA_LAUNCH_MYERS(5) RPA_LAUNCH_MYERS(6) RPA_LAUNCH_MYERS(7) RPA_LAUNCH_MYERS(8)
+    RPA_LAUNCH_MYERS(9) RPA_LAUNCH_MYERS(10) RPA_LAUNCH_MYERS(11) RPA_LAUNCH_MYERS(12)
     default: return hipErrorInvalidValue;
   }
 #undef RPA_LAUNCH_MYERS
@@ -744,6 +745,7 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
     break;
   switch (words) {
     RPA_LAUNCH_MYERS_BAND(5) RPA_LAUNCH_MYERS_BAND(6) RPA_LAUNCH_MYERS_BAND(7) RPA_LAUNCH_MYERS_BAND(8)
+    RPA_LAUNCH_MYERS_BAND(9) RPA_LAUNCH_MYERS_BAND(10) RPA_LAUNCH_MYERS_BAND(11) RPA_LAUNCH_MYERS_BAND(12)
     default: return hipErrorInvalidValue;
   }
 #undef RPA_LAUNCH_MYERS_BAND

@@ -887,9 +887,10 @@ __global__ __launch_bounds__(kFilterBlock) void k_defer_filter(BatchDev b, WorkD
 
 // In a sparse round every launch is latency-bound (a few thousand lanes at most), so all patterns of up to 256 nt go
 // into ONE list, run by the widest one-strip kernel (exact for any pattern that fits its strip), instead of one
-// serialised ~60 us launch per pattern-length class.
+// serialised ~60 us launch per pattern-length class; those of 257 ... 384 nt (beyond K1w's eight words) into a second one.
 __device__ __forceinline__ int sparse_bin(const Params& p, int bin) {
-  return (p.alphabet == 0 && bin >= 0 && bin < kShortWords && p.force_bin < 0) ? kShortWords - 1 : bin;
+  if (p.alphabet != 0 || bin < 0 || bin >= kShortWords || p.force_bin >= 0) return bin;
+  return bin < kWaveMaxWords ? kWaveMaxWords - 1 : kShortWords - 1;
 }
 
 // Sparse rounds: when only a small fraction of the record sets is still running, scanning every row of the batch

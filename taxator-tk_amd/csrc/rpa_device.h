@@ -8,10 +8,13 @@ namespace rpa {
 
 constexpr int kBlock = 256;          // 4 wave64 per workgroup everywhere
 constexpr uint32_t kRoot = 0;        // taxonomy node 0 is the root
-constexpr int kShortWords = 8;       // per-lane Myers kernel: pattern <= 8*32 = 256 residues in one register strip
+constexpr int kShortWords = 12;      // per-lane Myers kernels: pattern <= 12*32 = 384 residues in one register strip (8 words until round 5: the
+                                     // two-strip form of a 257 ... 384 nt pair ran at a third of the one-strip rate per cell, tools/pairs_bench.py)
+constexpr int kWaveMaxWords = 8;     // K1w (a pattern word per lane, eight lanes per pair): patterns of up to 256 residues
 constexpr int kStripMinWords = 5;    // longer patterns: register strips of 5..8 words, whichever wastes the fewest rows
-constexpr int kStripBins = kShortWords - kStripMinWords + 1;
-constexpr int kDnaBins = kShortWords + kStripBins;  // bins 0..7: one strip of bin+1 words ; bins 8..11: strips of bin-3 words
+constexpr int kStripMaxWords = 8;
+constexpr int kStripBins = kStripMaxWords - kStripMinWords + 1;
+constexpr int kDnaBins = kShortWords + kStripBins;  // bins 0..11: one strip of bin+1 words ; bins 12..15: strips of bin-7 words
 constexpr int kNumBins = 22;         // work lists per round: the nucleotide bins above, or the 22 protein bins below
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
@@ -549,15 +552,15 @@ __device__ __forceinline__ SegView seg_view(const WorkDev& w, uint32_t seg) {
   return v;
 }
 
-// bin of a pair whose shorter sequence has m residues (DNA).  Up to 8 words: one strip of exactly that many words.
+// bin of a pair whose shorter sequence has m residues (DNA).  Up to kShortWords words: one strip of exactly that many words.
 // Beyond: the strip height in 5..8 words with the smallest strips x (height x 16 + 20) issue-slot estimate, i.e. the
-// fewest wasted rows (9 words -> 2 x 5, 17 -> 3 x 6, 25 -> 4 x 7 ...); any length fits.
+// fewest wasted rows (13 words -> 2 x 7, 17 -> 3 x 6, 25 -> 4 x 7 ...); any length fits.
 __host__ __device__ __forceinline__ int dna_bin(uint32_t m) {
   const uint32_t words = (m + 31u) / 32u;
   if (words <= (uint32_t)kShortWords) return words ? (int)words - 1 : 0;
   uint32_t best = 0xFFFFFFFFu;
-  int best_nw = kShortWords;
-  for (int nw = kShortWords; nw >= kStripMinWords; --nw) {  // ties -> taller strips (fewer sweeps of the text)
+  int best_nw = kStripMaxWords;
+  for (int nw = kStripMaxWords; nw >= kStripMinWords; --nw) {  // ties -> taller strips (fewer sweeps of the text)
     const uint32_t strips = (words + (uint32_t)nw - 1u) / (uint32_t)nw;
     const uint32_t cost = strips > 0x00FFFFFFu ? 0xFFFFFFFEu : strips * ((uint32_t)nw * 16u + 20u);
     if (cost < best) { best = cost; best_nw = nw; }

@@ -111,6 +111,7 @@ struct rpa_engine {
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf side_ws[kSideStreams];  // the strip kernel's boundary-plane scratch, one per side stream
   bool rank_only = false;        // RPA_DEBUG_RANK_ONLY=1
+  bool debug_bins = false;       // RPA_DEBUG_BINS=1: one stderr line per alignment launch group (bin, pairs), to read beside a kernel trace
   bool side_streams_on = true;   // RPA_SIDE_STREAMS=0: every launch on the engine's stream (A/B)
   bool align_low_priority = false;  // RPA_ALIGN_PRIORITY=1: a job slot's alignment launches on a stream of the lowest priority (run_align_bins)
   hipStream_t lo_stream = nullptr;
@@ -372,6 +373,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
       if (rider < 0 && n < kRideAlongPairs && wider) { rider = bin; continue; }  // picked up by the next one-strip launch
       if (rider >= 0) { list2 = w.bin_list + (size_t)rider * w.T2; n2 = counts[rider]; rider = -1; }
     }
+    if (e->debug_bins) fprintf(stderr, "BIN\tbin=%d\tpairs=%u\trider_pairs=%u\n", bin, n, n2);
     LaunchTimer timer{e};
     int trc = timer.begin();
     if (trc) return trc;
@@ -385,7 +387,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
                                                  e->band4_wide > 0 || e->band4_wide == -1, acc));
           banded_short += (uint64_t)n + n2;
           widest_short = bin + 1;
-        } else if (e->short_wave_max && (uint64_t)n + n2 <= e->short_wave_max)  // few pairs: a pattern word per lane (K1w), any one-strip class
+        } else if (e->short_wave_max && (uint64_t)n + n2 <= e->short_wave_max && bin < kWaveMaxWords)  // few pairs: a pattern word per lane (K1w), any class of up to eight words
           HIP_TRY(e, launch_align_dna_short_wave(e->stream, list, n, nullptr, 0, list2, n2, w, acc));
         else HIP_TRY(e, launch_align_dna_short(e->stream, bin + 1, list, n, nullptr, 0, list2, n2, w, acc));
       } else {
@@ -463,7 +465,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
     // (how many pairs the list holds only the device knows; when even the banded launches were few pairs, K1w takes it.  Both
     // kernels on every list, each working on its side of a device-side threshold, was measured: the retry lists of config 2's
     // dense rounds hold 13 k - 100 k pairs, K1w's 41 us + an empty launch against 49 us -- not worth a second launch)
-    if (e->short_wave_max && bound <= e->short_wave_max)
+    if (e->short_wave_max && bound <= e->short_wave_max && widest_short <= kWaveMaxWords)
       HIP_TRY(e, launch_align_dna_short_wave(e->stream, e->retry_short.as<uint2>(), bound, w.counters + kCtrRetryShort, bound,
                                              nullptr, 0, w, nullptr));
     else
@@ -489,7 +491,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
     } else {
       const uint32_t blocks = 1024u;  // 4 workgroups per CU
       HIP_TRY(e, e->protein_ws.ensure(dna_strip_scratch_words(std::min(bound, blocks * (uint32_t)kBlock), max_len) * 4));
-      HIP_TRY(e, launch_align_dna_strips(e->stream, kShortWords, e->retry_list.as<uint2>(), bound, w.counters + kCtrRetry, blocks, w,
+      HIP_TRY(e, launch_align_dna_strips(e->stream, kStripMaxWords, e->retry_list.as<uint2>(), bound, w.counters + kCtrRetry, blocks, w,
                                          e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, true, 0u, nullptr, nullptr, nullptr));
     }
     trc = timer.end();
@@ -1011,6 +1013,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_SPEC2_FIRST")) e->params.spec2_first = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_SIDE_STREAMS")) e->side_streams_on = atoi(v) != 0;
   if (const char* v = getenv("RPA_DEBUG_RANK_ONLY")) e->rank_only = atoi(v) != 0;
+  if (const char* v = getenv("RPA_DEBUG_BINS")) e->debug_bins = atoi(v) != 0;
   if (const char* v = getenv("RPA_ALIGN_PRIORITY")) e->align_low_priority = atoi(v) != 0;
   e->params.defer2 = 0;
   if (const char* v = getenv("RPA_DEFER2")) e->defer_mode = !strcmp(v, "auto") ? 2 : (atoi(v) != 0 ? 1 : 0);

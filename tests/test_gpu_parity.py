@@ -74,7 +74,7 @@ def test_dna_pairs_golden(pkg, oracle, golden_dir, short_kernel, monkeypatch):
 
 @pytest.mark.parametrize("long_kernel", ["wave", "lane", None, "short-band", "short-pair-per-lane"])
 def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
-    """Every length bin of the nucleotide kernels against the oracle.  Patterns above 256 nt have two kernels (one pair
+    """Every length bin of the nucleotide kernels against the oracle.  Patterns above 384 nt have two kernels (one pair
     per wavefront for few pairs, register strips per lane for many, chosen by a cost model): both are forced in turn;
     above 16384 nt only the strip kernel applies."""
     monkeypatch.delenv("RPA_LONG_KERNEL", raising=False)
@@ -116,7 +116,7 @@ def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
 
 @pytest.mark.parametrize("band", ["forced", "forced-retries-pair-per-lane", "four-words", "five-words", "off"])
 def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
-    """Patterns of 5..8 words (129..256 nt) go through a one-strip kernel that only updates the pattern words within two
+    """Patterns of 5..12 words (129..384 nt) go through a one-strip kernel that only updates the pattern words within two
     words of the diagonal; pairs whose distance lies outside that band (or whose lengths differ by 64 and more) are
     re-run by the full kernel.  Forced on for launches of any size / switched off: the same bytes either way, and both
     equal to the oracle -- from identical pairs to unrelated ones, with N's, and every length difference class."""
@@ -129,7 +129,8 @@ def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     rng = np.random.default_rng(12)
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
     a_codes, b_codes = [], []
-    for la in [129, 150, 159, 160, 161, 180, 191, 192, 193, 200, 210, 223, 224, 225, 240, 255, 256]:
+    for la in [129, 150, 159, 160, 161, 180, 191, 192, 193, 200, 210, 223, 224, 225, 240, 255, 256,
+               257, 270, 288, 289, 300, 319, 320, 321, 340, 352, 353, 370, 383, 384]:  # (9 ... 12 words: one-strip classes since round 5)
         for rate in [0.0, 0.02, 0.1, 0.25, 0.32, 0.4, 0.6, 1.0]:
             for extra in [0, 3, 31, 40, 63, 64, 65, 100]:
                 a = rng.integers(0, 5 if rate > 0.3 else 4, la).astype(np.uint8)

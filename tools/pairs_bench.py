@@ -2,7 +2,7 @@
 
     python tools/pairs_bench.py [dna|protein] [len ...]
 
-For each length L: random pairs (B = A with ~15 % edits, so lengths differ slightly), sized to ~2e11 cells (DNA) per
+For each length L: random pairs (B = A with ~15 % edits -- PAIRS_MUT sets the substitution rate -- so lengths differ slightly), sized to ~2e11 cells (DNA) per
 launch, run through rpa_align_pairs with the engine's event timing on.  Prints alignments/s and cell updates/s inside
 the alignment kernels (rpa_profile.align_ms).  Measurement tool only; parity lives in tests/.
 """
@@ -17,7 +17,7 @@ def make_pairs(rng, alphabet, L, n_pairs):
     letters_set = np.frombuffer(b"ACGT" if alphabet == "dna" else b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
     a = letters_set[rng.integers(0, len(letters_set), (n_pairs, L))]
     b = a.copy()
-    mut = rng.random((n_pairs, L)) < 0.12
+    mut = rng.random((n_pairs, L)) < float(os.environ.get("PAIRS_MUT", "0.12"))  # (substitutions; PAIRS_MUT=0.4 ~ 30 % edits)
     b[mut] = letters_set[rng.integers(0, len(letters_set), int(mut.sum()))]
     # ragged lengths: trim 0..3 % off the end of B
     lens_b = L - rng.integers(0, max(1, L // 32), n_pairs)

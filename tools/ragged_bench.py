@@ -92,16 +92,18 @@ def run_variant(pkg, synth, torch, name, tax, batch, ds, steps, in_flight, oracl
         elapsed = time.perf_counter() - t0
         model.profile(enable=False)
         torch.cuda.synchronize()
+        sync_steps = int(os.environ.get("RAGGED_SYNC_STEPS", steps))  # (tools/kt_ragged_inflight.sh: a trace that is nearly all steps in flight)
         t1 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(sync_steps):
             model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=outs[0][0], stats=outs[0][1])
         torch.cuda.synchronize()
-        sync_ms = (time.perf_counter() - t1) / steps * 1e3
+        sync_ms = (time.perf_counter() - t1) / sync_steps * 1e3
         model.profile(enable=True, reset=True)
-        for _ in range(steps):
+        for _ in range(sync_steps):
             model.predict(dev, mem_kind=pkg.MEM_DEVICE, out=outs[0][0], stats=outs[0][1])
         torch.cuda.synchronize()
         prof = model.profile()
+        prof = dict(prof, **{k: prof[k] * steps / sync_steps for k in ("pairs", "demanded", "rounds", "launches", "align_ms", "total_ms", "cells")})
     rows = outs[0][0].cpu().numpy().view(pkg.PRED_DTYPE).reshape(-1)
     stats = outs[0][1].cpu().numpy().view(pkg.STATS_DTYPE).reshape(-1)
     demanded = int(stats["pass0"].astype(np.int64).sum() + stats["pass1"].astype(np.int64).sum() + stats["pass2"].astype(np.int64).sum())
