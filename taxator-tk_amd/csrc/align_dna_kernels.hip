@@ -583,6 +583,191 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// K1r (round 5): the out-of-phase window of k_myers_short_band4 for patterns of ANY length -- here 13 ... 32 words, 385 ... 1024 nt,
+// which until then went straight to the register strips of K1s (55 T cell-equivalents/s at 400-500 nt where the one-strip kernels
+// reach 240 T at 384) -- with a window of WW = 6 or 10 words and ONLY the window alive in registers.  Word w of the pattern lives
+// in register w mod WW and its match masks in ring slot w mod WW, for as long as it is inside the window: of the 32 columns of
+// text group g the first 16 update words g - WW/2 ... g + WW/2 - 1, then word g - WW/2 leaves (its vertical deltas go into the
+// running score T, which follows the row above the window as in band4), word g + WW/2 enters in the same register and slot (all
+// +1, its masks made from the pattern stream there and then), and the last 16 columns update words g - WW/2 + 1 ... g + WW/2.
+// The order of the carry chain through the registers rotates by one per group: a uniform switch over the WW rotations, every one
+// of them with compile-time register and slot indices (no register is ever indexed at run time).  Nothing clips the window at
+// the pattern's end -- rows past the pattern match nothing and lie below row m -- so no bound on the pattern length is compiled
+// in.  Guaranteed band |j - i| <= 16 (WW - 1): exact up to k = 32 (WW - 1) - |delta| edits (160 and 288); what lies beyond, and
+// pairs whose lengths differ by 16 (WW - 1) and more, go onto the strip kernels' retry list.  tools/band_model.py:
+// banded_window_ring (the same schedule, checked against plain Levenshtein by the CPU suite).
+// ------------------------------------------------------------------------------------------------------------
+template <int WW> __host__ __device__ constexpr uint32_t window_reach() { return 16u * (uint32_t)(WW - 1); }
+
+// one text column over CNT words of the window, the chain starting at register T0 and wrapping round
+template <int WW, int T0, int CNT>
+__device__ __forceinline__ void window_column(uint32_t (&VP)[WW], uint32_t (&VN)[WW], const uint32_t* __restrict__ e) {
+  static_assert(T0 >= 0 && T0 < WW && CNT >= 1 && CNT <= WW, "window");
+  uint32_t carry = 0, hp_prev = 0x80000000u, hn_prev = 0;
+  constexpr int kHead = CNT < WW - T0 ? CNT : WW - T0;  // registers T0 ... T0 + kHead - 1, then 0 ... CNT - kHead - 1
+  auto eq = [&](int wi) { return e[wi * kBlock]; };
+  myers_word_range<WW, T0, T0 + kHead - 1, true>(VP, VN, eq, carry, hp_prev, hn_prev);
+  if constexpr (CNT > kHead) myers_word_range<WW, 0, CNT - kHead - 1, false>(VP, VN, eq, carry, hp_prev, hn_prev);
+}
+// up to 16 columns (the nibbles of d0, then d1), two per trip: the steady state compiles WW rotations of this loop, so it is kept
+// small -- unrolled eight deep like band4's it would be 140 KB of code for WW = 10, a multiple of the instruction cache
+template <int WW, int T0, int CNT>
+__device__ __forceinline__ void window_sweep16(uint32_t (&VP)[WW], uint32_t (&VN)[WW], const uint32_t* __restrict__ peq_lane, uint32_t d0,
+                                               uint32_t d1, uint32_t ncols) {
+  uint64_t d = ((uint64_t)d1 << 32) | d0;
+#pragma unroll 1
+  for (uint32_t c = 0; c < ncols; c += 2u) {
+    window_column<WW, T0, CNT>(VP, VN, peq_lane + ((uint32_t)d & 7u) * (uint32_t)(WW * kBlock));
+    if (c + 1u < ncols) window_column<WW, T0, CNT>(VP, VN, peq_lane + ((uint32_t)(d >> 4) & 7u) * (uint32_t)(WW * kBlock));
+    d >>= 8;
+  }
+}
+// the five match masks of pattern word `wi` (the next 32 residues of the stream, or nothing past the pattern's end) into ring slot SLOT
+template <int WW, int SLOT>
+__device__ __forceinline__ void window_take_in(uint32_t* __restrict__ peq_lane, NtStream& ps, uint32_t wi, uint32_t m) {
+  uint32_t mask[5];
+  peq_word(ps, wi, m, mask);
+#pragma unroll
+  for (int c = 0; c < 5; ++c) peq_lane[(c * WW + SLOT) * kBlock] = mask[c];
+}
+// groups 0 ... WW/2 - 1: the window still starts at word 0 (register 0) and only grows
+template <int WW, int G>
+struct WindowHead {
+  static __device__ __forceinline__ void run(uint32_t (&VP)[WW], uint32_t (&VN)[WW], uint32_t* __restrict__ peq_lane, NtStream& ts, uint4& pending,
+                                             NtStream& ps, uint32_t m, uint32_t n, uint32_t n_groups, int32_t& T) {
+    constexpr int H = WW / 2;
+    if constexpr (G < H) {
+      if ((uint32_t)G >= n_groups) return;
+      const uint4 buf = ts.take32(pending);
+      if ((uint32_t)G + 1u < n_groups) pending = ts.load4();
+      const uint32_t cols = n - (uint32_t)G * 32u < 32u ? n - (uint32_t)G * 32u : 32u;
+      const uint32_t ca = cols < 16u ? cols : 16u;
+      window_sweep16<WW, 0, G + H>(VP, VN, peq_lane, buf.x, buf.y, ca);
+      T += (int32_t)ca;
+      if (cols > 16u) {
+        window_take_in<WW, G + H>(peq_lane, ps, (uint32_t)(G + H), m);  // (register G + H is still in its initial state)
+        window_sweep16<WW, 0, G + H + 1>(VP, VN, peq_lane, buf.z, buf.w, cols - 16u);
+        T += (int32_t)(cols - 16u);
+      }
+      WindowHead<WW, G + 1>::run(VP, VN, peq_lane, ts, pending, ps, m, n, n_groups, T);
+    }
+  }
+};
+// a group of the steady state whose window starts in register T0 (T0 = (g - WW/2) mod WW); returns false when the text ended in its first half
+template <int WW, int T0>
+__device__ __forceinline__ bool window_group(uint32_t (&VP)[WW], uint32_t (&VN)[WW], uint32_t* __restrict__ peq_lane, const uint4 buf, uint32_t cols,
+                                             NtStream& ps, uint32_t g, uint32_t m, int32_t& T) {
+  const uint32_t ca = cols < 16u ? cols : 16u;
+  window_sweep16<WW, T0, WW>(VP, VN, peq_lane, buf.x, buf.y, ca);
+  T += (int32_t)ca;
+  if (cols <= 16u) return false;
+  T += (int32_t)__popc(VP[T0]) - (int32_t)__popc(VN[T0]);  // word g - WW/2 leaves: a whole word of the pattern (n < m + reach)
+  VP[T0] = 0xFFFFFFFFu; VN[T0] = 0u;                        // word g + WW/2 enters
+  window_take_in<WW, T0>(peq_lane, ps, g + (uint32_t)(WW / 2), m);
+  window_sweep16<WW, (T0 + 1) % WW, WW>(VP, VN, peq_lane, buf.z, buf.w, cols - 16u);
+  T += (int32_t)(cols - 16u);
+  return true;
+}
+template <int WW, int T0>
+struct WindowSteady {
+  static __device__ __forceinline__ bool run(int t, uint32_t (&VP)[WW], uint32_t (&VN)[WW], uint32_t* __restrict__ peq_lane, const uint4 buf,
+                                             uint32_t cols, NtStream& ps, uint32_t g, uint32_t m, int32_t& T) {
+    if constexpr (T0 < WW) {
+      if (t == T0) return window_group<WW, T0>(VP, VN, peq_lane, buf, cols, ps, g, m, T);
+      return WindowSteady<WW, T0 + 1>::run(t, VP, VN, peq_lane, buf, cols, ps, g, m, T);
+    } else return false;
+  }
+};
+// word-columns the kernel sweeps for a text of n columns (its schedule restated, for rpa_profile.cells_updated)
+__device__ __forceinline__ unsigned long long window_word_columns(int WW, uint32_t n) {
+  unsigned long long wc = 0;
+  const uint32_t H = (uint32_t)WW / 2u;
+  for (uint32_t g = 0; g * 32u < n; ++g) {
+    const uint32_t cols = n - g * 32u < 32u ? n - g * 32u : 32u, ca = cols < 16u ? cols : 16u;
+    wc += (unsigned long long)ca * (g < H ? g + H : (uint32_t)WW) + (unsigned long long)(cols - ca) * (g < H ? g + H + 1u : (uint32_t)WW);
+  }
+  return wc;
+}
+
+template <int WW>
+__global__ __launch_bounds__(kBlock) void k_myers_window(const uint2* __restrict__ list, uint32_t n_list, WorkDev w, uint2* __restrict__ retry,
+                                                          uint32_t* __restrict__ retry_n, uint32_t* __restrict__ retry_total,
+                                                          unsigned long long* prof_acc) {
+  static_assert(WW % 2 == 0 && WW >= 4, "an even number of words");
+  extern __shared__ uint32_t peq_ring[];  // [symbol][slot][lane]: 5 x WW KB per workgroup (30 / 50 KB)
+  const int tid = threadIdx.x;
+  const uint32_t t = blockIdx.x * kBlock + tid;
+  const bool active = t < n_list;
+  uint32_t dst = 0, m = 0, n = 0;
+  SegView pat{}, txt{};
+  uint2 entry = make_uint2(0u, 0u);
+  if (active) {
+    uint32_t a, b;
+    entry = list[t];
+    resolve_pair(w, entry, a, b, dst);
+    SegView va = seg_view(w, a), vb = seg_view(w, b);
+    if (va.len < vb.len) { txt = vb; pat = va; } else { txt = va; pat = vb; }  // the shorter one is the pattern (any choice is exact; the window costs WW words per column either way)
+    n = txt.len; m = pat.len;
+  }
+  if (prof_acc) profile_add(prof_acc, active, n, m, window_word_columns(WW, n) * 32ull);
+  if (!active) return;
+  const uint32_t ad = n - m;
+  constexpr uint32_t kReach = window_reach<WW>();
+  if (ad >= kReach || m == 0u) {  // no band of this shape holds the corridor
+    retry[atomicAdd(retry_n, 1u)] = entry;
+    atomicAdd(retry_total, 1u);
+    return;
+  }
+  uint32_t* __restrict__ peq_lane = peq_ring + tid;
+  NtStream ps;
+  ps.init(pat, 0u);
+  constexpr int H = WW / 2;
+#pragma unroll
+  for (int wi = 0; wi < H; ++wi) {  // the first window: words 0 ... WW/2 - 1
+    uint32_t mask[5];
+    peq_word(ps, (uint32_t)wi, m, mask);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) peq_lane[(c * WW + wi) * kBlock] = mask[c];
+  }
+  uint32_t VP[WW], VN[WW];
+#pragma unroll
+  for (int k = 0; k < WW; ++k) { VP[k] = 0xFFFFFFFFu; VN[k] = 0u; }
+  const uint32_t n_groups = (n + 31u) >> 5;
+  int32_t T = 0;
+  uint32_t top_word = 0;  // first word of the window in effect
+  NtStream ts;
+  ts.init(txt, 0u);
+  uint4 pending = ts.load4();
+  WindowHead<WW, 0>::run(VP, VN, peq_lane, ts, pending, ps, m, n, n_groups, T);
+  for (uint32_t g = (uint32_t)H; g < n_groups; ++g) {
+    const uint4 buf = ts.take32(pending);
+    if (g + 1u < n_groups) pending = ts.load4();
+    const uint32_t cols = n - g * 32u < 32u ? n - g * 32u : 32u;
+    const int rot = (int)((g - (uint32_t)H) % (uint32_t)WW);
+    const bool moved = WindowSteady<WW, 0>::run(rot, VP, VN, peq_lane, buf, cols, ps, g, m, T);
+    top_word = g - (uint32_t)H + (moved ? 1u : 0u);
+  }
+  // the vertical deltas of the window's words (register r holds word top_word + ((r - top_word) mod WW); before the window has
+  // moved that is word r, the words it has not reached being in their initial state anyway) and of the rows below it, all +1
+  int32_t dist = T;
+  const uint32_t top_reg = top_word % (uint32_t)WW;
+#pragma unroll
+  for (int r = 0; r < WW; ++r) {
+    const uint32_t off = ((uint32_t)r + (uint32_t)WW - top_reg) % (uint32_t)WW;
+    const uint32_t pos = (top_word + off) * 32u;
+    const uint32_t vm = pos >= m ? 0u : (m - pos >= 32u ? 0xFFFFFFFFu : ((1u << (m - pos)) - 1u));
+    dist += (int32_t)__popc(VP[r] & vm) - (int32_t)__popc(VN[r] & vm);
+  }
+  const uint32_t below = (top_word + (uint32_t)WW) * 32u;
+  if (m > below) dist += (int32_t)(m - below);
+  if ((uint32_t)dist <= 2u * kReach - ad) store_dna_result(w, dst, dist, n, m);
+  else {
+    retry[atomicAdd(retry_n, 1u)] = entry;
+    atomicAdd(retry_total, 1u);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K1w: the same alignment with a pattern WORD per lane -- eight lanes per pair, eight pairs per wavefront -- for launches of a
 // few thousand pairs (the sparse rounds at the end of a batch, the retry lists of the later dense rounds).  With a pair per
 // lane such a launch takes what ONE lane takes, ~45 us for 200 columns x 8 words, however few pairs it carries; here lane l
@@ -749,6 +934,22 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
     default: return hipErrorInvalidValue;
   }
 #undef RPA_LAUNCH_MYERS_BAND
+  return hipGetLastError();
+}
+
+bool dna_window_available(int window_words) { return window_words == 6 || window_words == 10; }
+
+hipError_t launch_align_dna_window(hipStream_t st, int window_words, const uint2* list, uint32_t n, const WorkDev& w, uint2* retry,
+                                   uint32_t* retry_n, uint32_t* retry_total, unsigned long long* prof_acc) {
+  if (n == 0) return hipSuccess;
+  if (n > 0xFFFFFF00u || !retry || !retry_n || !retry_total) return hipErrorInvalidValue;
+  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+  const size_t lds = (size_t)5 * window_words * kBlock * sizeof(uint32_t);
+  switch (window_words) {
+    case 6: hipLaunchKernelGGL(k_myers_window<6>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, retry, retry_n, retry_total, prof_acc); break;
+    case 10: hipLaunchKernelGGL(k_myers_window<10>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, retry, retry_n, retry_total, prof_acc); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

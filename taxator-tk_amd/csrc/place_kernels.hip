@@ -1369,7 +1369,8 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
     if (threadIdx.x != (uint32_t)kCtrActive) w.counters[threadIdx.x] = 0u;
     if (threadIdx.x == 0) w.counters[w.ctr_live_in] = 0u;
   }
-  if (blockIdx.x == 0 && threadIdx.x >= 64u && threadIdx.x <= 64u + (uint32_t)kNumBins) w.counters[kCtrDeferred + (threadIdx.x - 64u)] = 0u;  // kCtrDeferred, kCtrSurvivor ..
+  if (blockIdx.x == 0 && threadIdx.x >= 64u && threadIdx.x <= 64u + (uint32_t)kNumBins + 1u) w.counters[kCtrDeferred + (threadIdx.x - 64u)] = 0u;  // kCtrDeferred, kCtrSurvivor .., kCtrWindowFail
+  static_assert(kCtrWindowFail == kCtrDeferred + kNumBins + 1 && 64 + kNumBins + 1 < kBlock, "the counters k_decide clears");
   __syncthreads();  // (the only barrier of the kernel: the wavefronts of a workgroup start together and finish far apart)
   // dense rounds: one thread per record set; sparse rounds (few sets still running): one thread per entry of the live list
   const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;

@@ -14,7 +14,11 @@ constexpr int kWaveMaxWords = 8;     // K1w (a pattern word per lane, eight lane
 constexpr int kStripMinWords = 5;    // longer patterns: register strips of 5..8 words, whichever wastes the fewest rows
 constexpr int kStripMaxWords = 8;
 constexpr int kStripBins = kStripMaxWords - kStripMinWords + 1;
-constexpr int kDnaBins = kShortWords + kStripBins;  // bins 0..11: one strip of bin+1 words ; bins 12..15: strips of bin-7 words
+constexpr int kWindowBins = 2;       // patterns of 13..16 / 17..32 words: the ring-window kernel (K1r, windows of 6 / 10 words) in front of the strips
+constexpr int kWindowMaxWords = 32;
+constexpr int kFirstStripBin = kShortWords + kWindowBins;
+constexpr int kDnaBins = kFirstStripBin + kStripBins;  // bins 0..11: one strip of bin+1 words; 12, 13: up to 16 / 32 words; 14..17: strips of bin-9 words
+__host__ __device__ constexpr int window_words_of_bin(int bin) { return bin == kShortWords ? 6 : 10; }
 constexpr int kNumBins = 22;         // work lists per round: the nucleotide bins above, or the 22 protein bins below
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
@@ -257,7 +261,9 @@ constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNum
               kCtrErrSet = kNumBins + 5, kCtrRetryTotal = kNumBins + 6, kCtrRetryShortTotal = kNumBins + 7, kCtrActiveB = kNumBins + 8,
               kCtrDeferred = kNumBins + 9,   // pass-2 hits of this round that wait for the round's second launch (k_emit; see kDeferredMark)
               kCtrSurvivor = kNumBins + 10,  // [kNumBins words] pairs per bin of that second launch (k_defer_filter)
-              kNumCounters = 2 * kNumBins + 10, kNumRoundCounters = kNumBins + 4;
+              kCtrWindowFail = 2 * kNumBins + 10,        // pairs of this round that left the ring-window kernel's band (length of its own list; cleared with kCtrSurvivor)
+              kCtrRetryWindowTotal = 2 * kNumBins + 11,  // ... added up over the batch
+              kNumCounters = 2 * kNumBins + 12, kNumRoundCounters = kNumBins + 4;
 static_assert(kNumCounters <= 64, "launch_publish_words moves up to 64 words");
 
 // Two launches inside ONE pass-2 round.  A pass-2 loop steps over every hit whose taxon lies at or below unode_global (:771), and
@@ -375,6 +381,9 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
 // margin / 16 = safety factor on the probe's distance estimate (21 by default; tests use tiny ones to force retries).
 // n_dev != null: the length of `list` is read on the device (bounded by n) and grid_blocks workgroups stride over it.
 size_t dna_strip_scratch_words(uint32_t n_pairs, uint32_t max_len);
+bool dna_window_available(int window_words);
+hipError_t launch_align_dna_window(hipStream_t st, int window_words, const uint2* list, uint32_t n, const WorkDev& w, uint2* retry,
+                                   uint32_t* retry_n, uint32_t* retry_total, unsigned long long* prof_acc);
 hipError_t launch_align_dna_strips(hipStream_t st, int strip_words, const uint2* list, uint32_t n, const uint32_t* n_dev,
                                    uint32_t grid_blocks, const WorkDev& w, uint32_t* scratch, size_t scratch_words, uint32_t max_len,
                                    bool wide_open, uint32_t margin, uint2* retry, uint32_t* retry_n, unsigned long long* prof_acc);
@@ -553,11 +562,13 @@ __device__ __forceinline__ SegView seg_view(const WorkDev& w, uint32_t seg) {
 }
 
 // bin of a pair whose shorter sequence has m residues (DNA).  Up to kShortWords words: one strip of exactly that many words.
-// Beyond: the strip height in 5..8 words with the smallest strips x (height x 16 + 20) issue-slot estimate, i.e. the
-// fewest wasted rows (13 words -> 2 x 7, 17 -> 3 x 6, 25 -> 4 x 7 ...); any length fits.
+// 13 ... 32 words: two classes for the ring-window kernel.  Beyond: the strip height in 5..8 words with the smallest
+// strips x (height x 16 + 20) issue-slot estimate, i.e. the fewest wasted rows (33 words -> 5 x 7, 41 -> 6 x 7 ...); any length fits.
 __host__ __device__ __forceinline__ int dna_bin(uint32_t m) {
   const uint32_t words = (m + 31u) / 32u;
   if (words <= (uint32_t)kShortWords) return words ? (int)words - 1 : 0;
+  if (words <= 16u) return kShortWords;
+  if (words <= (uint32_t)kWindowMaxWords) return kShortWords + 1;
   uint32_t best = 0xFFFFFFFFu;
   int best_nw = kStripMaxWords;
   for (int nw = kStripMaxWords; nw >= kStripMinWords; --nw) {  // ties -> taller strips (fewer sweeps of the text)
@@ -565,7 +576,9 @@ __host__ __device__ __forceinline__ int dna_bin(uint32_t m) {
     const uint32_t cost = strips > 0x00FFFFFFu ? 0xFFFFFFFEu : strips * ((uint32_t)nw * 16u + 20u);
     if (cost < best) { best = cost; best_nw = nw; }
   }
-  return kShortWords + best_nw - kStripMinWords;
+  return kFirstStripBin + best_nw - kStripMinWords;
 }
+// strip height (words) of the register-strip kernels for a pair of bin `bin` (>= kShortWords); the window classes fall back to the tallest
+__host__ __device__ __forceinline__ int strip_words_of_bin(int bin) { return bin < kFirstStripBin ? kStripMaxWords : bin - kFirstStripBin + kStripMinWords; }
 
 }  // namespace rpa

@@ -100,7 +100,7 @@ struct rpa_engine {
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
   DevBuf state, loop_save, rec_pre, hits, set_info, emit, emit_lite, emit_ext, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
-      protein_ws, lanes_counter, retry_list, retry_short;
+      protein_ws, lanes_counter, retry_list, retry_short, window_fail;
   uint32_t* h_counters = nullptr;  // pinned
   // The alignment launches of ONE round that do not depend on each other (one per length class: the strip-height classes of long
   // nucleotide pairs, the lanes-per-pair classes of protein pairs) go to side streams, forked from and joined to the engine's stream
@@ -137,8 +137,9 @@ struct rpa_engine {
                               // reads a slot nobody wrote this batch then reads garbage every time, not whatever the last batch left)
   // what the bands cost: pairs sent through the banded kernels / re-run wide open, per batch.  A band that sends more
   // than a quarter of its pairs to the retry list (unrelated sequences) is switched off for the next 16 batches.
-  uint64_t banded_short_batch = 0, banded_long_batch = 0;
-  int band_short_pause = 0, band_long_pause = 0;
+  uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch = 0;
+  int band_short_pause = 0, band_long_pause = 0, band_window_pause = 0;
+  bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..32 words go straight to the strip kernels (A/B; the same results)
   int band4_wide = 0;        // > 0: the one-strip band with four words all the way (k = 96 - |delta|) for this many more batches:
                              //      too many pairs of a batch left the narrow one (k = 80 - |delta|); -1 / -2: fixed by RPA_BAND4_PHASES=2 / 3
   bool band_short = true;     // RPA_BAND_SHORT=0: the one-strip kernel computes every cell of 5..8-word patterns too
@@ -351,7 +352,14 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
   uint64_t banded_short = 0;  // ... through the banded one-strip kernel (its own retry list and counter)
   int widest_short = 0;       // widest pattern class (in words) among the banded one-strip launches
   const bool use_band_long = e->band_long && e->band_long_pause == 0, use_band_short = e->band_short && e->band_short_pause == 0;
-  if (e->params.alphabet == RPA_DNA && use_band_long) {
+  const bool use_window = e->band_window && e->band_window_pause == 0;
+  uint64_t window_pairs = 0;  // pairs that went through the ring-window kernel this round: the bound of its own list of pairs that left its band
+  if (e->params.alphabet == RPA_DNA && use_window) {
+    uint64_t wp = 0;
+    for (int bin = kShortWords; bin < kFirstStripBin; ++bin) wp += counts[bin];
+    if (wp) HIP_TRY(e, e->window_fail.ensure((size_t)wp * sizeof(uint2)));
+  }
+  if (e->params.alphabet == RPA_DNA && (use_band_long || use_window)) {
     uint64_t strip_pairs = 0;
     for (int bin = kShortWords; bin < kNumBins; ++bin) strip_pairs += counts[bin];
     if (strip_pairs) HIP_TRY(e, e->retry_list.ensure((size_t)strip_pairs * sizeof(uint2)));
@@ -410,14 +418,21 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
         if (e->long_kernel == 2) wave = false;
         int sk = -1;
         hipStream_t st = fork ? take_side(&sk) : e->stream;
-        if (wave) HIP_TRY(e, launch_align_dna_long(st, (int)wpl, list, n, nullptr, 0, w, acc));
+        // Patterns of up to 32 words (bins kShortWords, kShortWords + 1), launches of the dense rounds: the ring-window kernel first
+        // (K1r: one lane per pair, a window of 6 / 10 words around the diagonal, exact up to 160 / 288 edits minus the length
+        // difference); what lies outside goes onto the strip kernels' retry list.
+        if (bin < kFirstStripBin && use_window && dna_window_available(window_words_of_bin(bin)) && n >= e->band_short_min && e->long_kernel == 0) {
+          HIP_TRY(e, launch_align_dna_window(st, window_words_of_bin(bin), list, n, w, e->window_fail.as<uint2>(), w.counters + kCtrWindowFail,
+                                             w.counters + kCtrRetryWindowTotal, acc));
+          window_pairs += n;
+        } else if (wave) HIP_TRY(e, launch_align_dna_long(st, (int)wpl, list, n, nullptr, 0, w, acc));
         else {
           DevBuf& ws = sk >= 0 ? e->side_ws[sk] : e->protein_ws;  // (a scratch per stream: the launches of a round run side by side)
           if (dna_strip_scratch_words(n, max_len) * 4 > ws.cap) {
             if (sk >= 0) HIP_TRY(e, hipStreamSynchronize(st));  // (growing frees the old buffer: nothing of an earlier round may still use it -- rounds are joined, this is for safety)
             HIP_TRY(e, ws.ensure(dna_strip_scratch_words(n, max_len) * 4));
           }
-          HIP_TRY(e, launch_align_dna_strips(st, bin - kShortWords + kStripMinWords, list, n, nullptr, 0, w, ws.as<uint32_t>(),
+          HIP_TRY(e, launch_align_dna_strips(st, strip_words_of_bin(bin), list, n, nullptr, 0, w, ws.as<uint32_t>(),
                                              ws.cap / 4, max_len, !use_band_long, e->band_margin, e->retry_list.as<uint2>(),
                                              w.counters + kCtrRetry, acc));
           if (use_band_long) banded_pairs += n;
@@ -475,6 +490,24 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
     if (trc) return trc;
   }
   { const int jrc = join_sides(); if (jrc) return jrc; }  // (the one-strip launches and their retries above ran beside the side streams' launches)
+  if (window_pairs) {
+    // What left the ring window (a device-side count: normally a few pairs, all of them when the batch is more divergent than the
+    // window is wide -- the engine then pauses the window for 16 batches): through the strip kernel with its adaptive band, as
+    // if the pairs had gone there in the first place; what leaves that band too joins the retry list below.
+    const uint32_t bound = window_pairs > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)window_pairs;
+    const uint32_t max_len = counts[kCtrMaxLen];
+    const uint32_t blocks = 1024u;
+    LaunchTimer timer{e};
+    int trc = timer.begin();
+    if (trc) return trc;
+    HIP_TRY(e, e->protein_ws.ensure(dna_strip_scratch_words(std::min(bound, blocks * (uint32_t)kBlock), max_len) * 4));
+    HIP_TRY(e, launch_align_dna_strips(e->stream, kStripMaxWords, e->window_fail.as<uint2>(), bound, w.counters + kCtrWindowFail, blocks, w,
+                                       e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, !use_band_long, e->band_margin,
+                                       e->retry_list.as<uint2>(), w.counters + kCtrRetry, nullptr));
+    if (use_band_long) banded_pairs += window_pairs;
+    trc = timer.end();
+    if (trc) return trc;
+  }
   if (banded_pairs) {
     // The pairs whose distance lies outside their band, with the band wide open.  How many there are only the device
     // knows (counters[kCtrRetry]): the launch is sized for "a few" and strides over the list.  One pair per wavefront
@@ -498,7 +531,8 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
     if (trc) return trc;
   }
   e->banded_short_batch += banded_short;
-  e->banded_long_batch += banded_pairs;
+  e->banded_long_batch += banded_pairs - (use_band_long ? window_pairs : 0);
+  e->banded_window_batch += window_pairs;
   return RPA_OK;
 }
 
@@ -702,9 +736,16 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
         if (e->band4_wide == 0 && e->banded_short_batch >= 65536 && (uint64_t)e->h_counters[kCtrRetryShortTotal] * 16 > e->banded_short_batch) e->band4_wide = 16;
         else if (e->band4_wide > 0) --e->band4_wide;
       }
-      if (e->banded_long_batch >= 1024 && (uint64_t)e->h_counters[kCtrRetryTotal] * 4 > e->banded_long_batch) e->band_long_pause = 16;
+      // (the retry launches count the whole retry list into kCtrRetryTotal; the ring-window kernel counts its own share)
+      const uint64_t from_window = e->h_counters[kCtrRetryWindowTotal];
+      const uint64_t from_strips = e->h_counters[kCtrRetryTotal] > from_window ? e->h_counters[kCtrRetryTotal] - from_window : 0;
+      if (e->banded_long_batch >= 1024 && from_strips * 4 > e->banded_long_batch) e->band_long_pause = 16;
       else if (e->band_long_pause) --e->band_long_pause;
-      e->banded_short_batch = 0; e->banded_long_batch = 0;
+      if (e->banded_window_batch >= 1024 && from_window * 4 > e->banded_window_batch) e->band_window_pause = 16;
+      else if (e->band_window_pause) --e->band_window_pause;
+      if (e->trace_rounds && e->banded_window_batch)
+        fprintf(stderr, "[rpa] batch done: %llu of %llu pairs left the ring window\n", (unsigned long long)from_window, (unsigned long long)e->banded_window_batch);
+      e->banded_short_batch = 0; e->banded_long_batch = 0; e->banded_window_batch = 0;
       break;
     }
     uint32_t counts[kNumRoundCounters];
@@ -825,7 +866,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
+  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->side_streams_on = e->side_streams_on;
   w->defer_mode = e->defer_mode;
@@ -1003,6 +1044,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_BAND")) e->band_long = atoi(v) != 0;
   if (const char* v = getenv("RPA_BAND_SHORT")) e->band_short = atoi(v) != 0;
   if (const char* v = getenv("RPA_BAND_SHORT_MIN")) e->band_short_min = (uint32_t)atoi(v);
+  if (const char* v = getenv("RPA_BAND_WINDOW")) e->band_window = atoi(v) != 0;
   if (const char* v = getenv("RPA_BAND_GAIN")) e->band_gain = atof(v);
   if (const char* v = getenv("RPA_BAND_MARGIN")) e->band_margin = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;

@@ -15,3 +15,4 @@ def test_band_model():
     assert mod.check_window(trials=1500, seed=4) == 1500              # K1: five words, in phase with the text groups
     assert mod.check_window_phase(trials=2000, seed=6) == 2000       # K1: four words, half a group out of phase
     assert mod.check_window_phase3(trials=3000, seed=8) == 3000      # K1: ... with a three-word middle (the default)
+    assert mod.check_window_ring(trials=3000, seed=10) == 3000       # K1r: 4 ... 10 words, only the window alive, any pattern length
