@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1r (round 5): the out-of-phase window of k_myers_short_band4 for patterns of ANY length -- here 13 ... 32 words, 385 ... 1024 nt,
+// K1r (round 5): the out-of-phase window of k_myers_short_band4 for patterns of ANY length -- here 13 ... 64 words, 385 ... 2048 nt,
 // which until then went straight to the register strips of K1s (55 T cell-equivalents/s at 400-500 nt where the one-strip kernels
 // reach 240 T at 384) -- with a window of WW = 6 or 10 words and ONLY the window alive in registers.  Word w of the pattern lives
 // in register w mod WW and its match masks in ring slot w mod WW, for as long as it is inside the window: of the 32 columns of

@@ -14,10 +14,10 @@ constexpr int kWaveMaxWords = 8;     // K1w (a pattern word per lane, eight lane
 constexpr int kStripMinWords = 5;    // longer patterns: register strips of 5..8 words, whichever wastes the fewest rows
 constexpr int kStripMaxWords = 8;
 constexpr int kStripBins = kStripMaxWords - kStripMinWords + 1;
-constexpr int kWindowBins = 2;       // patterns of 13..16 / 17..32 words: the ring-window kernel (K1r, windows of 6 / 10 words) in front of the strips
-constexpr int kWindowMaxWords = 32;
+constexpr int kWindowBins = 3;       // patterns of 13..16 / 17..32 / 33..64 words: the ring-window kernel (K1r, windows of 6 / 10 / 10 words) in front of the strips
+constexpr int kWindowMaxWords = 64;
 constexpr int kFirstStripBin = kShortWords + kWindowBins;
-constexpr int kDnaBins = kFirstStripBin + kStripBins;  // bins 0..11: one strip of bin+1 words; 12, 13: up to 16 / 32 words; 14..17: strips of bin-9 words
+constexpr int kDnaBins = kFirstStripBin + kStripBins;  // bins 0..11: one strip of bin+1 words; 12, 13, 14: up to 16 / 32 / 64 words; 15..18: strips of bin-10 words
 __host__ __device__ constexpr int window_words_of_bin(int bin) { return bin == kShortWords ? 6 : 10; }
 constexpr int kNumBins = 22;         // work lists per round: the nucleotide bins above, or the 22 protein bins below
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
@@ -562,13 +562,14 @@ __device__ __forceinline__ SegView seg_view(const WorkDev& w, uint32_t seg) {
 }
 
 // bin of a pair whose shorter sequence has m residues (DNA).  Up to kShortWords words: one strip of exactly that many words.
-// 13 ... 32 words: two classes for the ring-window kernel.  Beyond: the strip height in 5..8 words with the smallest
-// strips x (height x 16 + 20) issue-slot estimate, i.e. the fewest wasted rows (33 words -> 5 x 7, 41 -> 6 x 7 ...); any length fits.
+// 13 ... 64 words: three classes for the ring-window kernel.  Beyond: the strip height in 5..8 words with the smallest
+// strips x (height x 16 + 20) issue-slot estimate, i.e. the fewest wasted rows (65 words -> 9 x 8, 71 -> 9 x 8 ...); any length fits.
 __host__ __device__ __forceinline__ int dna_bin(uint32_t m) {
   const uint32_t words = (m + 31u) / 32u;
   if (words <= (uint32_t)kShortWords) return words ? (int)words - 1 : 0;
   if (words <= 16u) return kShortWords;
-  if (words <= (uint32_t)kWindowMaxWords) return kShortWords + 1;
+  if (words <= 32u) return kShortWords + 1;
+  if (words <= (uint32_t)kWindowMaxWords) return kShortWords + 2;
   uint32_t best = 0xFFFFFFFFu;
   int best_nw = kStripMaxWords;
   for (int nw = kStripMaxWords; nw >= kStripMinWords; --nw) {  // ties -> taller strips (fewer sweeps of the text)

@@ -418,7 +418,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
         if (e->long_kernel == 2) wave = false;
         int sk = -1;
         hipStream_t st = fork ? take_side(&sk) : e->stream;
-        // Patterns of up to 32 words (bins kShortWords, kShortWords + 1), launches of the dense rounds: the ring-window kernel first
+        // Patterns of up to 64 words (bins kShortWords ... kFirstStripBin - 1), launches of the dense rounds: the ring-window kernel first
         // (K1r: one lane per pair, a window of 6 / 10 words around the diagonal, exact up to 160 / 288 edits minus the length
         // difference); what lies outside goes onto the strip kernels' retry list.
         if (bin < kFirstStripBin && use_window && dna_window_available(window_words_of_bin(bin)) && n >= e->band_short_min && e->long_kernel == 0) {

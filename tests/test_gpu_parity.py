@@ -120,7 +120,7 @@ def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     words of the diagonal; pairs whose distance lies outside that band (or whose lengths differ by 64 and more) are
     re-run by the full kernel.  Forced on for launches of any size / switched off: the same bytes either way, and both
     equal to the oracle -- from identical pairs to unrelated ones, with N's, and every length difference class.
-    Patterns of 13..32 words (385..1024 nt) take the ring-window kernel (K1r: 6 / 10 words around the diagonal, only the window
+    Patterns of 13..64 words (385..2048 nt) take the ring-window kernel (K1r: 6 / 10 words around the diagonal, only the window
     alive in registers) in front of the strip kernels: the same lists of pairs, around its limits of 160 / 288 edits."""
     monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")
     monkeypatch.delenv("RPA_SHORT_WAVE_MAX", raising=False)
@@ -133,7 +133,8 @@ def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     a_codes, b_codes = [], []
     for la in [129, 150, 159, 160, 161, 180, 191, 192, 193, 200, 210, 223, 224, 225, 240, 255, 256,
                257, 270, 288, 289, 300, 319, 320, 321, 340, 352, 353, 370, 383, 384,   # (9 ... 12 words: one-strip classes since round 5)
-               385, 400, 415, 416, 417, 450, 480, 511, 512, 513, 530, 544, 545, 600, 700, 767, 768, 769, 900, 1000, 1023, 1024]:  # (13 ... 32 words: the ring window, K1r)
+               385, 400, 415, 416, 417, 450, 480, 511, 512, 513, 530, 544, 545, 600, 700, 767, 768, 769, 900, 1000, 1023, 1024,
+               1025, 1300, 1600, 2047, 2048, 2049]:  # (13 ... 64 words: the ring window, K1r)
         for rate in [0.0, 0.02, 0.1, 0.25, 0.32, 0.4, 0.6, 1.0]:
             for extra in [0, 3, 31, 40, 63, 64, 65, 100] + ([79, 80, 81, 143, 144, 145, 200] if la > 384 else []):  # (K1r: length differences around 80 and 144)
                 a = rng.integers(0, 5 if rate > 0.3 else 4, la).astype(np.uint8)
