@@ -139,7 +139,8 @@ struct rpa_engine {
   // than a quarter of its pairs to the retry list (unrelated sequences) is switched off for the next 16 batches.
   uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch = 0;
   int band_short_pause = 0, band_long_pause = 0, band_window_pause = 0;
-  bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..32 words go straight to the strip kernels (A/B; the same results)
+  bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..64 words go straight to the strip kernels (A/B; the same results)
+  uint32_t band_window_min = 65536;  // fewer pairs than this in a launch: strips / one pair per wavefront as before (RPA_BAND_WINDOW_MIN; mixed-shape stream: 16384 and 4096 gain 2-3 % in flight and lose 4-9 % synchronous)
   int band4_wide = 0;        // > 0: the one-strip band with four words all the way (k = 96 - |delta|) for this many more batches:
                              //      too many pairs of a batch left the narrow one (k = 80 - |delta|); -1 / -2: fixed by RPA_BAND4_PHASES=2 / 3
   bool band_short = true;     // RPA_BAND_SHORT=0: the one-strip kernel computes every cell of 5..8-word patterns too
@@ -421,7 +422,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
         // Patterns of up to 64 words (bins kShortWords ... kFirstStripBin - 1), launches of the dense rounds: the ring-window kernel first
         // (K1r: one lane per pair, a window of 6 / 10 words around the diagonal, exact up to 160 / 288 edits minus the length
         // difference); what lies outside goes onto the strip kernels' retry list.
-        if (bin < kFirstStripBin && use_window && dna_window_available(window_words_of_bin(bin)) && n >= e->band_short_min && e->long_kernel == 0) {
+        if (bin < kFirstStripBin && use_window && dna_window_available(window_words_of_bin(bin)) && n >= std::min(e->band_short_min, e->band_window_min) && e->long_kernel == 0) {
           HIP_TRY(e, launch_align_dna_window(st, window_words_of_bin(bin), list, n, w, e->window_fail.as<uint2>(), w.counters + kCtrWindowFail,
                                              w.counters + kCtrRetryWindowTotal, acc));
           window_pairs += n;
@@ -866,7 +867,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
+  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; w->band_window_min = e->band_window_min; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->side_streams_on = e->side_streams_on;
   w->defer_mode = e->defer_mode;
@@ -1045,6 +1046,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_BAND_SHORT")) e->band_short = atoi(v) != 0;
   if (const char* v = getenv("RPA_BAND_SHORT_MIN")) e->band_short_min = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_WINDOW")) e->band_window = atoi(v) != 0;
+  if (const char* v = getenv("RPA_BAND_WINDOW_MIN")) e->band_window_min = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_GAIN")) e->band_gain = atof(v);
   if (const char* v = getenv("RPA_BAND_MARGIN")) e->band_margin = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
