@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kFilterBlock) void k_defer_filter(BatchDev b, WorkD
   constexpr int PW = 4 * Q - 6;
   __shared__ uint32_t s_count[kNumBins], s_base[kNumBins];
   if (threadIdx.x < (uint32_t)kNumBins) s_count[threadIdx.x] = 0u;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { w.counters[kCtrRetry] = 0u; w.counters[kCtrRetryShort] = 0u; }  // the retry lists start over for the second launch
+  if (blockIdx.x == 0 && threadIdx.x == 0) { w.counters[kCtrRetry] = 0u; w.counters[kCtrRetryShort] = 0u; w.counters[kCtrWindowFail] = 0u; }  // the retry lists (and the ring window's list) start over for the second launch
   __syncthreads();
   const uint32_t s = blockIdx.x * kFilterBlock + threadIdx.x;
   unsigned long long survivors = 0ull;  // bit k: hit i_lo + k of my chunk goes into the second launch

@@ -569,6 +569,21 @@ def test_scores_of_any_sign_and_masked_records(pkg, oracle, synth):
             _engine_vs_oracle(pkg, oracle, synth, ds, alphabet, exclude_factor=x, reeval_bandwidth=t)
 
 
+@pytest.mark.parametrize("strips_band", ["1", "0"])
+def test_ring_window_lists_start_over_in_a_rounds_second_launch(pkg, oracle, synth, strips_band, monkeypatch):
+    """The ring-window kernel (K1r) keeps the pairs that left its band on a list of its own with a device-side count; a round with
+    two launches (RPA_DEFER2=1) runs it twice, and the second run must start that list over (the soak found it appending behind the
+    first run's entries: a result nobody wrote, the engine's ASSERT).  Segments of 1500 nt at ~30 % edits: every pair leaves the
+    window, in both launches; with the strip kernel's own band on and off."""
+    monkeypatch.setenv("RPA_DEFER2", "1")
+    monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")  # (the banded one-strip launches, K1r among them, for launches of any size)
+    monkeypatch.setenv("RPA_BAND", strips_band)
+    for seg, rate in ((1500, 0.06), (700, 0.03), (450, 0.06)):
+        ds = synth.make_dataset(n_sets=14, n_hits=30, seg_len=seg, branching=4, genome_len=4 * seg, seed=1075 + seg, level_rate=rate, query_rate=0.05, variety=True)
+        _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+        _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(3, 7))
+
+
 @pytest.mark.parametrize("mode", ["1", "0", "auto"])
 def test_two_launches_per_pass2_round(pkg, oracle, synth, mode, monkeypatch):
     """Round 5: pass-2 hits that an earlier hit of their chunk may take out of the loop (by lifting unode_global over them, :771,

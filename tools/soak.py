@@ -11,7 +11,7 @@ from helpers import oracle as O
 
 KNOBS = ("RPA_PASS1_FILTER", "RPA_LABEL_BITS", "RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
          "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND4_PHASES", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL",
-         "RPA_PROTEIN_LANES", "RPA_SHORT_WAVE_MAX", "RPA_DEFER2", "RPA_SIDE_STREAMS")
+         "RPA_PROTEIN_LANES", "RPA_SHORT_WAVE_MAX", "RPA_DEFER2", "RPA_SIDE_STREAMS", "RPA_BAND_WINDOW")
 
 
 def fill_windows(pkg, model, ds, tile):
@@ -59,8 +59,8 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
       n_hits = int(rng.integers(2, 41))
       branching = int(rng.integers(2, 5))
       if alphabet == 0:
-          seg = int(rng.choice([40, 90, 150, 200, 257, 320, 700, 1500]))
-          n_sets = int(rng.integers(50, 600)) if seg < 700 else int(rng.integers(10, 60))
+          seg = int(rng.choice([40, 90, 150, 200, 257, 320, 400, 520, 700, 1000, 1500]))  # (round 5: 257 ... 384 one strip, 385 ... 2048 the ring window first)
+          n_sets = int(rng.integers(50, 600)) if seg < 400 else int(rng.integers(10, 60))
           kw = dict(level_rate=float(rng.choice([0.01, 0.03, 0.06])), query_rate=float(rng.choice([0.0, 0.05, 0.1])))
       else:
           seg = int(rng.choice([20, 67, 120, 253, 312, 400]))
@@ -103,6 +103,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           if rng.random() < 0.3: env["RPA_BAND_DUO"] = "0"
           if rng.random() < 0.15: env["RPA_BAND"] = "0"
           if rng.random() < 0.15: env["RPA_BAND_SHORT"] = "0"
+          if rng.random() < 0.15: env["RPA_BAND_WINDOW"] = "0"
           if alphabet == 0 and seg > 256 and rng.random() < 0.5: env["RPA_LONG_KERNEL"] = "lane"
       if alphabet == 1 and rng.random() < 0.3: env["RPA_PROTEIN_LANES"] = "0"
       if alphabet == 0 and rng.random() < 0.4: env["RPA_SHORT_WAVE_MAX"] = str(int(rng.choice([0, 64, 1000000])))  # round 4: K1w (a pattern word per lane) never / for tiny launches / always

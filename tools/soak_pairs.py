@@ -43,8 +43,8 @@ def run(n_batches=20, rng_seed=777, verbose=True):
         alphabet = int(rng.random() < 0.4)
         asize = 5 if alphabet == 0 else 27
         if alphabet == 0:
-            top = int(rng.choice([64, 256, 300, 700, 2000, 5000, 18000]))
-            n = int(rng.integers(200, 3000)) if top <= 700 else int(rng.integers(20, 200)) if top <= 5000 else int(rng.integers(4, 20))
+            top = int(rng.choice([64, 256, 300, 400, 700, 1100, 2000, 5000, 18000]))
+            n = int(rng.integers(200, 3000)) if top <= 1100 else int(rng.integers(20, 200)) if top <= 5000 else int(rng.integers(4, 20))
             for kk in KNOBS: os.environ.pop(kk, None)
             lk = rng.choice(["", "wave", "lane"])
             if lk: os.environ["RPA_LONG_KERNEL"] = str(lk)
