@@ -262,8 +262,8 @@ constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNum
               kCtrDeferred = kNumBins + 9,   // pass-2 hits of this round that wait for the round's second launch (k_emit; see kDeferredMark)
               kCtrSurvivor = kNumBins + 10,  // [kNumBins words] pairs per bin of that second launch (k_defer_filter)
               kCtrWindowFail = 2 * kNumBins + 10,        // pairs of this round that left the ring-window kernel's band (length of its own list; cleared with kCtrSurvivor)
-              kCtrRetryWindowTotal = 2 * kNumBins + 11,  // ... added up over the batch
-              kNumCounters = 2 * kNumBins + 12, kNumRoundCounters = kNumBins + 4;
+              kCtrRetryWindowTotal = 2 * kNumBins + 11,  // [kWindowBins words] ... added up over the batch, per length class
+              kNumCounters = 2 * kNumBins + 11 + kWindowBins, kNumRoundCounters = kNumBins + 4;
 static_assert(kNumCounters <= 64, "launch_publish_words moves up to 64 words");
 
 // Two launches inside ONE pass-2 round.  A pass-2 loop steps over every hit whose taxon lies at or below unode_global (:771), and

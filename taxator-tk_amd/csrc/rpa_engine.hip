@@ -137,8 +137,8 @@ struct rpa_engine {
                               // reads a slot nobody wrote this batch then reads garbage every time, not whatever the last batch left)
   // what the bands cost: pairs sent through the banded kernels / re-run wide open, per batch.  A band that sends more
   // than a quarter of its pairs to the retry list (unrelated sequences) is switched off for the next 16 batches.
-  uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch = 0;
-  int band_short_pause = 0, band_long_pause = 0, band_window_pause = 0;
+  uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch[kWindowBins] = {};
+  int band_short_pause = 0, band_long_pause = 0, band_window_pause[kWindowBins] = {};  // (per length class: 500 nt reads may stay inside their window while 1500 nt contigs do not)
   bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..64 words go straight to the strip kernels (A/B; the same results)
   uint32_t band_window_min = 65536;  // fewer pairs than this in a launch: strips / one pair per wavefront as before (RPA_BAND_WINDOW_MIN; mixed-shape stream: 16384 and 4096 gain 2-3 % in flight and lose 4-9 % synchronous)
   int band4_wide = 0;        // > 0: the one-strip band with four words all the way (k = 96 - |delta|) for this many more batches:
@@ -353,7 +353,8 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
   uint64_t banded_short = 0;  // ... through the banded one-strip kernel (its own retry list and counter)
   int widest_short = 0;       // widest pattern class (in words) among the banded one-strip launches
   const bool use_band_long = e->band_long && e->band_long_pause == 0, use_band_short = e->band_short && e->band_short_pause == 0;
-  const bool use_window = e->band_window && e->band_window_pause == 0;
+  bool use_window = false, window_on[kWindowBins];
+  for (int k = 0; k < kWindowBins; ++k) { window_on[k] = e->band_window && e->band_window_pause[k] == 0; use_window = use_window || window_on[k]; }
   uint64_t window_pairs = 0;  // pairs that went through the ring-window kernel this round: the bound of its own list of pairs that left its band
   if (e->params.alphabet == RPA_DNA && use_window) {
     uint64_t wp = 0;
@@ -422,10 +423,11 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
         // Patterns of up to 64 words (bins kShortWords ... kFirstStripBin - 1), launches of the dense rounds: the ring-window kernel first
         // (K1r: one lane per pair, a window of 6 / 10 words around the diagonal, exact up to 160 / 288 edits minus the length
         // difference); what lies outside goes onto the strip kernels' retry list.
-        if (bin < kFirstStripBin && use_window && dna_window_available(window_words_of_bin(bin)) && n >= std::min(e->band_short_min, e->band_window_min) && e->long_kernel == 0) {
+        if (bin < kFirstStripBin && window_on[bin - kShortWords] && dna_window_available(window_words_of_bin(bin)) && n >= std::min(e->band_short_min, e->band_window_min) && e->long_kernel == 0) {
           HIP_TRY(e, launch_align_dna_window(st, window_words_of_bin(bin), list, n, w, e->window_fail.as<uint2>(), w.counters + kCtrWindowFail,
-                                             w.counters + kCtrRetryWindowTotal, acc));
+                                             w.counters + kCtrRetryWindowTotal + (bin - kShortWords), acc));
           window_pairs += n;
+          e->banded_window_batch[bin - kShortWords] += n;
         } else if (wave) HIP_TRY(e, launch_align_dna_long(st, (int)wpl, list, n, nullptr, 0, w, acc));
         else {
           DevBuf& ws = sk >= 0 ? e->side_ws[sk] : e->protein_ws;  // (a scratch per stream: the launches of a round run side by side)
@@ -533,7 +535,6 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
   }
   e->banded_short_batch += banded_short;
   e->banded_long_batch += banded_pairs - (use_band_long ? window_pairs : 0);
-  e->banded_window_batch += window_pairs;
   return RPA_OK;
 }
 
@@ -738,15 +739,20 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
         else if (e->band4_wide > 0) --e->band4_wide;
       }
       // (the retry launches count the whole retry list into kCtrRetryTotal; the ring-window kernel counts its own share)
-      const uint64_t from_window = e->h_counters[kCtrRetryWindowTotal];
+      uint64_t from_window = 0;
+      for (int k = 0; k < kWindowBins; ++k) {
+        const uint64_t left = e->h_counters[kCtrRetryWindowTotal + k];
+        from_window += left;
+        if (e->banded_window_batch[k] >= 1024 && left * 4 > e->banded_window_batch[k]) e->band_window_pause[k] = 16;
+        else if (e->band_window_pause[k]) --e->band_window_pause[k];
+        if (e->trace_rounds && e->banded_window_batch[k])
+          fprintf(stderr, "[rpa] batch done: %llu of %llu pairs left the ring window (class %d)\n", (unsigned long long)left, (unsigned long long)e->banded_window_batch[k], k);
+        e->banded_window_batch[k] = 0;
+      }
       const uint64_t from_strips = e->h_counters[kCtrRetryTotal] > from_window ? e->h_counters[kCtrRetryTotal] - from_window : 0;
       if (e->banded_long_batch >= 1024 && from_strips * 4 > e->banded_long_batch) e->band_long_pause = 16;
       else if (e->band_long_pause) --e->band_long_pause;
-      if (e->banded_window_batch >= 1024 && from_window * 4 > e->banded_window_batch) e->band_window_pause = 16;
-      else if (e->band_window_pause) --e->band_window_pause;
-      if (e->trace_rounds && e->banded_window_batch)
-        fprintf(stderr, "[rpa] batch done: %llu of %llu pairs left the ring window\n", (unsigned long long)from_window, (unsigned long long)e->banded_window_batch);
-      e->banded_short_batch = 0; e->banded_long_batch = 0; e->banded_window_batch = 0;
+      e->banded_short_batch = 0; e->banded_long_batch = 0;
       break;
     }
     uint32_t counts[kNumRoundCounters];
