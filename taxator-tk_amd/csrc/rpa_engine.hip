@@ -140,7 +140,7 @@ struct rpa_engine {
   uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch[kWindowBins] = {};
   int band_short_pause = 0, band_long_pause = 0, band_window_pause[kWindowBins] = {};  // (per length class: 500 nt reads may stay inside their window while 1500 nt contigs do not)
   bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..64 words go straight to the strip kernels (A/B; the same results)
-  uint32_t band_window_min = 65536;  // fewer pairs than this in a launch: strips / one pair per wavefront as before (RPA_BAND_WINDOW_MIN; mixed-shape stream: 16384 and 4096 gain 2-3 % in flight and lose 4-9 % synchronous)
+  uint32_t band_window_min = 16384;  // fewer pairs than this in a launch: strips / one pair per wavefront as before (RPA_BAND_WINDOW_MIN; mixed-shape stream, in flight / synchronous: 65536: 7.02 / 10.58 ms per step, 16384: 6.35 / 10.57, 4096: 6.49 / 10.63, 512: 6.27 / 10.86)
   int band4_wide = 0;        // > 0: the one-strip band with four words all the way (k = 96 - |delta|) for this many more batches:
                              //      too many pairs of a batch left the narrow one (k = 80 - |delta|); -1 / -2: fixed by RPA_BAND4_PHASES=2 / 3
   bool band_short = true;     // RPA_BAND_SHORT=0: the one-strip kernel computes every cell of 5..8-word patterns too
