@@ -602,7 +602,7 @@ int alloc_work(rpa_engine* e, uint32_t S, uint32_t H, uint32_t T, uint32_t T2, b
   if (e->poison) {
     DevBuf* bufs[] = {&e->state, &e->loop_save, &e->hits, &e->res_slot, &e->set_info, &e->emit, &e->emit_lite, &e->emit_ext, &e->hit_set, &e->block_first,
                       &e->flags, &e->lite, &e->seg, &e->pair_a, &e->pair_b, &e->pair_res, &e->pair_ext, &e->bin_list, &e->live_a, &e->live_b,
-                      &e->band_save, &e->og_idx, &e->og_dist, &e->retry_list, &e->retry_short, &e->protein_ws, &e->out_rows, &e->out_stats};
+                      &e->band_save, &e->og_idx, &e->og_dist, &e->retry_list, &e->retry_short, &e->window_fail, &e->protein_ws, &e->out_rows, &e->out_stats};
     for (DevBuf* b : bufs)
       if (b->p) HIP_TRY(e, hipMemsetAsync(b->p, 0xA5, b->cap, e->stream));
   }
@@ -1186,7 +1186,7 @@ void rpa_destroy(rpa_engine* e) {
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->emit_ext, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
-                    &e->protein_ws, &e->retry_list, &e->retry_short, &e->prof_acc, &e->part_offsets};
+                    &e->protein_ws, &e->retry_list, &e->retry_short, &e->window_fail, &e->prof_acc, &e->part_offsets};
   RPA_WHERE("rpa_destroy: hipFree of the buffers");
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();
