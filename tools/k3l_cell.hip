@@ -8,6 +8,9 @@
 //   MODE 3  the reads of column c+1 issued before the cells of column c (software pipeline, 24 more registers)
 //   MODE 4  reads in groups of 12
 //   MODE 5  MODE 3 with the reads of the second half of column c+1 issued in the middle of column c (12 more registers)
+//   MODE 6  MODE 0 with a table of 16-bit entries, [b][a][lane] (128 bytes per entry as before: two lanes per bank word), loaded into
+//           the HIGH half of a register whose low half holds the constant part of the addend (ds_read_u16_d16_hi): half the LDS bytes,
+//           no instruction more -- possible for the score-and-length cell, whose addend has nothing data-dependent below bit 16
 // Build: hipcc --offload-arch=gfx950 -O3 -o k3l_cell k3l_cell.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -27,8 +30,10 @@ __global__ __launch_bounds__(BLOCK) void k(uint32_t* out, uint32_t seed, uint32_
   for (int idx = threadIdx.x; idx < kAX * kAX * 32; idx += BLOCK) {
     const int b = idx / (kAX * 32), a = (idx / 32) % kAX;
     tab[idx] = ((uint32_t)(((a * 7 + b * 3) % 16) + 1) << kPkScore) + (1u << kPkMove) + (a == b ? 1u << kPkMatch : 0u) + 1u;
+    if (MODE == 6) { const uint32_t hi = tab[idx] >> 16; tab[idx] = hi | (hi << 16); }  // two identical 16-bit entries per word
   }
   __syncthreads();
+  const uint32_t lane2 = (threadIdx.x & 63u) * 2u;
   const uint8_t* __restrict__ tabb = reinterpret_cast<const uint8_t*>(tab);
   uint32_t c_horiz = 0u - (1u << kPkScore) - (1u << kPkMove), c_keep = ~(1u << kPkMove), c_one = 1u << kPkMove;
   asm volatile("" : "+v"(c_horiz), "+v"(c_keep), "+v"(c_one));
@@ -38,7 +43,7 @@ __global__ __launch_bounds__(BLOCK) void k(uint32_t* out, uint32_t seed, uint32_
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     h = h * 1664525u + 1013904223u;
-    rowoff[r] = ((h >> 24) % 27u) * (kAX * 128u) + bank4;
+    rowoff[r] = ((h >> 24) % 27u) * (kAX * 128u) + (MODE == 6 ? lane2 : bank4);
     L[r] = (300u << kPkScore) | c_one;
   }
   uint32_t dtop = L[0], bottom = L[0], res = 0;
@@ -75,7 +80,18 @@ __global__ __launch_bounds__(BLOCK) void k(uint32_t* out, uint32_t seed, uint32_
     else top = above + row0;
     uint32_t up = top, dg = dtop;
     dtop = top;
-    if (MODE == 0 || MODE == 1) {
+    if (MODE == 6) {  // (inline asm: the compiler selects ds_read_u16 + a v_perm for this pattern, not the d16_hi load; the wait is then ours to place)
+      uint32_t tv[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        tv[r] = 1u;
+        asm volatile("ds_read_u16_d16_hi %0, %1" : "+v"(tv[r]) : "v"(rowoff[r] + colterm));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r) asm volatile("" : "+v"(tv[r]));
+      cells(tv, 0, R, up, dg);
+    } else if (MODE == 0 || MODE == 1) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const uint32_t tv = MODE == 1 ? rowoff[r] + colterm : *reinterpret_cast<const uint32_t*>(tabb + rowoff[r] + colterm);
@@ -168,6 +184,8 @@ int main() {
   run<3, 512>("3 reads one column ahead", d_out, n);
   run<5, 1024>("5 reads half a column ahead", d_out, n);
   run<5, 768>("5 reads half a column ahead", d_out, n);
+  run<6, 1024>("6 16-bit table, d16_hi loads", d_out, n);
+  run<6, 512>("6 16-bit table, d16_hi loads", d_out, n);
   run<0, 1024, 1>("0 + the two selects as bitop3 masks", d_out, n);
   run<0, 1024, 2>("0 + no selects (add / xor instead)", d_out, n);
   run<1, 1024, 2>("1 no table, no selects", d_out, n);
