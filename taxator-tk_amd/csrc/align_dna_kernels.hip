@@ -995,6 +995,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_band(const uint2* __restrict__
   constexpr uint32_t HS = NW * 32u;
   const int tid = threadIdx.x;
   const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
+  if (n_list_dev && (*n_list_dev <= w.dev_count_lo || (w.dev_count_hi && *n_list_dev > w.dev_count_hi))) return;  // (another kernel's share of this list)
   if (n_list_dev && blockIdx.x == 0 && tid == 0 && total) atomicAdd(&w.counters[kCtrRetryTotal], total);
   uint32_t* __restrict__ sc = scratch + (blockIdx.x * kBlock + tid);  // boundary planes: group g, plane p at sc[(2g + p) * stride]
   unsigned long long upd_cells = 0;  // (profile) cells this lane updated: NW x 32 rows x 32 columns per group a strip swept
@@ -1176,6 +1177,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_myers_band_duo(const uint2* __res
   const int tid = threadIdx.x;
   const uint32_t lag = (uint32_t)tid & 1u;  // 0: lane A (upper strip of a round), 1: lane B (lower strip, one group behind)
   const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
+  if (n_list_dev && (*n_list_dev <= w.dev_count_lo || (w.dev_count_hi && *n_list_dev > w.dev_count_hi))) return;  // (another kernel's share of this list)
   if (n_list_dev && blockIdx.x == 0 && tid == 0 && total) atomicAdd(&w.counters[kCtrRetryTotal], total);
   uint32_t* __restrict__ sc = scratch + (blockIdx.x * kPairs + ((uint32_t)tid >> 1));  // per PAIR: group g, plane p at sc[(2g + p) * stride]
   unsigned long long upd_cells = 0;  // (profile) cells this lane updated: NW x 32 rows x 32 columns per group it swept
@@ -1429,6 +1431,7 @@ __global__ __launch_bounds__(64) void k_myers_long(const uint2* __restrict__ lis
   // n_list_dev != null: a retry list whose length only the device knows (n_list bounds it); the grid strides over it
   const uint32_t total = n_list_dev ? (*n_list_dev < n_list ? *n_list_dev : n_list) : n_list;
   const int lane = threadIdx.x;
+  if (n_list_dev && (*n_list_dev <= w.dev_count_lo || (w.dev_count_hi && *n_list_dev > w.dev_count_hi))) return;  // (another kernel's share of this list)
   if (n_list_dev && blockIdx.x == 0 && lane == 0 && total) atomicAdd(&w.counters[kCtrRetryTotal], total);
   for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
   uint32_t a, b, dst;

@@ -231,6 +231,9 @@ struct WorkDev {
   // pass-1 scratch (per set region like the pair slots)
   float* band_save;     // S * 2*band_ranks: BandFactor accumulators of paused pass-1 loops
   uint32_t band_ranks;  // deepest taxonomy level + 1: rows of the LDS accumulators of k_decide
+  // a launch over a list whose length only the device knows (k_myers_band / _band_duo / k_myers_long): the kernel works only if
+  // dev_count_lo < length (and length <= dev_count_hi, when that is not 0) -- two kernels queued on one list, the right one runs
+  uint32_t dev_count_lo, dev_count_hi;
   // live lists: plan/decide append every set that is still running to live_out; a sparse round (few live sets) runs
   // emit/decide over live_in instead of over the whole batch
   const uint32_t* live_in;  // null in dense rounds

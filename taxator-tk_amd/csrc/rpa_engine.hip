@@ -140,6 +140,7 @@ struct rpa_engine {
   uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch[kWindowBins] = {};
   int band_short_pause = 0, band_long_pause = 0, band_window_pause[kWindowBins] = {};  // (per length class: 500 nt reads may stay inside their window while 1500 nt contigs do not)
   bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..64 words go straight to the strip kernels (A/B; the same results)
+  uint32_t window_fail_wave_max = 8192;  // up to this many pairs that left the ring window: one pair per wavefront (RPA_WINDOW_FAIL_WAVE_MAX; 0: always the strips)
   uint32_t band_window_min = 16384;  // fewer pairs than this in a launch: strips / one pair per wavefront as before (RPA_BAND_WINDOW_MIN; mixed-shape stream, in flight / synchronous: 65536: 7.02 / 10.58 ms per step, 16384: 6.35 / 10.57, 4096: 6.49 / 10.63, 512: 6.27 / 10.86)
   int band4_wide = 0;        // > 0: the one-strip band with four words all the way (k = 96 - |delta|) for this many more batches:
                              //      too many pairs of a batch left the narrow one (k = 80 - |delta|); -1 / -2: fixed by RPA_BAND4_PHASES=2 / 3
@@ -503,8 +504,19 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
     LaunchTimer timer{e};
     int trc = timer.begin();
     if (trc) return trc;
+    // (a few thousand pairs: one per wavefront, every cell -- a strip launch takes ~0.5 ms however few pairs it carries, as every
+    // lane-per-pair kernel takes what one lane takes.  Both are queued; the list's length decides on the device which of them works.)
+    const uint32_t few = max_len <= kWaveMaxPattern ? e->window_fail_wave_max : 0u;
+    WorkDev wk = w;
+    if (few) {
+      const uint32_t wpl = ((max_len + 31u) / 32u + 63u) / 64u;
+      wk.dev_count_lo = 0; wk.dev_count_hi = few;
+      HIP_TRY(e, launch_align_dna_long(e->stream, (int)(wpl ? wpl : 1u), e->window_fail.as<uint2>(), std::min(bound, few), w.counters + kCtrWindowFail,
+                                       16384u, wk, nullptr));
+    }
+    wk.dev_count_lo = few; wk.dev_count_hi = 0;
     HIP_TRY(e, e->protein_ws.ensure(dna_strip_scratch_words(std::min(bound, blocks * (uint32_t)kBlock), max_len) * 4));
-    HIP_TRY(e, launch_align_dna_strips(e->stream, kStripMaxWords, e->window_fail.as<uint2>(), bound, w.counters + kCtrWindowFail, blocks, w,
+    HIP_TRY(e, launch_align_dna_strips(e->stream, kStripMaxWords, e->window_fail.as<uint2>(), bound, w.counters + kCtrWindowFail, blocks, wk,
                                        e->protein_ws.as<uint32_t>(), e->protein_ws.cap / 4, max_len, !use_band_long, e->band_margin,
                                        e->retry_list.as<uint2>(), w.counters + kCtrRetry, nullptr));
     if (use_band_long) banded_pairs += window_pairs;
@@ -873,7 +885,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; w->band_window_min = e->band_window_min; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
+  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; w->band_window_min = e->band_window_min; w->window_fail_wave_max = e->window_fail_wave_max; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->side_streams_on = e->side_streams_on;
   w->defer_mode = e->defer_mode;
@@ -1053,6 +1065,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_BAND_SHORT_MIN")) e->band_short_min = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_WINDOW")) e->band_window = atoi(v) != 0;
   if (const char* v = getenv("RPA_BAND_WINDOW_MIN")) e->band_window_min = (uint32_t)atoi(v);
+  if (const char* v = getenv("RPA_WINDOW_FAIL_WAVE_MAX")) e->window_fail_wave_max = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_GAIN")) e->band_gain = atof(v);
   if (const char* v = getenv("RPA_BAND_MARGIN")) e->band_margin = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
