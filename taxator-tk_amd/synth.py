@@ -418,7 +418,7 @@ def write_files(ds, folder, line_width=80):
     n_species = len(ds.ref_offsets) - 1
     with open(os.path.join(folder, "mapping.tax"), "w") as f:
         for s in range(n_species):
-            f.write("ref%d\t%s\n" % (s, ds.tax.taxid[int(ds.tax.species[s])]))
+            f.write("ref%d\t%s\n" % (s, ds.tax.taxid[int(ds.tax.species[s % len(ds.tax.species)])]))  # (make_ragged_dataset: one reference collection per class, back to back)
     with open(os.path.join(folder, "ref" + ext), "wb") as f, open(os.path.join(folder, "ref" + ext + ".fai"), "w") as fai:
         for s in range(n_species):
             seq = ds.ref_letters[int(ds.ref_offsets[s]):int(ds.ref_offsets[s + 1])].tobytes()
@@ -431,7 +431,7 @@ def write_files(ds, folder, line_width=80):
         qo = np.asarray(ds.query_offsets).astype(np.int64).tolist()
         whole = ds.query_letters.tobytes()
         parts = []
-        for s in range(ds.n_sets):
+        for s in range(len(qo) - 1):
             seq = whole[qo[s]:qo[s + 1]]
             parts.append(b">q%d\n" % s)
             parts.extend(seq[i:i + line_width] + b"\n" for i in range(0, len(seq), line_width))
@@ -443,13 +443,14 @@ def write_files(ds, folder, line_width=80):
     so = np.asarray(b["set_offsets"]).astype(np.int64)
     set_of = np.repeat(np.arange(ds.n_sets, dtype=np.int64), np.diff(so))
     qlen = np.asarray(b["query_len"])[set_of]
+    qname = np.asarray(b["query_seq"]).astype(np.int64)[set_of] if "query_seq" in b else set_of  # (the query of set s is query_seq[s]: s itself except in make_ragged_dataset's shuffled streams)
     star = np.asarray(b["filtered"]).astype(bool) if "filtered" in b and b["filtered"] is not None else np.zeros(len(set_of), bool)
     fmt = "%sq%d\t%d\t%d\t%d\tref%d\t%d\t%d\t%g\t0\t%d\t%d\n"
     with open(os.path.join(folder, "aln.tsv"), "w") as f:
         step = 250000
         for lo in range(0, len(set_of), step):
             hi = min(len(set_of), lo + step)
-            cols = [np.where(star[lo:hi], "*", "").tolist(), set_of[lo:hi].tolist(), b["qstart"][lo:hi].tolist(), b["qstop"][lo:hi].tolist(),
+            cols = [np.where(star[lo:hi], "*", "").tolist(), qname[lo:hi].tolist(), b["qstart"][lo:hi].tolist(), b["qstop"][lo:hi].tolist(),
                     qlen[lo:hi].tolist(), b["ref_seq"][lo:hi].tolist(), b["rstart"][lo:hi].tolist(), b["rstop"][lo:hi].tolist(),
                     np.asarray(b["score"][lo:hi], np.float64).tolist(), b["identities"][lo:hi].tolist(), b["alnlen"][lo:hi].tolist()]
             f.write("".join([fmt % r for r in zip(*cols)]))

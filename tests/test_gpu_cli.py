@@ -146,6 +146,32 @@ def test_cli_config1_plumbing(oracle, tmp_path):
     assert [int(l[3]) + int(l[4]) + int(l[5]) for l in stats_lines] == [int(x) for x in st["pass0"] + st["pass1"] + st["pass2"]]
 
 
+@pytest.mark.parametrize("force_bands", [False, True])
+def test_cli_mixed_segment_lengths(oracle, tmp_path, force_bands, monkeypatch):
+    """A stream of record sets of mixed shape through the driver -- segments of 120 ... 1500 nt, 8 ... 100 hits per set, shuffled --
+    so that one batch holds every nucleotide kernel family: one-strip classes up to 12 words, the ring-window classes (385 ... 2048 nt)
+    in front of the register strips, one pair per wavefront for the few.  With the banded launches forced onto launches of any size
+    and with the engine's own choices; several GPU calls; GFF3 equal to the oracle's either way."""
+    graft.load_package()
+    synth = importlib.import_module("taxator_tk_amd.synth")
+    if force_bands: monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")
+    ds = synth.make_ragged_dataset([(150, 8, 150), (40, 20, 300), (30, 12, 500), (16, 10, 1000), (6, 10, 1500), (10, 100, 120)], seed=11, branching=3)
+    folder = str(tmp_path / "ragged")
+    synth.write_files(ds, folder)
+    r = _run(folder, ".fna", ["--batch", "61"])
+    assert r.returncode == 0, r.stderr
+    r2 = _run(folder, ".fna", ["--record-objects"])
+    assert r2.returncode == 0 and r2.stdout == r.stdout
+    fds = R.Dataset(folder, 0)
+    b = fds.batch()
+    tax = oracle.TaxArrays(fds.tax.parent, fds.tax.left, fds.tax.right, fds.tax.depth)
+    q = oracle.StoreArrays(fds.query.residues, fds.query.offsets)
+    db = oracle.StoreArrays(fds.ref.residues, fds.ref.offsets)
+    rc, out, st = oracle.predict_batch(tax, q, db, 0, b["offsets"], b["qseq"], b["qlen"], b["recs"])
+    assert rc == 0
+    assert r.stdout == fds.gff3(out, b["qids"], b["qlen"])
+
+
 def _multi_segment_dataset(synth, folder, seed, shuffle):
     """A synthetic data set whose queries carry SEVERAL segments (1-4 record sets of the generator joined into one query,
     some of them overlapping so that the split rule has to merge them), lines of a query position-sorted or shuffled."""
