@@ -935,6 +935,13 @@ def main():
                 sec["c2_ragged"] = ragged_bench.run(pkg, synth, torch, steps=5, in_flight=args.in_flight)
             except Exception as e:
                 sec["c2_ragged"] = {"error": repr(e)}
+            try:  # the pair rate across the kernel families' length classes (tools/pairs_bench.py): no cliff between them
+                import pairs_bench
+                rates = pairs_bench.sweep(pkg, synth, "dna", [200, 256, 260, 320, 384, 390, 512, 768, 1024, 1536], mut=0.12, calls=2)
+                sec["dna_pair_rates"] = {"workload": "launches of up to 400 k random nucleotide pairs of one length (~12 % edits) through rpa_align_pairs, in-kernel time: one-strip kernels up to 384 nt, the ring-window kernel (K1r) up to 2048 nt, register strips beyond",
+                                         "rates": [{"length": r["length"], "pairs": r["pairs"], "alignments_per_s": r["alignments_per_s"], "cell_equivalents_per_s": r["cell_equivalents_per_s"]} for r in rates]}
+            except Exception as e:
+                sec["dna_pair_rates"] = {"error": repr(e)}
             sec["c2_hbm_store"] = measure_hbm_store(4000, out["ms_per_step"], out["sync_unprofiled_ms_per_step"])
             out["secondary"] = sec
         print(json.dumps(out))

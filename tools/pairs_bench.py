@@ -9,8 +9,6 @@ the alignment kernels (rpa_profile.align_ms).  Measurement tool only; parity liv
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-rpa = importlib.import_module("taxator-tk_amd")
-synth = importlib.import_module("taxator-tk_amd.synth")
 
 
 def make_pairs(rng, alphabet, L, n_pairs):
@@ -30,25 +28,38 @@ def make_pairs(rng, alphabet, L, n_pairs):
     return letters, np.array(offs, np.uint64), pa, pa + 1
 
 
-def main():
-    alphabet = sys.argv[1] if len(sys.argv) > 1 else "dna"
-    lens = [int(x) for x in sys.argv[2:]] or ([100, 200, 256, 300, 400, 600, 1000, 1500, 2048, 3000, 5000, 10000, 16000] if alphabet == "dna" else [67, 200, 500])
+def sweep(rpa, synth, alphabet, lens, mut=None, calls=3):
+    """[{length, pairs, alignments_per_s, cell_equivalents_per_s, ms_per_call}] for launches of random pairs of each length through
+    rpa_align_pairs (in-kernel time); bench.py reports a short one as secondary.dna_pair_rates."""
+    if mut is not None: os.environ["PAIRS_MUT"] = str(mut)
     tax = synth.MockTaxonomy(2)
     model = rpa.RPAPredictionModel(tax, rpa.DNA if alphabet == "dna" else rpa.PROTEIN)
     model.profile(enable=True)
     rng = np.random.default_rng(7)
     budget = 2e11 if alphabet == "dna" else 4e9
+    out = []
     for L in lens:
         n_pairs = int(min(400000, max(256, budget / (L * L))))
         letters, offs, pa, pb = make_pairs(rng, alphabet, L, n_pairs)
         model.align_pairs(letters, offs, pa, pb)  # warm-up
         model.profile(reset=True)
-        for _ in range(3):
+        for _ in range(calls):
             model.align_pairs(letters, offs, pa, pb)
         p = model.profile()
         s = p["align_ms"] / 1e3
-        print(f"{alphabet} L={L:6d} pairs/launch={n_pairs:7d}  {p['pairs'] / s:12.4g} alignments/s  {p['cells'] / s / 1e12:7.2f} T cells/s"
-              f"  ({p['align_ms'] / 3:.2f} ms per call)", flush=True)
+        out.append({"length": L, "pairs": n_pairs, "alignments_per_s": p["pairs"] / s, "cell_equivalents_per_s": p["cells"] / s, "ms_per_call": p["align_ms"] / calls})
+    model.close()
+    return out
+
+
+def main():
+    rpa = importlib.import_module("taxator-tk_amd")
+    synth = importlib.import_module("taxator-tk_amd.synth")
+    alphabet = sys.argv[1] if len(sys.argv) > 1 else "dna"
+    lens = [int(x) for x in sys.argv[2:]] or ([100, 200, 256, 300, 400, 600, 1000, 1500, 2048, 3000, 5000, 10000, 16000] if alphabet == "dna" else [67, 200, 500])
+    for r in sweep(rpa, synth, alphabet, lens):
+        print(f"{alphabet} L={r['length']:6d} pairs/launch={r['pairs']:7d}  {r['alignments_per_s']:12.4g} alignments/s  {r['cell_equivalents_per_s'] / 1e12:7.2f} T cells/s"
+              f"  ({r['ms_per_call']:.2f} ms per call)", flush=True)
 
 
 if __name__ == "__main__":
