@@ -501,7 +501,7 @@ def embed_in_big_tree(tax, n_total, max_depth, seed=7):
     return t
 
 
-def make_ragged_dataset(classes, seed=1, device="cpu", branching=4, shuffle=True, level_rate=0.03, query_rate=0.05):
+def make_ragged_dataset(classes, seed=1, device="cpu", branching=4, shuffle=True, level_rate=0.03, query_rate=0.05, alphabet=0):
     """Record sets of MIXED shape in one batch: `classes` = [(n_sets, n_hits, seg_len), ...]; every class is a make_dataset()
     workload of its own (own genomes, same mock taxonomy), the classes' reference and query collections laid out back to back
     in one store each, the record sets of all classes shuffled into one stream.  Sets of 1 ... hundreds of hits and segments
@@ -511,9 +511,9 @@ def make_ragged_dataset(classes, seed=1, device="cpu", branching=4, shuffle=True
     parts = []
     for k, (n_sets, n_hits, seg_len) in enumerate(classes):
         parts.append(make_dataset(n_sets=n_sets, n_hits=n_hits, seg_len=seg_len, branching=branching, genome_len=max(2000, 4 * seg_len),
-                                  seed=seed * 1000 + k, device=device, level_rate=level_rate, query_rate=query_rate))
+                                  seed=seed * 1000 + k, device=device, level_rate=level_rate, query_rate=query_rate, alphabet=alphabet))
     ds = Dataset()
-    ds.alphabet = 0
+    ds.alphabet = alphabet
     ds.tax = parts[0].tax
     ds.n_sets = sum(p.n_sets for p in parts)
     ds.n_hits = None
