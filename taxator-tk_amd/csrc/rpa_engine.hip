@@ -769,6 +769,11 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     }
     uint32_t counts[kNumRoundCounters];
     memcpy(counts, e->h_counters, sizeof(counts));
+    // (a length class whose pairs are leaving the ring window in this very batch -- the totals of the rounds so far came with the
+    // counters -- does not try it again in the rounds that follow; the pause then lasts its 16 batches from the end of this one)
+    for (int k = 0; k < kWindowBins; ++k)
+      if (e->band_window_pause[k] == 0 && e->banded_window_batch[k] >= 1024 && (uint64_t)e->h_counters[kCtrRetryWindowTotal + k] * 4 > e->banded_window_batch[k])
+        e->band_window_pause[k] = 1;
     if (rounds == 0 && e->params.alphabet == RPA_DNA) {
       uint64_t all = 0, strips = 0;
       for (int k = 0; k < kNumBins; ++k) { all += counts[k]; if (k >= kShortWords) strips += counts[k]; }
