@@ -694,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void k_myers_window(const uint2* __restrict
                                                           uint32_t* __restrict__ retry_n, uint32_t* __restrict__ retry_total,
                                                           unsigned long long* prof_acc) {
   static_assert(WW % 2 == 0 && WW >= 4, "an even number of words");
-  extern __shared__ uint32_t peq_ring[];  // [symbol][slot][lane]: 5 x WW KB per workgroup (30 / 50 KB)
+  extern __shared__ uint32_t peq_ring[];  // [symbol][slot][lane]: 5 x WW KB per workgroup (30 / 50 / 70 KB)
   const int tid = threadIdx.x;
   const uint32_t t = blockIdx.x * kBlock + tid;
   const bool active = t < n_list;
@@ -937,7 +937,7 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
   return hipGetLastError();
 }
 
-bool dna_window_available(int window_words) { return window_words == 6 || window_words == 10; }
+bool dna_window_available(int window_words) { return window_words == 6 || window_words == 10 || window_words == 14; }
 
 hipError_t launch_align_dna_window(hipStream_t st, int window_words, const uint2* list, uint32_t n, const WorkDev& w, uint2* retry,
                                    uint32_t* retry_n, uint32_t* retry_total, unsigned long long* prof_acc) {
@@ -948,6 +948,13 @@ hipError_t launch_align_dna_window(hipStream_t st, int window_words, const uint2
   switch (window_words) {
     case 6: hipLaunchKernelGGL(k_myers_window<6>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, retry, retry_n, retry_total, prof_acc); break;
     case 10: hipLaunchKernelGGL(k_myers_window<10>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, retry, retry_n, retry_total, prof_acc); break;
+    case 14: {  // 70 KB of ring: beyond what a launch may ask for without saying so
+      // (per launch, not once: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive several -- taxator --devices)
+      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_myers_window<14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (attr != hipSuccess) return attr;
+      hipLaunchKernelGGL(k_myers_window<14>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, retry, retry_n, retry_total, prof_acc);
+      break;
+    }
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -18,7 +18,8 @@ constexpr int kWindowBins = 3;       // patterns of 13..16 / 17..32 / 33..64 wor
 constexpr int kWindowMaxWords = 64;
 constexpr int kFirstStripBin = kShortWords + kWindowBins;
 constexpr int kDnaBins = kFirstStripBin + kStripBins;  // bins 0..11: one strip of bin+1 words; 12, 13, 14: up to 16 / 32 / 64 words; 15..18: strips of bin-10 words
-__host__ __device__ constexpr int window_words_of_bin(int bin) { return bin == kShortWords ? 6 : 10; }
+// window words of a class: the narrow instance, and the wide one the engine moves to when more than a quarter of a batch's pairs left the narrow one
+__host__ __device__ constexpr int window_words_of_bin(int bin, bool wide = false) { return bin == kShortWords ? (wide ? 10 : 6) : (wide ? 14 : 10); }
 constexpr int kNumBins = 22;         // work lists per round: the nucleotide bins above, or the 22 protein bins below
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;

@@ -139,6 +139,8 @@ struct rpa_engine {
   // than a quarter of its pairs to the retry list (unrelated sequences) is switched off for the next 16 batches.
   uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch[kWindowBins] = {};
   int band_short_pause = 0, band_long_pause = 0, band_window_pause[kWindowBins] = {};  // (per length class: 500 nt reads may stay inside their window while 1500 nt contigs do not)
+  int band_window_wide[kWindowBins] = {};  // > 0: the class runs the wide instance of the ring window for that many more batches (-1: always, RPA_BAND_WINDOW_WIDE=1)
+  uint64_t window_seen_pairs[kWindowBins] = {}, window_seen_left[kWindowBins] = {};  // what the current instance's share of the batch's counters starts from
   bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..64 words go straight to the strip kernels (A/B; the same results)
   uint32_t window_fail_wave_max = 8192;  // up to this many pairs that left the ring window: one pair per wavefront (RPA_WINDOW_FAIL_WAVE_MAX; 0: always the strips)
   uint32_t band_window_min = 16384;  // fewer pairs than this in a launch: strips / one pair per wavefront as before (RPA_BAND_WINDOW_MIN; mixed-shape stream, in flight / synchronous: 65536: 7.02 / 10.58 ms per step, 16384: 6.35 / 10.57, 4096: 6.49 / 10.63, 512: 6.27 / 10.86)
@@ -424,8 +426,9 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
         // Patterns of up to 64 words (bins kShortWords ... kFirstStripBin - 1), launches of the dense rounds: the ring-window kernel first
         // (K1r: one lane per pair, a window of 6 / 10 words around the diagonal, exact up to 160 / 288 edits minus the length
         // difference); what lies outside goes onto the strip kernels' retry list.
-        if (bin < kFirstStripBin && window_on[bin - kShortWords] && dna_window_available(window_words_of_bin(bin)) && n >= std::min(e->band_short_min, e->band_window_min) && e->long_kernel == 0) {
-          HIP_TRY(e, launch_align_dna_window(st, window_words_of_bin(bin), list, n, w, e->window_fail.as<uint2>(), w.counters + kCtrWindowFail,
+        const int wwords = bin < kFirstStripBin ? window_words_of_bin(bin, e->band_window_wide[bin - kShortWords] != 0) : 0;
+        if (bin < kFirstStripBin && window_on[bin - kShortWords] && dna_window_available(wwords) && n >= std::min(e->band_short_min, e->band_window_min) && e->long_kernel == 0) {
+          HIP_TRY(e, launch_align_dna_window(st, wwords, list, n, w, e->window_fail.as<uint2>(), w.counters + kCtrWindowFail,
                                              w.counters + kCtrRetryWindowTotal + (bin - kShortWords), acc));
           window_pairs += n;
           e->banded_window_batch[bin - kShortWords] += n;
@@ -660,6 +663,18 @@ struct GateOpener {  // opens the gate on every way out of predict_part
   ~GateOpener() { g.open(); }
 };
 
+// The ring window's feedback, per length class, from the counters every round publishes (`left_total` = pairs of the class that
+// left the window in this batch so far): more than a quarter of the pairs the CURRENT instance saw left it -> the narrow instance
+// hands over to the wide one (for this batch's remaining rounds and 16 batches), the wide one to the strips (a pause of 16 batches).
+void window_feedback(rpa_engine* e, int k, uint64_t left_total) {
+  const uint64_t pairs = e->banded_window_batch[k] - e->window_seen_pairs[k], left = left_total - e->window_seen_left[k];
+  if (e->band_window_pause[k] != 0 || pairs < 1024 || left * 4 <= pairs) return;
+  if (e->band_window_wide[k] == 0) e->band_window_wide[k] = 17;   // (17: the end of this batch takes one off)
+  else e->band_window_pause[k] = 17;
+  e->window_seen_pairs[k] = e->banded_window_batch[k];
+  e->window_seen_left[k] = left_total;
+}
+
 int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const StoreDev& db, void* rows_dev, void* stats_dev, PartGate& gate) {
   GateOpener opener{gate};
   const uint32_t S = b.n_sets, H = b.n_records, T = H + S;
@@ -755,11 +770,13 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
       for (int k = 0; k < kWindowBins; ++k) {
         const uint64_t left = e->h_counters[kCtrRetryWindowTotal + k];
         from_window += left;
-        if (e->banded_window_batch[k] >= 1024 && left * 4 > e->banded_window_batch[k]) e->band_window_pause[k] = 16;
-        else if (e->band_window_pause[k]) --e->band_window_pause[k];
+        window_feedback(e, k, left);
         if (e->trace_rounds && e->banded_window_batch[k])
-          fprintf(stderr, "[rpa] batch done: %llu of %llu pairs left the ring window (class %d)\n", (unsigned long long)left, (unsigned long long)e->banded_window_batch[k], k);
-        e->banded_window_batch[k] = 0;
+          fprintf(stderr, "[rpa] batch done: %llu of %llu pairs left the ring window (class %d; next batch: %s)\n", (unsigned long long)left, (unsigned long long)e->banded_window_batch[k], k,
+                  e->band_window_pause[k] > 1 ? "strips" : e->band_window_wide[k] > 1 || e->band_window_wide[k] < 0 ? "wide window" : "narrow window");
+        if (e->band_window_pause[k]) { if (--e->band_window_pause[k] == 0) e->band_window_wide[k] = e->band_window_wide[k] < 0 ? -1 : 0; }  // (after a pause: the narrow one again)
+        else if (e->band_window_wide[k] > 0) --e->band_window_wide[k];
+        e->banded_window_batch[k] = 0; e->window_seen_pairs[k] = 0; e->window_seen_left[k] = 0;
       }
       const uint64_t from_strips = e->h_counters[kCtrRetryTotal] > from_window ? e->h_counters[kCtrRetryTotal] - from_window : 0;
       if (e->banded_long_batch >= 1024 && from_strips * 4 > e->banded_long_batch) e->band_long_pause = 16;
@@ -771,9 +788,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     memcpy(counts, e->h_counters, sizeof(counts));
     // (a length class whose pairs are leaving the ring window in this very batch -- the totals of the rounds so far came with the
     // counters -- does not try it again in the rounds that follow; the pause then lasts its 16 batches from the end of this one)
-    for (int k = 0; k < kWindowBins; ++k)
-      if (e->band_window_pause[k] == 0 && e->banded_window_batch[k] >= 1024 && (uint64_t)e->h_counters[kCtrRetryWindowTotal + k] * 4 > e->banded_window_batch[k])
-        e->band_window_pause[k] = 1;
+    for (int k = 0; k < kWindowBins; ++k) window_feedback(e, k, e->h_counters[kCtrRetryWindowTotal + k]);
     if (rounds == 0 && e->params.alphabet == RPA_DNA) {
       uint64_t all = 0, strips = 0;
       for (int k = 0; k < kNumBins; ++k) { all += counts[k]; if (k >= kShortWords) strips += counts[k]; }
@@ -890,7 +905,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; w->band_window_min = e->band_window_min; w->window_fail_wave_max = e->window_fail_wave_max; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
+  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; for (int k = 0; k < kWindowBins; ++k) w->band_window_wide[k] = e->band_window_wide[k] < 0 ? -1 : 0; w->band_window_min = e->band_window_min; w->window_fail_wave_max = e->window_fail_wave_max; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->side_streams_on = e->side_streams_on;
   w->defer_mode = e->defer_mode;
@@ -1070,6 +1085,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_BAND_SHORT_MIN")) e->band_short_min = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_WINDOW")) e->band_window = atoi(v) != 0;
   if (const char* v = getenv("RPA_BAND_WINDOW_MIN")) e->band_window_min = (uint32_t)atoi(v);
+  if (const char* v = getenv("RPA_BAND_WINDOW_WIDE")) { if (atoi(v) != 0) for (int k = 0; k < kWindowBins; ++k) e->band_window_wide[k] = -1; }
   if (const char* v = getenv("RPA_WINDOW_FAIL_WAVE_MAX")) e->window_fail_wave_max = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_GAIN")) e->band_gain = atof(v);
   if (const char* v = getenv("RPA_BAND_MARGIN")) e->band_margin = (uint32_t)atoi(v);

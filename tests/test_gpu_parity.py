@@ -114,7 +114,7 @@ def test_dna_pairs_random_all_bins(pkg, oracle, long_kernel, monkeypatch):
     assert out.tobytes() == out2.tobytes()
 
 
-@pytest.mark.parametrize("band", ["forced", "forced-retries-pair-per-lane", "four-words", "five-words", "off"])
+@pytest.mark.parametrize("band", ["forced", "forced-retries-pair-per-lane", "four-words", "five-words", "off", "wide-ring-window"])
 def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     """Patterns of 5..12 words (129..384 nt) go through a one-strip kernel that only updates the pattern words within two
     words of the diagonal; pairs whose distance lies outside that band (or whose lengths differ by 64 and more) are
@@ -128,6 +128,7 @@ def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
     if band == "off": monkeypatch.setenv("RPA_BAND_SHORT", "0")
     if band == "five-words": monkeypatch.setenv("RPA_BAND_WORDS", "5")  # the in-phase window (k = 128 - |delta|)
     if band == "four-words": monkeypatch.setenv("RPA_BAND4_PHASES", "2")  # four words all the way, out of phase (96); default: a three-word middle (80)
+    if band == "wide-ring-window": monkeypatch.setenv("RPA_BAND_WINDOW_WIDE", "1")  # K1r's wide instances (10 / 14 words: 288 / 416 edits) instead of 6 / 10
     rng = np.random.default_rng(12)
     m = pkg.RPAPredictionModel(OneNodeTax(), alphabet=pkg.DNA)
     a_codes, b_codes = [], []
@@ -136,7 +137,7 @@ def test_dna_short_pairs_band(pkg, oracle, band, monkeypatch):
                385, 400, 415, 416, 417, 450, 480, 511, 512, 513, 530, 544, 545, 600, 700, 767, 768, 769, 900, 1000, 1023, 1024,
                1025, 1300, 1600, 2047, 2048, 2049]:  # (13 ... 64 words: the ring window, K1r)
         for rate in [0.0, 0.02, 0.1, 0.25, 0.32, 0.4, 0.6, 1.0]:
-            for extra in [0, 3, 31, 40, 63, 64, 65, 100] + ([79, 80, 81, 143, 144, 145, 200] if la > 384 else []):  # (K1r: length differences around 80 and 144)
+            for extra in [0, 3, 31, 40, 63, 64, 65, 100] + ([79, 80, 81, 143, 144, 145, 200, 207, 208, 209] if la > 384 else []):  # (K1r: length differences around 80, 144 and 208)
                 a = rng.integers(0, 5 if rate > 0.3 else 4, la).astype(np.uint8)
                 r = rng.random(la)
                 b = a.copy()

@@ -217,7 +217,7 @@ def check_window_ring(trials=4000, seed=9):
     rng = random.Random(seed)
     hit = 0
     for t in range(trials):
-        W = rng.choice([4, 8]); WW = rng.choice([4, 6, 8, 10])
+        W = rng.choice([4, 8]); WW = rng.choice([4, 6, 8, 10, 14])
         m = rng.randint(1, 14 * W)
         a = [rng.randrange(3) for _ in range(m)]
         b = []

@@ -11,7 +11,7 @@ from helpers import oracle as O
 
 KNOBS = ("RPA_PASS1_FILTER", "RPA_LABEL_BITS", "RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
          "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND4_PHASES", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL",
-         "RPA_PROTEIN_LANES", "RPA_SHORT_WAVE_MAX", "RPA_DEFER2", "RPA_SIDE_STREAMS", "RPA_BAND_WINDOW")
+         "RPA_PROTEIN_LANES", "RPA_SHORT_WAVE_MAX", "RPA_DEFER2", "RPA_SIDE_STREAMS", "RPA_BAND_WINDOW", "RPA_BAND_WINDOW_WIDE")
 
 
 def fill_windows(pkg, model, ds, tile):
@@ -104,6 +104,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
           if rng.random() < 0.15: env["RPA_BAND"] = "0"
           if rng.random() < 0.15: env["RPA_BAND_SHORT"] = "0"
           if rng.random() < 0.15: env["RPA_BAND_WINDOW"] = "0"
+          elif rng.random() < 0.3: env["RPA_BAND_WINDOW_WIDE"] = "1"
           if alphabet == 0 and seg > 256 and rng.random() < 0.5: env["RPA_LONG_KERNEL"] = "lane"
       if alphabet == 1 and rng.random() < 0.3: env["RPA_PROTEIN_LANES"] = "0"
       if alphabet == 0 and rng.random() < 0.4: env["RPA_SHORT_WAVE_MAX"] = str(int(rng.choice([0, 64, 1000000])))  # round 4: K1w (a pattern word per lane) never / for tiny launches / always

@@ -30,7 +30,7 @@ def mutate(a, rng, asize, rate):
     return b.astype(np.uint8)
 
 
-KNOBS = ("RPA_LONG_KERNEL", "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND4_PHASES", "RPA_BAND_DUO")
+KNOBS = ("RPA_LONG_KERNEL", "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND4_PHASES", "RPA_BAND_DUO", "RPA_BAND_WINDOW_WIDE")
 
 
 def run(n_batches=20, rng_seed=777, verbose=True):
@@ -54,6 +54,7 @@ def run(n_batches=20, rng_seed=777, verbose=True):
                 if rng.random() < 0.3: os.environ["RPA_BAND_WORDS"] = "5"
                 elif rng.random() < 0.3: os.environ["RPA_BAND4_PHASES"] = "2"
                 if rng.random() < 0.3: os.environ["RPA_BAND_DUO"] = "0"
+                if rng.random() < 0.3: os.environ["RPA_BAND_WINDOW_WIDE"] = "1"  # (round 5: K1r's wide instances)
         else:
             top = int(rng.choice([30, 80, 260, 330, 520, 800]))
             n = int(rng.integers(100, 1500)) if top <= 330 else int(rng.integers(20, 200))
