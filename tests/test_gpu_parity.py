@@ -715,6 +715,39 @@ def test_band_widens_when_too_many_pairs_leave_it(pkg, oracle, synth, monkeypatc
     assert left[1][2] == "four" and left[2][2] == "four" and left[1][0] < left[0][0], left  # ... so the next batches run in the wide one
 
 
+def test_ring_window_moves_to_its_wide_instance_and_then_to_the_strips(pkg, oracle, synth, monkeypatch, capfd):
+    """K1r's feedback per length class: divergent 500 nt segments (~150 edits against the narrow window's 160) make the class move
+    to its wide instance (10 words: 288) -- within the batch, from the totals every round's counters carry -- and stay there for
+    the following batches, where hardly a pair leaves; 1500 nt segments at ~30 % edits (450) leave the wide one (14 words: 416)
+    too and end on the strips.  Every batch equals the oracle whatever instance ran."""
+    import re
+    monkeypatch.setenv("RPA_TRACE_ROUNDS", "1")
+    monkeypatch.setenv("RPA_BAND_SHORT_MIN", "1")
+    for seg, n_sets, cls, expect in ((500, 400, "0", "wide window"), (1500, 60, "2", "strips")):
+        ds = synth.make_dataset(n_sets=n_sets, n_hits=20, seg_len=seg, branching=4, genome_len=4 * seg, seed=77 + seg, level_rate=0.05, query_rate=0.06)
+        model = pkg.RPAPredictionModel(ds.tax, alphabet=pkg.DNA)
+        model.load_store(pkg.STORE_QUERY, ds.query_letters, ds.query_offsets)
+        model.load_store(pkg.STORE_DB, ds.ref_letters, ds.ref_offsets)
+        tax = oracle.TaxArrays(ds.tax.parent, ds.tax.left, ds.tax.right, ds.tax.depth)
+        q = oracle.StoreArrays(synth.encode(ds.query_letters, 0), ds.query_offsets)
+        db = oracle.StoreArrays(synth.encode(ds.ref_letters, 0), ds.ref_offsets)
+        rc, exp, est = oracle.predict_batch(tax, q, db, 0, ds.batch["set_offsets"], ds.batch["query_seq"], ds.batch["query_len"],
+                                            synth.records_aos(ds.batch, oracle.RECORD_DTYPE))
+        assert rc == 0
+        seen = []  # per batch: {length class: what it runs on next}
+        for _ in range(4):
+            capfd.readouterr()
+            rows, stats = model.predict(ds.batch)
+            assert rows.tobytes() == exp.tobytes() and stats.tobytes() == est.tobytes()
+            err = capfd.readouterr().err
+            seen.append({c: nxt for (_l, _n, c, nxt) in re.findall(r"batch done: (\d+) of (\d+) pairs left the ring window \(class (\d); next batch: ([a-z ]+)\)", err)})
+        if expect == "wide window":  # the first batch already ends on the wide instance (the move happens between its rounds) and the class stays there
+            assert all(b.get(cls) == "wide window" for b in seen), (seg, seen)
+        else:  # narrow -> wide -> strips (an instance is judged on 1024 pairs of its own: with 1200 pairs per round that takes a batch or two), then no window at all
+            said = [b.get(cls) for b in seen]
+            assert "strips" in said and said[-1] is None and said.index("strips") < len(said) - 1 and all(x is None for x in said[said.index("strips") + 1:]), (seg, seen)
+
+
 def test_predict_dna_ragged_sets_and_lengths(pkg, oracle, synth):
     """Record sets of different sizes (1..40 records) and segment lengths from 40 to 700 bp in one batch."""
     parts = [synth.make_dataset(n_sets=150, n_hits=h, seg_len=L, branching=3, genome_len=2500, seed=10 + k, variety=True)
