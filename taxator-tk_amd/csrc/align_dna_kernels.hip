@@ -527,7 +527,7 @@ template <int NW, int PH>
 __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __restrict__ list, uint32_t n_list,
                                                                const uint2* __restrict__ list2, uint32_t n_list2, WorkDev w,
                                                                uint2* __restrict__ retry, uint32_t* __restrict__ retry_n,
-                                                               unsigned long long* prof_acc) {
+                                                               unsigned long long* prof_acc, uint32_t* __restrict__ retry_total) {
   // match masks of the four pattern words in the window, [symbol][word & 3][lane]: 20 KB per workgroup whatever NW is
   // (the flat table of the full kernel is 5 NW KB and holds the kernel at 4 waves per SIMD; this one leaves that to the
   // registers).  A word's masks are made when the window takes the word in.
@@ -551,7 +551,11 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
   if (!active) return;
   const uint32_t ad = n > m ? n - m : m - n;
   constexpr uint32_t kReach = band4_reach(PH);
-  if (ad >= kReach) { retry[atomicAdd(retry_n, 1u)] = entry; return; }  // no band of this shape holds the corridor
+  if (ad >= kReach) {  // no band of this shape holds the corridor
+    retry[atomicAdd(retry_n, 1u)] = entry;
+    if (retry_total) atomicAdd(retry_total, 1u);  // (the 9..12-word classes: what the engine's ladder of banded kernels reads)
+    return;
+  }
   NtStream ps;
   ps.init(pat, 0u);
 #pragma unroll
@@ -579,7 +583,10 @@ __global__ __launch_bounds__(kBlock) void k_myers_short_band4(const uint2* __res
     if (wi >= top) dist += (int32_t)__popc(VP[wi] & vm) - (int32_t)__popc(VN[wi] & vm);
   }
   if ((uint32_t)dist <= 2u * kReach - ad) store_dna_result(w, dst, dist, n, m);
-  else retry[atomicAdd(retry_n, 1u)] = entry;
+  else {
+    retry[atomicAdd(retry_n, 1u)] = entry;
+    if (retry_total) atomicAdd(retry_total, 1u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -907,7 +914,8 @@ hipError_t launch_align_dna_short(hipStream_t st, int words, const uint2* list, 
 bool dna_short_band_available(int words) { return words >= 5 && words <= kShortWords; }
 
 hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
-                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, bool wide, unsigned long long* prof_acc) {
+                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, bool wide, unsigned long long* prof_acc,
+                                       uint32_t* retry_total) {
   if ((uint64_t)n + n2 == 0) return hipSuccess;
   if ((uint64_t)n + n2 > 0xFFFFFF00ull || !retry || !retry_n) return hipErrorInvalidValue;
   const uint32_t blocks = (n + n2 + kBlock - 1) / kBlock;
@@ -925,8 +933,8 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
 #define RPA_LAUNCH_MYERS_BAND(NWV) \
   case NWV: \
     if (five) hipLaunchKernelGGL((k_myers_short_band<NWV, 2>), dim3(blocks), dim3(kBlock), lds, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
-    else if (wide) hipLaunchKernelGGL((k_myers_short_band4<NWV, 2>), dim3(blocks), dim3(kBlock), pad4, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
-    else hipLaunchKernelGGL((k_myers_short_band4<NWV, 3>), dim3(blocks), dim3(kBlock), pad4, st, list, n, list2, n2, w, retry, retry_n, prof_acc); \
+    else if (wide) hipLaunchKernelGGL((k_myers_short_band4<NWV, 2>), dim3(blocks), dim3(kBlock), pad4, st, list, n, list2, n2, w, retry, retry_n, prof_acc, retry_total); \
+    else hipLaunchKernelGGL((k_myers_short_band4<NWV, 3>), dim3(blocks), dim3(kBlock), pad4, st, list, n, list2, n2, w, retry, retry_n, prof_acc, retry_total); \
     break;
   switch (words) {
     RPA_LAUNCH_MYERS_BAND(5) RPA_LAUNCH_MYERS_BAND(6) RPA_LAUNCH_MYERS_BAND(7) RPA_LAUNCH_MYERS_BAND(8)
@@ -937,7 +945,7 @@ hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* l
   return hipGetLastError();
 }
 
-bool dna_window_available(int window_words) { return window_words == 6 || window_words == 10 || window_words == 14; }
+bool dna_window_available(int window_words) { return window_words == 6 || window_words == 8 || window_words == 10 || window_words == 14; }
 
 hipError_t launch_align_dna_window(hipStream_t st, int window_words, const uint2* list, uint32_t n, const WorkDev& w, uint2* retry,
                                    uint32_t* retry_n, uint32_t* retry_total, unsigned long long* prof_acc) {
@@ -947,6 +955,7 @@ hipError_t launch_align_dna_window(hipStream_t st, int window_words, const uint2
   const size_t lds = (size_t)5 * window_words * kBlock * sizeof(uint32_t);
   switch (window_words) {
     case 6: hipLaunchKernelGGL(k_myers_window<6>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, retry, retry_n, retry_total, prof_acc); break;
+    case 8: hipLaunchKernelGGL(k_myers_window<8>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, retry, retry_n, retry_total, prof_acc); break;
     case 10: hipLaunchKernelGGL(k_myers_window<10>, dim3(blocks), dim3(kBlock), lds, st, list, n, w, retry, retry_n, retry_total, prof_acc); break;
     case 14: {  // 70 KB of ring: beyond what a launch may ask for without saying so
       // (per launch, not once: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive several -- taxator --devices)

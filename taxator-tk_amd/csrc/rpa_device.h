@@ -19,7 +19,10 @@ constexpr int kWindowMaxWords = 64;
 constexpr int kFirstStripBin = kShortWords + kWindowBins;
 constexpr int kDnaBins = kFirstStripBin + kStripBins;  // bins 0..11: one strip of bin+1 words; 12, 13, 14: up to 16 / 32 / 64 words; 15..18: strips of bin-10 words
 // window words of a class: the narrow instance, and the wide one the engine moves to when more than a quarter of a batch's pairs left the narrow one
-__host__ __device__ constexpr int window_words_of_bin(int bin, bool wide = false) { return bin == kShortWords ? (wide ? 10 : 6) : (wide ? 14 : 10); }
+__host__ __device__ constexpr int window_words_of_bin(int bin, bool wide = false) { return bin == kShortWords ? (wide ? 8 : 6) : (wide ? 14 : 10); }
+// Classes with a ladder of banded kernels the engine climbs per batch (rpa_engine.hip: window_feedback): the one-strip classes of 9..12
+// words (the four-word band, 80 edits -> the ring window of 6 words, 160 -> every cell) and the ring-window classes (narrow -> wide -> strips)
+constexpr int kLadderBins = kFirstStripBin - kWaveMaxWords;  // bins kWaveMaxWords .. kFirstStripBin - 1
 constexpr int kNumBins = 22;         // work lists per round: the nucleotide bins above, or the 22 protein bins below
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
@@ -266,8 +269,8 @@ constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNum
               kCtrDeferred = kNumBins + 9,   // pass-2 hits of this round that wait for the round's second launch (k_emit; see kDeferredMark)
               kCtrSurvivor = kNumBins + 10,  // [kNumBins words] pairs per bin of that second launch (k_defer_filter)
               kCtrWindowFail = 2 * kNumBins + 10,        // pairs of this round that left the ring-window kernel's band (length of its own list; cleared with kCtrSurvivor)
-              kCtrRetryWindowTotal = 2 * kNumBins + 11,  // [kWindowBins words] ... added up over the batch, per length class
-              kNumCounters = 2 * kNumBins + 11 + kWindowBins, kNumRoundCounters = kNumBins + 4;
+              kCtrRetryWindowTotal = 2 * kNumBins + 11,  // [kLadderBins words] pairs that left their class's banded kernel, added up over the batch, per ladder class
+              kNumCounters = 2 * kNumBins + 11 + kLadderBins, kNumRoundCounters = kNumBins + 4;
 static_assert(kNumCounters <= 64, "launch_publish_words moves up to 64 words");
 
 // Two launches inside ONE pass-2 round.  A pass-2 loop steps over every hit whose taxon lies at or below unode_global (:771), and
@@ -379,7 +382,8 @@ hipError_t launch_align_dna_short_wave(hipStream_t st, const uint2* list, uint32
 // outside it are appended to retry[*retry_n] instead of being answered
 bool dna_short_band_available(int words);
 hipError_t launch_align_dna_short_band(hipStream_t st, int words, const uint2* list, uint32_t n, const uint2* list2, uint32_t n2,
-                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, bool wide, unsigned long long* prof_acc);
+                                       const WorkDev& w, uint2* retry, uint32_t* retry_n, bool shared_gpu, bool wide, unsigned long long* prof_acc,
+                                       uint32_t* retry_total = nullptr);
 // multi-strip per-lane kernel inside Ukkonen's band; scratch holds two boundary bits per text column per thread in
 // flight.  A pair whose distance lies outside its band is appended to retry[*retry_n] (wide_open: never happens).
 // margin / 16 = safety factor on the probe's distance estimate (21 by default; tests use tiny ones to force retries).

@@ -137,10 +137,11 @@ struct rpa_engine {
                               // reads a slot nobody wrote this batch then reads garbage every time, not whatever the last batch left)
   // what the bands cost: pairs sent through the banded kernels / re-run wide open, per batch.  A band that sends more
   // than a quarter of its pairs to the retry list (unrelated sequences) is switched off for the next 16 batches.
-  uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch[kWindowBins] = {};
-  int band_short_pause = 0, band_long_pause = 0, band_window_pause[kWindowBins] = {};  // (per length class: 500 nt reads may stay inside their window while 1500 nt contigs do not)
-  int band_window_wide[kWindowBins] = {};  // > 0: the class runs the wide instance of the ring window for that many more batches (-1: always, RPA_BAND_WINDOW_WIDE=1)
-  uint64_t window_seen_pairs[kWindowBins] = {}, window_seen_left[kWindowBins] = {};  // what the current instance's share of the batch's counters starts from
+  // ladder classes (rpa_device.h: kLadderBins; index = bin - kWaveMaxWords): 0..3 the one-strip classes of 9..12 words, then the ring-window classes
+  uint64_t banded_short_batch = 0, banded_long_batch = 0, banded_window_batch[kLadderBins] = {};
+  int band_short_pause = 0, band_long_pause = 0, band_window_pause[kLadderBins] = {};  // (per length class: 500 nt reads may stay inside their window while 1500 nt contigs do not)
+  int band_window_wide[kLadderBins] = {};  // > 0: the class runs the second instance of its ladder for that many more batches (-1: always, RPA_BAND_WINDOW_WIDE=1)
+  uint64_t window_seen_pairs[kLadderBins] = {}, window_seen_left[kLadderBins] = {};  // what the current instance's share of the batch's counters starts from
   bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..64 words go straight to the strip kernels (A/B; the same results)
   uint32_t window_fail_wave_max = 8192;  // up to this many pairs that left the ring window: one pair per wavefront (RPA_WINDOW_FAIL_WAVE_MAX; 0: always the strips)
   uint32_t band_window_min = 16384;  // fewer pairs than this in a launch: strips / one pair per wavefront as before (RPA_BAND_WINDOW_MIN; mixed-shape stream, in flight / synchronous: 65536: 7.02 / 10.58 ms per step, 16384: 6.35 / 10.57, 4096: 6.49 / 10.63, 512: 6.27 / 10.86)
@@ -354,10 +355,14 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
   int rider = -1;  // a narrower one-strip class waiting for the next launch
   uint64_t banded_pairs = 0;  // pairs that went through the banded strip kernel this round: the retry list's bound
   uint64_t banded_short = 0;  // ... through the banded one-strip kernel (its own retry list and counter)
+  uint64_t ladder_short = 0;  // ... of those, the classes of 9..12 words (judged per class, not with the narrower ones)
   int widest_short = 0;       // widest pattern class (in words) among the banded one-strip launches
   const bool use_band_long = e->band_long && e->band_long_pause == 0, use_band_short = e->band_short && e->band_short_pause == 0;
-  bool use_window = false, window_on[kWindowBins];
-  for (int k = 0; k < kWindowBins; ++k) { window_on[k] = e->band_window && e->band_window_pause[k] == 0; use_window = use_window || window_on[k]; }
+  bool use_window = false, window_on[kLadderBins];
+  for (int k = 0; k < kLadderBins; ++k) {
+    window_on[k] = e->band_window && e->band_window_pause[k] == 0;
+    if (k >= kShortWords - kWaveMaxWords) use_window = use_window || window_on[k];  // (the ring-window classes proper: their own list of pairs that left)
+  }
   uint64_t window_pairs = 0;  // pairs that went through the ring-window kernel this round: the bound of its own list of pairs that left its band
   if (e->params.alphabet == RPA_DNA && use_window) {
     uint64_t wp = 0;
@@ -369,7 +374,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
     for (int bin = kShortWords; bin < kNumBins; ++bin) strip_pairs += counts[bin];
     if (strip_pairs) HIP_TRY(e, e->retry_list.ensure((size_t)strip_pairs * sizeof(uint2)));
   }
-  if (e->params.alphabet == RPA_DNA && use_band_short) {
+  if (e->params.alphabet == RPA_DNA && e->band_short) {  // (the 9..12-word classes run their banded kernels whatever the narrower classes' pause says)
     uint64_t short_pairs = 0;
     for (int bin = 0; bin < kShortWords; ++bin) short_pairs += counts[bin];
     if (short_pairs) HIP_TRY(e, e->retry_short.ensure((size_t)short_pairs * sizeof(uint2)));
@@ -394,7 +399,24 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
       if (bin < kShortWords) {
         // Patterns of 5..8 words inside a band of two words either side of the diagonal (exact: what falls outside goes
         // onto a retry list).  A launch of the dense rounds only: the sparse rounds put every class into one list.
-        if (use_band_short && dna_short_band_available(bin + 1) && (uint64_t)n + n2 >= e->band_short_min) {
+        const int lk = bin - kWaveMaxWords;  // >= 0: a class of 9..12 words with a ladder of its own
+        if (lk >= 0 && e->band_short && window_on[lk] && (uint64_t)n + n2 >= e->band_short_min) {
+          // the four-word band (exact up to 80 - |delta| edits), or -- once more than a quarter of a batch's pairs have left it -- the
+          // ring window of six words (160 - |delta|: 384 nt at 40 % edits) in its place; both hand what they cannot hold to the
+          // every-cell kernel's retry list, and a class that loses its pairs there too computes every cell for 16 batches
+          uint32_t* left_total = w.counters + kCtrRetryWindowTotal + lk;
+          if (e->band_window_wide[lk] == 0)
+            HIP_TRY(e, launch_align_dna_short_band(e->stream, bin + 1, list, n, list2, n2, w, e->retry_short.as<uint2>(), w.counters + kCtrRetryShort,
+                                                   e->owner != nullptr, e->band4_wide > 0 || e->band4_wide == -1, acc, left_total));
+          else {
+            HIP_TRY(e, launch_align_dna_window(e->stream, 6, list, n, w, e->retry_short.as<uint2>(), w.counters + kCtrRetryShort, left_total, acc));
+            if (n2) HIP_TRY(e, launch_align_dna_window(e->stream, 6, list2, n2, w, e->retry_short.as<uint2>(), w.counters + kCtrRetryShort, left_total, acc));
+          }
+          banded_short += (uint64_t)n + n2;
+          ladder_short += (uint64_t)n + n2;
+          widest_short = bin + 1;
+          e->banded_window_batch[lk] += (uint64_t)n + n2;
+        } else if (lk < 0 && use_band_short && dna_short_band_available(bin + 1) && (uint64_t)n + n2 >= e->band_short_min) {
           HIP_TRY(e, launch_align_dna_short_band(e->stream, bin + 1, list, n, list2, n2, w, e->retry_short.as<uint2>(),
                                                  w.counters + kCtrRetryShort, e->owner != nullptr /* a job slot: other batches are in flight */,
                                                  e->band4_wide > 0 || e->band4_wide == -1, acc));
@@ -426,12 +448,12 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
         // Patterns of up to 64 words (bins kShortWords ... kFirstStripBin - 1), launches of the dense rounds: the ring-window kernel first
         // (K1r: one lane per pair, a window of 6 / 10 words around the diagonal, exact up to 160 / 288 edits minus the length
         // difference); what lies outside goes onto the strip kernels' retry list.
-        const int wwords = bin < kFirstStripBin ? window_words_of_bin(bin, e->band_window_wide[bin - kShortWords] != 0) : 0;
-        if (bin < kFirstStripBin && window_on[bin - kShortWords] && dna_window_available(wwords) && n >= std::min(e->band_short_min, e->band_window_min) && e->long_kernel == 0) {
+        const int wwords = bin < kFirstStripBin ? window_words_of_bin(bin, e->band_window_wide[bin - kWaveMaxWords] != 0) : 0;
+        if (bin < kFirstStripBin && window_on[bin - kWaveMaxWords] && dna_window_available(wwords) && n >= std::min(e->band_short_min, e->band_window_min) && e->long_kernel == 0) {
           HIP_TRY(e, launch_align_dna_window(st, wwords, list, n, w, e->window_fail.as<uint2>(), w.counters + kCtrWindowFail,
-                                             w.counters + kCtrRetryWindowTotal + (bin - kShortWords), acc));
+                                             w.counters + kCtrRetryWindowTotal + (bin - kWaveMaxWords), acc));
           window_pairs += n;
-          e->banded_window_batch[bin - kShortWords] += n;
+          e->banded_window_batch[bin - kWaveMaxWords] += n;
         } else if (wave) HIP_TRY(e, launch_align_dna_long(st, (int)wpl, list, n, nullptr, 0, w, acc));
         else {
           DevBuf& ws = sk >= 0 ? e->side_ws[sk] : e->protein_ws;  // (a scratch per stream: the launches of a round run side by side)
@@ -548,7 +570,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
     trc = timer.end();
     if (trc) return trc;
   }
-  e->banded_short_batch += banded_short;
+  e->banded_short_batch += banded_short - ladder_short;
   e->banded_long_batch += banded_pairs - (use_band_long ? window_pairs : 0);
   return RPA_OK;
 }
@@ -663,14 +685,17 @@ struct GateOpener {  // opens the gate on every way out of predict_part
   ~GateOpener() { g.open(); }
 };
 
-// The ring window's feedback, per length class, from the counters every round publishes (`left_total` = pairs of the class that
-// left the window in this batch so far): more than a quarter of the pairs the CURRENT instance saw left it -> the narrow instance
-// hands over to the wide one (for this batch's remaining rounds and 16 batches), the wide one to the strips (a pause of 16 batches).
+// The feedback of a ladder class, from the counters every round publishes (`left_total` = pairs of the class that left its banded
+// kernel in this batch so far): too many of the pairs the CURRENT instance saw left it -> the first instance hands over to the
+// second (for this batch's remaining rounds and 16 batches), the second to the fallback behind the ladder (a pause of 16 batches).
 void window_feedback(rpa_engine* e, int k, uint64_t left_total) {
   const uint64_t pairs = e->banded_window_batch[k] - e->window_seen_pairs[k], left = left_total - e->window_seen_left[k];
-  if (e->band_window_pause[k] != 0 || pairs < 1024 || left * 4 <= pairs) return;
-  if (e->band_window_wide[k] == 0) e->band_window_wide[k] = 17;   // (17: the end of this batch takes one off)
-  else e->band_window_pause[k] = 17;
+  if (e->band_window_pause[k] != 0 || pairs < 1024) return;
+  // A pair that leaves the first instance costs that instance and the fallback behind the ladder (the strips: 4 x a narrow window's
+  // price; every cell: 2 x the band's), the second instance 1.5 x: one pair in sixteen leaving is where the second instance is cheaper
+  // (the one-strip band's own rule).  The second instance still pays while half of its pairs stay.
+  if (e->band_window_wide[k] == 0) { if (left * 16 <= pairs) return; e->band_window_wide[k] = 17; }   // (17: the end of this batch takes one off)
+  else { if (left * 2 <= pairs) return; e->band_window_pause[k] = 17; }
   e->window_seen_pairs[k] = e->banded_window_batch[k];
   e->window_seen_left[k] = left_total;
 }
@@ -754,26 +779,31 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     if (rc) return rc;
     const uint32_t live_now = e->h_counters[w.ctr_live_in];
     if (live_now == 0) {  // the batch is done: what did the bands cost? (totals added up by the retry launches)
-      if (e->banded_short_batch >= 65536 && (uint64_t)e->h_counters[kCtrRetryShortTotal] * 4 > e->banded_short_batch) e->band_short_pause = 16;
+      // (the classes of 9..12 words are judged per class below: their pairs are not in banded_short_batch, their share of the retried ones comes off here)
+      uint64_t short_left = e->h_counters[kCtrRetryShortTotal];
+      for (int k = 0; k < kShortWords - kWaveMaxWords; ++k) short_left -= std::min<uint64_t>(short_left, e->h_counters[kCtrRetryWindowTotal + k]);
+      if (e->banded_short_batch >= 65536 && short_left * 4 > e->banded_short_batch) e->band_short_pause = 16;
       else if (e->band_short_pause) --e->band_short_pause;
       // the narrow band: a pair that leaves it costs the band and every cell (2.2 x the wide band's price), one that stays saves an
       // eighth -- beyond one pair in sixteen the wide band is cheaper
       if (e->trace_rounds && e->banded_short_batch)
-        fprintf(stderr, "[rpa] batch done: %u of %llu pairs left the one-strip band (%s)\n", e->h_counters[kCtrRetryShortTotal],
+        fprintf(stderr, "[rpa] batch done: %u of %llu pairs left the one-strip band (%s)\n", (uint32_t)short_left,
                 (unsigned long long)e->banded_short_batch, (e->band4_wide > 0 || e->band4_wide == -1) ? "four words: 96 - |delta|" : "three-word middle: 80 - |delta|");
       if (e->band4_wide >= 0) {
-        if (e->band4_wide == 0 && e->banded_short_batch >= 65536 && (uint64_t)e->h_counters[kCtrRetryShortTotal] * 16 > e->banded_short_batch) e->band4_wide = 16;
+        if (e->band4_wide == 0 && e->banded_short_batch >= 65536 && short_left * 16 > e->banded_short_batch) e->band4_wide = 16;
         else if (e->band4_wide > 0) --e->band4_wide;
       }
       // (the retry launches count the whole retry list into kCtrRetryTotal; the ring-window kernel counts its own share)
       uint64_t from_window = 0;
-      for (int k = 0; k < kWindowBins; ++k) {
+      for (int k = 0; k < kLadderBins; ++k) {
         const uint64_t left = e->h_counters[kCtrRetryWindowTotal + k];
-        from_window += left;
+        if (k >= kShortWords - kWaveMaxWords) from_window += left;  // (the ring-window classes proper share the strips' retry counters)
         window_feedback(e, k, left);
         if (e->trace_rounds && e->banded_window_batch[k])
-          fprintf(stderr, "[rpa] batch done: %llu of %llu pairs left the ring window (class %d; next batch: %s)\n", (unsigned long long)left, (unsigned long long)e->banded_window_batch[k], k,
-                  e->band_window_pause[k] > 1 ? "strips" : e->band_window_wide[k] > 1 || e->band_window_wide[k] < 0 ? "wide window" : "narrow window");
+          fprintf(stderr, "[rpa] batch done: %llu of %llu pairs left the ring window (class %d; next batch: %s)\n", (unsigned long long)left, (unsigned long long)e->banded_window_batch[k],
+                  k - (kShortWords - kWaveMaxWords),  // (>= 0: the ring-window classes; -4 .. -1: the one-strip classes of 9 .. 12 words)
+                  k < kShortWords - kWaveMaxWords ? (e->band_window_pause[k] > 1 ? "every cell" : e->band_window_wide[k] > 1 || e->band_window_wide[k] < 0 ? "ring window" : "four-word band")
+                                                  : (e->band_window_pause[k] > 1 ? "strips" : e->band_window_wide[k] > 1 || e->band_window_wide[k] < 0 ? "wide window" : "narrow window"));
         if (e->band_window_pause[k]) { if (--e->band_window_pause[k] == 0) e->band_window_wide[k] = e->band_window_wide[k] < 0 ? -1 : 0; }  // (after a pause: the narrow one again)
         else if (e->band_window_wide[k] > 0) --e->band_window_wide[k];
         e->banded_window_batch[k] = 0; e->window_seen_pairs[k] = 0; e->window_seen_left[k] = 0;
@@ -788,7 +818,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     memcpy(counts, e->h_counters, sizeof(counts));
     // (a length class whose pairs are leaving the ring window in this very batch -- the totals of the rounds so far came with the
     // counters -- does not try it again in the rounds that follow; the pause then lasts its 16 batches from the end of this one)
-    for (int k = 0; k < kWindowBins; ++k) window_feedback(e, k, e->h_counters[kCtrRetryWindowTotal + k]);
+    for (int k = 0; k < kLadderBins; ++k) window_feedback(e, k, e->h_counters[kCtrRetryWindowTotal + k]);
     if (rounds == 0 && e->params.alphabet == RPA_DNA) {
       uint64_t all = 0, strips = 0;
       for (int k = 0; k < kNumBins; ++k) { all += counts[k]; if (k >= kShortWords) strips += counts[k]; }
@@ -905,7 +935,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; for (int k = 0; k < kWindowBins; ++k) w->band_window_wide[k] = e->band_window_wide[k] < 0 ? -1 : 0; w->band_window_min = e->band_window_min; w->window_fail_wave_max = e->window_fail_wave_max; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
+  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; for (int k = 0; k < kLadderBins; ++k) w->band_window_wide[k] = e->band_window_wide[k] < 0 ? -1 : 0; w->band_window_min = e->band_window_min; w->window_fail_wave_max = e->window_fail_wave_max; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->side_streams_on = e->side_streams_on;
   w->defer_mode = e->defer_mode;
@@ -1085,7 +1115,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_BAND_SHORT_MIN")) e->band_short_min = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_WINDOW")) e->band_window = atoi(v) != 0;
   if (const char* v = getenv("RPA_BAND_WINDOW_MIN")) e->band_window_min = (uint32_t)atoi(v);
-  if (const char* v = getenv("RPA_BAND_WINDOW_WIDE")) { if (atoi(v) != 0) for (int k = 0; k < kWindowBins; ++k) e->band_window_wide[k] = -1; }
+  if (const char* v = getenv("RPA_BAND_WINDOW_WIDE")) { if (atoi(v) != 0) for (int k = 0; k < kLadderBins; ++k) e->band_window_wide[k] = -1; }
   if (const char* v = getenv("RPA_WINDOW_FAIL_WAVE_MAX")) e->window_fail_wave_max = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_GAIN")) e->band_gain = atof(v);
   if (const char* v = getenv("RPA_BAND_MARGIN")) e->band_margin = (uint32_t)atoi(v);
