@@ -330,6 +330,10 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
   uint32_t beg, end;
   if (in_window) { beg = s_off[lo]; end = s_off[lo + 1]; }  // staged above: no second trip to memory
   else { beg = b.set_offsets[s]; end = b.set_offsets[s + 1]; }
+  // (record sets of w.big_min ... kBigSetMax records are k_rank_big_sets' -- a workgroup per set, everything staged: the scans below are
+  // one trip over the set PER RECORD, and a set that does not fit this workgroup's window makes every one of them a walk through memory)
+  const bool big_set = w.big_min && end - beg >= w.big_min && end - beg <= kBigSetMax;
+  if (!big_set) {
   const uint32_t me = r - w0;  // my record inside the window
   const bool me_filtered = s_filt[me] != 0;
   const float sc = __uint_as_float(s_rec[me].x);
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(kBlock, RPA_RANK_WAVES) void k_rank_records(BatchDe
     w.set_info[s] = make_uint4(n, qrstart, qrstop, qp.x | (qp.y << 29));
   }
   w.hit_set[r] = s;  // rows and records of a set share the index range [set_off[s], set_off[s+1])
+  }  // !big_set
   }  // r < n_records
 
   // ---- write the rows out.  Tiled layout: quad q of the row at slot x lives at quad index (x & ~63) Q + 64 q + (x & 63), i.e.
@@ -2093,6 +2098,245 @@ __global__ __launch_bounds__(kBlock) void k_block_first(const uint32_t* __restri
     if (set_offsets[mid] <= r0) lo = mid; else hi = mid;
   }
   block_first[blk] = lo;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Rank + gather for LARGE record sets (round 5): a workgroup per set of w.big_min ... kBigSetMax records.  k_rank_records gives every
+// record a trip over its whole set (its rank) and over the records in front of it (its path labels): quadratic per set, and once a
+// set no longer fits that kernel's window of 384 staged records every step of those trips is a load from memory -- 11.6 ms instead of
+// 1.2 per config-2-sized step when the 20 M records come in sets of 400 (profiles/r05_dna_hits.txt; BLAST's default of 500 targets
+// per query makes such sets ordinary).  Here the set's columns are staged once (score, identities, query range, preorder number of
+// the taxon: 20 bytes per record), the set's totals come from a workgroup reduction, and the two trips read LDS.  Same outputs,
+// bit for bit: rows at their SortFilter rank, segment descriptors, per-row words, set header (see k_rank_records for the semantics).
+// The list of such sets comes from k_list_big_sets (a compaction over the set offsets in front of the batch's first host read).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_list_big_sets(const uint32_t* __restrict__ set_offsets, uint32_t n_sets, uint32_t big_min,
+                                                          uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_sets) return;
+  const uint32_t n = set_offsets[s + 1] - set_offsets[s];
+  if (n >= big_min && n <= kBigSetMax) list[atomicAdd(count, 1u)] = s;  // (k_rank_records skips a record by exactly this test)
+}
+
+// (BLOCK / NMAX: 256 threads for sets of up to 1024 records.  A wavefront per set of up to 256 records was measured for the sets of 64 ... 190
+// records: parity-green and 2 ms per step SLOWER than k_rank_records there -- a set's rows lie 64 slots apart in the tiled layout, so a
+// kernel that owns one set stores every quad into a line of its own, where k_rank_records writes 64 neighbouring sets' rows together)
+template <int Q, int BLOCK, uint32_t NMAX>
+__global__ __launch_bounds__(BLOCK) void k_rank_big_sets(BatchDev b, WorkDev w, TaxDev tax, StoreDev qstore, StoreDev dbstore, Params p,
+                                                          const uint32_t* __restrict__ big_list) {
+  constexpr uint32_t kPer = NMAX / BLOCK;  // records of a set per thread, at most
+  constexpr uint32_t kTab = 2u * NMAX, kEmpty = 0xFFFFFFFFu;
+  __shared__ uint32_t s_score[NMAX];  // score bits; a masked record: a NaN
+  __shared__ uint32_t s_ident[NMAX];
+  __shared__ uint32_t s_qs[NMAX], s_qe[NMAX];  // query range of the record; masked: (0xFFFFFFFF, 0)
+  __shared__ uint16_t s_ord[NMAX];    // the sort's permutation: s_ord[p] = record at rank p
+  __shared__ uint16_t s_rank[NMAX];
+  __shared__ uint8_t s_filt[NMAX];
+  __shared__ uint32_t s_hkey[kTab], s_hval[kTab];  // per taxonomy level: ancestor at that level -> first record of the set under it
+  __shared__ uint32_t s_red[4];  // masked records, first unmasked record, qrstart, qrstop
+  __shared__ float s_smax;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t s = big_list[blockIdx.x];
+  const uint32_t beg = b.set_offsets[s], end = b.set_offsets[s + 1], cnt = end - beg;
+  uint32_t n_pad = 2u;
+  while (n_pad < cnt) n_pad <<= 1;
+  if (tid == 0) { s_red[0] = 0u; s_red[1] = 0xFFFFFFFFu; s_red[2] = 0xFFFFFFFFu; s_red[3] = 0u; s_smax = -INFINITY; }
+  __syncthreads();
+  {
+    uint32_t n_filt = 0, first_act = 0xFFFFFFFFu, qlo = 0xFFFFFFFFu, qhi = 0u;
+    float smax_nn = -INFINITY;
+    for (uint32_t i = tid; i < n_pad; i += BLOCK) {
+      s_ord[i] = (uint16_t)i;
+      if (i >= cnt) continue;
+      const uint32_t r = beg + i;
+      const bool filt = rec_filtered(b, r);
+      const uint32_t sb = filt ? 0x7FC00000u : __float_as_uint(b.score[r]);
+      const uint32_t a = filt ? 0xFFFFFFFFu : b.qstart[r], e = filt ? 0u : b.qstop[r];
+      s_score[i] = sb; s_ident[i] = b.identities[r]; s_qs[i] = a; s_qe[i] = e; s_filt[i] = filt ? 1 : 0;
+      n_filt += filt ? 1u : 0u;
+      first_act = min(first_act, filt ? 0xFFFFFFFFu : i);
+      qlo = min(qlo, a); qhi = max(qhi, e);
+      smax_nn = __builtin_fmaxf(smax_nn, __uint_as_float(sb));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      n_filt += (uint32_t)__shfl_xor(n_filt, d, 64);
+      first_act = min(first_act, (uint32_t)__shfl_xor(first_act, d, 64));
+      qlo = min(qlo, (uint32_t)__shfl_xor(qlo, d, 64));
+      qhi = max(qhi, (uint32_t)__shfl_xor(qhi, d, 64));
+      smax_nn = __builtin_fmaxf(smax_nn, __shfl_xor(smax_nn, d, 64));
+    }
+    if ((tid & 63u) == 0u) {
+      atomicAdd(&s_red[0], n_filt); atomicMin(&s_red[1], first_act); atomicMin(&s_red[2], qlo); atomicMax(&s_red[3], qhi);
+      // (the largest score that is not a NaN: a float maximum over four wavefronts by compare-and-swap on its bits)
+      uint32_t* sm = reinterpret_cast<uint32_t*>(&s_smax);
+      uint32_t old = *sm;
+      while (__uint_as_float(old) < smax_nn) { const uint32_t seen = atomicCAS(sm, old, __float_as_uint(smax_nn)); if (seen == old) break; old = seen; }
+    }
+  }
+  __syncthreads();
+  const uint32_t n = cnt - s_red[0], qrstart = s_red[2], qrstop = s_red[3];
+  float smax = 0.f;  // score of the set's best record: starts from the first unmasked one (a NaN there stays), any other NaN is passed over
+  if (n) { const float s_first = __uint_as_float(s_score[s_red[1]]); smax = isnan(s_first) ? s_first : s_smax; }
+  const uint32_t L = qrstop - qrstart + 1;
+  // ---- SortFilter order by a bitonic sort of the record indices in LDS: score desc, identities desc, input order; masked records
+  // and the padding behind everything (n log^2 n compare-exchanges per set where a count per record was n^2: 45 stages for 512)
+  auto before = [&](uint32_t x, uint32_t y) {  // does record x come before record y?
+    const bool rx = x < cnt && !s_filt[x < cnt ? x : 0u], ry = y < cnt && !s_filt[y < cnt ? y : 0u];
+    if (!rx || !ry) return rx ? true : (ry ? false : x < y);
+    const float sx = __uint_as_float(s_score[x]), sy = __uint_as_float(s_score[y]);
+    if (sx > sy) return true;
+    if (!(sx == sy)) return sy > sx ? false : x < y;  // (a NaN among the sorted records is refused below: any total order will do here)
+    const uint32_t ix = s_ident[x], iy = s_ident[y];
+    return ix > iy || (ix == iy && x < y);
+  };
+  for (uint32_t k = 2u; k <= n_pad; k <<= 1) {
+    for (uint32_t jj = k >> 1; jj > 0u; jj >>= 1) {
+      for (uint32_t t = tid; t < (n_pad >> 1); t += BLOCK) {
+        const uint32_t lo = ((t & ~(jj - 1u)) << 1) | (t & (jj - 1u)), hi = lo | jj;  // the pair (lo, lo ^ jj) with bit jj of lo clear
+        const uint32_t a = s_ord[lo], c = s_ord[hi];
+        const bool up = (lo & k) == 0u;  // this stretch is being sorted into "before" order
+        if (before(c, a) == up) { s_ord[lo] = (uint16_t)c; s_ord[hi] = (uint16_t)a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t q = tid; q < n_pad; q += BLOCK) { const uint32_t x = s_ord[q]; if (x < cnt) s_rank[x] = (uint16_t)q; }
+  __syncthreads();
+  uint4* __restrict__ hits4 = reinterpret_cast<uint4*>(w.hits);
+  const SetRows<Q> R = set_rows<Q>(w, s, beg);
+  const bool tiled = w.tile_base != nullptr;
+  const size_t sq = tiled ? 64 : 1;
+  uint32_t my_node[kPer];
+  uint32_t* my_row[kPer];  // where the row of my k-th record starts (null: none -- past the end, or masked)
+#pragma unroll
+  for (uint32_t k = 0; k < kPer; ++k) {
+    const uint32_t i = tid + k * BLOCK;
+    my_row[k] = nullptr; my_node[k] = 0u;
+    if (i >= cnt) continue;
+    const uint32_t r = beg + i;
+    w.hit_set[r] = s;
+    my_node[k] = b.node[r];  // (a masked record's taxon counts for the path labels of the others, as in k_rank_records)
+    if (s_filt[i]) continue;
+    const float sc = __uint_as_float(s_score[i]);
+    const uint32_t id = s_ident[i];
+    const uint32_t rank = s_rank[i];
+    if (n >= 2 && sc != sc) raise_error(w, kErrNanScore, s);  // (a NaN among the sorted records: refused, as in k_rank_records)
+    const uint32_t pos = beg + rank;
+    uint2 sp = make_uint2(0u, 0u);
+    SegDesc sdesc{0u, 0u, 0u, 0u};
+    if (n >= 2) {
+      const uint32_t left_ext = s_qs[i] - qrstart, right_ext = qrstop - s_qe[i];  // :523
+      const uint32_t start = b.rstart[r], stop = b.rstop[r];
+      if (start <= stop) {
+        sdesc = plan_segment_desc(dbstore, false, b.ref_seq[r], left_ext < start ? start - left_ext : 1u, stop + right_ext, false, sp);
+      } else if (p.alphabet != 0) {
+        sdesc = SegDesc{0u, 0u, 0u, (uint32_t)kErrAssert << 4};
+        sp = make_uint2(0u, (uint32_t)kErrAssert);
+      } else {
+        sdesc = plan_segment_desc(dbstore, false, b.ref_seq[r], right_ext < stop ? stop - right_ext : 1u, start + left_ext, true, sp);
+      }
+    }
+    const uint32_t node = my_node[k];
+    const bool perfect = b.alnlen[r] == L && id == L;
+    const uint32_t meta = (perfect ? kMetaPerfect : 0u) | (sp.y << kMetaErrShift) | ((uint32_t)tax.depth[node] << kMetaDepthShift);
+    float qd = FLT_MAX, qs = (float)id;
+    if (n == 1) { qd = __uint_as_float(s_qs[i]); qs = __uint_as_float(s_qe[i]); }
+    const uint32_t slot = (uint32_t)((R.res + (size_t)rank * R.sr) - w.pair_res);
+    w.seg[pos] = sdesc;
+    if (w.res_slot) w.res_slot[pos] = slot;
+    if (sp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); sp.x = 0; }
+    w.lite[pos] = sp.x | ((n >= 2 && !perfect && sc >= p.reeval_factor * smax) ? kLiteWant0 : 0u) | (perfect ? kLitePerfect : 0u);
+    // the row with every label word "none"; the labels follow level by level
+    const size_t base = tiled ? (size_t)(slot & ~63u) * Q + (slot & 63u) : (size_t)slot * Q;
+    hits4[base] = make_uint4(__float_as_uint(sc), id, node, meta);
+    hits4[base + sq] = make_uint4(__float_as_uint(qd), __float_as_uint(qs), 0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+    for (int qd4 = 2; qd4 < Q; ++qd4) hits4[base + (size_t)qd4 * sq] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    my_row[k] = reinterpret_cast<uint32_t*>(hits4 + base);
+  }
+  if (tid == 0) {  // the set header (:415): the query range's segment
+    uint2 qp = make_uint2(0u, 0u);
+    SegDesc qdesc{0u, 0u, 0u, 0u};
+    if (n >= 2) qdesc = plan_segment_desc(qstore, true, b.query_seq[s], qrstart, qrstop, false, qp);
+    w.seg[b.n_records + s] = qdesc;
+    if (qp.x > kLiteLenMask) { raise_error(w, kErrUnsupported, s); qp.x = 0; }
+    w.set_info[s] = make_uint4(n, qrstart, qrstop, qp.x | (qp.y << 29));
+  }
+  if (n < 2) return;  // (uniform: no alignments, no labels)
+  // ---- taxon path labels: label_d(record) = the first record of the set (input order) whose taxon lies under the record's ancestor
+  // at level d.  k_rank_records asks every record in front of me, level by level; here one hash table per level (ancestor ->
+  // smallest record index, LDS atomics) answers all records of the set at once: n x D operations instead of n^2 x D / 2.
+  const uint32_t D = tax.max_depth, Dpad = (D + 7u) & ~7u;
+  const uint32_t tab = 2u * n_pad, tab_shift = 32u - (uint32_t)__ffs((int)tab) + 1u;  // a table of twice the (padded) set: 8 ... kTab slots, cleared per level
+  auto slot_of = [&](uint32_t key) { return (key * 2654435761u) >> tab_shift; };
+  for (uint32_t c = 0; c < D; c += 8u) {
+    uint32_t lab[kPer][8];
+    for (uint32_t d = c; d < c + 8u && d < D; ++d) {
+      for (uint32_t t = tid; t < tab; t += BLOCK) { s_hkey[t] = kEmpty; s_hval[t] = 0xFFFFFFFFu; }
+      __syncthreads();
+      uint32_t key[kPer];
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; ++k) {
+        const uint32_t i = tid + k * BLOCK;
+        key[k] = kEmpty;
+        if (i >= cnt) continue;
+        key[k] = tax.anc_iv[(size_t)my_node[k] * Dpad + d].x;  // first preorder number of my ancestor at this level; 0xFFFFFFFF: none (I am above it)
+        if (key[k] == kEmpty) continue;
+        uint32_t h = slot_of(key[k]);
+        for (;;) {
+          const uint32_t seen = atomicCAS(&s_hkey[h], kEmpty, key[k]);
+          if (seen == kEmpty || seen == key[k]) { atomicMin(&s_hval[h], i); break; }
+          h = (h + 1u) & (tab - 1u);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; ++k) {
+        const uint32_t i = tid + k * BLOCK;
+        uint32_t v = i;  // levels below my own keep my own index (nobody shares them)
+        if (i < cnt && key[k] != kEmpty) {
+          uint32_t h = slot_of(key[k]);
+          while (s_hkey[h] != key[k]) h = (h + 1u) & (tab - 1u);
+          v = s_hval[h];
+        }
+#pragma unroll
+        for (uint32_t dd = 0; dd < 8u; ++dd) if (dd == d - c) lab[k][dd] = v;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+      if (!my_row[k]) continue;
+      const uint32_t i = tid + k * BLOCK;
+#pragma unroll
+      for (uint32_t dd = 0; dd < 8u; ++dd) if (c + dd >= D) lab[k][dd] = i;  // (levels past the deepest: never compared; what k_rank_records leaves there)
+      auto put = [&](uint32_t word, uint32_t value) { my_row[k][(size_t)(word >> 2) * sq * 4u + (word & 3u)] = value; };  // word of the row -> its quad
+      if (w.lb_shift == 3u) {
+        put(6u + c / 4u, (lab[k][0] & 255u) | ((lab[k][1] & 255u) << 8) | ((lab[k][2] & 255u) << 16) | (lab[k][3] << 24));
+        put(6u + c / 4u + 1u, (lab[k][4] & 255u) | ((lab[k][5] & 255u) << 8) | ((lab[k][6] & 255u) << 16) | (lab[k][7] << 24));
+      } else if (w.lb_shift == 4u) {
+#pragma unroll
+        for (uint32_t q4 = 0; q4 < 4u; ++q4) put(6u + c / 2u + q4, (lab[k][2 * q4] & 0xFFFFu) | (lab[k][2 * q4 + 1] << 16));
+      } else {
+#pragma unroll
+        for (uint32_t q8 = 0; q8 < 8u; ++q8) put(6u + c + q8, lab[k][q8]);
+      }
+    }
+  }
+}
+
+hipError_t launch_list_big_sets(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t big_min, uint32_t* list, uint32_t* count) {
+  if (n_sets == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_list_big_sets, dim3((n_sets + kBlock - 1) / kBlock), dim3(kBlock), 0, st, set_offsets, n_sets, big_min, list, count);
+  return hipGetLastError();
+}
+
+hipError_t launch_rank_big_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q, const StoreDev& db,
+                                const Params& p, const uint32_t* big_list, uint32_t n_big) {
+  if (n_big == 0) return hipSuccess;
+  RPA_DISPATCH_Q(w.row_quads, hipLaunchKernelGGL((k_rank_big_sets<Q, kBlock, kBigSetMax>), dim3(n_big), dim3(kBlock), 0, st, b, w, tax, q, db, p, big_list));
+  return hipGetLastError();
 }
 
 hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q,

@@ -24,6 +24,7 @@ __host__ __device__ constexpr int window_words_of_bin(int bin, bool wide = false
 // words (the four-word band, 80 edits -> the ring window of 6 words, 160 -> every cell) and the ring-window classes (narrow -> wide -> strips)
 constexpr int kLadderBins = kFirstStripBin - kWaveMaxWords;  // bins kWaveMaxWords .. kFirstStripBin - 1
 constexpr int kNumBins = 22;         // work lists per round: the nucleotide bins above, or the 22 protein bins below
+constexpr uint32_t kBigSetMax = 1024; // largest record set k_rank_big_sets takes (a workgroup per set: 21 bytes of LDS per record, two hash words per table slot)
 constexpr int kLongMaxWPL = 8;       // wave-per-pair Myers kernel (few long pairs): pattern <= 64 lanes * 8 words * 32 = 16384 residues
 constexpr uint32_t kWaveMaxPattern = 64u * kLongMaxWPL * 32u;
 constexpr int kProfParts = 64;        // profiling accumulators are split 64 ways (block index & 63) and summed on the host
@@ -238,6 +239,7 @@ struct WorkDev {
   // a launch over a list whose length only the device knows (k_myers_band / _band_duo / k_myers_long): the kernel works only if
   // dev_count_lo < length (and length <= dev_count_hi, when that is not 0) -- two kernels queued on one list, the right one runs
   uint32_t dev_count_lo, dev_count_hi;
+  uint32_t big_min;     // record sets of big_min ... kBigSetMax records are ranked by k_rank_big_sets (a workgroup per set); 0: none
   // live lists: plan/decide append every set that is still running to live_out; a sparse round (few live sets) runs
   // emit/decide over live_in instead of over the whole batch
   const uint32_t* live_in;  // null in dense rounds
@@ -350,6 +352,9 @@ hipError_t launch_rank_records(hipStream_t st, const BatchDev& b, const WorkDev&
 hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                             void* out_rows, void* out_stats);
 hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p);
+hipError_t launch_list_big_sets(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t big_min, uint32_t* list, uint32_t* count);
+hipError_t launch_rank_big_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q, const StoreDev& db,
+                                const Params& p, const uint32_t* big_list, uint32_t n_big);
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc);
 // between the two launches of a round (kDeferredMark): the held-back pass-2 hits that are still needed -> bin lists, counters[kCtrSurvivor ..]

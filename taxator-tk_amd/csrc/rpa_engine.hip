@@ -100,7 +100,7 @@ struct rpa_engine {
   DevBuf in_u32[11], in_f32, in_u8, in_f64, in_uncl;
   DevBuf state, loop_save, rec_pre, hits, set_info, emit, emit_lite, emit_ext, hit_set, block_first, flags, lite, tile_base, res_slot, seg, pair_a, pair_b,
       pair_res, pair_ext, bin_list, counters, og_idx, og_dist, band_save, live_a, live_b, out_rows, out_stats, tmp_letters,
-      protein_ws, lanes_counter, retry_list, retry_short, window_fail;
+      protein_ws, lanes_counter, retry_list, retry_short, window_fail, big_sets;
   uint32_t* h_counters = nullptr;  // pinned
   // The alignment launches of ONE round that do not depend on each other (one per length class: the strip-height classes of long
   // nucleotide pairs, the lanes-per-pair classes of protein pairs) go to side streams, forked from and joined to the engine's stream
@@ -143,6 +143,7 @@ struct rpa_engine {
   int band_window_wide[kLadderBins] = {};  // > 0: the class runs the second instance of its ladder for that many more batches (-1: always, RPA_BAND_WINDOW_WIDE=1)
   uint64_t window_seen_pairs[kLadderBins] = {}, window_seen_left[kLadderBins] = {};  // what the current instance's share of the batch's counters starts from
   bool band_window = true;    // RPA_BAND_WINDOW=0: patterns of 13..64 words go straight to the strip kernels (A/B; the same results)
+  uint32_t big_set_min = 192;  // (100-record sets: 13.9 ms per step with their own workgroups -- 100 of 256 lanes at work -- against 10.7 without) record sets from this many records on (up to kBigSetMax) are ranked a workgroup per set (RPA_BIG_SET_MIN; 0: never)
   uint32_t window_fail_wave_max = 8192;  // up to this many pairs that left the ring window: one pair per wavefront (RPA_WINDOW_FAIL_WAVE_MAX; 0: always the strips)
   uint32_t band_window_min = 16384;  // fewer pairs than this in a launch: strips / one pair per wavefront as before (RPA_BAND_WINDOW_MIN; mixed-shape stream, in flight / synchronous: 65536: 7.02 / 10.58 ms per step, 16384: 6.35 / 10.57, 4096: 6.49 / 10.63, 512: 6.27 / 10.86)
   int band4_wide = 0;        // > 0: the one-strip band with four words all the way (k = 96 - |delta|) for this many more batches:
@@ -707,18 +708,23 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   // row accesses coalesced; it pads every tile to its largest set, so batches whose padding would exceed ~50 % of the
   // rows (wildly different set sizes) keep the linear layout.  The slot count comes back from the device.
   const uint32_t n_tiles = (S + 63u) / 64u;
-  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 5) * 4));  // + total slots, + the two words of k_validate_batch, + largest set
+  HIP_TRY(e, e->tile_base.ensure((size_t)(n_tiles + 6) * 4));  // + total slots, + the two words of k_validate_batch, + largest set, + number of large sets
   uint32_t P = H;
   bool tiled = false;
   uint32_t lb_shift = 3;
   int row_quads = 2;
+  uint32_t n_big_sets = 0;
   {
     uint32_t* tail = e->tile_base.as<uint32_t>() + n_tiles;
-    HIP_TRY(e, hipMemsetAsync(tail, 0, 16, e->stream));
+    HIP_TRY(e, hipMemsetAsync(tail, 0, 20, e->stream));
     HIP_TRY(e, e->rec_pre.ensure((size_t)(H ? H : 1) * 4));
     HIP_TRY(e, launch_validate_batch(e->stream, b, e->tax.n_nodes, tail + 1, e->tax.pre, e->rec_pre.as<uint32_t>()));
     HIP_TRY(e, launch_tile_plan(e->stream, b.set_offsets, S, e->tile_base.as<uint32_t>(), tail + 3, !e->linear_rows));
-    HIP_TRY(e, launch_publish_words(e->stream, tail, e->h_counters, 4));
+    if (e->big_set_min && H >= e->big_set_min) {  // the record sets a workgroup of its own will rank (k_rank_big_sets): listed now, counted in tail[4]
+      HIP_TRY(e, e->big_sets.ensure((size_t)(H / e->big_set_min + 1) * 4));
+      HIP_TRY(e, launch_list_big_sets(e->stream, b.set_offsets, S, e->big_set_min, e->big_sets.as<uint32_t>(), tail + 4));
+    }
+    HIP_TRY(e, launch_publish_words(e->stream, tail, e->h_counters, 5));
     RPA_WHERE("predict_part: sync after validate/tile plan");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (e->h_counters[1]) return fail(e, RPA_ERR_INVALID, "batch rejected: set_offsets must run from 0 to n_records without decreasing and every node index must lie inside the taxonomy (set / record %u)", e->h_counters[2]);
@@ -727,6 +733,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     // Row shape of this batch: a taxon path label is a record's index inside its set, so its width follows the largest set
     // (8 bits up to 256 records), and a row must hold one label per taxonomy level.
     const uint32_t max_set = e->h_counters[3];
+    n_big_sets = e->h_counters[4];
     lb_shift = e->force_label_shift ? e->force_label_shift : label_shift_for(max_set);
     if (lb_shift < label_shift_for(max_set)) lb_shift = label_shift_for(max_set);
     row_quads = row_quads_for(e->tax.max_depth, lb_shift);
@@ -745,7 +752,9 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   // (w.seg needs no clearing: k_rank_records writes the descriptor of every row position and query range a list entry can name)
   w.set_offsets = b.set_offsets;
   w.store_q = q.words; w.store_db = db.words;
+  w.big_min = n_big_sets ? e->big_set_min : 0u;
   HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
+  HIP_TRY(e, launch_rank_big_sets(e->stream, b, w, e->tax, q, db, e->params, e->big_sets.as<uint32_t>(), n_big_sets));
   if (e->rank_only) {  // RPA_DEBUG_RANK_ONLY=1 (tools/rank_parts.sh: timing builds of k_rank_records whose rows are not usable): stop here
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return fail(e, RPA_ERR_UNSUPPORTED, "RPA_DEBUG_RANK_ONLY: stopped behind k_rank_records");
@@ -935,7 +944,7 @@ rpa_engine* make_worker(rpa_engine* e) {
   if (!w) { fail(e, RPA_ERR_DEVICE, "out of host memory"); return nullptr; }
   w->is_worker = true;
   w->device = e->device; w->params = e->params; w->tax = e->tax;
-  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; for (int k = 0; k < kLadderBins; ++k) w->band_window_wide[k] = e->band_window_wide[k] < 0 ? -1 : 0; w->band_window_min = e->band_window_min; w->window_fail_wave_max = e->window_fail_wave_max; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
+  w->profiling = e->profiling; w->prof_counters = e->prof_counters; w->long_kernel = e->long_kernel; w->band_long = e->band_long; w->band_short = e->band_short; w->band_window = e->band_window; for (int k = 0; k < kLadderBins; ++k) w->band_window_wide[k] = e->band_window_wide[k] < 0 ? -1 : 0; w->band_window_min = e->band_window_min; w->window_fail_wave_max = e->window_fail_wave_max; w->big_set_min = e->big_set_min; w->band_short_min = e->band_short_min; w->band_gain = e->band_gain; w->band_margin = e->band_margin; w->trace_rounds = e->trace_rounds; w->linear_rows = e->linear_rows; w->poison = e->poison; w->force_label_shift = e->force_label_shift; w->short_wave_max = e->short_wave_max;
   w->fixed_speculation = e->fixed_speculation;
   w->side_streams_on = e->side_streams_on;
   w->defer_mode = e->defer_mode;
@@ -1119,6 +1128,7 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_BAND_WINDOW_MIN")) e->band_window_min = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_WINDOW_WIDE")) { if (atoi(v) != 0) for (int k = 0; k < kLadderBins; ++k) e->band_window_wide[k] = -1; }
   if (const char* v = getenv("RPA_WINDOW_FAIL_WAVE_MAX")) e->window_fail_wave_max = (uint32_t)atoi(v);
+  if (const char* v = getenv("RPA_BIG_SET_MIN")) e->big_set_min = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_BAND_GAIN")) e->band_gain = atof(v);
   if (const char* v = getenv("RPA_BAND_MARGIN")) e->band_margin = (uint32_t)atoi(v);
   if (const char* v = getenv("RPA_LONG_KERNEL")) e->long_kernel = !strcmp(v, "wave") ? 1 : !strcmp(v, "lane") ? 2 : 0;
@@ -1252,7 +1262,7 @@ void rpa_destroy(rpa_engine* e) {
                     &e->set_info, &e->seg,
                     &e->pair_a, &e->pair_b, &e->emit, &e->emit_lite, &e->emit_ext, &e->hit_set, &e->block_first, &e->flags, &e->lite, &e->tile_base, &e->res_slot, &e->pair_res, &e->pair_ext, &e->bin_list, &e->counters,
                     &e->og_idx, &e->og_dist, &e->band_save, &e->live_a, &e->live_b, &e->out_rows, &e->out_stats, &e->tmp_letters,
-                    &e->protein_ws, &e->retry_list, &e->retry_short, &e->window_fail, &e->prof_acc, &e->part_offsets};
+                    &e->protein_ws, &e->retry_list, &e->retry_short, &e->window_fail, &e->big_sets, &e->prof_acc, &e->part_offsets};
   RPA_WHERE("rpa_destroy: hipFree of the buffers");
   for (DevBuf* b : bufs) b->release();
   for (auto& b : e->in_u32) b.release();

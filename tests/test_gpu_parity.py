@@ -767,6 +767,28 @@ def test_predict_dna_group_bit_sets(pkg, oracle, synth, n_hits):
     _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(5, 3))
 
 
+@pytest.mark.parametrize("big_min", ["2", "7", "default", "0"])
+def test_rank_with_a_workgroup_per_record_set(pkg, oracle, synth, big_min, monkeypatch):
+    """Round 5: record sets from RPA_BIG_SET_MIN records on (192 by default, up to 1024) are ranked by k_rank_big_sets -- a workgroup per
+    set, the set's columns staged in LDS -- instead of by k_rank_records' thread per record.  With the threshold at 2 EVERY record set
+    of these batches takes the new kernel (sets of one record, masked records, perfect hits, ties, 8- / 16- / 32-bit labels, deep
+    taxonomies, protein, windows of a resident store all included), at 7 a batch mixes both kernels tile by tile, 0 switches it off:
+    the same rows and counters as the oracle every time."""
+    if big_min != "default": monkeypatch.setenv("RPA_BIG_SET_MIN", big_min)
+    ds = synth.make_dataset(n_sets=900, n_hits=20, seg_len=150, branching=4, genome_len=3000, seed=311, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0, speculation=(5, 3))
+    ds = synth.make_ragged_dataset([(300, 3, 120), (200, 9, 100), (60, 40, 90), (30, 100, 80), (12, 300, 60), (3, 700, 60)], seed=31, branching=3)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    ds = synth.make_dataset(n_sets=300, n_hits=12, seg_len=67, branching=3, genome_len=1500, seed=312, alphabet=1, level_rate=0.06, query_rate=0.08, variety=True)
+    _engine_vs_oracle(pkg, oracle, synth, ds, 1)
+    for bits in ("16", "32"):  # wider taxon path labels than the batch needs: the other two packings of a row's label words
+        monkeypatch.setenv("RPA_LABEL_BITS", bits)
+        ds = synth.make_dataset(n_sets=200, n_hits=24, seg_len=100, branching=3, genome_len=2000, seed=313, variety=True)
+        _engine_vs_oracle(pkg, oracle, synth, ds, 0)
+    monkeypatch.delenv("RPA_LABEL_BITS")
+
+
 @pytest.mark.parametrize("n_hits", [100, 300, 530])
 def test_predict_dna_large_record_sets(pkg, oracle, synth, n_hits):
     """Record sets of hundreds of hits (k_decide keeps their outgroup as lists in memory, path labels of 8 and 16 bits), with

@@ -11,7 +11,7 @@ from helpers import oracle as O
 
 KNOBS = ("RPA_PASS1_FILTER", "RPA_LABEL_BITS", "RPA_SPEC1", "RPA_SPEC2", "RPA_SPEC_GROW", "RPA_SPARSE_DECIDE", "RPA_SPARSE_EMIT", "RPA_NO_COMBINED", "RPA_PARTS",
          "RPA_BAND_MARGIN", "RPA_BAND_SHORT_MIN", "RPA_BAND_WORDS", "RPA_BAND4_PHASES", "RPA_BAND_DUO", "RPA_BAND", "RPA_BAND_SHORT", "RPA_LONG_KERNEL",
-         "RPA_PROTEIN_LANES", "RPA_SHORT_WAVE_MAX", "RPA_DEFER2", "RPA_SIDE_STREAMS", "RPA_BAND_WINDOW", "RPA_BAND_WINDOW_WIDE")
+         "RPA_PROTEIN_LANES", "RPA_SHORT_WAVE_MAX", "RPA_DEFER2", "RPA_SIDE_STREAMS", "RPA_BAND_WINDOW", "RPA_BAND_WINDOW_WIDE", "RPA_BIG_SET_MIN")
 
 
 def fill_windows(pkg, model, ds, tile):
@@ -109,6 +109,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
       if alphabet == 1 and rng.random() < 0.3: env["RPA_PROTEIN_LANES"] = "0"
       if alphabet == 0 and rng.random() < 0.4: env["RPA_SHORT_WAVE_MAX"] = str(int(rng.choice([0, 64, 1000000])))  # round 4: K1w (a pattern word per lane) never / for tiny launches / always
       if rng.random() < 0.6: env["RPA_DEFER2"] = str(rng.choice(["0", "1", "1", "auto"]))  # round 5: two launches per pass-2 round (kDeferredMark) never / always / by pattern length
+      if rng.random() < 0.5: env["RPA_BIG_SET_MIN"] = str(int(rng.choice([0, 2, 7, 30])))  # round 5: which record sets a workgroup of its own ranks (default: from 192 records on)
       if rng.random() < 0.3: env["RPA_SIDE_STREAMS"] = "0"  # round 5: the launches of a round one after the other on the engine's stream
       for kk in KNOBS:
           os.environ.pop(kk, None)
