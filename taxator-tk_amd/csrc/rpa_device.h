@@ -354,7 +354,7 @@ hipError_t launch_plan_sets(hipStream_t st, const BatchDev& b, const WorkDev& w,
 hipError_t launch_emit(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p);
 hipError_t launch_list_big_sets(hipStream_t st, const uint32_t* set_offsets, uint32_t n_sets, uint32_t big_min, uint32_t* list, uint32_t* count);
 hipError_t launch_rank_big_sets(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const StoreDev& q, const StoreDev& db,
-                                const Params& p, const uint32_t* big_list, uint32_t n_big);
+                                const Params& p, const uint32_t* big_list, uint32_t n_big, uint32_t largest_set);
 hipError_t launch_decide(hipStream_t st, const BatchDev& b, const WorkDev& w, const TaxDev& tax, const Params& p,
                          void* out_rows, void* out_stats, unsigned long long* prof_acc);
 // between the two launches of a round (kDeferredMark): the held-back pass-2 hits that are still needed -> bin lists, counters[kCtrSurvivor ..]

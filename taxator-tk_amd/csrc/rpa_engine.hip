@@ -713,7 +713,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   bool tiled = false;
   uint32_t lb_shift = 3;
   int row_quads = 2;
-  uint32_t n_big_sets = 0;
+  uint32_t n_big_sets = 0, largest_set = 0;
   {
     uint32_t* tail = e->tile_base.as<uint32_t>() + n_tiles;
     HIP_TRY(e, hipMemsetAsync(tail, 0, 20, e->stream));
@@ -733,7 +733,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     // Row shape of this batch: a taxon path label is a record's index inside its set, so its width follows the largest set
     // (8 bits up to 256 records), and a row must hold one label per taxonomy level.
     const uint32_t max_set = e->h_counters[3];
-    n_big_sets = e->h_counters[4];
+    n_big_sets = e->h_counters[4]; largest_set = max_set;
     lb_shift = e->force_label_shift ? e->force_label_shift : label_shift_for(max_set);
     if (lb_shift < label_shift_for(max_set)) lb_shift = label_shift_for(max_set);
     row_quads = row_quads_for(e->tax.max_depth, lb_shift);
@@ -754,7 +754,7 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
   w.store_q = q.words; w.store_db = db.words;
   w.big_min = n_big_sets ? e->big_set_min : 0u;
   HIP_TRY(e, launch_rank_records(e->stream, b, w, e->tax, q, db, e->params));
-  HIP_TRY(e, launch_rank_big_sets(e->stream, b, w, e->tax, q, db, e->params, e->big_sets.as<uint32_t>(), n_big_sets));
+  HIP_TRY(e, launch_rank_big_sets(e->stream, b, w, e->tax, q, db, e->params, e->big_sets.as<uint32_t>(), n_big_sets, largest_set));
   if (e->rank_only) {  // RPA_DEBUG_RANK_ONLY=1 (tools/rank_parts.sh: timing builds of k_rank_records whose rows are not usable): stop here
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return fail(e, RPA_ERR_UNSUPPORTED, "RPA_DEBUG_RANK_ONLY: stopped behind k_rank_records");
