@@ -401,12 +401,12 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
         // Patterns of 5..8 words inside a band of two words either side of the diagonal (exact: what falls outside goes
         // onto a retry list).  A launch of the dense rounds only: the sparse rounds put every class into one list.
         const int lk = bin - kWaveMaxWords;  // >= 0: a class of 9..12 words with a ladder of its own
-        if (lk >= 0 && e->band_short && window_on[lk] && (uint64_t)n + n2 >= e->band_short_min) {
+        if (lk >= 0 && e->band_short && e->band_window_pause[lk] == 0 && (uint64_t)n + n2 >= e->band_short_min) {
           // the four-word band (exact up to 80 - |delta| edits), or -- once more than a quarter of a batch's pairs have left it -- the
           // ring window of six words (160 - |delta|: 384 nt at 40 % edits) in its place; both hand what they cannot hold to the
           // every-cell kernel's retry list, and a class that loses its pairs there too computes every cell for 16 batches
           uint32_t* left_total = w.counters + kCtrRetryWindowTotal + lk;
-          if (e->band_window_wide[lk] == 0)
+          if (e->band_window_wide[lk] == 0 || !e->band_window)  // (RPA_BAND_WINDOW=0: no ring window anywhere -- the ladder is band -> every cell)
             HIP_TRY(e, launch_align_dna_short_band(e->stream, bin + 1, list, n, list2, n2, w, e->retry_short.as<uint2>(), w.counters + kCtrRetryShort,
                                                    e->owner != nullptr, e->band4_wide > 0 || e->band4_wide == -1, acc, left_total));
           else {
@@ -695,7 +695,8 @@ void window_feedback(rpa_engine* e, int k, uint64_t left_total) {
   // A pair that leaves the first instance costs that instance and the fallback behind the ladder (the strips: 4 x a narrow window's
   // price; every cell: 2 x the band's), the second instance 1.5 x: one pair in sixteen leaving is where the second instance is cheaper
   // (the one-strip band's own rule).  The second instance still pays while half of its pairs stay.
-  if (e->band_window_wide[k] == 0) { if (left * 16 <= pairs) return; e->band_window_wide[k] = 17; }   // (17: the end of this batch takes one off)
+  const bool second_exists = e->band_window || k >= kShortWords - kWaveMaxWords;  // (the 9..12-word classes' second instance is the ring window)
+  if (e->band_window_wide[k] == 0 && second_exists) { if (left * 16 <= pairs) return; e->band_window_wide[k] = 17; }   // (17: the end of this batch takes one off)
   else { if (left * 2 <= pairs) return; e->band_window_pause[k] = 17; }
   e->window_seen_pairs[k] = e->banded_window_batch[k];
   e->window_seen_left[k] = left_total;
