@@ -932,7 +932,7 @@ def main():
             try:  # record sets of mixed shape (1 ... 500 hits, 50 ... 1500 nt, 500 k-node taxonomy pruned and whole): tools/ragged_bench.py
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import ragged_bench
-                sec["c2_ragged"] = ragged_bench.run(pkg, synth, torch, steps=5, in_flight=args.in_flight)
+                sec["c2_ragged"] = ragged_bench.run(pkg, synth, torch, steps=8, in_flight=args.in_flight)  # (eight steps: the first ones of a job slot are where the length classes settle on their kernels)
             except Exception as e:
                 sec["c2_ragged"] = {"error": repr(e)}
             try:  # the pair rate across the kernel families' length classes (tools/pairs_bench.py): no cliff between them
