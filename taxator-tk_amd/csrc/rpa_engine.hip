@@ -401,7 +401,7 @@ int run_align_bins_on_stream(rpa_engine* e, const WorkDev& w, const uint32_t* co
         // Patterns of 5..8 words inside a band of two words either side of the diagonal (exact: what falls outside goes
         // onto a retry list).  A launch of the dense rounds only: the sparse rounds put every class into one list.
         const int lk = bin - kWaveMaxWords;  // >= 0: a class of 9..12 words with a ladder of its own
-        if (lk >= 0 && e->band_short && e->band_window_pause[lk] == 0 && (uint64_t)n + n2 >= e->band_short_min) {
+        if (lk >= 0 && e->band_short && e->band_window_pause[lk] == 0 && (uint64_t)n + n2 >= std::min(e->band_short_min, e->band_window_min)) {
           // the four-word band (exact up to 80 - |delta| edits), or -- once more than a quarter of a batch's pairs have left it -- the
           // ring window of six words (160 - |delta|: 384 nt at 40 % edits) in its place; both hand what they cannot hold to the
           // every-cell kernel's retry list, and a class that loses its pairs there too computes every cell for 16 batches
