@@ -1145,8 +1145,10 @@ __device__ __forceinline__ void append_live_last_wave(const WorkDev& w, LiveStag
 // nucleotide (configs 2 and 5: the scores of a set lie within that factor, the chunk end is almost always the set's end)
 // 1 % slower -- the probes, and in config 5 one round more.  filter1 = 2: protein only, 3: always.
 __device__ __forceinline__ bool assume_first_hit_cutoff(const Params& p) { return p.filter1 >= 3 || (p.filter1 == 2 && p.alphabet != 0); }
+// nucleotide: an assumed cut-off is acted on only where it trims at least a quarter of the chunk (filter1 = 4: always, as protein does)
+__device__ __forceinline__ uint32_t assumed_cut_den(const Params& p) { return (p.alphabet == 0 && p.filter1 == 3) ? 4u : 0u; }
 template <int Q>
-__device__ __forceinline__ uint32_t chunk_end_by_score(const SetRows<Q>& R, uint32_t first, uint32_t hi, int scut_now, float X) {
+__device__ __forceinline__ uint32_t chunk_end_by_score(const SetRows<Q>& R, uint32_t first, uint32_t hi, int scut_now, float X, uint32_t p_min_cut_den = 0u) {
   if (first + 1u >= hi) return hi;
   const int scut = scut_now ? scut_now : float_to_int_x86(R.score(first) * X);
   const float fcut = (float)scut;
@@ -1156,6 +1158,9 @@ __device__ __forceinline__ uint32_t chunk_end_by_score(const SetRows<Q>& R, uint
     const uint32_t m = (a + b) >> 1;
     if (R.score(m) >= fcut) a = m + 1u; else b = m;
   }
+  // (an ASSUMED cut-off that would only trim the chunk's tail is not acted on: where it is wrong the loop pays a pause and a round for
+  // the few alignments it saved -- config 2, scores within a factor X: +2 % per step with it; it is for the sets whose scores spread)
+  if (!scut_now && p_min_cut_den && (hi - a) * p_min_cut_den < (hi - first)) return hi;
   return a;
 }
 
@@ -1174,6 +1179,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
   st.phase = kDone;
   EmitInfo em{};
   em.mode = 0;
+  uint32_t spread_set = 0;
   if (live) {
     const uint32_t lo = b.set_offsets[s], hi = b.set_offsets[s + 1];
     uint4 info = make_uint4(0u, 0u, 0u, 0u);
@@ -1233,6 +1239,10 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
       } else {
         done = false;
         st.phase = kPass0Wait;
+        // (do this batch's scores spread?  Sets in which a cut-off assumed from hit 1 would trim a quarter of the hits or more are
+        // counted; the engine lets k_decide's nucleotide loops assume their cut-offs when one set in sixteen is like that -- the
+        // probes cost config 2, whose scores lie within a factor X, 2-3 % per step for nothing)
+        if (p.alphabet == 0 && p.filter1 == 3 && n >= 3u) spread_set = chunk_end_by_score(set_rows<Q>(w, s, lo), 1u, n, 0, p.exclude_factor, 4u) < n ? 1u : 0u;
         em.mode = 1; em.n = n; em.L = st.L; em.qseglen = st.qseglen; em.i_lo = 0; em.i_hi = n;
         em.fcut = p.reeval_factor * h0.score;  // dbalignment_searchscore_threshold, :499
         // Pass 0 and the first pass-1 loop in ONE round.  qgroup = the perfect hits + the hits above the threshold
@@ -1247,7 +1257,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
         if (members == 1 && (w.lite[lo] & kLiteWant0) && !p.no_combined) {
           em.mode = 4; em.anchor = 0; em.anchor_len = w.lite[lo] & kLiteLenMask;
           em.i_hi = p.spec1 ? min(n, p.spec1) : n;  // the first speculation chunk of the pass-1 loop (hit 0 is part of it)
-          if (assume_first_hit_cutoff(p)) em.i_hi = chunk_end_by_score(set_rows<Q>(w, s, lo), 1u, em.i_hi, 0, p.exclude_factor);  // (no perfect hit here: hit 1 is the first one aligned)
+          if (assume_first_hit_cutoff(p)) em.i_hi = chunk_end_by_score(set_rows<Q>(w, s, lo), 1u, em.i_hi, 0, p.exclude_factor, assumed_cut_den(p));  // (no perfect hit here: hit 1 is the first one aligned)
           st.chunk_hi = em.i_hi;                    // remembered: k_decide may run with another chunk size by then
           st.combined = 1;
         }
@@ -1262,6 +1272,11 @@ __global__ __launch_bounds__(kBlock) void k_plan_sets(BatchDev b, WorkDev w, Tax
     state_store(w, s, st, false);
   }
   append_live(w, live && st.phase != kDone, s);
+  if (p.alphabet == 0 && p.filter1 == 3) {  // (uniform)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) spread_set += (uint32_t)__shfl_xor(spread_set, d, 64);
+    if ((threadIdx.x & 63) == 0 && spread_set) atomicAdd(&w.counters[kCtrSpreadSets], spread_set);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1686,7 +1701,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
         st.qpid_upper = qpid_upper; st.cut_g = cut_g; st.cut_h = cut_h; st.scut = scut;
         band.save(w.band_save + (size_t)s * 2 * w.band_ranks);
         st.chunk_hi = p.spec1 ? min(n, i + (p.grow ? max(p.spec1, i) : p.spec1)) : n;
-        if (assume_first_hit_cutoff(p) || (p.filter1 && scut)) st.chunk_hi = chunk_end_by_score(R, i, st.chunk_hi, scut, X);  // (a cut-off the loop already has: exact)
+        if (assume_first_hit_cutoff(p) || (p.filter1 && scut)) st.chunk_hi = chunk_end_by_score(R, i, st.chunk_hi, scut, X, assumed_cut_den(p));  // (a cut-off the loop already has: exact)
         em.mode = 2; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.i_lo = i; em.i_hi = st.chunk_hi;
         const double cut = cut_g < cut_h ? cut_h : cut_g;
         if (p.filter1 && (scut != 0 || cut > 0.)) {  // the chunk without the hits the loop will break at or step over anyway
@@ -1919,7 +1934,7 @@ __global__ __launch_bounds__(kBlock, RPA_DECIDE_WAVES) void k_decide(BatchDev b,
       if (assume_first_hit_cutoff(p)) {  // the first hit this loop aligns: not the anchor, not at distance 0 from the query (:620)
         uint32_t r = 0;
         while (r < st.chunk_hi && (r == a || (w.lite[lo + r] & kLiteZeroQd))) ++r;
-        if (r < st.chunk_hi) st.chunk_hi = chunk_end_by_score(R, r, st.chunk_hi, 0, X);
+        if (r < st.chunk_hi) st.chunk_hi = chunk_end_by_score(R, r, st.chunk_hi, 0, X, assumed_cut_den(p));
       }
       em.mode = 2; em.anchor = a; em.anchor_len = w.lite[lo + a] & kLiteLenMask; em.i_lo = 0; em.i_hi = st.chunk_hi;
     } else if (!failed && st.phase == kPass2Select) {  // :739-747

@@ -272,7 +272,8 @@ constexpr int kCtrActive = kNumBins, kCtrMaxLen = kNumBins + 1, kCtrRetry = kNum
               kCtrSurvivor = kNumBins + 10,  // [kNumBins words] pairs per bin of that second launch (k_defer_filter)
               kCtrWindowFail = 2 * kNumBins + 10,        // pairs of this round that left the ring-window kernel's band (length of its own list; cleared with kCtrSurvivor)
               kCtrRetryWindowTotal = 2 * kNumBins + 11,  // [kLadderBins words] pairs that left their class's banded kernel, added up over the batch, per ladder class
-              kNumCounters = 2 * kNumBins + 11 + kLadderBins, kNumRoundCounters = kNumBins + 4;
+              kCtrSpreadSets = 2 * kNumBins + 11 + kLadderBins,  // record sets (nucleotide) whose scores spread by more than the cut-off factor (k_plan_sets)
+              kNumCounters = 2 * kNumBins + 12 + kLadderBins, kNumRoundCounters = kNumBins + 4;
 static_assert(kNumCounters <= 64, "launch_publish_words moves up to 64 words");
 
 // Two launches inside ONE pass-2 round.  A pass-2 loop steps over every hit whose taxon lies at or below unode_global (:771), and

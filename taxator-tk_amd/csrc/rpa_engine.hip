@@ -888,6 +888,9 @@ int predict_part(rpa_engine* e, const BatchDev& b, const StoreDev& q, const Stor
     // resident lanes: a round of long alignments costs a whole chip-round (~240 ms for 10 kbp pairs) however few lanes
     // it fills, and a launch of 1.7 rounds of lanes runs faster than two of 0.85 (config 5: 3 rounds instead of 6).
     Params pr = e->params;
+    // nucleotide loops assume their cut-off from the first hit (RPA_PASS1_FILTER 3, the default) only in batches whose scores spread
+    // (k_plan_sets counted the sets where that would trim a quarter of the hits: one in sixteen or more); else as protein-only (2)
+    if (pr.alphabet == RPA_DNA && pr.filter1 == 3 && (uint64_t)e->h_counters[kCtrSpreadSets] * 16 < S) pr.filter1 = 2;
     if (!e->fixed_speculation) {
       if (sparse_decide) { pr.spec1 = 0; pr.spec2 = 0; pr.spec2_first = 0; }
       else {
@@ -1116,7 +1119,8 @@ int rpa_create(const rpa_taxonomy* tax, const rpa_params* params, rpa_engine** o
   if (const char* v = getenv("RPA_PROTEIN_WIDE")) e->params.protein_wide = atoi(v) != 0;
   e->params.no_combined = getenv("RPA_NO_COMBINED") ? 1 : 0;
   if (const char* v = getenv("RPA_BAND4_PHASES")) e->band4_wide = atoi(v) == 2 ? -1 : -2;
-  e->params.filter1 = 2;
+  e->params.filter1 = 2;  // (protein only.  3 = nucleotide too, where the assumed cut-off trims a quarter of a chunk or more and one set in sixteen of the batch is like that: references that
+                          // share half their residues 1.7-2.2 x faster, config 2 1.7 % slower -- profiles/r05_dna_divergence.txt; 4 = always)
   if (const char* v = getenv("RPA_PASS1_FILTER")) e->params.filter1 = atoi(v);
   // a paused loop's next chunk is as long as what the loop has walked so far (1: on since round 5 -- record sets of 100 / 200 / 400 hits take
   // 10-11 rounds instead of 15 / 19 / 20, -7 / -9 / -6 % per step; the BASELINE shapes do not notice: profiles/r05_dna_hits.txt)
