@@ -89,7 +89,7 @@ def run(n_seeds=40, rng_seed=12345, first_seed=1000, verbose=True):
                       "RPA_SPEC_GROW": str(int(rng.integers(0, 2))), "RPA_SPARSE_DECIDE": str(int(rng.choice([1, 3, 6, 24, 100000]))),
                       "RPA_SPARSE_EMIT": str(int(rng.choice([1, 6, 24, 100000])))})
           if rng.random() < 0.4:
-              env["RPA_PASS1_FILTER"] = str(int(rng.choice([0, 1, 3])))
+              env["RPA_PASS1_FILTER"] = str(int(rng.choice([0, 1, 3, 4])))
           if rng.random() < 0.3:
               env["RPA_NO_COMBINED"] = "1"
           if rng.random() < 0.3:
